@@ -1,0 +1,292 @@
+// Device-side multi-precision Montgomery arithmetic for gfx950 (CDNA4).
+//
+// This is the replacement for the reference's un-vendored IPP-Crypto kernel mbx_exp{1024..4096}_mb8
+// (8 moduli in 8 AVX-512 lanes, 52-bit IFMA limbs; named at README.md:32, reached through
+// ipcl::modExp from bindings/ipcl_bindings_classes.cpp:57,130,325).  The CDNA4 mapping is different
+// on purpose:
+//
+//  * A big integer of NL = T*NLL radix-2^29 limbs is held by a *group of T adjacent lanes*
+//    (T = 1,2,4,8; NLL = 36 or 27 limbs per lane), so a wavefront carries 64/T integers.  The
+//    O(NL^2) inner loops are pure v_mad_u64_u32 on compile-time register indices (measured on
+//    MI355X: half rate, 4 cycles per wave64 => 36 T MAC32/s per GPU —
+//    profiles/r01/ubench_valu_mi355x.jsonl).  gfx950 VALU operands are limited to 256 VGPRs per
+//    lane, which is what fixes NLL: a[NLL] + n[NLL] + a 2*(NLL+U)-register accumulator window must
+//    fit with room for 2-3 waves per SIMD.
+//  * radix 2^29 limbs in 32-bit VGPRs with *lazy* 64-bit column accumulators: a product is < 2^58,
+//    so ~30 rows can be accumulated with plain v_mad_u64_u32 (which adds a 64-bit addend for free)
+//    before a carry normalisation.  On gfx950 every carry instruction (v_add_co/v_addc_co,
+//    v_lshl_add_u64) costs as much as a multiply, so a radix-2^32 CIOS would spend half its issue
+//    slots on carries.
+//  * the multiplier limbs b[i] stream from LDS, layout [limb][element] (conflict-free, broadcast
+//    inside a lane group), one ds_read per row; the quotient digit q_i is computed by the group's
+//    lane 0 and broadcast; the limb that leaves the bottom of lane t's window is handed to lane
+//    t-1's top once per block of U rows.
+//  * rows are processed U at a time with register renaming; the accumulator window is shifted down
+//    by U limbs once per block and carry-normalised every NORM_ROWS rows.
+//
+// Montgomery domain: R = 2^(29*NL) with R > 4M, so operands stay in [0, 2M) and no conditional
+// subtraction is needed between multiplications (Walter).  Values are canonicalised once at the
+// end of an operation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pai {
+
+constexpr int RB = 29;                          // radix bits
+constexpr uint32_t RMASK = (1u << RB) - 1u;
+constexpr int NORM_ROWS = 24;                   // rows between carry normalisations (must stay < 30)
+
+#define PAI_DEV __device__ __forceinline__
+
+// Per-modulus constants in device memory (all limbs radix 2^29, zero-padded to NLMAX).
+constexpr int NLMAX = 288;                      // 8192-bit moduli (+2 bits) => 283 limbs, padded
+struct MontCtx {
+    uint32_t n[NLMAX];        // modulus M
+    uint32_t r2[NLMAX];       // R^2 mod M
+    uint32_t one[NLMAX];      // R mod M
+    uint32_t n0inv;           // -M^-1 mod 2^29
+    uint32_t nl;              // limbs in use (template instance must match)
+    uint32_t bits;            // bit length of M
+    uint32_t pad_;
+};
+
+// ---- lane-group helpers -------------------------------------------------------------------------
+template <int T> PAI_DEV int group_lane() { return (int)(threadIdx.x & (T - 1)); }
+
+// value held by lane 0 of the caller's group
+template <int T> PAI_DEV uint32_t bcast0(uint32_t v) {
+    if constexpr (T == 1) return v;
+    else return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63) & ~(T - 1)), 64);
+}
+// value held by the next lane of the group (lane T-1 receives 0)
+template <int T> PAI_DEV uint32_t from_next(uint32_t v) {
+    if constexpr (T == 1) return 0u;
+    else {
+        uint32_t r = (uint32_t)__shfl_down((int)v, 1, 64);
+        return (group_lane<T>() == T - 1) ? 0u : r;
+    }
+}
+// value held by the previous lane of the group (lane 0 receives 0)
+template <int T> PAI_DEV uint32_t from_prev(uint32_t v) {
+    if constexpr (T == 1) return 0u;
+    else {
+        uint32_t r = (uint32_t)__shfl_up((int)v, 1, 64);
+        return (group_lane<T>() == 0) ? 0u : r;
+    }
+}
+template <int T> PAI_DEV bool group_any(bool p) {
+    if constexpr (T == 1) return p;
+    else {
+        unsigned long long m = __ballot(p);
+        const int base = (threadIdx.x & 63) & ~(T - 1);
+        return ((m >> base) & ((1ull << T) - 1ull)) != 0ull;
+    }
+}
+// orders this wave's LDS writes before its later LDS reads (lane groups never span waves)
+PAI_DEV void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// ---- the row engine ---------------------------------------------------------------------------
+// Each lane owns NLL limbs; acc is its window of NLL+U lazy 64-bit columns.  Row i adds
+// a[j]*b_i (+ q_i*n[j]) into columns j, retires column 0 and slides the window.
+template <int NLL, int U, int T>
+struct Rows {
+    static constexpr int NW = NLL + U;
+    static constexpr int NL = NLL * T;
+
+    PAI_DEV static void zero(uint64_t (&acc)[NW]) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc[j] = 0;
+    }
+
+    // parallel carry-save normalisation of the window: afterwards every column < 2^29 + 2^35
+    PAI_DEV static void normalize(uint64_t (&acc)[NW]) {
+#pragma unroll
+        for (int j = NW - 1; j >= 1; --j) {
+            uint64_t keep = (j == NW - 1) ? acc[j] : (acc[j] & RMASK);
+            acc[j] = keep + (acc[j - 1] >> RB);
+        }
+        acc[0] &= RMASK;
+    }
+
+    // U Montgomery rows, then the window moves down by U columns.
+    template <bool AB, bool QN, class NM>
+    PAI_DEV static void block(uint64_t (&acc)[NW], const uint32_t (&a)[NLL], const uint32_t (&bv)[U],
+                              const NM& nm, uint32_t n0inv) {
+        uint32_t low[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (AB) {
+#pragma unroll
+                for (int j = 0; j < NLL; ++j) acc[j + u] += (uint64_t)a[j] * bv[u];
+            }
+            if constexpr (QN) {
+                const uint32_t q = bcast0<T>(((uint32_t)acc[u] * n0inv) & RMASK);
+                nm.template mac<NLL>(acc, u, q);
+            }
+            acc[u + 1] += acc[u] >> RB;
+            low[u] = (uint32_t)acc[u] & RMASK;     // zero in group lane 0 when QN
+        }
+        // hand the retired low parts to the previous lane's top columns, then slide the window
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) acc[j] = acc[j + U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (T > 1) acc[NLL - U + u] += (uint64_t)from_next<T>(low[u]);
+            acc[NLL + u] = 0;
+        }
+    }
+
+    // full carry propagation into canonical 29-bit limbs (across the T lanes of the group)
+    PAI_DEV static void finish(const uint64_t (&acc)[NW], uint32_t (&r)[NLL]) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) {
+            uint64_t t = acc[j] + c;
+            r[j] = (uint32_t)t & RMASK;
+            c = t >> RB;
+        }
+        if constexpr (T > 1) {
+            // c (< 2^36) belongs to the next lane's limb 0.  Each pass adds the incoming carry and
+            // re-propagates locally; after the first pass carries are 0/1 and die out quickly.
+            uint32_t cin_lo = from_prev<T>((uint32_t)c), cin_hi = from_prev<T>((uint32_t)(c >> 32));
+            uint64_t cin = ((uint64_t)cin_hi << 32) | cin_lo;
+            while (__any(cin != 0)) {
+                uint64_t cc = cin;
+#pragma unroll
+                for (int j = 0; j < NLL; ++j) {
+                    uint64_t t = (uint64_t)r[j] + cc;
+                    r[j] = (uint32_t)t & RMASK;
+                    cc = t >> RB;
+                }
+                cin = (uint64_t)from_prev<T>((uint32_t)cc);   // 0 or 1 now
+            }
+        }
+    }
+};
+
+// Where the lane's slice of the modulus comes from during the q*n step.
+//  NmRegs: NLL VGPRs (or SGPRs when T == 1 and the compiler proves uniformity).
+//  NmLds : read back from LDS ([lane-slice][limb], 16-byte aligned) four limbs at a time — frees
+//          NLL registers at the price of NLL/4 ds_read_b128 per row.
+template <int NLL>
+struct NmRegs {
+    uint32_t v[NLL];
+    template <int N, int NW>
+    PAI_DEV void mac(uint64_t (&acc)[NW], int u, uint32_t q) const {
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j + u] += (uint64_t)v[j] * q;
+    }
+    PAI_DEV uint32_t limb(int j) const { return v[j]; }
+};
+template <int NLL>
+struct NmLds {
+    const uint32_t* p;      // this lane's slice in LDS
+    template <int N, int NW>
+    PAI_DEV void mac(uint64_t (&acc)[NW], int u, uint32_t q) const {
+        static_assert(N % 4 == 0, "NLL must be a multiple of 4 for vector LDS reads");
+        const uint4* p4 = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+            const uint4 w = p4[j / 4];
+            acc[j + 0 + u] += (uint64_t)w.x * q;
+            acc[j + 1 + u] += (uint64_t)w.y * q;
+            acc[j + 2 + u] += (uint64_t)w.z * q;
+            acc[j + 3 + u] += (uint64_t)w.w * q;
+        }
+    }
+    PAI_DEV uint32_t limb(int j) const { return p[j]; }
+};
+
+// r = a * b * R^-1 mod M (lazy: < 2M when a,b < 2M).  b limbs are read from b_ptr[i * bstride]
+// (LDS, [limb][element]); nm = this lane's slice of the modulus.
+template <int NLL, int U, int T, class NM>
+PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32_t* b_ptr, int bstride,
+                      const NM& nm, uint32_t n0inv) {
+    static_assert(NLL % U == 0, "NLL must be a multiple of the row-block size U");
+    static_assert(NORM_ROWS % U == 0, "NORM_ROWS must be a multiple of U");
+    using RW = Rows<NLL, U, T>;
+    uint64_t acc[RW::NW];
+    RW::zero(acc);
+    constexpr int NB = RW::NL / U;
+    constexpr int NORM_BLOCKS = NORM_ROWS / U;
+    int since = 0;
+#pragma unroll 1
+    for (int blk = 0; blk < NB; ++blk) {
+        uint32_t bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) bv[u] = b_ptr[(blk * U + u) * bstride];
+        RW::template block<true, true>(acc, a, bv, nm, n0inv);
+        if (++since == NORM_BLOCKS) { RW::normalize(acc); since = 0; }
+    }
+    RW::finish(acc, r);
+}
+
+// Montgomery reduction of a 2*NL-limb value t (< M*R): r = t * R^-1 mod M (lazy, < 2M).
+// lo = this lane's slice of the low NL limbs; the high limbs are read from hi_ptr[i*hstride]
+// (LDS [limb][element], limb index relative to NL).
+template <int NLL, int U, int T, class NM>
+PAI_DEV void mont_redc(uint32_t (&r)[NLL], const uint32_t (&lo)[NLL], const uint32_t* hi_ptr, int hstride,
+                       const NM& nm, uint32_t n0inv) {
+    using RW = Rows<NLL, U, T>;
+    uint64_t acc[RW::NW];
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) acc[j] = lo[j];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[NLL + u] = 0;
+    constexpr int NB = RW::NL / U;
+    constexpr int NORM_BLOCKS = NORM_ROWS / U;
+    int since = 0;
+    const bool top = (group_lane<T>() == T - 1);
+    uint32_t bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) bv[u] = 0;
+#pragma unroll 1
+    for (int blk = 0; blk < NB; ++blk) {
+        // the window top of the group's last lane is where the high half enters
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t h = hi_ptr[(blk * U + u) * hstride];
+            acc[NLL + u] = top ? (uint64_t)h : 0ull;
+        }
+        RW::template block<false, true>(acc, lo, bv, nm, n0inv);
+        if (++since == NORM_BLOCKS) { RW::normalize(acc); since = 0; }
+    }
+    RW::finish(acc, r);
+}
+
+// canonicalise x (< 2M, 29-bit limbs, distributed over the group) into [0, M)
+template <int NLL, int T, class NM>
+PAI_DEV void cond_sub(uint32_t (&x)[NLL], const NM& nm) {
+    uint32_t d[NLL];
+    int32_t borrow = 0;        // 0 or -1, assuming no borrow-in
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) {
+        int32_t t = (int32_t)x[j] - (int32_t)nm.limb(j) + borrow;   // 29-bit limbs: fits in int32
+        d[j] = (uint32_t)t & RMASK;
+        borrow = t >> RB;
+    }
+    if constexpr (T > 1) {
+        // ripple the borrow through the group, lane by lane (T <= 8, once per operation)
+        for (int step = 1; step < T; ++step) {
+            int32_t bin = (int32_t)from_prev<T>((uint32_t)borrow);   // 0 or 0xffffffff(-1)
+            int32_t b2 = (group_lane<T>() == step) ? bin : 0;
+            int32_t bo = b2;
+#pragma unroll
+            for (int j = 0; j < NLL; ++j) {
+                int32_t t = (int32_t)d[j] + bo;
+                d[j] = (uint32_t)t & RMASK;
+                bo = t >> RB;
+            }
+            if (group_lane<T>() == step) borrow = borrow + bo;   // combined borrow-out is 0 or -1
+        }
+        // the decision is the borrow out of the group's last lane
+        int32_t last = (int32_t)__shfl((int)borrow, (int)(((threadIdx.x & 63) & ~(T - 1)) + T - 1), 64);
+        borrow = last;
+    }
+    const bool ge = (borrow == 0);
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) x[j] = ge ? d[j] : x[j];
+}
+
+}  // namespace pai
