@@ -1,0 +1,120 @@
+/* paillier_hip.h — C ABI of libpaillier_hip.so, the MI355X (gfx950) Paillier engine.
+ *
+ * This library is the drop-in replacement for the native layer under the reference's Python API:
+ * the pybind11 module `ipcl_bindings` (src/ipcl_python/bindings/ipcl_bindings.cpp:21-63) plus the
+ * un-vendored ipcl / IPP-Crypto libraries it forwards to.  Each entry point cites the reference
+ * interface it replaces.  Conventions:
+ *
+ *  - every function returns 0 on success, a negative PAI_E_* code on failure; pai_last_error()
+ *    returns a thread-local message for the last failure (C++ exceptions never cross the ABI);
+ *  - big integers are little-endian arrays of native-endian uint32_t words (the wire order of
+ *    pyByte2BN / BN2bytes, ipcl_bindings.cpp:100-138), batches are row-major [N][words];
+ *  - pointers named d_* are DEVICE pointers on the key's device; h_* are HOST pointers;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are asynchronous
+ *    with respect to the host unless stated otherwise;
+ *  - there is NO CPU fallback: without a usable gfx950 device key creation fails with
+ *    PAI_E_NODEVICE.
+ *
+ * Word counts for a key of `key_bits` bits: n_words = ceil(key_bits/32) (plaintext residues mod n),
+ * ct_words = 2*n_words (ciphertexts mod n^2), r_words = ceil(randbits/32) (DJN randomness).
+ */
+#ifndef PAILLIER_HIP_H_
+#define PAILLIER_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAI_OK 0
+#define PAI_E_INVALID (-1)    /* bad argument */
+#define PAI_E_NODEVICE (-2)   /* no gfx950 device / HIP runtime failure at set-up */
+#define PAI_E_HIP (-3)        /* HIP runtime error during a call */
+#define PAI_E_UNSUPPORTED (-4)/* key size outside the compiled geometries (moduli up to 8192 bits) */
+#define PAI_E_INTERNAL (-5)
+
+typedef struct pai_pubkey pai_pubkey;      /* replaces ipclPublicKey  (ipcl_bindings_classes.cpp:12-91)  */
+typedef struct pai_privkey pai_privkey;    /* replaces ipclPrivateKey (ipcl_bindings_classes.cpp:93-163) */
+typedef struct pai_modulus pai_modulus;    /* a bare odd modulus for pai_modmul / pai_modexp_*           */
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int pai_version(void);                                   /* 100*major + minor */
+int pai_device_count(int* count);                        /* number of visible HIP devices */
+const char* pai_last_error(void);
+
+/* ---- device memory helpers (for callers that do not bring their own allocator) ---------------- */
+int pai_malloc(int device, size_t bytes, void** d_ptr);
+int pai_free(int device, void* d_ptr);
+int pai_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes, void* stream);
+int pai_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
+int pai_stream_sync(int device, void* stream);
+
+/* ---- keys ------------------------------------------------------------------------------------- */
+/* ipclPublicKey(n, bits, enableDJN) — classes.cpp:24-27 — and the pickle form
+ * (scheme, n, bits, hs, randbits) — ipcl_bindings.cpp:66-98.  h_hs == NULL selects the standard
+ * scheme (obfuscator r^n); otherwise the DJN scheme (obfuscator hs^r, r of `randbits` bits) and the
+ * fixed-base table for hs is built on the device. */
+int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint32_t* h_hs, int hs_words,
+                      int randbits, int device, pai_pubkey** out);
+void pai_pubkey_destroy(pai_pubkey* pk);
+/* fills any non-NULL out-parameter */
+int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_words, int* r_words,
+                    int* randbits, int* is_djn, int* device);
+
+/* ipclPrivateKey(pubkey, p, q) — classes.cpp:96-101.  p and q may come in either order; n == p*q is
+ * checked.  Derives p^2, q^2, hp, hq, p^-1 mod q. */
+int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, const uint32_t* h_q, int q_words,
+                       pai_privkey** out);
+void pai_privkey_destroy(pai_privkey* sk);
+
+/* ---- hot path --------------------------------------------------------------------------------- */
+/* ipclPublicKey.encrypt(pt, make_secure=false) — classes.cpp:53-60; L3 raw_encrypt, ipcl_python.py:103-106.
+ * d_ct[i] = (1 + d_m[i] * n) mod n^2.   d_m: [N][n_words], each < n.   d_ct: [N][ct_words]. */
+int pai_raw_encrypt(const pai_pubkey* pk, const uint32_t* d_m, size_t N, uint32_t* d_ct, void* stream);
+
+/* ipclPublicKey.encrypt(pt, make_secure=true) — classes.cpp:53-60 with the randomness made explicit.
+ * DJN keys:      d_r: [N][r_words], r_i < 2^randbits;   ct_i = (1 + m_i n) * hs^{r_i} mod n^2.
+ * standard keys: d_r: [N][n_words], 0 < r_i < n;         ct_i = (1 + m_i n) * r_i^n   mod n^2. */
+int pai_encrypt(const pai_pubkey* pk, const uint32_t* d_m, const uint32_t* d_r, size_t N, uint32_t* d_ct,
+                void* stream);
+
+/* ipclPublicKey.apply_obfuscator(CipherText) — classes.cpp:77-83: d_ct[i] <- d_ct[i] * obf(r_i) mod n^2. */
+int pai_obfuscate(const pai_pubkey* pk, uint32_t* d_ct, const uint32_t* d_r, size_t N, void* stream);
+
+/* ipclPrivateKey.decrypt(CipherText) — classes.cpp:127-133 (CRT).  d_m: [N][n_words]. */
+int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream);
+
+/* ipclCipherText.__add__(ct, ct) — classes.cpp:318-321: d_out[i] = d_a[i] * d_b[i] mod n^2.
+ * b_bcast != 0: d_b holds one ciphertext used for every i (size-1 broadcast).  d_out may alias d_a. */
+int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N,
+               uint32_t* d_out, void* stream);
+
+/* ipclCipherText.__mul__(ct, pt) — classes.cpp:324-325: d_out[i] = d_ct[i] ^ e_i mod n^2, e_i >= 0.
+ * d_e: [N][e_words] (or one row if e_bcast); ebits_max bounds the bit length of every e_i. */
+int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, int e_words, int ebits_max,
+               int e_bcast, size_t N, uint32_t* d_out, void* stream);
+
+/* Exponent alignment, ipcl_python.py:570-741 (ct * 2^delta as ciphertext^(2^delta)):
+ * for delta_i > 0: d_ct[i] <- d_ct[i]^(2^delta_i) mod n^2; other elements are left untouched. */
+int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N,
+                void* stream);
+
+/* ---- generic modular building blocks (arbitrary odd modulus up to 8192 bits) ------------------- */
+int pai_modulus_create(const uint32_t* h_m, int m_words, int device, pai_modulus** out);
+void pai_modulus_destroy(pai_modulus* m);
+/* out[i] = a[i] * b[i] mod M; rows of w32 words (w32 = ceil(bits(M)/32)) */
+int pai_modmul(pai_modulus* m, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N, uint32_t* d_out,
+               void* stream);
+/* out[i] = base[i] ^ E mod M, E given on the HOST (wave-uniform exponent, fixed 5-bit window) */
+int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e, int e_words, size_t N,
+                     uint32_t* d_out, void* stream);
+/* out[i] = base[i] ^ e[i] mod M, per-element exponents on the DEVICE */
+int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const uint32_t* d_e, int e_words,
+                   int ebits_max, int e_bcast, size_t N, uint32_t* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAILLIER_HIP_H_ */

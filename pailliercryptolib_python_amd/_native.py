@@ -1,0 +1,92 @@
+"""ctypes binding of ``libpaillier_hip.so`` (C ABI: ``include/paillier_hip.h``).
+
+This module takes the place of ``from .bindings.ipcl_bindings import ...`` in the reference
+(``src/ipcl_python/ipcl_python.py:5-12``).  The library is loaded from ``pailliercryptolib_python_amd/lib``
+and nowhere else; if it is missing the import of any hot-path entry fails loudly — there is no CPU
+fallback behind this boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpaillier_hip.so"
+
+PAI_OK = 0
+PAI_E_INVALID, PAI_E_NODEVICE, PAI_E_HIP, PAI_E_UNSUPPORTED, PAI_E_INTERNAL = -1, -2, -3, -4, -5
+
+
+class NativeError(RuntimeError):
+    """A C-ABI call failed (the reference raises RuntimeError for native failures too:
+    pybind11 maps std::runtime_error, bindings/ipcl_bindings_classes.cpp:206,212,223)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libpaillier_hip error {code}: {msg}")
+        self.code = code
+
+
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+voidp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/paillier_hip.h
+PROTOTYPES = {
+    "pai_version": (C.c_int, []),
+    "pai_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pai_last_error": (C.c_char_p, []),
+    "pai_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(voidp)]),
+    "pai_free": (C.c_int, [C.c_int, voidp]),
+    "pai_memcpy_h2d": (C.c_int, [C.c_int, voidp, voidp, C.c_size_t, voidp]),
+    "pai_memcpy_d2h": (C.c_int, [C.c_int, voidp, voidp, C.c_size_t, voidp]),
+    "pai_stream_sync": (C.c_int, [C.c_int, voidp]),
+    "pai_pubkey_create": (C.c_int, [voidp, C.c_int, C.c_int, voidp, C.c_int, C.c_int, C.c_int, C.POINTER(voidp)]),
+    "pai_pubkey_destroy": (None, [voidp]),
+    "pai_pubkey_info": (C.c_int, [voidp] + [C.POINTER(C.c_int)] * 7),
+    "pai_privkey_create": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, C.POINTER(voidp)]),
+    "pai_privkey_destroy": (None, [voidp]),
+    "pai_raw_encrypt": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
+    "pai_encrypt": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp, voidp]),
+    "pai_obfuscate": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp]),
+    "pai_decrypt": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
+    "pai_ct_add": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp, voidp]),
+    "pai_ct_mul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_int, C.c_int, C.c_size_t, voidp, voidp]),
+    "pai_ct_pow2": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp]),
+    "pai_modulus_create": (C.c_int, [voidp, C.c_int, C.c_int, C.POINTER(voidp)]),
+    "pai_modulus_destroy": (None, [voidp]),
+    "pai_modmul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp, voidp]),
+    "pai_modexp_fixed": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp, voidp]),
+    "pai_modexp_var": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, C.c_int, C.c_int, C.c_size_t, voidp, voidp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library (once) and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m pailliercryptolib_python_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI/header mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != PAI_OK:
+        msg = load().pai_last_error()
+        raise NativeError(code, msg.decode("utf-8", "replace") if msg else "")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().pai_device_count(C.byref(n)))
+    return n.value

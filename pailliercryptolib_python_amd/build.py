@@ -1,0 +1,81 @@
+"""Builds the native HIP library (libpaillier_hip.so) for gfx950 in-tree.
+
+Replaces the reference's CMake/FetchContent build (CMakeLists.txt, lib/ipcl.cmake, setup.py:38-60):
+there is nothing to fetch — every kernel is in ``csrc/`` — and the only tool needed is ``hipcc``.
+The objects are compiled in parallel, one translation unit per lane-group geometry.
+
+    python -m pailliercryptolib_python_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OBJ = CSRC / "build"
+LIBDIR = PKG / "lib"
+LIB = LIBDIR / "libpaillier_hip.so"
+ARCH = "gfx950"
+
+SOURCES = [
+    "geo_36x1.hip",
+    "geo_36x2.hip",
+    "geo_28x4.hip",
+    "geo_36x4.hip",
+    "geo_28x8.hip",
+    "geo_36x8.hip",
+    "paillier_capi.hip",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _deps_mtime() -> float:
+    files = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "paillier_hip.h"]
+    return max(f.stat().st_mtime for f in files)
+
+
+def _compile(src: str) -> None:
+    obj = OBJ / (Path(src).stem + ".o")
+    if obj.exists() and obj.stat().st_mtime >= _deps_mtime():
+        return
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(CSRC / src), "-o", str(obj)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")
+
+
+def build_native(force: bool = False, jobs: int | None = None, verbose: bool = False) -> Path:
+    """Compile (if stale) and return the path of libpaillier_hip.so."""
+    OBJ.mkdir(parents=True, exist_ok=True)
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    if force:
+        for o in OBJ.glob("*.o"):
+            o.unlink()
+    if LIB.exists() and not force and LIB.stat().st_mtime >= _deps_mtime():
+        return LIB
+    jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1))
+    if verbose:
+        print(f"[build] hipcc --offload-arch={ARCH}: {len(SOURCES)} translation units, {jobs} jobs", flush=True)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(_compile, SOURCES))
+    objs = [str(OBJ / (Path(s).stem + ".o")) for s in SOURCES]
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB)] + objs
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"link failed:\n{res.stderr[-4000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build_native(force="--force" in sys.argv, verbose=True)
+    print(path)

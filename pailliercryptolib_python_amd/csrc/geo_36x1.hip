@@ -1,0 +1,3 @@
+// Kernel instantiations for the geometry: 36 radix-2^29 limbs per lane x 1 lanes per integer.
+#include "geo_inst.hpp"
+namespace pai { const GeoOps* geo_ops_36x1() { return GeoInst<Geo<36, 1, 6, false>>::ops(); } }

@@ -1,0 +1,62 @@
+// Instantiates every kernel for one geometry and fills its GeoOps table.
+#pragma once
+#include "geo_ops.hpp"
+#include "kernels_modexp.hpp"
+
+namespace pai {
+
+template <class G>
+struct GeoInst {
+    static void set_lds(const void* fn, int bytes) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    }
+    static void modmul(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                       int n, int w32, int b_bcast) {
+        set_lds((const void*)k_modmul<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_modmul<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, a, b, out, n, w32, b_bcast);
+    }
+    static void modexp_fixed(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32,
+                             const uint32_t* expo, int ewords, int ebits, uint32_t* out, int out_w32, int n,
+                             uint32_t* table, int keep_mont) {
+        set_lds((const void*)k_modexp_fixed<G, MODEXP_WINDOW>, G::LDS_BYTES);
+        hipLaunchKernelGGL((k_modexp_fixed<G, MODEXP_WINDOW>), dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, base,
+                           base_w32, expo, ewords, ebits, out, out_w32, n, table, keep_mont);
+    }
+    static void modexp_var(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32, int base_shift,
+                           const uint32_t* expo, int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32,
+                           int n, int keep_mont, int out_raw) {
+        set_lds((const void*)k_modexp_var<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_modexp_var<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, base, base_w32,
+                           base_shift, expo, ew, ebits_max, exp_bcast, out, out_w32, n, keep_mont, out_raw);
+    }
+    static void encrypt(hipStream_t s, int grid, EncParams P, const uint32_t* m, const uint32_t* r,
+                        const uint32_t* ct_in, uint32_t* ct_out, int n, int mode) {
+        set_lds((const void*)k_encrypt<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_encrypt<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, m, r, ct_in, ct_out, n, mode);
+    }
+    static void dec_a(hipStream_t s, int gridx, DecAParams P, const uint32_t* ct, uint32_t* u_out, int n,
+                      uint32_t* table) {
+        set_lds((const void*)k_dec_a<G, MODEXP_WINDOW>, G::LDS_BYTES);
+        hipLaunchKernelGGL((k_dec_a<G, MODEXP_WINDOW>), dim3(gridx, 2), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, ct,
+                           u_out, n, table);
+    }
+    static void dec_b(hipStream_t s, int grid, DecBParams P, const uint32_t* u_in, uint32_t* m_out, int n) {
+        constexpr int bytes = 2 * G::LDS_WORDS * 4;
+        set_lds((const void*)k_dec_b<G>, bytes);
+        hipLaunchKernelGGL(k_dec_b<G>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, u_in, m_out, n);
+    }
+    static void pow2(hipStream_t s, int grid, const MontCtx* c, uint32_t* ct, const int32_t* delta, int delta_bcast,
+                     int n, int w32) {
+        set_lds((const void*)k_pow2<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_pow2<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, ct, delta, delta_bcast, n, w32);
+    }
+    static size_t table_words(size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * G::NL * blocks * G::EPB; }
+
+    static const GeoOps* ops() {
+        static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
+                                 &modmul, &modexp_fixed, &modexp_var, &encrypt, &dec_a, &dec_b, &pow2, &table_words};
+        return &o;
+    }
+};
+
+}  // namespace pai

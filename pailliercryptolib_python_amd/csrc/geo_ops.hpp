@@ -1,0 +1,45 @@
+// Table of kernel launchers for one lane-group geometry (NLL limbs per lane x T lanes per integer).
+// One translation unit per geometry instantiates it (geo_*.hip) so the build parallelises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "kernels_paillier.hpp"
+
+namespace pai {
+
+constexpr int MODEXP_WINDOW = 5;     // fixed-window width of the uniform-exponent kernels
+
+struct GeoOps {
+    int nll, t, u, nl, epb;
+    int lds_bytes;        // one operand buffer + modulus copy
+    int lds_bytes_b;      // stage-B decrypt kernel (two operand buffers)
+    void (*modmul)(hipStream_t, int grid, const MontCtx*, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                   int n, int w32, int b_bcast);
+    void (*modexp_fixed)(hipStream_t, int grid, const MontCtx*, const uint32_t* base, int base_w32,
+                         const uint32_t* expo, int ewords, int ebits, uint32_t* out, int out_w32, int n,
+                         uint32_t* table, int keep_mont);
+    void (*modexp_var)(hipStream_t, int grid, const MontCtx*, const uint32_t* base, int base_w32, int base_shift,
+                       const uint32_t* expo, int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32,
+                       int n, int keep_mont, int out_raw);
+    void (*encrypt)(hipStream_t, int grid, EncParams, const uint32_t* m, const uint32_t* r, const uint32_t* ct_in,
+                    uint32_t* ct_out, int n, int mode);
+    void (*dec_a)(hipStream_t, int gridx, DecAParams, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table);
+    void (*dec_b)(hipStream_t, int grid, DecBParams, const uint32_t* u_in, uint32_t* m_out, int n);
+    void (*pow2)(hipStream_t, int grid, const MontCtx*, uint32_t* ct, const int32_t* delta, int delta_bcast, int n,
+                 int w32);
+    // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups
+    size_t (*table_words)(size_t blocks);
+};
+
+const GeoOps* geo_ops_36x1();
+const GeoOps* geo_ops_36x2();
+const GeoOps* geo_ops_28x4();
+const GeoOps* geo_ops_36x4();
+const GeoOps* geo_ops_28x8();
+const GeoOps* geo_ops_36x8();
+
+// smallest geometry whose capacity covers a modulus of `bits` bits (R = 2^(29 NL) > 4 M), or nullptr
+const GeoOps* geo_for_bits(int bits);
+
+}  // namespace pai

@@ -111,9 +111,9 @@ k_modexp_fixed(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ bas
 // binary method; the multiply step is skipped when no element of the wave needs it.
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
-k_modexp_var(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, int base_w32, int base_bcast,
+k_modexp_var(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, int base_w32, int base_shift,
              const uint32_t* __restrict__ expo, int ew, int ebits_max, int exp_bcast,
-             uint32_t* __restrict__ out, int out_w32, int n, int keep_mont) {
+             uint32_t* __restrict__ out, int out_w32, int n, int keep_mont, int out_raw) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
@@ -127,7 +127,7 @@ k_modexp_var(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base,
         uint32_t bR[G::NLL], x[G::NLL];
         {
             uint32_t r2[G::NLL];
-            load_elem<G>(bR, base + (size_t)(base_bcast ? 0 : es) * base_w32, base_w32);
+            load_elem<G>(bR, base + (size_t)(es >> base_shift) * base_w32, base_w32);   // base_shift: 0 per element, 31 broadcast
             load_const_slice<G>(r2, ctx->r2);
             mm_times<G>(bR, r2, lds, nm, n0inv);
         }
@@ -160,8 +160,18 @@ k_modexp_var(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base,
             set_plain_one<G>(one);
             mm_times<G>(x, one, lds, nm, n0inv);
             cond_sub<G::NLL, G::T>(x, nm);
+        } else {
+            cond_sub<G::NLL, G::T>(x, nm);               // canonical Montgomery representative
         }
-        if (live) store_elem<G>(x, out + (size_t)ei * out_w32, out_w32, lds);
+        if (live) {
+            if (out_raw) {                               // radix-29 limbs, NL words per element (tables)
+                const int t = G::gl();
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) out[(size_t)ei * G::NL + G::NLL * t + j] = x[j];
+            } else {
+                store_elem<G>(x, out + (size_t)ei * out_w32, out_w32, lds);
+            }
+        }
     }
 }
 

@@ -1,0 +1,353 @@
+// Paillier-specific kernels built on the Montgomery row engine.
+//
+//   k_encrypt     ct = (1 + m n) * hs^r mod n^2   (ipcl::PublicKey::encrypt reached from
+//                 bindings/ipcl_bindings_classes.cpp:53-60; raw form ipcl_python.py:103-106), or
+//                 ct <- ct * hs^r (apply_obfuscator, classes.cpp:71-83).  hs^r uses a per-key
+//                 fixed-base table T[j][d] = hs^(d * 2^(WB j)) (Montgomery form) so the obfuscator
+//                 costs ceil(randbits/WB) multiplications and no squarings.
+//   k_dec_a       per (element, prime s in {p,q}): u_s = (ct mod s^2)^(s-1) mod s^2
+//   k_dec_b       m = CRT( L_p(u_p) hp mod p , L_q(u_q) hq mod q )     (PrivateKey::decrypt reached
+//                 from classes.cpp:127-133; maths in SURVEY.md App. D)
+//   k_pow2        ct <- ct^(2^delta_i) for delta_i > 0 (exponent alignment, ipcl_python.py:570-741)
+#pragma once
+#include "kernels_common.hpp"
+
+namespace pai {
+
+constexpr int FB_WBITS = 8;                  // fixed-base window width
+constexpr int FB_ENTRIES = 1 << FB_WBITS;
+
+// limbs [limb_base, limb_base + NL) of a packed row (for operands wider than the modulus)
+template <class G>
+PAI_DEV void load_elem_off(uint32_t (&x)[G::NLL], const uint32_t* __restrict__ row, int W32, int limb_base) {
+    const int t = G::gl();
+#pragma unroll
+    for (int j = 0; j < G::NLL; ++j) {
+        const int bit = RB * (limb_base + G::NLL * t + j);
+        const int k = bit >> 5, s = bit & 31;
+        const int k0 = k < W32 ? k : W32 - 1, k1 = k + 1 < W32 ? k + 1 : W32 - 1;
+        uint32_t lo = row[k0], hi = row[k1];
+        lo = k < W32 ? lo : 0u;
+        hi = k + 1 < W32 ? hi : 0u;
+        const uint64_t v = ((uint64_t)hi << 32) | lo;
+        x[j] = (uint32_t)(v >> s) & RMASK;
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// x += y limb-wise then canonical 29-bit limbs again (no modular reduction)
+template <class G>
+PAI_DEV void add_limbs(uint32_t (&x)[G::NLL], const uint32_t (&y)[G::NLL]) {
+    using RW = Rows<G::NLL, G::U, G::T>;
+    uint64_t acc[RW::NW];
+#pragma unroll
+    for (int j = 0; j < G::NLL; ++j) acc[j] = (uint64_t)x[j] + y[j];
+#pragma unroll
+    for (int u = 0; u < G::U; ++u) acc[G::NLL + u] = 0;
+    RW::finish(acc, x);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct EncParams {
+    const MontCtx* nsq;          // modulus n^2
+    const uint32_t* nR;          // n * R mod n^2, radix-29, NLMAX-padded (for 1 + m n)
+    const uint32_t* fb_table;    // [J][256][NL] radix-29 limbs, Montgomery form (DJN) or NULL
+    int fb_windows;              // J
+    int pt_words, ct_words, r_words;
+};
+
+// mode 0: ct = 1 + m n                 (raw_encrypt)
+// mode 1: ct = (1 + m n) * hs^r        (encrypt, DJN)
+// mode 2: ct = ct_in * hs^r            (apply_obfuscator, DJN)
+// mode 3: ct = (1 + m n) * obf         (obf = precomputed r^n mod n^2, standard scheme, read from `r`)
+// mode 4: ct = ct_in * obf
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_encrypt(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
+          const uint32_t* __restrict__ ct_in, uint32_t* __restrict__ ct_out, int n, int mode) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typename G::NM nm;
+    load_modulus<G>(nm, P.nsq, lds);
+    const uint32_t n0inv = P.nsq->n0inv;
+    const int t = G::gl();
+    const int tiles = (n + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * G::EPB + G::elem();
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        uint32_t c0[G::NLL];
+        if (mode == 0 || mode == 1 || mode == 3) {
+            // c0 = m * (n R) * R^-1 + 1 = 1 + m n   (m < n so no reduction is involved)
+            uint32_t mm[G::NLL], nr[G::NLL];
+            load_elem<G>(mm, m + (size_t)es * P.pt_words, P.pt_words);
+            load_const_slice<G>(nr, P.nR);
+            mm_times<G>(mm, nr, lds, nm, n0inv);
+            uint32_t one[G::NLL];
+            set_plain_one<G>(one);
+            add_limbs<G>(mm, one);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) c0[j] = mm[j];
+        } else {
+            load_elem<G>(c0, ct_in + (size_t)es * P.ct_words, P.ct_words);
+        }
+        if (mode == 1 || mode == 2) {
+            const uint32_t* rrow = r + (size_t)es * P.r_words;
+            uint32_t x[G::NLL];
+#pragma unroll 1
+            for (int jw = 0; jw < P.fb_windows; ++jw) {
+                const int bit = jw * FB_WBITS;
+                const uint32_t d = (rrow[bit >> 5] >> (bit & 31)) & (FB_ENTRIES - 1);   // 8-bit windows never straddle words
+                const uint32_t* ent = P.fb_table + ((size_t)jw * FB_ENTRIES + d) * G::NL + G::NLL * t;
+                if (jw == 0) {
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) x[j] = ent[j];
+                } else {
+                    uint32_t y[G::NLL];
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) y[j] = ent[j];
+                    mm_times<G>(x, y, lds, nm, n0inv);
+                }
+            }
+            // (hs^r R) * c0 * R^-1 = hs^r * c0
+            mm_times<G>(x, c0, lds, nm, n0inv);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) c0[j] = x[j];
+        } else if (mode == 3 || mode == 4) {
+            // obf given in plain form: c0 * obf = MM(MM(c0, obf), R^2)
+            uint32_t ob[G::NLL], r2[G::NLL];
+            load_elem<G>(ob, r + (size_t)es * P.ct_words, P.ct_words);
+            mm_times<G>(c0, ob, lds, nm, n0inv);
+            load_const_slice<G>(r2, P.nsq->r2);
+            mm_times<G>(c0, r2, lds, nm, n0inv);
+        }
+        cond_sub<G::NLL, G::T>(c0, nm);
+        if (live) store_elem<G>(c0, ct_out + (size_t)ei * P.ct_words, P.ct_words, lds);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decrypt stage A.  blockIdx.y selects the prime (0: p, 1: q).  The ciphertext (2 NL limbs of the
+// s^2 geometry) is folded into Montgomery form as lo*R + hi*R^2 = MM(lo, R^2) + MM(hi, R^3).
+struct DecAParams {
+    const MontCtx* sq[2];        // moduli p^2, q^2
+    const uint32_t* r3[2];       // R^3 mod s^2, radix-29, NLMAX-padded
+    const uint32_t* expo[2];     // s - 1, packed u32 words
+    int ewords[2], ebits[2];
+    int ct_words, u_words;       // u_words = words of an s^2 residue
+};
+
+template <class G, int W>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out /*[2][n][u_words]*/, int n,
+        uint32_t* __restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int which = blockIdx.y;
+    const MontCtx* ctx = P.sq[which];
+    const uint32_t* expo = P.expo[which];
+    const int ewords = P.ewords[which], ebits = P.ebits[which];
+    const int t = G::gl();
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t n0inv = ctx->n0inv;
+    const size_t nslots = (size_t)gridDim.x * gridDim.y * G::EPB;
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * G::EPB + G::elem();
+    auto tbl = [&](int entry, int j) -> uint32_t& {
+        return table[((size_t)entry * G::NL + (G::NLL * t + j)) * nslots + slot];
+    };
+    const int nwin = (ebits + W - 1) / W;
+    const int tiles = (n + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * G::EPB + G::elem();
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        const uint32_t* row = ct + (size_t)es * P.ct_words;
+        uint32_t x[G::NLL];
+        {
+            uint32_t bR[G::NLL];
+            {
+                uint32_t hi[G::NLL], c[G::NLL];
+                load_elem_off<G>(hi, row, P.ct_words, G::NL);
+                load_const_slice<G>(c, P.r3[which]);
+                mm_times<G>(hi, c, lds, nm, n0inv);                 // hi * R^2
+                load_elem_off<G>(bR, row, P.ct_words, 0);
+                load_const_slice<G>(c, ctx->r2);
+                mm_times<G>(bR, c, lds, nm, n0inv);                 // lo * R
+                add_limbs<G>(bR, hi);
+                cond_sub<G::NLL, G::T>(bR, nm);                     // < 4M -> < 2M
+                cond_sub<G::NLL, G::T>(bR, nm);
+            }
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) { x[j] = bR[j]; tbl(1, j) = bR[j]; }
+#pragma unroll 1
+            for (int k = 2; k < (1 << W); ++k) {
+                mm_times<G>(x, bR, lds, nm, n0inv);
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) tbl(k, j) = x[j];
+            }
+        }
+        {
+            const uint32_t wv = exp_bits(expo, ewords, (nwin - 1) * W, W);
+            if (wv == 0) load_const_slice<G>(x, ctx->one);
+            else {
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) x[j] = tbl((int)wv, j);
+            }
+        }
+#pragma unroll 1
+        for (int wi = nwin - 2; wi >= 0; --wi) {
+            const uint32_t wv = exp_bits(expo, ewords, wi * W, W);
+#pragma unroll 1
+            for (int s = 0; s < W; ++s) mm_square<G>(x, lds, nm, n0inv);
+            if (wv != 0) {
+                uint32_t y[G::NLL];
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) y[j] = tbl((int)wv, j);
+                mm_times<G>(x, y, lds, nm, n0inv);
+            }
+        }
+        {
+            uint32_t one[G::NLL];
+            set_plain_one<G>(one);
+            mm_times<G>(x, one, lds, nm, n0inv);
+            cond_sub<G::NLL, G::T>(x, nm);
+        }
+        if (live) store_elem<G>(x, u_out + ((size_t)which * n + ei) * P.u_words, P.u_words, lds);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decrypt stage B in the geometry of the primes themselves.
+struct DecBParams {
+    const MontCtx* pr[2];        // moduli p, q
+    const uint32_t* sinv2[2];    // s^-1 mod 2^(29 NL)
+    const uint32_t* nsinv2[2];   // 2^(29 NL) - s^-1   (so that (u-1) s^-1 = u s^-1 + nsinv2 mod 2^(29 NL))
+    const uint32_t* hR[2];       // hp R mod p, hq R mod q
+    const uint32_t* pinvqR;      // (p^-1 mod q) R mod q
+    int u_words, pt_words;
+};
+
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_dec_b(DecBParams P, const uint32_t* __restrict__ u_in /*[2][n][u_words]*/, uint32_t* __restrict__ m_out, int n) {
+    static_assert(!G::NMLDS, "stage B keeps the (small) prime moduli in registers");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];       // 2 operand buffers
+    uint32_t* ldsA = lds;
+    uint32_t* ldsB = lds + G::LDS_WORDS;
+    const int t = G::gl(), e = G::elem();
+    const int tiles = (n + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * G::EPB + e;
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        uint32_t ms[2][G::NLL];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            NmRegs<G::NLL> nm;
+            load_const_slice<G>(nm.v, P.pr[which]->n);
+            const uint32_t n0inv = P.pr[which]->n0inv;
+            // L = (u - 1) / s = low half of (u_low * sinv2 + nsinv2)
+            uint32_t ulo[G::NLL], c[G::NLL], init[G::NLL], hi[G::NLL];
+            load_elem_off<G>(ulo, u_in + ((size_t)which * n + es) * P.u_words, P.u_words, 0);
+            stage_b<G>(ulo, ldsA);
+            load_const_slice<G>(c, P.sinv2[which]);
+            load_const_slice<G>(init, P.nsinv2[which]);
+            mul_plain<G::NLL, G::U, G::T>(hi, init, c, ldsA + e, G::EPB, ldsB + e, G::EPB);
+            wave_lds_fence();
+            // ms = L * h mod s  with L read back from LDS as the multiplier
+            load_const_slice<G>(c, P.hR[which]);
+            mont_mul<G::NLL, G::U, G::T>(ms[which], c, ldsB + e, G::EPB, nm, n0inv);
+            cond_sub<G::NLL, G::T>(ms[which], nm);
+            wave_lds_fence();
+        }
+        // t = (mq - mp + q) * pinvq mod q ;  m = mp + p * t
+        NmRegs<G::NLL> nq;
+        load_const_slice<G>(nq.v, P.pr[1]->n);
+        uint32_t d[G::NLL];
+        {
+            using RW = Rows<G::NLL, G::U, G::T>;
+            int64_t sd[G::NLL];
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) sd[j] = (int64_t)ms[1][j] - (int64_t)ms[0][j] + (int64_t)nq.v[j];
+            RW::finish_signed(sd, d);
+        }
+        uint32_t c[G::NLL];
+        load_const_slice<G>(c, P.pinvqR);
+        mm_times<G>(d, c, ldsA, nq, P.pr[1]->n0inv);
+        cond_sub<G::NLL, G::T>(d, nq);
+        stage_b<G>(d, ldsA);
+        uint32_t pl[G::NLL], hi[G::NLL];
+        load_const_slice<G>(pl, P.pr[0]->n);
+        mul_plain<G::NLL, G::U, G::T>(hi, ms[0], pl, ldsA + e, G::EPB, ldsB + e, G::EPB);
+        wave_lds_fence();
+        // assemble m = lo (LDS B, NL limbs) + hi (registers) * 2^(29 NL) into packed words
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) ldsA[(G::NLL * t + j) * G::EPB + e] = hi[j];
+        wave_lds_fence();
+        if (live) {
+            uint32_t* row = m_out + (size_t)ei * P.pt_words;
+            auto limb = [&](int J) -> uint64_t {
+                if (J < G::NL) return ldsB[J * G::EPB + e];
+                if (J < 2 * G::NL) return ldsA[(J - G::NL) * G::EPB + e];
+                return 0;
+            };
+            for (int k = t; k < P.pt_words; k += G::T) {
+                const int j0 = (32 * k) / RB;
+                const int s0 = 32 * k - RB * j0;
+                uint64_t v = limb(j0) >> s0;
+                v |= limb(j0 + 1) << (RB - s0);
+                v |= limb(j0 + 2) << (2 * RB - s0);
+                row[k] = (uint32_t)v;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ct_i <- ct_i^(2^delta_i) mod n^2 for delta_i > 0; other elements are left untouched.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_pow2(const MontCtx* __restrict__ ctx, uint32_t* __restrict__ ct, const int32_t* __restrict__ delta, int delta_bcast,
+       int n, int w32) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t n0inv = ctx->n0inv;
+    const int tiles = (n + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * G::EPB + G::elem();
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        int dl = live ? delta[delta_bcast ? 0 : es] : 0;
+        if (dl < 0) dl = 0;
+        int dmax = dl;
+        for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(dmax, off, 64); dmax = o > dmax ? o : dmax; }
+        if (dmax == 0) continue;                                     // wave-uniform
+        uint32_t x[G::NLL];
+        {
+            uint32_t r2[G::NLL];
+            load_elem<G>(x, ct + (size_t)es * w32, w32);
+            load_const_slice<G>(r2, ctx->r2);
+            mm_times<G>(x, r2, lds, nm, n0inv);
+        }
+#pragma unroll 1
+        for (int s = 0; s < dmax; ++s) {
+            uint32_t y[G::NLL];
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) y[j] = x[j];
+            mm_square<G>(y, lds, nm, n0inv);
+            const bool need = s < dl;
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) x[j] = need ? y[j] : x[j];
+        }
+        {
+            uint32_t one[G::NLL];
+            set_plain_one<G>(one);
+            mm_times<G>(x, one, lds, nm, n0inv);
+            cond_sub<G::NLL, G::T>(x, nm);
+        }
+        if (live && dl > 0) store_elem<G>(x, ct + (size_t)ei * w32, w32, lds);
+    }
+}
+
+}  // namespace pai

@@ -110,10 +110,11 @@ struct Rows {
     }
 
     // U Montgomery rows, then the window moves down by U columns.
+    // low[u] receives the 29-bit limb retired by row u (meaningful in group lane 0: it is the next
+    // output limb of a plain product; it is zero when QN).
     template <bool AB, bool QN, class NM>
     PAI_DEV static void block(uint64_t (&acc)[NW], const uint32_t (&a)[NLL], const uint32_t (&bv)[U],
-                              const NM& nm, uint32_t n0inv) {
-        uint32_t low[U];
+                              const NM& nm, uint32_t n0inv, uint32_t (&low)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (AB) {
@@ -160,6 +161,33 @@ struct Rows {
                     cc = t >> RB;
                 }
                 cin = (uint64_t)from_prev<T>((uint32_t)cc);   // 0 or 1 now
+            }
+        }
+    }
+
+    // Same for signed per-limb values (|s[j]| < 2^62) whose total is known to be non-negative and
+    // to fit in 29*NL bits: used for limb-wise differences such as mq - mp + q.
+    PAI_DEV static void finish_signed(const int64_t (&s)[NLL], uint32_t (&r)[NLL]) {
+        int64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) {
+            int64_t t = s[j] + c;
+            r[j] = (uint32_t)t & RMASK;
+            c = t >> RB;                       // arithmetic shift: floor division
+        }
+        if constexpr (T > 1) {
+            uint32_t cin_lo = from_prev<T>((uint32_t)c), cin_hi = from_prev<T>((uint32_t)((uint64_t)c >> 32));
+            int64_t cin = (int64_t)(((uint64_t)cin_hi << 32) | cin_lo);
+            while (__any(cin != 0)) {
+                int64_t cc = cin;
+#pragma unroll
+                for (int j = 0; j < NLL; ++j) {
+                    int64_t t = (int64_t)r[j] + cc;
+                    r[j] = (uint32_t)t & RMASK;
+                    cc = t >> RB;
+                }
+                uint32_t lo2 = from_prev<T>((uint32_t)cc), hi2 = from_prev<T>((uint32_t)((uint64_t)cc >> 32));
+                cin = (int64_t)(((uint64_t)hi2 << 32) | lo2);
             }
         }
     }
@@ -216,10 +244,43 @@ PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32
         uint32_t bv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) bv[u] = b_ptr[(blk * U + u) * bstride];
-        RW::template block<true, true>(acc, a, bv, nm, n0inv);
+        uint32_t low[U];
+        RW::template block<true, true>(acc, a, bv, nm, n0inv, low);
         if (++since == NORM_BLOCKS) { RW::normalize(acc); since = 0; }
     }
     RW::finish(acc, r);
+}
+
+// Plain product with an additive constant: a*b + init, where `init` (this lane's slice, < 2^(29*NL))
+// seeds the accumulator.  The low NL limbs are written by the group's lane 0 to lo_ptr[i*lstride]
+// (LDS), the high NL limbs are returned distributed over the group in `hi`.
+template <int NLL, int U, int T>
+PAI_DEV void mul_plain(uint32_t (&hi)[NLL], const uint32_t (&init)[NLL], const uint32_t (&a)[NLL],
+                       const uint32_t* b_ptr, int bstride, uint32_t* lo_ptr, int lstride) {
+    using RW = Rows<NLL, U, T>;
+    uint64_t acc[RW::NW];
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) acc[j] = init[j];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[NLL + u] = 0;
+    constexpr int NB = RW::NL / U;
+    constexpr int NORM_BLOCKS = NORM_ROWS / U;
+    int since = 0;
+    const bool lane0 = (group_lane<T>() == 0);
+    NmRegs<1> none{};
+#pragma unroll 1
+    for (int blk = 0; blk < NB; ++blk) {
+        uint32_t bv[U], low[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) bv[u] = b_ptr[(blk * U + u) * bstride];
+        RW::template block<true, false>(acc, a, bv, none, 0u, low);
+        if (lane0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) lo_ptr[(blk * U + u) * lstride] = low[u];
+        }
+        if (++since == NORM_BLOCKS) { RW::normalize(acc); since = 0; }
+    }
+    RW::finish(acc, hi);
 }
 
 // Montgomery reduction of a 2*NL-limb value t (< M*R): r = t * R^-1 mod M (lazy, < 2M).
@@ -249,7 +310,8 @@ PAI_DEV void mont_redc(uint32_t (&r)[NLL], const uint32_t (&lo)[NLL], const uint
             uint32_t h = hi_ptr[(blk * U + u) * hstride];
             acc[NLL + u] = top ? (uint64_t)h : 0ull;
         }
-        RW::template block<false, true>(acc, lo, bv, nm, n0inv);
+        uint32_t low[U];
+        RW::template block<false, true>(acc, lo, bv, nm, n0inv, low);
         if (++since == NORM_BLOCKS) { RW::normalize(acc); since = 0; }
     }
     RW::finish(acc, r);

@@ -1,0 +1,627 @@
+// C ABI of libpaillier_hip.so (see include/paillier_hip.h): key set-up on the host, dispatch of the
+// gfx950 kernels.  There is deliberately no CPU implementation of any hot operation in this file.
+#include "../../include/paillier_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "geo_ops.hpp"
+#include "hostbn.hpp"
+
+using namespace pai;
+using hbn::Limbs;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct PaiError : std::runtime_error {
+    int code;
+    PaiError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_CHECK(x)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess)                                                                         \
+            throw PaiError(PAI_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return PAI_OK;
+    } catch (const PaiError& e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return PAI_E_INTERNAL;
+    } catch (...) {
+        g_err = "unknown error";
+        return PAI_E_INTERNAL;
+    }
+}
+
+void require(bool ok, const char* msg) {
+    if (!ok) throw PaiError(PAI_E_INVALID, msg);
+}
+
+int words_for_bits(int bits) { return (bits + 31) / 32; }
+
+struct DeviceInfo {
+    int ncu = 0;
+};
+
+DeviceInfo use_device(int device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+        throw PaiError(PAI_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= cnt) throw PaiError(PAI_E_INVALID, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) throw PaiError(PAI_E_NODEVICE, "hipSetDevice failed");
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) throw PaiError(PAI_E_NODEVICE, "hipGetDeviceProperties failed");
+    DeviceInfo d;
+    d.ncu = p.multiProcessorCount;
+    return d;
+}
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void ensure(size_t need) {
+        if (need <= bytes) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr;
+        bytes = 0;
+        HIP_CHECK(hipMalloc(&p, need));
+        bytes = need;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// NLMAX-padded radix-29 constant on the device
+uint32_t* upload_r29(const Limbs& v, int nl) {
+    std::vector<uint32_t> h(NLMAX, 0);
+    auto r = hbn::to_r29(v, nl);
+    std::memcpy(h.data(), r.data(), (size_t)nl * 4);
+    uint32_t* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, NLMAX * 4));
+    HIP_CHECK(hipMemcpy(d, h.data(), NLMAX * 4, hipMemcpyHostToDevice));
+    return d;
+}
+uint32_t* upload_words(const Limbs& v, int words) {
+    std::vector<uint32_t> h(words, 0);
+    for (size_t i = 0; i < v.size() && i < (size_t)words; ++i) h[i] = v[i];
+    uint32_t* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, (size_t)words * 4));
+    HIP_CHECK(hipMemcpy(d, h.data(), (size_t)words * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+// One modulus prepared for a geometry: host values + device MontCtx
+struct ModSetup {
+    Limbs M, R, R2, R3;
+    const GeoOps* geo = nullptr;
+    MontCtx* d_ctx = nullptr;
+    int bits = 0, w32 = 0;
+    void init(const Limbs& mod_) {
+        M = mod_;
+        require(hbn::is_odd(M), "modulus must be odd");
+        bits = hbn::bitlen(M);
+        w32 = words_for_bits(bits);
+        geo = geo_for_bits(bits);
+        if (!geo) throw PaiError(PAI_E_UNSUPPORTED, "modulus wider than 8192 bits is not supported");
+        const int nl = geo->nl;
+        R = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * nl), M);
+        R2 = hbn::mulmod(R, R, M);
+        R3 = hbn::mulmod(R2, R, M);
+        MontCtx h;
+        std::memset(&h, 0, sizeof(h));
+        auto put = [&](uint32_t* dst, const Limbs& v) {
+            auto r = hbn::to_r29(v, nl);
+            std::memcpy(dst, r.data(), (size_t)nl * 4);
+        };
+        put(h.n, M);
+        put(h.r2, R2);
+        put(h.one, R);
+        h.n0inv = hbn::neg_inv32(M[0]) & ((1u << hbn::RB) - 1u);
+        h.nl = (uint32_t)nl;
+        h.bits = (uint32_t)bits;
+        HIP_CHECK(hipMalloc((void**)&d_ctx, sizeof(MontCtx)));
+        HIP_CHECK(hipMemcpy(d_ctx, &h, sizeof(MontCtx), hipMemcpyHostToDevice));
+    }
+    void release() {
+        if (d_ctx) (void)hipFree(d_ctx);
+        d_ctx = nullptr;
+    }
+};
+
+int grid_for(const GeoOps* g, size_t N, int ncu, int blocks_per_cu = 2) {
+    size_t tiles = (N + g->epb - 1) / g->epb;
+    size_t cap = (size_t)ncu * blocks_per_cu;
+    return (int)std::max<size_t>(1, std::min(tiles, cap));
+}
+
+}  // namespace
+
+namespace pai {
+const GeoOps* geo_for_bits(int bits) {
+    const GeoOps* all[] = {geo_ops_36x1(), geo_ops_36x2(), geo_ops_28x4(), geo_ops_36x4(), geo_ops_28x8(), geo_ops_36x8()};
+    for (const GeoOps* g : all)
+        if (hbn::RB * g->nl >= bits + 2) return g;
+    return nullptr;
+}
+}  // namespace pai
+
+// ------------------------------------------------------------------------------------------------
+struct pai_modulus {
+    int device = 0;
+    DeviceInfo dev;
+    ModSetup ms;
+    DevBuf table, expo;
+    std::mutex mu;
+};
+
+struct pai_pubkey {
+    int device = 0;
+    DeviceInfo dev;
+    int key_bits = 0, n_words = 0, ct_words = 0, r_words = 0, randbits = 0;
+    bool djn = false;
+    Limbs n, nsq, hs;
+    ModSetup msq;                 // n^2
+    uint32_t* d_nR = nullptr;     // n * R mod n^2 (radix 29)
+    uint32_t* d_fb = nullptr;     // fixed-base table [J][256][NL]
+    uint32_t* d_nexp = nullptr;   // n as packed words (exponent of the standard obfuscator)
+    int fb_windows = 0;
+    mutable DevBuf table, tmp;    // standard-scheme scratch
+    mutable std::mutex mu;
+    EncParams enc_params() const {
+        EncParams P;
+        P.nsq = msq.d_ctx;
+        P.nR = d_nR;
+        P.fb_table = d_fb;
+        P.fb_windows = fb_windows;
+        P.pt_words = n_words;
+        P.ct_words = ct_words;
+        P.r_words = r_words;
+        return P;
+    }
+};
+
+struct pai_privkey {
+    const pai_pubkey* pk = nullptr;
+    Limbs p, q;
+    ModSetup sq[2];               // p^2, q^2
+    ModSetup pr[2];               // p, q
+    uint32_t* d_r3[2] = {nullptr, nullptr};
+    uint32_t* d_expo[2] = {nullptr, nullptr};
+    int ewords[2] = {0, 0}, ebits[2] = {0, 0};
+    uint32_t* d_sinv2[2] = {nullptr, nullptr};
+    uint32_t* d_nsinv2[2] = {nullptr, nullptr};
+    uint32_t* d_hR[2] = {nullptr, nullptr};
+    uint32_t* d_pinvqR = nullptr;
+    int u_words = 0;
+    DevBuf table, ubuf;
+    std::mutex mu;
+};
+
+extern "C" {
+
+int pai_version(void) { return 100; }
+
+const char* pai_last_error(void) { return g_err.c_str(); }
+
+int pai_device_count(int* count) {
+    return guarded([&] {
+        require(count != nullptr, "count is NULL");
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+        *count = c;
+    });
+}
+
+int pai_malloc(int device, size_t bytes, void** d_ptr) {
+    return guarded([&] {
+        require(d_ptr != nullptr, "d_ptr is NULL");
+        use_device(device);
+        HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 4));
+    });
+}
+int pai_free(int device, void* d_ptr) {
+    return guarded([&] {
+        use_device(device);
+        if (d_ptr) HIP_CHECK(hipFree(d_ptr));
+    });
+}
+int pai_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    return guarded([&] {
+        use_device(device);
+        HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    });
+}
+int pai_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes, void* stream) {
+    return guarded([&] {
+        use_device(device);
+        HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    });
+}
+int pai_stream_sync(int device, void* stream) {
+    return guarded([&] {
+        use_device(device);
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    });
+}
+
+// ---- generic modulus ------------------------------------------------------------------------------
+int pai_modulus_create(const uint32_t* h_m, int m_words, int device, pai_modulus** out) {
+    return guarded([&] {
+        require(h_m && out && m_words > 0, "bad arguments");
+        std::unique_ptr<pai_modulus> m(new pai_modulus());
+        m->device = device;
+        m->dev = use_device(device);
+        m->ms.init(hbn::from_u32(h_m, (size_t)m_words));
+        *out = m.release();
+    });
+}
+void pai_modulus_destroy(pai_modulus* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    m->ms.release();
+    m->table.release();
+    m->expo.release();
+    delete m;
+}
+int pai_modmul(pai_modulus* m, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N, uint32_t* d_out,
+               void* stream) {
+    return guarded([&] {
+        require(m && d_a && d_b && d_out, "NULL argument");
+        if (N == 0) return;
+        use_device(m->device);
+        const GeoOps* g = m->ms.geo;
+        g->modmul((hipStream_t)stream, grid_for(g, N, m->dev.ncu), m->ms.d_ctx, d_a, d_b, d_out, (int)N, m->ms.w32, b_bcast);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e, int e_words, size_t N,
+                     uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(m && d_base && h_e && d_out && e_words > 0, "bad arguments");
+        if (N == 0) return;
+        std::lock_guard<std::mutex> lk(m->mu);
+        use_device(m->device);
+        const GeoOps* g = m->ms.geo;
+        Limbs e = hbn::from_u32(h_e, (size_t)e_words);
+        const int ebits = hbn::bitlen(e);
+        hipStream_t s = (hipStream_t)stream;
+        m->expo.ensure((size_t)e_words * 4);
+        HIP_CHECK(hipMemcpyAsync(m->expo.p, h_e, (size_t)e_words * 4, hipMemcpyHostToDevice, s));
+        const int grid = grid_for(g, N, m->dev.ncu);
+        m->table.ensure(g->table_words((size_t)grid) * 4);
+        g->modexp_fixed(s, grid, m->ms.d_ctx, d_base, m->ms.w32, m->expo.as<uint32_t>(), e_words, ebits > 0 ? ebits : 1,
+                        d_out, m->ms.w32, (int)N, m->table.as<uint32_t>(), 0);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(s));     // the staged exponent / table are reused by the next call
+    });
+}
+int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const uint32_t* d_e, int e_words,
+                   int ebits_max, int e_bcast, size_t N, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(m && d_base && d_e && d_out && e_words > 0 && ebits_max > 0 && ebits_max <= 32 * e_words, "bad arguments");
+        if (N == 0) return;
+        use_device(m->device);
+        const GeoOps* g = m->ms.geo;
+        g->modexp_var((hipStream_t)stream, grid_for(g, N, m->dev.ncu), m->ms.d_ctx, d_base, m->ms.w32, base_bcast ? 31 : 0,
+                      d_e, e_words, ebits_max, e_bcast, d_out, m->ms.w32, (int)N, 0, 0);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+// ---- public key -----------------------------------------------------------------------------------
+int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint32_t* h_hs, int hs_words,
+                      int randbits, int device, pai_pubkey** out) {
+    return guarded([&] {
+        require(h_n && out && n_words > 0 && key_bits > 0, "bad arguments");
+        std::unique_ptr<pai_pubkey> pk(new pai_pubkey());
+        pk->device = device;
+        pk->dev = use_device(device);
+        pk->n = hbn::from_u32(h_n, (size_t)n_words);
+        require(hbn::is_odd(pk->n) && hbn::bitlen(pk->n) > 16, "n must be an odd integer of more than 16 bits");
+        require(hbn::bitlen(pk->n) <= key_bits, "n is wider than key_bits");
+        pk->key_bits = key_bits;
+        pk->n_words = words_for_bits(key_bits);
+        pk->ct_words = 2 * pk->n_words;
+        pk->nsq = hbn::mul(pk->n, pk->n);
+        pk->msq.init(pk->nsq);
+        const int nl = pk->msq.geo->nl;
+        pk->d_nR = upload_r29(hbn::mulmod(pk->n, pk->msq.R, pk->nsq), nl);
+        pk->d_nexp = upload_words(pk->n, pk->n_words);
+        if (h_hs) {
+            require(hs_words > 0 && randbits > 0 && randbits % FB_WBITS == 0, "DJN key needs hs and randbits (multiple of 8)");
+            pk->djn = true;
+            pk->hs = hbn::from_u32(h_hs, (size_t)hs_words);
+            require(hbn::cmp(pk->hs, pk->nsq) < 0 && !hbn::is_zero(pk->hs), "hs must lie in (0, n^2)");
+            pk->randbits = randbits;
+            pk->r_words = words_for_bits(randbits);
+            const int J = randbits / FB_WBITS;
+            pk->fb_windows = J;
+            // window bases B_j = hs^(2^(8 j)) on the host, then T[j][d] = B_j^d on the device
+            hbn::Mont32 mt(pk->nsq);
+            std::vector<uint32_t> bases((size_t)J * pk->ct_words, 0);
+            Limbs b = mt.to_mont(pk->hs);
+            for (int j = 0; j < J; ++j) {
+                Limbs plain = mt.from_mont(b);
+                std::memcpy(&bases[(size_t)j * pk->ct_words], plain.data(), plain.size() * 4);
+                for (int s = 0; s < FB_WBITS; ++s) b = mt.mmul(b, b);
+            }
+            const size_t NE = (size_t)J * FB_ENTRIES;
+            std::vector<uint32_t> expo(NE);
+            for (size_t i = 0; i < NE; ++i) expo[i] = (uint32_t)(i & (FB_ENTRIES - 1));
+            uint32_t *d_bases = nullptr, *d_expo = nullptr;
+            HIP_CHECK(hipMalloc((void**)&d_bases, bases.size() * 4));
+            HIP_CHECK(hipMalloc((void**)&d_expo, NE * 4));
+            HIP_CHECK(hipMemcpy(d_bases, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(d_expo, expo.data(), NE * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMalloc((void**)&pk->d_fb, NE * (size_t)nl * 4));
+            const GeoOps* g = pk->msq.geo;
+            g->modexp_var(nullptr, grid_for(g, NE, pk->dev.ncu), pk->msq.d_ctx, d_bases, pk->ct_words, 8 /* base = i>>8 */,
+                          d_expo, 1, FB_WBITS, 0, pk->d_fb, 0, (int)NE, 1 /*keep_mont*/, 1 /*out_raw*/);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipFree(d_bases));
+            HIP_CHECK(hipFree(d_expo));
+        } else {
+            pk->djn = false;
+            pk->randbits = 0;
+            pk->r_words = pk->n_words;
+        }
+        *out = pk.release();
+    });
+}
+
+void pai_pubkey_destroy(pai_pubkey* pk) {
+    if (!pk) return;
+    (void)hipSetDevice(pk->device);
+    pk->msq.release();
+    if (pk->d_nR) (void)hipFree(pk->d_nR);
+    if (pk->d_fb) (void)hipFree(pk->d_fb);
+    if (pk->d_nexp) (void)hipFree(pk->d_nexp);
+    pk->table.release();
+    pk->tmp.release();
+    delete pk;
+}
+
+int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_words, int* r_words, int* randbits,
+                    int* is_djn, int* device) {
+    return guarded([&] {
+        require(pk != nullptr, "pk is NULL");
+        if (key_bits) *key_bits = pk->key_bits;
+        if (n_words) *n_words = pk->n_words;
+        if (ct_words) *ct_words = pk->ct_words;
+        if (r_words) *r_words = pk->r_words;
+        if (randbits) *randbits = pk->randbits;
+        if (is_djn) *is_djn = pk->djn ? 1 : 0;
+        if (device) *device = pk->device;
+    });
+}
+
+static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint32_t* d_r, const uint32_t* d_ct_in,
+                           uint32_t* d_ct_out, size_t N, void* stream, bool from_plain) {
+    use_device(pk->device);
+    const GeoOps* g = pk->msq.geo;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(g, N, pk->dev.ncu);
+    EncParams P = pk->enc_params();
+    if (d_r == nullptr) {
+        require(from_plain, "obfuscation needs randomness");
+        g->encrypt(s, grid, P, d_m, nullptr, nullptr, d_ct_out, (int)N, 0);
+    } else if (pk->djn) {
+        g->encrypt(s, grid, P, d_m, d_r, d_ct_in, d_ct_out, (int)N, from_plain ? 1 : 2);
+    } else {
+        // standard scheme: obf_i = r_i^n mod n^2 (uniform exponent), then one fused multiply
+        std::lock_guard<std::mutex> lk(pk->mu);
+        pk->tmp.ensure(N * (size_t)pk->ct_words * 4);
+        pk->table.ensure(g->table_words((size_t)grid) * 4);
+        g->modexp_fixed(s, grid, pk->msq.d_ctx, d_r, pk->n_words, pk->d_nexp, pk->n_words, hbn::bitlen(pk->n),
+                        pk->tmp.as<uint32_t>(), pk->ct_words, (int)N, pk->table.as<uint32_t>(), 0);
+        g->encrypt(s, grid, P, d_m, pk->tmp.as<uint32_t>(), d_ct_in, d_ct_out, (int)N, from_plain ? 3 : 4);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(s));     // scratch is shared between calls
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+int pai_raw_encrypt(const pai_pubkey* pk, const uint32_t* d_m, size_t N, uint32_t* d_ct, void* stream) {
+    return guarded([&] {
+        require(pk && d_m && d_ct, "NULL argument");
+        if (N == 0) return;
+        encrypt_common(pk, d_m, nullptr, nullptr, d_ct, N, stream, true);
+    });
+}
+int pai_encrypt(const pai_pubkey* pk, const uint32_t* d_m, const uint32_t* d_r, size_t N, uint32_t* d_ct,
+                void* stream) {
+    return guarded([&] {
+        require(pk && d_m && d_ct, "NULL argument");
+        if (N == 0) return;
+        encrypt_common(pk, d_m, d_r, nullptr, d_ct, N, stream, true);
+    });
+}
+int pai_obfuscate(const pai_pubkey* pk, uint32_t* d_ct, const uint32_t* d_r, size_t N, void* stream) {
+    return guarded([&] {
+        require(pk && d_ct && d_r, "NULL argument");
+        if (N == 0) return;
+        encrypt_common(pk, nullptr, d_r, d_ct, d_ct, N, stream, false);
+    });
+}
+
+int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N,
+               uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && d_a && d_b && d_out, "NULL argument");
+        if (N == 0) return;
+        use_device(pk->device);
+        const GeoOps* g = pk->msq.geo;
+        g->modmul((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, int e_words, int ebits_max,
+               int e_bcast, size_t N, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && d_ct && d_e && d_out, "NULL argument");
+        require(e_words > 0 && ebits_max > 0 && ebits_max <= 32 * e_words, "bad exponent shape");
+        if (N == 0) return;
+        use_device(pk->device);
+        const GeoOps* g = pk->msq.geo;
+        g->modexp_var((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, pk->ct_words, 0, d_e, e_words,
+                      ebits_max, e_bcast, d_out, pk->ct_words, (int)N, 0, 0);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N,
+                void* stream) {
+    return guarded([&] {
+        require(pk && d_ct && d_delta, "NULL argument");
+        if (N == 0) return;
+        use_device(pk->device);
+        const GeoOps* g = pk->msq.geo;
+        g->pow2((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+// ---- private key ----------------------------------------------------------------------------------
+int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, const uint32_t* h_q, int q_words,
+                       pai_privkey** out) {
+    return guarded([&] {
+        require(pk && h_p && h_q && out && p_words > 0 && q_words > 0, "bad arguments");
+        std::unique_ptr<pai_privkey> sk(new pai_privkey());
+        use_device(pk->device);
+        sk->pk = pk;
+        Limbs p = hbn::from_u32(h_p, (size_t)p_words), q = hbn::from_u32(h_q, (size_t)q_words);
+        if (hbn::cmp(p, q) > 0) std::swap(p, q);            // upstream keeps p < q
+        require(hbn::cmp(p, q) != 0, "p and q must differ");
+        require(hbn::cmp(hbn::mul(p, q), pk->n) == 0, "p*q does not match the public key");
+        require(hbn::is_odd(p) && hbn::is_odd(q), "p and q must be odd primes");
+        sk->p = p;
+        sk->q = q;
+        const Limbs one{1u};
+        const Limbs g = hbn::add(pk->n, one);
+        const Limbs prime[2] = {p, q};
+        // both primes share the geometry of the wider one
+        for (int w = 0; w < 2; ++w) {
+            const Limbs& s = prime[w];
+            Limbs s2 = hbn::mul(s, s);
+            sk->sq[w].init(s2);
+            sk->pr[w].init(s);
+        }
+        require(sk->sq[0].geo == sk->sq[1].geo && sk->pr[0].geo == sk->pr[1].geo,
+                "p and q must have (nearly) the same bit length");
+        sk->u_words = std::max(sk->sq[0].w32, sk->sq[1].w32);
+        for (int w = 0; w < 2; ++w) {
+            const Limbs& s = prime[w];
+            const Limbs& s2 = sk->sq[w].M;
+            sk->d_r3[w] = upload_r29(sk->sq[w].R3, sk->sq[w].geo->nl);
+            Limbs e = hbn::sub(s, one);
+            sk->ebits[w] = hbn::bitlen(e);
+            sk->ewords[w] = words_for_bits(sk->ebits[w]);
+            sk->d_expo[w] = upload_words(e, sk->ewords[w]);
+            // h_s = (L_s(g^(s-1) mod s^2))^-1 mod s
+            hbn::Mont32 m2(s2);
+            Limbs gs = m2.powmod(hbn::mod(g, s2), e);
+            Limbs rem;
+            Limbs L = hbn::divq(hbn::sub(gs, one), s, &rem);
+            require(hbn::is_zero(rem), "L function not exact: p/q are not the factors of n");
+            Limbs h = hbn::inv_mod_prime(hbn::mod(L, s), s);
+            require(hbn::cmp(hbn::mulmod(h, L, s), one) == 0, "p or q is not prime (inverse check failed)");
+            const int nl = sk->pr[w].geo->nl;
+            sk->d_hR[w] = upload_r29(hbn::mulmod(h, sk->pr[w].R, s), nl);
+            const int k = hbn::RB * nl;
+            Limbs sinv2 = hbn::inv_mod_pow2(s, k);
+            require(hbn::cmp(hbn::low_bits(hbn::mul(sinv2, s), k), one) == 0, "2-adic inverse check failed");
+            sk->d_sinv2[w] = upload_r29(sinv2, nl);
+            sk->d_nsinv2[w] = upload_r29(hbn::sub(hbn::shl(one, k), sinv2), nl);
+        }
+        Limbs pinvq = hbn::inv_mod_prime(hbn::mod(p, q), q);
+        require(hbn::cmp(hbn::mulmod(pinvq, p, q), one) == 0, "q is not prime (inverse check failed)");
+        sk->d_pinvqR = upload_r29(hbn::mulmod(pinvq, sk->pr[1].R, q), sk->pr[1].geo->nl);
+        *out = sk.release();
+    });
+}
+
+void pai_privkey_destroy(pai_privkey* sk) {
+    if (!sk) return;
+    (void)hipSetDevice(sk->pk ? sk->pk->device : 0);
+    for (int w = 0; w < 2; ++w) {
+        sk->sq[w].release();
+        sk->pr[w].release();
+        if (sk->d_r3[w]) (void)hipFree(sk->d_r3[w]);
+        if (sk->d_expo[w]) (void)hipFree(sk->d_expo[w]);
+        if (sk->d_sinv2[w]) (void)hipFree(sk->d_sinv2[w]);
+        if (sk->d_nsinv2[w]) (void)hipFree(sk->d_nsinv2[w]);
+        if (sk->d_hR[w]) (void)hipFree(sk->d_hR[w]);
+    }
+    if (sk->d_pinvqR) (void)hipFree(sk->d_pinvqR);
+    sk->table.release();
+    sk->ubuf.release();
+    delete sk;
+}
+
+int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream) {
+    return guarded([&] {
+        require(sk && d_ct && d_m, "NULL argument");
+        if (N == 0) return;
+        std::lock_guard<std::mutex> lk(sk->mu);
+        const pai_pubkey* pk = sk->pk;
+        DeviceInfo dev = use_device(pk->device);
+        hipStream_t s = (hipStream_t)stream;
+        const GeoOps* ga = sk->sq[0].geo;
+        const GeoOps* gb = sk->pr[0].geo;
+        const int gridx = grid_for(ga, N, dev.ncu, 1);          // x2 primes => 2 workgroups per CU
+        sk->table.ensure(ga->table_words((size_t)gridx * 2) * 4);
+        sk->ubuf.ensure(2 * N * (size_t)sk->u_words * 4);
+        DecAParams A;
+        for (int w = 0; w < 2; ++w) {
+            A.sq[w] = sk->sq[w].d_ctx;
+            A.r3[w] = sk->d_r3[w];
+            A.expo[w] = sk->d_expo[w];
+            A.ewords[w] = sk->ewords[w];
+            A.ebits[w] = sk->ebits[w];
+        }
+        A.ct_words = pk->ct_words;
+        A.u_words = sk->u_words;
+        ga->dec_a(s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>());
+        HIP_CHECK(hipGetLastError());
+        DecBParams B;
+        for (int w = 0; w < 2; ++w) {
+            B.pr[w] = sk->pr[w].d_ctx;
+            B.sinv2[w] = sk->d_sinv2[w];
+            B.nsinv2[w] = sk->d_nsinv2[w];
+            B.hR[w] = sk->d_hR[w];
+        }
+        B.pinvqR = sk->d_pinvqR;
+        B.u_words = sk->u_words;
+        B.pt_words = pk->n_words;
+        gb->dec_b(s, grid_for(gb, N, dev.ncu), B, sk->ubuf.as<uint32_t>(), d_m, (int)N);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(s));     // table / u scratch are reused by the next call
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""GPU parity of the Paillier hot path through the C ABI against the Python-int oracle
+(oracle/paillier_oracle.py).  Bit-exact ciphertexts with explicit randomness; bit-exact plaintexts."""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import paillier_oracle as orc
+from pailliercryptolib_python_amd import _native
+from tests._util import DevArray, host_ptr, ints_to_limbs, limbs_to_ints, rand_below
+
+pytestmark = pytest.mark.gpu
+
+
+class NativeKey:
+    def __init__(self, key: orc.OracleKey):
+        self.lib = _native.load()
+        self.key = key
+        self.nw = (key.bits + 31) // 32
+        self.cw = 2 * self.nw
+        pk = C.c_void_p()
+        n_l = ints_to_limbs([key.n], self.nw)
+        if key.hs is not None:
+            hs_l = ints_to_limbs([key.hs], self.cw)
+            _native.check(self.lib.pai_pubkey_create(host_ptr(n_l), self.nw, key.bits, host_ptr(hs_l), self.cw,
+                                                     key.randbits, 0, C.byref(pk)))
+            self.rw = (key.randbits + 31) // 32
+        else:
+            _native.check(self.lib.pai_pubkey_create(host_ptr(n_l), self.nw, key.bits, None, 0, 0, 0, C.byref(pk)))
+            self.rw = self.nw
+        self.pk = pk
+        sk = C.c_void_p()
+        pw = (key.q.bit_length() + 31) // 32
+        # deliberately pass the primes in the "wrong" order (bench passes P > Q)
+        _native.check(self.lib.pai_privkey_create(pk, host_ptr(ints_to_limbs([key.q], pw)), pw,
+                                                  host_ptr(ints_to_limbs([key.p], pw)), pw, C.byref(sk)))
+        self.sk = sk
+
+    def __del__(self):
+        try:
+            self.lib.pai_privkey_destroy(self.sk)
+            self.lib.pai_pubkey_destroy(self.pk)
+        except Exception:
+            pass
+
+
+def bench_key(djn=True):
+    return orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567 if djn else None, bits=2048)
+
+
+def seeded_key(bits, djn=True):
+    fx = json.loads((Path(__file__).parent / "golden" / "fixture_keys.json").read_text())[str(bits)]
+    return orc.make_key(int(fx["p"], 16), int(fx["q"], 16), djn_x=(1 << 70) + 12345 if djn else None, bits=bits)
+
+
+@pytest.fixture(scope="module")
+def k2048():
+    return NativeKey(bench_key())
+
+
+def plaintexts(key, N, seed):
+    rng = np.random.default_rng(seed)
+    m = rand_below(rng, key.n, N)
+    m[0], m[1], m[2] = 0, 1, key.n - 1
+    return m
+
+
+def test_raw_encrypt_and_decrypt_2048(k2048):
+    key, N = k2048.key, 300
+    m = plaintexts(key, N, 1)
+    dm = DevArray(ints_to_limbs(m, k2048.nw))
+    ct = DevArray(shape=(N, k2048.cw))
+    _native.check(k2048.lib.pai_raw_encrypt(k2048.pk, dm.ptr, N, ct.ptr, None))
+    got = limbs_to_ints(ct.get())
+    assert got == [orc.raw_encrypt(x, key.n) for x in m]
+    out = DevArray(shape=(N, k2048.nw))
+    _native.check(k2048.lib.pai_decrypt(k2048.sk, ct.ptr, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == m
+
+
+def test_djn_encrypt_bits_and_roundtrip_2048(k2048):
+    key, N = k2048.key, 257
+    m = plaintexts(key, N, 2)
+    r_l = orc.synth_r_limbs(4002, N, key.randbits)
+    r_l[0] = 0                      # r = 0 -> obfuscator 1
+    r_l[1] = 0xFFFFFFFF             # r = 2^randbits - 1
+    r = limbs_to_ints(r_l)
+    dm, dr = DevArray(ints_to_limbs(m, k2048.nw)), DevArray(r_l)
+    ct = DevArray(shape=(N, k2048.cw))
+    _native.check(k2048.lib.pai_encrypt(k2048.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+    got = limbs_to_ints(ct.get())
+    want = [orc.encrypt(key, x, rr) for x, rr in zip(m, r)]
+    assert got == want
+    out = DevArray(shape=(N, k2048.nw))
+    _native.check(k2048.lib.pai_decrypt(k2048.sk, ct.ptr, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == m
+    # decrypt agrees with the non-CRT definition too
+    assert orc.decrypt_lambda(key, want[5]) == m[5]
+    # apply_obfuscator on existing ciphertexts
+    r2_l = orc.synth_r_limbs(4003, N, key.randbits)
+    dr2 = DevArray(r2_l)
+    _native.check(k2048.lib.pai_obfuscate(k2048.pk, ct.ptr, dr2.ptr, N, None))
+    assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, limbs_to_ints(r2_l))]
+
+
+def test_ct_add_mul_pow2_2048(k2048):
+    key, N = k2048.key, 200
+    rng = np.random.default_rng(7)
+    a = rand_below(rng, key.nsq, N)
+    b = rand_below(rng, key.nsq, N)
+    da, db = DevArray(ints_to_limbs(a, k2048.cw)), DevArray(ints_to_limbs(b, k2048.cw))
+    out = DevArray(shape=(N, k2048.cw))
+    _native.check(k2048.lib.pai_ct_add(k2048.pk, da.ptr, db.ptr, 0, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == [orc.ct_add(x, y, key.nsq) for x, y in zip(a, b)]
+    _native.check(k2048.lib.pai_ct_add(k2048.pk, da.ptr, db.ptr, 1, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == [orc.ct_add(x, b[0], key.nsq) for x in a]
+    es = [int(x) for x in rng.integers(0, 1 << 53, size=N)]
+    es[0], es[1] = 0, 1
+    de = DevArray(ints_to_limbs(es, 2))
+    _native.check(k2048.lib.pai_ct_mul(k2048.pk, da.ptr, de.ptr, 2, 53, 0, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == [orc.ct_mul(x, e, key.nsq) for x, e in zip(a, es)]
+    delta = rng.integers(-5, 60, size=N).astype(np.int32)
+    delta[:4] = [0, 1, -3, 59]
+    dd = DevArray(delta)
+    _native.check(k2048.lib.pai_ct_pow2(k2048.pk, da.ptr, dd.ptr, 0, N, None))
+    assert limbs_to_ints(da.get()) == [orc.ct_mul(x, 2 ** int(d), key.nsq) if d > 0 else x for x, d in zip(a, delta)]
+
+
+@pytest.mark.parametrize("bits", [1024, 3072, 4096])
+def test_other_key_sizes_roundtrip_and_bits(bits):
+    nk = NativeKey(seeded_key(bits))
+    key, N = nk.key, 130 if bits < 4096 else 66
+    m = plaintexts(key, N, bits)
+    r_l = orc.synth_r_limbs(4000 + bits, N, key.randbits)
+    dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r_l)
+    ct = DevArray(shape=(N, nk.cw))
+    _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+    got = limbs_to_ints(ct.get())
+    r = limbs_to_ints(r_l)
+    check = range(N) if bits <= 3072 else range(0, N, 4)
+    for i in check:
+        assert got[i] == orc.encrypt(key, m[i], r[i]), i
+    out = DevArray(shape=(N, nk.nw))
+    _native.check(nk.lib.pai_decrypt(nk.sk, ct.ptr, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == m
+
+
+def test_standard_scheme_2048():
+    nk = NativeKey(bench_key(djn=False))
+    key, N = nk.key, 70
+    m = plaintexts(key, N, 9)
+    rng = np.random.default_rng(10)
+    r = [x + 1 for x in rand_below(rng, key.n - 1, N)]
+    dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(ints_to_limbs(r, nk.nw))
+    ct = DevArray(shape=(N, nk.cw))
+    _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+    assert limbs_to_ints(ct.get()) == [orc.encrypt(key, x, rr) for x, rr in zip(m, r)]
+    out = DevArray(shape=(N, nk.nw))
+    _native.check(nk.lib.pai_decrypt(nk.sk, ct.ptr, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == m
