@@ -44,6 +44,12 @@ int pai_version(void);                                   /* 100*major + minor */
 int pai_device_count(int* count);                        /* number of visible HIP devices */
 const char* pai_last_error(void);
 
+/* Per-kernel timing (HIP events on the caller's stream).  While enabled, pai_encrypt / pai_decrypt
+ * become synchronous and record the duration of each kernel they launch; pai_profile_last(i, ...)
+ * returns entry i of the calling thread's last call (PAI_E_INVALID past the end). */
+int pai_profile_enable(int on);
+int pai_profile_last(int index, char* name_out, size_t name_cap, float* ms_out);
+
 /* ---- device memory helpers (for callers that do not bring their own allocator) ---------------- */
 int pai_malloc(int device, size_t bytes, void** d_ptr);
 int pai_free(int device, void* d_ptr);

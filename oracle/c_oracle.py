@@ -1,0 +1,180 @@
+"""ctypes front end of the plain-C oracle ``oracle/paillier_ref.c`` (TEST INFRASTRUCTURE ONLY).
+
+Used by tests for batches too large for CPython ``pow`` and by ``bench.py`` as the ``cpu_baseline``
+("kind": "port": the reference's own CPU path — ipcl + IPP-Crypto — is not in /root/reference and
+cannot be built here).  Constants that need division are computed here with Python ints.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from . import paillier_oracle as orc
+
+HERE = Path(__file__).resolve().parent
+SRC = HERE / "paillier_ref.c"
+LIB = HERE / "_build" / "libpaillier_oracle.so"
+
+
+def build(force: bool = False) -> Path:
+    if LIB.exists() and not force and LIB.stat().st_mtime >= SRC.stat().st_mtime:
+        return LIB
+    LIB.parent.mkdir(parents=True, exist_ok=True)
+    cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", str(SRC), "-o", str(LIB), "-ldl"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("gcc failed:\n" + res.stderr)
+    return LIB
+
+
+_lib = None
+
+
+class _PrimeCtx(C.Structure):
+    _fields_ = [
+        ("s2", C.c_void_p), ("s2_r2", C.c_void_p), ("s2_0inv", C.c_uint64),
+        ("e", C.c_void_p), ("ebits", C.c_int),
+        ("s", C.c_void_p), ("s_r2", C.c_void_p), ("s_0inv", C.c_uint64),
+        ("sinv2", C.c_void_p), ("hR", C.c_void_p),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(str(build()))
+        _lib.orc_max_threads.restype = C.c_int
+    return _lib
+
+
+def gmp_available() -> bool:
+    lib().orc_gmp_available.restype = C.c_int
+    return bool(lib().orc_gmp_available())
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def _u64(v: int, L: int) -> np.ndarray:
+    return np.frombuffer(int(v).to_bytes(8 * L, "little"), dtype="<u8").copy()
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _mont_consts(M: int, L: int):
+    R = 1 << (64 * L)
+    return _u64(M, L), C.c_uint64((-pow(M, -1, 1 << 64)) % (1 << 64)), _u64(R * R % M, L)
+
+
+def _as_u64_rows(a32: np.ndarray, L64: int) -> np.ndarray:
+    a32 = np.ascontiguousarray(a32, dtype=np.uint32)
+    N, W = a32.shape
+    if W < 2 * L64:
+        a32 = np.concatenate([a32, np.zeros((N, 2 * L64 - W), dtype=np.uint32)], axis=1)
+    assert a32.shape[1] == 2 * L64
+    return np.ascontiguousarray(a32).view(np.uint64)
+
+
+def modexp(M: int, base32: np.ndarray, e: int, threads: int = 0) -> np.ndarray:
+    """out[i] = base[i]^e mod M on [N][W] u32 limb matrices."""
+    L = (M.bit_length() + 63) // 64
+    n, n0, r2 = _mont_consts(M, L)
+    b = _as_u64_rows(base32, L)
+    ebits = max(e.bit_length(), 1)
+    ev = _u64(e, (ebits + 63) // 64)
+    out = np.zeros_like(b)
+    rc = lib().orc_modexp_batch(b.shape[0], L, _p(n), n0, _p(r2), _p(b), _p(ev), 0, ebits, _p(out), threads)
+    assert rc == 0
+    return out.view(np.uint32)[:, : base32.shape[1]]
+
+
+def modmul(M: int, a32: np.ndarray, b32: np.ndarray, threads: int = 0) -> np.ndarray:
+    L = (M.bit_length() + 63) // 64
+    n, n0, r2 = _mont_consts(M, L)
+    a, b = _as_u64_rows(a32, L), _as_u64_rows(b32, L)
+    out = np.zeros_like(a)
+    rc = lib().orc_modmul_batch(a.shape[0], L, _p(n), n0, _p(r2), _p(a), _p(b), _p(out), threads)
+    assert rc == 0
+    return out.view(np.uint32)[:, : a32.shape[1]]
+
+
+class COracleKey:
+    """Pre-computed constants of one key for the C oracle."""
+
+    def __init__(self, key: orc.OracleKey):
+        self.key = key
+        self.Ln = (key.bits + 63) // 64
+        self.Lh = (max(key.p.bit_length(), key.q.bit_length()) + 63) // 64
+        assert 2 * self.Lh == self.Ln or 2 * self.Lh >= self.Ln
+        self.n = _u64(key.n, self.Ln)
+        self.nsq, self.nsq0, self.nsq_r2 = _mont_consts(key.nsq, 2 * self.Ln)
+        self.hs = _u64(key.hs, 2 * self.Ln) if key.hs is not None else None
+        k = orc.crt_constants(key)
+        self._keep = []
+        self.pc = self._prime(key.p, k["hp"])
+        self.qc = self._prime(key.q, k["hq"])
+        Rq = 1 << (64 * self.Lh)
+        self.pinvqR = _u64(k["pinv_q"] * Rq % key.q, self.Lh)
+
+    def _prime(self, s: int, h: int) -> _PrimeCtx:
+        Ln, Lh = self.Ln, self.Lh
+        s2n, s20, s2r2 = _mont_consts(s * s, Ln)
+        sn, s0, sr2 = _mont_consts(s, Lh)
+        e = s - 1
+        ev = _u64(e, (e.bit_length() + 63) // 64)
+        sinv2 = _u64(pow(s, -1, 1 << (64 * Lh)), Lh)
+        hR = _u64(h * (1 << (64 * Lh)) % s, Lh)
+        self._keep += [s2n, s2r2, sn, sr2, ev, sinv2, hR]
+        return _PrimeCtx(_p(s2n), _p(s2r2), s20, _p(ev), e.bit_length(), _p(sn), _p(sr2), s0, _p(sinv2), _p(hR))
+
+    def encrypt_djn(self, m32: np.ndarray, r32: np.ndarray, threads: int = 0) -> np.ndarray:
+        key = self.key
+        m = _as_u64_rows(m32, self.Ln)
+        Lr = (key.randbits + 63) // 64
+        r = _as_u64_rows(r32, Lr)
+        N = m.shape[0]
+        ct = np.zeros((N, 2 * self.Ln), dtype=np.uint64)
+        rc = lib().orc_encrypt_djn_batch(N, self.Ln, _p(self.n), _p(self.nsq), self.nsq0, _p(self.nsq_r2), _p(self.hs),
+                                         _p(m), _p(r), Lr, key.randbits, _p(ct), threads)
+        assert rc == 0
+        return ct.view(np.uint32)
+
+    def decrypt_crt(self, ct32: np.ndarray, threads: int = 0) -> np.ndarray:
+        ct = _as_u64_rows(ct32, 2 * self.Ln)
+        N = ct.shape[0]
+        m = np.zeros((N, self.Ln), dtype=np.uint64)
+        rc = lib().orc_decrypt_crt_batch(N, self.Ln, self.Lh, C.byref(self.pc), C.byref(self.qc), _p(self.pinvqR),
+                                         _p(ct), _p(m), threads)
+        assert rc == 0
+        return m.view(np.uint32)
+
+    # ---- the same two operations through libgmp (dlopen'ed by the C side) when it is installed ----
+    def gmp_encrypt_djn(self, m32: np.ndarray, r32: np.ndarray, threads: int = 0) -> np.ndarray:
+        key = self.key
+        m = _as_u64_rows(m32, self.Ln)
+        Lr = (key.randbits + 63) // 64
+        r = _as_u64_rows(r32, Lr)
+        N = m.shape[0]
+        ct = np.zeros((N, 2 * self.Ln), dtype=np.uint64)
+        rc = lib().orc_gmp_encrypt_djn_batch(N, self.Ln, _p(self.n), _p(self.nsq), _p(self.hs), _p(m), _p(r), Lr,
+                                             _p(ct), threads)
+        assert rc == 0, "libgmp not available"
+        return ct.view(np.uint32)
+
+    def gmp_decrypt_crt(self, ct32: np.ndarray, threads: int = 0) -> np.ndarray:
+        key = self.key
+        k = orc.crt_constants(key)
+        ct = _as_u64_rows(ct32, 2 * self.Ln)
+        N = ct.shape[0]
+        m = np.zeros((N, self.Ln), dtype=np.uint64)
+        args = [_u64(v, self.Lh) for v in (key.p, key.q, k["hp"], k["hq"], k["pinv_q"])]
+        rc = lib().orc_gmp_decrypt_crt_batch(N, self.Ln, self.Lh, *[_p(a) for a in args], _p(ct), _p(m), threads)
+        assert rc == 0, "libgmp not available"
+        return m.view(np.uint32)

@@ -34,6 +34,8 @@ PROTOTYPES = {
     "pai_version": (C.c_int, []),
     "pai_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "pai_last_error": (C.c_char_p, []),
+    "pai_profile_enable": (C.c_int, [C.c_int]),
+    "pai_profile_last": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_float)]),
     "pai_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(voidp)]),
     "pai_free": (C.c_int, [C.c_int, voidp]),
     "pai_memcpy_h2d": (C.c_int, [C.c_int, voidp, voidp, C.c_size_t, voidp]),

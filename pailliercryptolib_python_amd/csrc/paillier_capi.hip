@@ -149,6 +149,39 @@ struct ModSetup {
     }
 };
 
+// Optional per-kernel timing with HIP events on the caller's stream (pai_profile_enable): used by
+// bench.py to report the dominant kernel's duration next to the rocprofv3 numbers.
+bool g_profile = false;
+struct KernelTime { std::string name; float ms; };
+thread_local std::vector<KernelTime> g_last_times;
+struct ScopedKernelTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t s;
+    const char* name;
+    bool on;
+    ScopedKernelTimer(const char* n, hipStream_t st) : s(st), name(n), on(g_profile) {
+        if (!on) return;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, s));
+    }
+    void stop() {
+        if (!on || !e0) return;
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        g_last_times.push_back({name, ms});
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        e0 = e1 = nullptr;
+    }
+    ~ScopedKernelTimer() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
 int grid_for(const GeoOps* g, size_t N, int ncu, int blocks_per_cu = 2) {
     size_t tiles = (N + g->epb - 1) / g->epb;
     size_t cap = (size_t)ncu * blocks_per_cu;
@@ -231,6 +264,20 @@ int pai_device_count(int* count) {
         if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
         *count = c;
     });
+}
+
+int pai_profile_enable(int on) {
+    g_profile = on != 0;
+    return PAI_OK;
+}
+int pai_profile_last(int index, char* name_out, size_t name_cap, float* ms_out) {
+    if (index < 0 || (size_t)index >= g_last_times.size()) return PAI_E_INVALID;
+    if (name_out && name_cap) {
+        std::strncpy(name_out, g_last_times[index].name.c_str(), name_cap - 1);
+        name_out[name_cap - 1] = 0;
+    }
+    if (ms_out) *ms_out = g_last_times[index].ms;
+    return PAI_OK;
 }
 
 int pai_malloc(int device, size_t bytes, void** d_ptr) {
@@ -426,11 +473,16 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for(g, N, pk->dev.ncu);
     EncParams P = pk->enc_params();
+    g_last_times.clear();
     if (d_r == nullptr) {
         require(from_plain, "obfuscation needs randomness");
+        ScopedKernelTimer t("k_encrypt(raw)", s);
         g->encrypt(s, grid, P, d_m, nullptr, nullptr, d_ct_out, (int)N, 0);
+        t.stop();
     } else if (pk->djn) {
+        ScopedKernelTimer t("k_encrypt(djn)", s);
         g->encrypt(s, grid, P, d_m, d_r, d_ct_in, d_ct_out, (int)N, from_plain ? 1 : 2);
+        t.stop();
     } else {
         // standard scheme: obf_i = r_i^n mod n^2 (uniform exponent), then one fused multiply
         std::lock_guard<std::mutex> lk(pk->mu);
@@ -606,7 +658,12 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         }
         A.ct_words = pk->ct_words;
         A.u_words = sk->u_words;
-        ga->dec_a(s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>());
+        g_last_times.clear();
+        {
+            ScopedKernelTimer t("k_dec_a", s);
+            ga->dec_a(s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>());
+            t.stop();
+        }
         HIP_CHECK(hipGetLastError());
         DecBParams B;
         for (int w = 0; w < 2; ++w) {
@@ -618,7 +675,11 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         B.pinvqR = sk->d_pinvqR;
         B.u_words = sk->u_words;
         B.pt_words = pk->n_words;
-        gb->dec_b(s, grid_for(gb, N, dev.ncu), B, sk->ubuf.as<uint32_t>(), d_m, (int)N);
+        {
+            ScopedKernelTimer t("k_dec_b", s);
+            gb->dec_b(s, grid_for(gb, N, dev.ncu), B, sk->ubuf.as<uint32_t>(), d_m, (int)N);
+            t.stop();
+        }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(s));     // table / u scratch are reused by the next call
     });

@@ -1,0 +1,222 @@
+"""Device-side engine objects: thin, typed wrappers over the C ABI working on torch tensors.
+
+These take the place of the pybind11 classes ``ipclPublicKey`` / ``ipclPrivateKey`` /
+``ipclPlainText`` / ``ipclCipherText`` (``bindings/ipcl_bindings_classes.cpp:12-378``).  Where the
+reference moves ``std::vector<BigNumber>`` copies through Python lists on every call, a batch here is
+ONE device tensor of little-endian 32-bit limbs, shape ``[N, words]``, dtype ``torch.int32`` (bit
+pattern of uint32), and it stays in HBM between operations.  torch is used only for allocation,
+streams and (in ``sharding.py``) ``torch.distributed``; all arithmetic is in ``libpaillier_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native
+
+
+def _require_cuda(device: torch.device) -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "pailliercryptolib_python_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False "
+            "and there is no CPU fallback"
+        )
+    return device
+
+
+def int_to_words(v: int, words: int) -> np.ndarray:
+    return np.frombuffer(int(v).to_bytes(4 * words, "little"), dtype="<u4").copy()
+
+
+def ints_to_words(vals, words: int) -> np.ndarray:
+    """list of non-negative Python ints -> [N][words] uint32 (little-endian limbs)."""
+    n = len(vals)
+    buf = bytearray(4 * words * n)
+    step = 4 * words
+    for i, v in enumerate(vals):
+        buf[i * step:(i + 1) * step] = int(v).to_bytes(step, "little")
+    return np.frombuffer(bytes(buf), dtype="<u4").reshape(n, words).copy()
+
+
+def words_to_ints(arr: np.ndarray):
+    arr = np.ascontiguousarray(arr, dtype="<u4")
+    if arr.ndim == 1:
+        arr = arr[None, :]
+    raw = arr.tobytes()
+    step = 4 * arr.shape[1]
+    return [int.from_bytes(raw[i * step:(i + 1) * step], "little") for i in range(arr.shape[0])]
+
+
+def to_device_words(host: np.ndarray, device: torch.device) -> torch.Tensor:
+    """[N][W] uint32 numpy -> int32 torch tensor on `device` (same bits)."""
+    host = np.ascontiguousarray(host, dtype=np.uint32)
+    return torch.from_numpy(host.view(np.int32)).to(device, non_blocking=False)
+
+
+def to_host_words(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().numpy().view(np.uint32)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device: torch.device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class PublicKeyHandle:
+    """Owns a ``pai_pubkey`` on one device."""
+
+    def __init__(self, n: int, key_bits: int, hs: Optional[int], randbits: int, device="cuda:0"):
+        self.lib = _native.load()
+        self.device = _require_cuda(torch.device(device))
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n, self.key_bits, self.hs, self.randbits = int(n), int(key_bits), hs, int(randbits)
+        self.n_words = (key_bits + 31) // 32
+        self.ct_words = 2 * self.n_words
+        self.r_words = (randbits + 31) // 32 if hs is not None else self.n_words
+        h = C.c_void_p()
+        n_w = int_to_words(n, self.n_words)
+        if hs is not None:
+            hs_w = int_to_words(hs, self.ct_words)
+            rc = self.lib.pai_pubkey_create(n_w.ctypes.data_as(C.c_void_p), self.n_words, key_bits,
+                                            hs_w.ctypes.data_as(C.c_void_p), self.ct_words, randbits,
+                                            self.device.index, C.byref(h))
+        else:
+            rc = self.lib.pai_pubkey_create(n_w.ctypes.data_as(C.c_void_p), self.n_words, key_bits, None, 0, 0,
+                                            self.device.index, C.byref(h))
+        _native.check(rc)
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.pai_pubkey_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def empty_ct(self, n: int) -> torch.Tensor:
+        return torch.empty((n, self.ct_words), dtype=torch.int32, device=self.device)
+
+    def empty_pt(self, n: int) -> torch.Tensor:
+        return torch.empty((n, self.n_words), dtype=torch.int32, device=self.device)
+
+    def _chk(self, t: torch.Tensor, words: int, name: str):
+        if t.dtype != torch.int32 or t.dim() != 2 or t.shape[1] != words or not t.is_contiguous() or t.device != self.device:
+            raise ValueError(f"{name}: expected contiguous int32 [N,{words}] on {self.device}, got {t.dtype} {tuple(t.shape)} {t.device}")
+
+    # -- hot ops ----------------------------------------------------------------------------------
+    def raw_encrypt(self, m: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._chk(m, self.n_words, "m")
+        out = self.empty_ct(m.shape[0]) if out is None else out
+        _native.check(self.lib.pai_raw_encrypt(self.h, _ptr(m), m.shape[0], _ptr(out), _stream(self.device)))
+        return out
+
+    def encrypt(self, m: torch.Tensor, r: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._chk(m, self.n_words, "m")
+        self._chk(r, self.r_words, "r")
+        if r.shape[0] != m.shape[0]:
+            raise ValueError("m and r must have the same number of rows")
+        out = self.empty_ct(m.shape[0]) if out is None else out
+        _native.check(self.lib.pai_encrypt(self.h, _ptr(m), _ptr(r), m.shape[0], _ptr(out), _stream(self.device)))
+        return out
+
+    def obfuscate_(self, ct: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
+        self._chk(ct, self.ct_words, "ct")
+        self._chk(r, self.r_words, "r")
+        _native.check(self.lib.pai_obfuscate(self.h, _ptr(ct), _ptr(r), ct.shape[0], _stream(self.device)))
+        return ct
+
+    def ct_add(self, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._chk(a, self.ct_words, "a")
+        self._chk(b, self.ct_words, "b")
+        bcast = 1 if (b.shape[0] == 1 and a.shape[0] != 1) else 0
+        if not bcast and a.shape[0] != b.shape[0]:
+            raise RuntimeError("Size mismatch")      # classes.cpp:206 wording
+        out = self.empty_ct(a.shape[0]) if out is None else out
+        _native.check(self.lib.pai_ct_add(self.h, _ptr(a), _ptr(b), bcast, a.shape[0], _ptr(out), _stream(self.device)))
+        return out
+
+    def ct_mul(self, ct: torch.Tensor, e: torch.Tensor, ebits_max: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._chk(ct, self.ct_words, "ct")
+        if e.dtype != torch.int32 or e.dim() != 2 or not e.is_contiguous():
+            raise ValueError("e: expected contiguous int32 [N or 1, e_words]")
+        bcast = 1 if (e.shape[0] == 1 and ct.shape[0] != 1) else 0
+        if not bcast and e.shape[0] != ct.shape[0]:
+            raise RuntimeError("Size mismatch")
+        out = self.empty_ct(ct.shape[0]) if out is None else out
+        _native.check(self.lib.pai_ct_mul(self.h, _ptr(ct), _ptr(e), e.shape[1], int(ebits_max), bcast, ct.shape[0],
+                                          _ptr(out), _stream(self.device)))
+        return out
+
+    def ct_pow2_(self, ct: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
+        self._chk(ct, self.ct_words, "ct")
+        if delta.dtype != torch.int32 or delta.dim() != 1 or not delta.is_contiguous():
+            raise ValueError("delta: expected contiguous int32 [N] or [1]")
+        bcast = 1 if (delta.shape[0] == 1 and ct.shape[0] != 1) else 0
+        _native.check(self.lib.pai_ct_pow2(self.h, _ptr(ct), _ptr(delta), bcast, ct.shape[0], _stream(self.device)))
+        return ct
+
+    def random_r(self, n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Device-side randomness of the right shape for throughput runs (NOT cryptographic: torch's
+        Philox generator).  The Python API draws from the OS CSPRNG instead (paillier.py)."""
+        if self.hs is None:
+            raise NotImplementedError("random_r is only provided for DJN keys")
+        r = torch.randint(-(2**31), 2**31, (n, self.r_words), dtype=torch.int64, device=self.device,
+                          generator=generator).to(torch.int32)
+        top = self.randbits - 32 * (self.r_words - 1)
+        if top < 32:
+            r[:, -1] &= (1 << top) - 1
+        return r.contiguous()
+
+
+class PrivateKeyHandle:
+    """Owns a ``pai_privkey`` bound to a PublicKeyHandle."""
+
+    def __init__(self, pub: PublicKeyHandle, p: int, q: int):
+        self.lib = pub.lib
+        self.pub = pub
+        self.p, self.q = (p, q) if p < q else (q, p)
+        pw = (max(p.bit_length(), q.bit_length()) + 31) // 32
+        h = C.c_void_p()
+        pa, qa = int_to_words(p, pw), int_to_words(q, pw)
+        _native.check(self.lib.pai_privkey_create(pub.h, pa.ctypes.data_as(C.c_void_p), pw,
+                                                  qa.ctypes.data_as(C.c_void_p), pw, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.pai_privkey_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def decrypt(self, ct: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self.pub._chk(ct, self.pub.ct_words, "ct")
+        out = self.pub.empty_pt(ct.shape[0]) if out is None else out
+        _native.check(self.lib.pai_decrypt(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.pub.device)))
+        return out
+
+
+def profile_enable(on: bool) -> None:
+    _native.check(_native.load().pai_profile_enable(1 if on else 0))
+
+
+def profile_last() -> dict:
+    """{kernel name: ms} recorded by the last profiled call on this thread."""
+    lib = _native.load()
+    out, i = {}, 0
+    name = C.create_string_buffer(64)
+    ms = C.c_float(0)
+    while lib.pai_profile_last(i, name, 64, C.byref(ms)) == 0:
+        out[name.value.decode()] = float(ms.value)
+        i += 1
+    return out

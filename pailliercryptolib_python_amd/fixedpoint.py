@@ -1,0 +1,192 @@
+"""Fixed-point codec: float/int <-> (mantissa mod n, base-2 exponent).
+
+Host-side mirror of the part of ``src/ipcl_python/bindings/fixedpoint.py`` that the reference API
+actually calls: ``FixedPointNumber.encode`` (``:54-96``), ``.decode`` (``:98-115``), the constructor
+(``:35-47``) and the constants ``BASE``/``FLOAT_MANTISSA_BITS`` (``:29-31``).  The operator overloads
+and ``FixedPointEndec`` of that file are never used by ``ipcl_python.py`` and are out of scope
+(SURVEY.md §2 row 2).
+
+The reference encodes one Python object at a time (6.5 us per element measured); the array paths
+here (`encode_array`, `decode_array`) are vectorised with numpy and produce/consume the flat
+``[N][words]`` little-endian limb matrices of the C ABI.  They are bit-identical to the scalar
+definition (checked against golden vectors produced by the reference's own file:
+``tests/golden/fixedpoint_golden.json``).
+"""
+from __future__ import annotations
+
+import math
+import sys
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+class FixedPointNumber(object):
+    """Scalar codec object with the reference's interface (encoding, exponent, n, max_int)."""
+
+    BASE = 2
+    LOG2_BASE = math.log(BASE, 2)
+    FLOAT_MANTISSA_BITS = sys.float_info.mant_dig
+
+    def __init__(self, encoding, exponent, n, max_int=None):
+        self.n = n
+        self.max_int = n // 2 if max_int is None else max_int
+        self.encoding = encoding
+        self.exponent = exponent
+
+    @classmethod
+    def encode(cls, scalar, n, max_int=None):
+        """(scalar) -> FixedPointNumber.  Same rules, same exceptions as fixedpoint.py:54-96 for
+        precision=None / max_exponent=None (the only way ipcl_python.py calls it)."""
+        if max_int is None:
+            max_int = n // 2
+        if np.abs(scalar) < 1e-200:                       # :64-65
+            scalar = 0
+        if isinstance(scalar, (int, np.int16, np.int32, np.int64)):      # :72-74
+            exponent = 0
+        elif isinstance(scalar, (float, np.float16, np.float32, np.float64)):   # :75-79
+            scalar = float(scalar)     # numpy>=2 would overflow float16/32 * 2**k; numpy 1.23 (pinned upstream) promoted
+            exponent = cls.FLOAT_MANTISSA_BITS - math.frexp(scalar)[1]
+        else:
+            raise TypeError("Don't know the precision of type %s." % type(scalar))
+        int_fixpoint = int(round(scalar * pow(cls.BASE, exponent)))     # :89
+        if abs(int_fixpoint) > max_int:                   # :91-94
+            raise ValueError(
+                f"Integer needs to be within +/- {max_int},but got {int_fixpoint},"
+                f"basic info, scalar={scalar}, base={cls.BASE}, exponent={exponent}"
+            )
+        return cls(int_fixpoint % n, exponent, n, max_int)
+
+    def decode(self):
+        """fixedpoint.py:98-115: int when exponent <= 0, float otherwise."""
+        if self.encoding >= self.n:
+            raise ValueError("Attempted to decode corrupted number")
+        elif self.encoding <= self.max_int:
+            mantissa = self.encoding
+        elif self.encoding >= self.n - self.max_int:
+            mantissa = self.encoding - self.n
+        else:
+            raise OverflowError(
+                f"Overflow detected in decode number, encoding: {self.encoding}, {self.exponent} {self.n}"
+            )
+        return mantissa * pow(self.BASE, -self.exponent)
+
+
+# ---------------------------------------------------------------------------------------------------
+# array paths
+# ---------------------------------------------------------------------------------------------------
+_MANT = FixedPointNumber.FLOAT_MANTISSA_BITS
+
+
+def _words_of(v: int, words: int) -> np.ndarray:
+    return np.frombuffer(int(v).to_bytes(4 * words, "little"), dtype="<u4").copy()
+
+
+def encode_float64_array(x: np.ndarray, n: int, n_words: int) -> Tuple[np.ndarray, np.ndarray]:
+    """float64[N] -> (residues uint32[N][n_words], exponents int32[N]); requires n > 2^66."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if not np.all(np.isfinite(x)):
+        bad = x[~np.isfinite(x)][0]
+        if np.isnan(bad):
+            raise ValueError("cannot convert float NaN to integer")
+        raise OverflowError("cannot convert float infinity to integer")
+    if n.bit_length() <= 66:
+        raise ValueError("vectorised encode needs a modulus of more than 66 bits")
+    tiny = np.abs(x) < 1e-200
+    man, ex = np.frexp(x)
+    expo = (_MANT - ex).astype(np.int32)
+    mant = np.ldexp(man, _MANT).astype(np.int64)          # exact: |mant| < 2^53
+    expo[tiny] = 0
+    mant[tiny] = 0
+    neg = mant < 0
+    a = np.abs(mant).astype(np.uint64)
+    N = x.shape[0]
+    out = np.zeros((N, n_words), dtype=np.uint32)
+    # non-negative: the mantissa itself
+    out[:, 0] = (a & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    out[:, 1] = (a >> np.uint64(32)).astype(np.uint32)
+    if neg.any():
+        # n - a with a < 2^53: low 64 bits wrap, a single borrow may reach the upper words
+        n_lo = np.uint64(n & 0xFFFFFFFFFFFFFFFF)
+        an = a[neg]
+        lo = n_lo - an                                     # wraps mod 2^64
+        borrow = an > n_lo
+        hi_words = _words_of(n >> 64, n_words - 2)
+        hi_words_b = _words_of((n >> 64) - 1, n_words - 2)
+        rows = np.where(borrow[:, None], hi_words_b[None, :], hi_words[None, :])
+        blk = np.empty((an.shape[0], n_words), dtype=np.uint32)
+        blk[:, 0] = (lo & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        blk[:, 1] = (lo >> np.uint64(32)).astype(np.uint32)
+        blk[:, 2:] = rows
+        out[neg] = blk
+    return out, expo
+
+
+def encode_array(values, n: int, max_int: int, n_words: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Sequence of ints/floats (list or 1-D ndarray) -> (residues, exponents).
+
+    float64 / float32 / float16 ndarrays and lists of Python floats take the vectorised path; anything
+    else (Python ints of arbitrary size, mixed lists, numpy ints) goes element by element through
+    the scalar definition so that type checks and errors are the reference's."""
+    if isinstance(values, np.ndarray) and values.dtype in (np.float64, np.float32, np.float16) and values.ndim == 1 \
+            and n.bit_length() > 66:
+        return encode_float64_array(values.astype(np.float64), n, n_words)
+    if isinstance(values, (list, tuple)) and len(values) > 0 and all(type(v) is float for v in values) \
+            and n.bit_length() > 66:
+        return encode_float64_array(np.asarray(values, dtype=np.float64), n, n_words)
+    N = len(values)
+    out = np.zeros((N, n_words), dtype=np.uint32)
+    expo = np.zeros(N, dtype=np.int32)
+    step = 4 * n_words
+    buf = bytearray(step * N)
+    for i, v in enumerate(values):
+        enc = FixedPointNumber.encode(v, n, max_int)
+        buf[i * step:(i + 1) * step] = enc.encoding.to_bytes(step, "little")
+        expo[i] = enc.exponent
+    out = np.frombuffer(bytes(buf), dtype="<u4").reshape(N, n_words).copy()
+    return out, expo
+
+
+def decode_array(residues: np.ndarray, exponents: Sequence[int], n: int, max_int: int) -> List:
+    """(residues uint32[N][n_words], exponents) -> list of decoded values, element types as the
+    reference returns them (int when exponent <= 0, float otherwise; fixedpoint.py:115)."""
+    residues = np.ascontiguousarray(residues, dtype="<u4")
+    raw = residues.tobytes()
+    step = 4 * residues.shape[1]
+    out = []
+    thr = n - max_int
+    for i in range(residues.shape[0]):
+        enc = int.from_bytes(raw[i * step:(i + 1) * step], "little")
+        if enc >= n:
+            raise ValueError("Attempted to decode corrupted number")
+        elif enc <= max_int:
+            mant = enc
+        elif enc >= thr:
+            mant = enc - n
+        else:
+            raise OverflowError(f"Overflow detected in decode number, encoding: {enc}, {exponents[i]} {n}")
+        out.append(mant * pow(2, -int(exponents[i])))
+    return out
+
+
+def decode_float64_array(residues: np.ndarray, exponents: np.ndarray, n: int, max_int: int) -> np.ndarray:
+    """Fast path to a float64 ndarray for mantissas of magnitude < 2^63 (always true right after
+    encrypt->decrypt of floats); falls back to the exact element-wise path otherwise."""
+    residues = np.ascontiguousarray(residues, dtype=np.uint32)
+    N, W = residues.shape
+    expo = np.asarray(exponents, dtype=np.int64)
+    lo = residues[:, 0].astype(np.uint64) | (residues[:, 1].astype(np.uint64) << np.uint64(32))
+    hi_zero = ~residues[:, 2:].any(axis=1)
+    pos = hi_zero & (lo < np.uint64(1 << 63))
+    n_lo = np.uint64(n & 0xFFFFFFFFFFFFFFFF)
+    hi_words = _words_of(n >> 64, W - 2)
+    hi_words_b = _words_of((n >> 64) - 1, W - 2)
+    eq_hi = (residues[:, 2:] == hi_words[None, :]).all(axis=1)
+    eq_hib = (residues[:, 2:] == hi_words_b[None, :]).all(axis=1)
+    a = n_lo - lo                                          # |mantissa| mod 2^64 for negatives
+    neg = (~pos) & ((eq_hi & (lo <= n_lo)) | (eq_hib & (lo > n_lo))) & (a < np.uint64(1 << 63)) & (a > 0)
+    if not np.all(pos | neg):
+        vals = decode_array(residues, expo, n, max_int)
+        return np.asarray([float(v) for v in vals], dtype=np.float64)
+    mant = np.where(pos, lo.astype(np.float64), -(a.astype(np.float64)))
+    return np.ldexp(mant, (-expo).astype(np.int64).astype(np.int32))

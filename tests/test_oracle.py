@@ -1,0 +1,114 @@
+"""CPU: pins the oracle itself.  The Python-int restatement is checked against the mathematical
+definitions (two independent decryption formulas, homomorphic identities, the reference's behavioural
+tests tests/ipcl_python_test.py:21-66 restated with assertions), and the plain-C restatement
+(oracle/paillier_ref.c) — plus libgmp when installed — is checked bit-for-bit against it."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import paillier_oracle as orc
+
+
+def key2048(djn=True):
+    return orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567 if djn else None, bits=2048)
+
+
+def fixture_key(bits):
+    fx = json.loads((Path(__file__).parent / "golden" / "fixture_keys.json").read_text())[str(bits)]
+    return orc.make_key(int(fx["p"], 16), int(fx["q"], 16), djn_x=(1 << 70) + 12345, bits=bits)
+
+
+def test_bench_constants_are_a_valid_key():
+    assert orc.is_probable_prime(orc.BENCH_P) and orc.is_probable_prime(orc.BENCH_Q)
+    k = key2048()
+    assert k.p < k.q and k.n.bit_length() == 2048 and k.randbits == 1024
+    assert pow(k.hs, 1, k.nsq) == k.hs and 0 < k.hs < k.nsq
+
+
+@pytest.mark.parametrize("djn", [True, False])
+def test_crt_and_lambda_decryption_agree(djn):
+    k = key2048(djn)
+    rng = np.random.default_rng(1)
+    for i in range(6):
+        m = int.from_bytes(rng.bytes(256), "little") % k.n
+        r = int.from_bytes(rng.bytes(128), "little") % k.n or 1
+        c = orc.encrypt(k, m, r)
+        assert orc.decrypt_crt(k, c) == m == orc.decrypt_lambda(k, c)
+    assert orc.decrypt_crt(k, orc.raw_encrypt(0, k.n)) == 0 and orc.raw_encrypt(0, k.n) == 1
+
+
+def test_reference_behavioural_tests_hold_for_the_oracle():
+    """tests/ipcl_python_test.py:21-66 (test_add, test_mul) with a fixed seed, asserted exactly as there."""
+    k = key2048()
+    rng = np.random.default_rng(2)
+    N = 12
+    x = np.ones(N) * rng.integers(100)
+    y = np.ones(N) * rng.integers(1000)
+    z = np.ones(N) * rng.random()
+    t = list(range(N))
+    rs = [int(v) for v in rng.integers(1, 1 << 62, 4 * N)]
+    ex, ee = orc.api_encrypt(k, x, rs[:N])
+    ey, eye = orc.api_encrypt(k, y, rs[N:2 * N])
+    ez, eze = orc.api_encrypt(k, z, rs[2 * N:3 * N])
+    et, ete = orc.api_encrypt(k, t, rs[3 * N:])
+    c, e = orc.api_add_ct(k, ex, ee, ey, eye)
+    c, e = orc.api_add_ct(k, c, e, ez, eze)
+    c, e = orc.api_add_ct(k, c, e, et, ete)
+    for got, want in zip(orc.api_decrypt(k, c, e), x + y + z + np.array(t)):
+        assert round(abs(got - want), 7) == 0
+    # (E(x) * y + z) * t with negative y
+    yn = y * -1
+    c, e = orc.api_mul_plain(k, ex, ee, yn)
+    c, e = orc.api_add_plain(k, c, e, z)
+    c, e = orc.api_mul_plain(k, c, e, t)
+    for got, want in zip(orc.api_decrypt(k, c, e), (x * yn + z) * np.array(t)):
+        assert round(abs(got - want), 7) == 0
+    # scalar +5000 / -0.2 chain
+    cx, cxe = orc.api_encrypt(k, [9], [77])
+    val = 9
+    for _ in range(5):
+        cx, cxe = orc.api_add_plain(k, cx, cxe, 5000)
+        cx, cxe = orc.api_sub_plain(k, cx, cxe, 0.2)
+        val = val + 5000 - 0.2
+        assert round(abs(orc.api_decrypt(k, cx, cxe)[0] - val), 7) == 0
+
+
+def test_sub_ct_composition():
+    k = key2048()
+    a, ae = orc.api_encrypt(k, [10.5, -3.0], [5, 6])
+    b, be = orc.api_encrypt(k, [0.25, 8.0], [7, 8])
+    c, e = orc.api_sub_ct(k, a, ae, b, be)
+    assert orc.api_decrypt(k, c, e) == [10.25, -11.0]
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072])
+def test_c_oracle_matches_python_oracle(bits):
+    k = key2048() if bits == 2048 else fixture_key(bits)
+    ck = co.COracleKey(k)
+    rng = np.random.default_rng(bits)
+    N = 24 if bits <= 2048 else 10
+    m = [int.from_bytes(rng.bytes(bits // 8 + 8), "little") % k.n for _ in range(N)]
+    m[0], m[1] = 0, k.n - 1
+    r_l = orc.synth_r_limbs(bits, N, k.randbits)
+    r_l[2] = 0
+    nw = bits // 32
+    ct = ck.encrypt_djn(orc.ints_to_limbs(m, nw), r_l)
+    assert orc.limbs_to_ints(ct) == [orc.encrypt(k, x, rr) for x, rr in zip(m, orc.limbs_to_ints(r_l))]
+    assert orc.limbs_to_ints(ck.decrypt_crt(ct)) == m
+    if co.gmp_available():
+        assert np.array_equal(ck.gmp_encrypt_djn(orc.ints_to_limbs(m, nw), r_l), ct)
+        assert orc.limbs_to_ints(ck.gmp_decrypt_crt(ct)) == m
+
+
+def test_c_oracle_modexp_modmul():
+    rng = np.random.default_rng(3)
+    M = int.from_bytes(rng.bytes(256), "little") | (1 << 2047) | 1
+    a = [int.from_bytes(rng.bytes(256), "little") % M for _ in range(9)]
+    b = [int.from_bytes(rng.bytes(256), "little") % M for _ in range(9)]
+    e = int.from_bytes(rng.bytes(40), "little")
+    al, bl = orc.ints_to_limbs(a, 64), orc.ints_to_limbs(b, 64)
+    assert orc.limbs_to_ints(co.modexp(M, al, e)) == [pow(x, e, M) for x in a]
+    assert orc.limbs_to_ints(co.modmul(M, al, bl)) == [x * y % M for x, y in zip(a, b)]
