@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Paillier encrypt+decrypt ops/sec, 2048-bit key, batch = 1 M per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
+DJN-obfuscated encryption of B plaintext residues (pai_encrypt) followed by CRT decryption of the B
+ciphertexts (pai_decrypt).  One op = one element encrypted AND decrypted (BASELINE.json metric,
+SURVEY.md §8d).  With N > 1 every rank runs the same per-GPU batch on its own device (the path shards
+by independent elements, no data-path collective: "weak" scaling); the timed region is bracketed by a
+barrier + torch.cuda.synchronize() and the maximum over ranks is taken.
+
+Inputs: key = the reference's bench constants P, Q (bench/bench_ipcl_python.py:83-97) with a fixed
+DJN base; plaintexts = fixed-point encodings of default_rng(1002).uniform(-1000, 1000, B); randomness
+r = seeded device generator (1024 random bits per element), all uploaded before the timed region.
+
+The JSON line also carries
+  roofline     — the dominant kernel (k_dec_a: the two CRT half-size modexps) priced in canonical
+                 32x32->64 MACs against the measured v_mad_u64_u32 peak of the
+                 chip (profiles/r01/ubench_valu_mi355x.jsonl); the path is integer-VALU bound, so the
+                 "bound" is "valu_int" — the HBM view is reported beside it in "hbm".
+  cpu_baseline — the same two operations on the host cores (oracle/paillier_ref.c, through libgmp's
+                 mpz_powm when present, else the plain-C port), on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+KEY_BITS = 2048
+DJN_X = 0x1234567
+PEAK_MAC32_PER_S = 35.9e12        # measured v_mad_u64_u32 rate, 8 waves/SIMD (profiles/r01/ubench_valu_mi355x.jsonl)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md
+# canonical MAC32 per op at 2048-bit keys (CIOS 2L^2+L, 5-bit window)
+CANON_MAC_ENC, CANON_MAC_DEC = 41.52e6, 20.86e6
+BYTES_ENC, BYTES_DEC = 648, 520   # algorithmic bytes per op
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="elements per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from oracle import paillier_oracle as orc          # checker + synthetic-input definitions only
+    from pailliercryptolib_python_amd import engine, fixedpoint
+
+    key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=DJN_X, bits=KEY_BITS)
+    pub = engine.PublicKeyHandle(key.n, KEY_BITS, key.hs, key.randbits, device=device)
+    priv = engine.PrivateKeyHandle(pub, orc.BENCH_P, orc.BENCH_Q)
+
+    B = args.batch
+    x = np.random.default_rng(1002 + rank).uniform(-1000.0, 1000.0, B)
+    res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
+    m = engine.to_device_words(res, device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(4002 + rank)
+    r = pub.random_r(B, generator=gen)
+    ct = pub.empty_ct(B)
+    out = pub.empty_pt(B)
+    torch.cuda.synchronize()
+
+    def step():
+        pub.encrypt(m, r, out=ct)
+        priv.decrypt(ct, out=out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness of what was just timed (outside the timed region) ---------------------------
+    ok = bool(torch.equal(out, m))
+    got_x = fixedpoint.decode_float64_array(engine.to_host_words(out[:4096]), expo[:4096], key.n, key.max_int)
+    ok = ok and bool(np.array_equal(got_x, x[:4096]))
+    idx = [0, 1, B // 2, B - 1]
+    ct_h = engine.to_host_words(ct[idx])
+    r_h = engine.words_to_ints(engine.to_host_words(r[idx]))
+    m_h = engine.words_to_ints(res[idx])
+    ok = ok and engine.words_to_ints(ct_h) == [orc.encrypt(key, mm, rr) for mm, rr in zip(m_h, r_h)]
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if not ok:
+        raise SystemExit("bench.py: parity check failed (decrypt(encrypt(m)) != m or ciphertext bits differ from the oracle)")
+
+    # ---- per-kernel durations with HIP events on the launch stream (rank 0) ----------------------
+    kern = {}
+    if rank == 0:
+        engine.profile_enable(True)
+        acc = {}
+        reps = max(1, min(args.steps, 3))
+        for _ in range(reps):
+            pub.encrypt(m, r, out=ct)
+            for k_, v in engine.profile_last().items():
+                acc[k_] = acc.get(k_, 0.0) + v
+            priv.decrypt(ct, out=out)
+            for k_, v in engine.profile_last().items():
+                acc[k_] = acc.get(k_, 0.0) + v
+        engine.profile_enable(False)
+        kern = {k_: v / reps for k_, v in acc.items()}
+
+    # ---- CPU baseline on the host cores (rank 0, N = 1 only) -------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle as co
+
+        ck = co.COracleKey(key)
+        use_gmp = co.gmp_available()
+        enc = ck.gmp_encrypt_djn if use_gmp else ck.encrypt_djn
+        dec = ck.gmp_decrypt_crt if use_gmp else ck.decrypt_crt
+        threads = co.max_threads()
+        r_host = engine.to_host_words(r[: 64 * threads])
+        probe = 4 * threads
+        t1 = time.perf_counter()
+        dec(enc(res[:probe], r_host[:probe]))
+        t_probe = time.perf_counter() - t1
+        sample = int(min(64 * threads, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-3))))
+        t1 = time.perf_counter()
+        c_ct = enc(res[:sample], r_host[:sample])
+        c_m = dec(c_ct)
+        t_cpu = time.perf_counter() - t1
+        assert np.array_equal(c_m, res[:sample]), "CPU baseline failed its own round trip"
+        assert np.array_equal(c_ct[:256], engine.to_host_words(ct[:256])), "CPU baseline and GPU ciphertexts differ"
+        cpu = {
+            "value": sample / t_cpu, "unit": "encrypt+decrypt ops/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} elements of the same batch, same key and randomness; "
+                      + ("libgmp mpz_powm via oracle/paillier_ref.c" if use_gmp else "plain-C CIOS port oracle/paillier_ref.c")
+                      + f", OpenMP over {threads} host threads, {t_cpu:.1f} s",
+        }
+
+    if rank == 0:
+        total_ops = float(B) * world * args.steps
+        value = total_ops / elapsed
+        t_deca = kern.get("k_dec_a", 0.0) * 1e-3
+        t_enc = kern.get("k_encrypt(djn)", 0.0) * 1e-3
+        achieved = (CANON_MAC_DEC * B / t_deca) if t_deca > 0 else None
+        line = {
+            "metric": "Paillier encrypt+decrypt ops/sec, 2048-bit key",
+            "value": value,
+            "unit": "ops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (radix-2^29 in 32-bit registers, 64-bit accumulators)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"2048-bit key (reference bench P,Q), DJN encrypt + CRT decrypt, batch={B} per GPU, "
+                            f"inputs resident in HBM",
+                "key_bits": KEY_BITS, "batch_per_gpu": B, "scheme": "DJN", "parallelism": f"shard{world}",
+            },
+            "roofline": {
+                "bound": "valu_int",
+                "kernel": "k_dec_a (CRT half-size modexps)",
+                "achieved": (achieved / 1e12) if achieved else None,
+                "peak": PEAK_MAC32_PER_S / 1e12,
+                "unit": "T MAC32/s (canonical 32x32->64 multiply-accumulates, SURVEY §8d)",
+                "frac": (achieved / PEAK_MAC32_PER_S) if achieved else None,
+                "kernel_ms": kern,
+                "traffic": None,
+                "hbm": {
+                    "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                    "achieved_decrypt": (BYTES_DEC * B / t_deca / 1e9) if t_deca > 0 else None,
+                    "achieved_encrypt": (BYTES_ENC * B / t_enc / 1e9) if t_enc > 0 else None,
+                },
+                "encrypt_canonical_T_MAC32_s": (CANON_MAC_ENC * B / t_enc / 1e12) if t_enc > 0 else None,
+            },
+            "cpu_baseline": cpu,
+            "parity_checked": True,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

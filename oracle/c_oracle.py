@@ -57,7 +57,19 @@ def gmp_available() -> bool:
 
 
 def max_threads() -> int:
-    return int(lib().orc_max_threads())
+    """Host threads worth using: min(OpenMP default, CPU affinity, cgroup CPU quota)."""
+    n = int(lib().orc_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def _u64(v: int, L: int) -> np.ndarray:
