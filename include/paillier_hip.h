@@ -102,6 +102,11 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
 int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, int e_words, int ebits_max,
                int e_bcast, size_t N, uint32_t* d_out, void* stream);
 
+/* Replaces the per-element gmpy2.invert of PaillierEncryptedNumber.__invert_ct (ipcl_python.py:272-276):
+ * d_out[i] = d_ct[i]^-1 mod n^2 (batched: simultaneous inversion + one extended GCD per chunk).
+ * Synchronous; fails with PAI_E_INVALID if some ciphertext shares a factor with n. d_out must not alias d_ct. */
+int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream);
+
 /* Exponent alignment, ipcl_python.py:570-741 (ct * 2^delta as ciphertext^(2^delta)):
  * for delta_i > 0: d_ct[i] <- d_ct[i]^(2^delta_i) mod n^2; other elements are left untouched. */
 int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N,

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "pai_decrypt": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_add": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp, voidp]),
     "pai_ct_mul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_int, C.c_int, C.c_size_t, voidp, voidp]),
+    "pai_ct_invert": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_pow2": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp]),
     "pai_modulus_create": (C.c_int, [voidp, C.c_int, C.c_int, C.POINTER(voidp)]),
     "pai_modulus_destroy": (None, [voidp]),

@@ -28,6 +28,7 @@ SOURCES = [
     "geo_36x4.hip",
     "geo_28x8.hip",
     "geo_36x8.hip",
+    "inv_eea.hip",
     "paillier_capi.hip",
 ]
 

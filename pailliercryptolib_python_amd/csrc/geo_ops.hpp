@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include "kernels_invert.hpp"
 #include "kernels_paillier.hpp"
 
 namespace pai {
@@ -28,6 +29,10 @@ struct GeoOps {
     void (*dec_b)(hipStream_t, int grid, DecBParams, const uint32_t* u_in, uint32_t* m_out, int n);
     void (*pow2)(hipStream_t, int grid, const MontCtx*, uint32_t* ct, const int32_t* delta, int delta_bcast, int n,
                  int w32);
+    void (*inv_prefix)(hipStream_t, int grid, const MontCtx*, const uint32_t* ct, int w32, int n, int K,
+                       uint32_t* prefix, uint32_t* tot);
+    void (*inv_back)(hipStream_t, int grid, const MontCtx*, const uint32_t* ct, int w32, int n, int K,
+                     const uint32_t* prefix, const uint32_t* tot_inv, uint32_t* out);
     // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups
     size_t (*table_words)(size_t blocks);
 };
@@ -41,5 +46,10 @@ const GeoOps* geo_ops_36x8();
 
 // smallest geometry whose capacity covers a modulus of `bits` bits (R = 2^(29 NL) > 4 M), or nullptr
 const GeoOps* geo_for_bits(int bits);
+
+// x = a^-1 mod M for `count` values of `words` 32-bit words each (words in {64,128,192,256}); *fail counts
+// non-invertible inputs.  Returns false if `words` has no instantiation.
+bool launch_inv_eea(hipStream_t s, int words, const uint32_t* mod, const uint32_t* a, uint32_t* out, int count,
+                    int max_steps, int* fail);
 
 }  // namespace pai

@@ -3,6 +3,7 @@
 #include "../../include/paillier_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -219,7 +220,9 @@ struct pai_pubkey {
     uint32_t* d_fb = nullptr;     // fixed-base table [J][256][NL]
     uint32_t* d_nexp = nullptr;   // n as packed words (exponent of the standard obfuscator)
     int fb_windows = 0;
+    uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
+    mutable DevBuf inv_prefix, inv_tot, inv_totinv, inv_fail;
     mutable std::mutex mu;
     EncParams enc_params() const {
         EncParams P;
@@ -397,6 +400,7 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         const int nl = pk->msq.geo->nl;
         pk->d_nR = upload_r29(hbn::mulmod(pk->n, pk->msq.R, pk->nsq), nl);
         pk->d_nexp = upload_words(pk->n, pk->n_words);
+        pk->d_nsq_words = upload_words(pk->nsq, pk->ct_words);
         if (h_hs) {
             require(hs_words > 0 && randbits > 0 && randbits % FB_WBITS == 0, "DJN key needs hs and randbits (multiple of 8)");
             pk->djn = true;
@@ -447,6 +451,11 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_nR) (void)hipFree(pk->d_nR);
     if (pk->d_fb) (void)hipFree(pk->d_fb);
     if (pk->d_nexp) (void)hipFree(pk->d_nexp);
+    if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
+    pk->inv_prefix.release();
+    pk->inv_tot.release();
+    pk->inv_totinv.release();
+    pk->inv_fail.release();
     pk->table.release();
     pk->tmp.release();
     delete pk;
@@ -555,6 +564,45 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
         const GeoOps* g = pk->msq.geo;
         g->pow2((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words);
         HIP_CHECK(hipGetLastError());
+    });
+}
+
+int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && d_ct && d_out, "NULL argument");
+        if (N == 0) return;
+        std::lock_guard<std::mutex> lk(pk->mu);
+        use_device(pk->device);
+        const GeoOps* g = pk->msq.geo;
+        hipStream_t s = (hipStream_t)stream;
+        // chunk length: long enough to amortise the extended GCD, short enough to keep every CU busy
+        int K = 32;
+        while (K > 1 && (N / (size_t)K) < (size_t)pk->dev.ncu * 2 * g->epb) K >>= 1;
+        if (const char* env = std::getenv("PAI_INVERT_CHUNK")) {     // test hook: force the chunk length
+            int k = std::atoi(env);
+            if (k >= 1 && k <= 1024) K = k;
+        }
+        const size_t nchunks = (N + K - 1) / K;
+        pk->inv_prefix.ensure(N * (size_t)g->nl * 4);
+        pk->inv_tot.ensure(nchunks * (size_t)pk->ct_words * 4);
+        pk->inv_totinv.ensure(nchunks * (size_t)pk->ct_words * 4);
+        pk->inv_fail.ensure(4);
+        HIP_CHECK(hipMemsetAsync(pk->inv_fail.p, 0, 4, s));
+        const int grid = grid_for(g, nchunks, pk->dev.ncu);
+        g->inv_prefix(s, grid, pk->msq.d_ctx, d_ct, pk->ct_words, (int)N, K, pk->inv_prefix.as<uint32_t>(),
+                      pk->inv_tot.as<uint32_t>());
+        HIP_CHECK(hipGetLastError());
+        if (!launch_inv_eea(s, pk->ct_words, pk->d_nsq_words, pk->inv_tot.as<uint32_t>(), pk->inv_totinv.as<uint32_t>(),
+                            (int)nchunks, 2 * 32 * pk->ct_words + 64, pk->inv_fail.as<int>()))
+            throw PaiError(PAI_E_UNSUPPORTED, "ct_invert: key size without an extended-GCD instantiation");
+        HIP_CHECK(hipGetLastError());
+        g->inv_back(s, grid, pk->msq.d_ctx, d_ct, pk->ct_words, (int)N, K, pk->inv_prefix.as<uint32_t>(),
+                    pk->inv_totinv.as<uint32_t>(), d_out);
+        HIP_CHECK(hipGetLastError());
+        int fail = 0;
+        HIP_CHECK(hipMemcpyAsync(&fail, pk->inv_fail.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (fail) throw PaiError(PAI_E_INVALID, "ct_invert: a ciphertext is not invertible modulo n^2");
     });
 }
 

@@ -156,6 +156,12 @@ class PublicKeyHandle:
                                           _ptr(out), _stream(self.device)))
         return out
 
+    def ct_invert(self, ct: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._chk(ct, self.ct_words, "ct")
+        out = self.empty_ct(ct.shape[0]) if out is None else out
+        _native.check(self.lib.pai_ct_invert(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.device)))
+        return out
+
     def ct_pow2_(self, ct: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
         self._chk(ct, self.ct_words, "ct")
         if delta.dtype != torch.int32 or delta.dim() != 1 or not delta.is_contiguous():

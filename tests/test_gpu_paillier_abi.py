@@ -160,3 +160,49 @@ def test_standard_scheme_2048():
     out = DevArray(shape=(N, nk.nw))
     _native.check(nk.lib.pai_decrypt(nk.sk, ct.ptr, N, out.ptr, None))
     assert limbs_to_ints(out.get()) == m
+
+
+@pytest.mark.parametrize("chunk,N", [(None, 1), (None, 77), (8, 1000), (32, 4099), (5, 333)])
+def test_ct_invert_2048(k2048, chunk, N, monkeypatch):
+    """Batched inversion (simultaneous-inversion trick + device extended GCD) against pow(x, -1, n^2)."""
+    import os
+
+    if chunk is None:
+        monkeypatch.delenv("PAI_INVERT_CHUNK", raising=False)
+    else:
+        monkeypatch.setenv("PAI_INVERT_CHUNK", str(chunk))
+    key = k2048.key
+    rng = np.random.default_rng(1000 + N)
+    a = rand_below(rng, key.nsq, N)
+    a[0] = 1
+    if N > 3:
+        a[1], a[2], a[3] = key.nsq - 1, 2, key.n + 1
+    da = DevArray(ints_to_limbs(a, k2048.cw))
+    out = DevArray(shape=(N, k2048.cw))
+    _native.check(k2048.lib.pai_ct_invert(k2048.pk, da.ptr, N, out.ptr, None))
+    got = limbs_to_ints(out.get())
+    step = max(1, N // 400)
+    for i in list(range(0, N, step)) + [N - 1]:
+        assert got[i] == pow(a[i], -1, key.nsq), i
+    assert all(0 < g < key.nsq for g in got)
+
+
+def test_ct_invert_rejects_non_units(k2048):
+    key = k2048.key
+    a = [5, key.p * 12345, 7]
+    da = DevArray(ints_to_limbs(a, k2048.cw))
+    out = DevArray(shape=(3, k2048.cw))
+    rc = k2048.lib.pai_ct_invert(k2048.pk, da.ptr, 3, out.ptr, None)
+    assert rc == _native.PAI_E_INVALID
+
+
+def test_ct_invert_other_key_sizes():
+    for bits in (1024, 4096):
+        nk = NativeKey(seeded_key(bits))
+        key, N = nk.key, 40
+        rng = np.random.default_rng(bits)
+        a = rand_below(rng, key.nsq, N)
+        da = DevArray(ints_to_limbs(a, nk.cw))
+        out = DevArray(shape=(N, nk.cw))
+        _native.check(nk.lib.pai_ct_invert(nk.pk, da.ptr, N, out.ptr, None))
+        assert limbs_to_ints(out.get()) == [pow(x, -1, key.nsq) for x in a]
