@@ -1,0 +1,608 @@
+"""Python-visible surface of the reference's native module ``ipcl_python.bindings.ipcl_bindings``
+(``bindings/ipcl_bindings.cpp:21-63``), re-created over the HIP engine.
+
+The class and method names are the reference's so that code written against
+``ipclPublicKey / ipclPrivateKey / ipclPlainText / ipclCipherText / ipclBigNumber / ipclKeypair /
+context / hybridControl / hybridMode`` keeps working, but the containers are device-resident limb
+matrices (``engine.py``) instead of ``std::vector<BigNumber>``; a Python ``ipclBigNumber`` object is only
+materialised when somebody asks for an individual element (``getTexts()``, ``[i]``).
+
+Wire formats kept bit-for-bit: little-endian bytes padded to a multiple of 4 (``BN2bytes``,
+ipcl_bindings.cpp:121-138); public-key tuple ``(scheme, n, bits, hs|0, randbits|0)`` (:66-98);
+private-key tuple ``(n, p, q)`` (ipcl_bindings_classes.cpp:142-162); container tuples
+``(len, [bytes])`` / ``(len, [bytes], pubkey tuple)`` (:248-265, :356-377); BigNumber ``(bytes,)`` (:481-490).
+"""
+from __future__ import annotations
+
+import enum
+import math
+import secrets
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import engine
+
+# ------------------------------------------------------------------------------------------------
+# BigNumber
+# ------------------------------------------------------------------------------------------------
+
+
+class ipclBigNumber:
+    """Value object for one non-negative integer (bindings/ipcl_bindings_classes.cpp:380-491)."""
+
+    __slots__ = ("_v",)
+
+    def __init__(self, data: Union[bytes, bytearray, int, "ipclBigNumber", np.ndarray] = 0):
+        if isinstance(data, ipclBigNumber):
+            self._v = data._v
+        elif isinstance(data, (bytes, bytearray)):
+            self._v = int.from_bytes(bytes(data), "little")       # pyByte2BN: little-endian bytes
+        elif isinstance(data, np.ndarray):
+            self._v = int.from_bytes(np.ascontiguousarray(data, dtype="<u4").tobytes(), "little")
+        elif isinstance(data, (int, np.integer)):
+            if int(data) < 0:
+                raise ValueError("ipclBigNumber: negative values are not supported")
+            self._v = int(data)
+        else:
+            raise TypeError(f"ipclBigNumber: cannot build from {type(data)}")
+
+    def to_bytes(self) -> bytes:
+        """BN2bytes: little-endian, length = ceil(bits/32)*4 (0 encodes as 4 zero bytes upstream)."""
+        words = max(1, (self._v.bit_length() + 31) // 32)
+        return self._v.to_bytes(4 * words, "little")
+
+    def __int__(self):
+        return self._v
+
+    __index__ = __int__
+
+    def __eq__(self, other):
+        if isinstance(other, ipclBigNumber):
+            return self._v == other._v
+        if isinstance(other, (int, np.integer)):
+            return self._v == int(other)
+        return NotImplemented
+
+    def __hash__(self):
+        return hash(self._v)
+
+    def __repr__(self):
+        return str(self._v)
+
+    __str__ = __repr__
+
+    def __getstate__(self):
+        return (self.to_bytes(),)
+
+    def __setstate__(self, state):
+        self._v = int.from_bytes(state[0], "little")
+
+    # the arithmetic operators of classes.cpp:433-457 (not used by the L3 API)
+    def __add__(self, o):
+        return ipclBigNumber(self._v + int(o))
+
+    def __sub__(self, o):
+        return ipclBigNumber(self._v - int(o))
+
+    def __mul__(self, o):
+        return ipclBigNumber(self._v * int(o))
+
+    def __mod__(self, o):
+        return ipclBigNumber(self._v % int(o))
+
+    def __lt__(self, o):
+        return self._v < int(o)
+
+    def __le__(self, o):
+        return self._v <= int(o)
+
+    def __gt__(self, o):
+        return self._v > int(o)
+
+    def __ge__(self, o):
+        return self._v >= int(o)
+
+
+ipclBigNumber.Zero = ipclBigNumber(0)
+ipclBigNumber.One = ipclBigNumber(1)
+ipclBigNumber.Two = ipclBigNumber(2)
+
+
+def _as_int(x) -> int:
+    return int(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# keys
+# ------------------------------------------------------------------------------------------------
+
+
+def _default_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("pailliercryptolib_python_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _random_unit(n: int) -> int:
+    while True:
+        x = secrets.randbelow(n - 2) + 2
+        if math.gcd(x, n) == 1:
+            return x
+
+
+class ipclPublicKey:
+    """Replaces the pybind class at bindings/ipcl_bindings_classes.cpp:12-91."""
+
+    def __init__(self, n: Union[ipclBigNumber, int], bits: int = 1024, enableDJN: bool = False, *,
+                 hs: Optional[int] = None, randbits: Optional[int] = None, device=None):
+        self._n = _as_int(n)
+        self._bits = int(bits)
+        if self._n.bit_length() > self._bits:
+            raise RuntimeError("ipclPublicKey: n is wider than the declared key length")
+        self._djn = bool(enableDJN) or hs is not None
+        if self._djn:
+            if hs is None:
+                # upstream DJN set-up: hs = (-x^2)^n mod n^2 for a random unit x
+                nsq = self._n * self._n
+                x = _random_unit(self._n)
+                hs = pow((-x * x) % nsq, self._n, nsq)
+            self._hs = int(hs)
+            self._randbits = int(randbits) if randbits is not None else self._bits // 2
+        else:
+            self._hs, self._randbits = None, 0
+        self._device = torch.device(device) if device is not None else None
+        self._handle: Optional[engine.PublicKeyHandle] = None
+
+    # -- lazily created device handle --------------------------------------------------------------
+    @property
+    def handle(self) -> engine.PublicKeyHandle:
+        if self._handle is None:
+            dev = self._device or _default_device()
+            self._handle = engine.PublicKeyHandle(self._n, self._bits, self._hs, self._randbits, device=dev)
+            self._device = self._handle.device
+        return self._handle
+
+    @property
+    def device(self) -> torch.device:
+        return self.handle.device
+
+    # -- reference surface -------------------------------------------------------------------------
+    @property
+    def n(self) -> ipclBigNumber:
+        return ipclBigNumber(self._n)
+
+    @property
+    def length(self) -> int:
+        return self._bits
+
+    @property
+    def nsquare(self) -> ipclBigNumber:
+        return ipclBigNumber(self._n * self._n)
+
+    def isDJN(self) -> bool:
+        return self._djn
+
+    def __repr__(self):
+        return "<ipclPublicKey %s>" % str(hash(self))[:10]
+
+    def __eq__(self, other):
+        # upstream compares the underlying object identity (App. A); value equality is the evident intent
+        return isinstance(other, ipclPublicKey) and self._n == other._n
+
+    def __hash__(self):
+        return hash(("ipclPublicKey", self._n))
+
+    def __getstate__(self):
+        if self._djn:
+            return (1, ipclBigNumber(self._n).to_bytes(), self._bits, ipclBigNumber(self._hs).to_bytes(), self._randbits)
+        return (0, ipclBigNumber(self._n).to_bytes(), self._bits, 0, 0)
+
+    def __setstate__(self, t):
+        scheme, n_b, bits = t[0], t[1], t[2]
+        self._n = int.from_bytes(n_b, "little")
+        self._bits = int(bits)
+        self._djn = scheme != 0
+        if self._djn:
+            self._hs = int.from_bytes(t[3], "little")
+            self._randbits = int(t[4])
+        else:
+            self._hs, self._randbits = None, 0
+        self._device = None
+        self._handle = None
+
+    # randomness for the obfuscator: OS CSPRNG on the host, uploaded as limbs
+    def _draw_r(self, count: int) -> torch.Tensor:
+        h = self.handle
+        if self._djn:
+            raw = np.frombuffer(secrets.token_bytes(4 * h.r_words * count), dtype="<u4").reshape(count, h.r_words).copy()
+            top = self._randbits - 32 * (h.r_words - 1)
+            if top < 32:
+                raw[:, -1] &= np.uint32((1 << top) - 1)
+            return engine.to_device_words(raw, h.device)
+        vals = [secrets.randbelow(self._n - 1) + 1 for _ in range(count)]
+        return engine.to_device_words(engine.ints_to_words(vals, h.n_words), h.device)
+
+    def encrypt(self, pt: "ipclPlainText", make_secure: bool = True, *, r: Optional[torch.Tensor] = None) -> "ipclCipherText":
+        """classes.cpp:53-60.  ``r`` (extension) injects the obfuscator randomness for reproducible runs."""
+        h = self.handle
+        m = pt._device_words(h)
+        if not make_secure:
+            return ipclCipherText(self, h.raw_encrypt(m))
+        if r is None:
+            r = self._draw_r(m.shape[0])
+        return ipclCipherText(self, h.encrypt(m, r))
+
+    def apply_obfuscator(self, x, *, r: Optional[torch.Tensor] = None):
+        """classes.cpp:71-83: BigNumber -> BigNumber, CipherText -> list of BigNumber (as upstream)."""
+        h = self.handle
+        if isinstance(x, (ipclBigNumber, int)):
+            ct = engine.to_device_words(engine.ints_to_words([_as_int(x)], h.ct_words), h.device)
+            h.obfuscate_(ct, self._draw_r(1) if r is None else r)
+            return ipclBigNumber(engine.to_host_words(ct)[0])
+        if isinstance(x, ipclCipherText):
+            ct = x._t.clone()
+            h.obfuscate_(ct, self._draw_r(ct.shape[0]) if r is None else r)
+            return ipclCipherText(self, ct).getTexts()
+        raise TypeError("apply_obfuscator: expected ipclBigNumber or ipclCipherText")
+
+
+class ipclPrivateKey:
+    """Replaces the pybind class at bindings/ipcl_bindings_classes.cpp:93-163."""
+
+    def __init__(self, pk: Union[ipclPublicKey, ipclBigNumber, int], p, q, _q=None):
+        if isinstance(pk, ipclPublicKey):
+            self._pk = pk
+        else:
+            # (n, p, q) form used by the pickle constructor (classes.cpp:161)
+            n = _as_int(pk)
+            self._pk = ipclPublicKey(n, n.bit_length(), False)
+        p, q = _as_int(p), _as_int(q)
+        self._p, self._q = (p, q) if p < q else (q, p)
+        if self._p * self._q != self._pk._n:
+            raise RuntimeError("ipclPrivateKey: p*q does not match the public key")
+        self._handle: Optional[engine.PrivateKeyHandle] = None
+
+    @property
+    def handle(self) -> engine.PrivateKeyHandle:
+        if self._handle is None:
+            self._handle = engine.PrivateKeyHandle(self._pk.handle, self._p, self._q)
+        return self._handle
+
+    @property
+    def n(self):
+        return ipclBigNumber(self._pk._n)
+
+    @property
+    def p(self):
+        return ipclBigNumber(self._p)
+
+    @property
+    def q(self):
+        return ipclBigNumber(self._q)
+
+    def __repr__(self):
+        return "<ipclPrivateKey %s>" % str(hash(self))[:10]
+
+    def __hash__(self):
+        return hash(("ipclPrivateKey", self._p, self._q))
+
+    def __eq__(self, other):
+        return isinstance(other, ipclPrivateKey) and (self._p, self._q) == (other._p, other._q)
+
+    def decrypt(self, ct: "ipclCipherText") -> "ipclPlainText":
+        """classes.cpp:127-133."""
+        if ct.public_key._n != self._pk._n:
+            raise RuntimeError("ipclPrivateKey.decrypt: public key mismatch")
+        hpub = self.handle.pub
+        words = ct._t if ct._t.device == hpub.device else ct._t.to(hpub.device)
+        return ipclPlainText(self.handle.decrypt(words))
+
+    def __getstate__(self):
+        return (ipclBigNumber(self._pk._n).to_bytes(), ipclBigNumber(self._p).to_bytes(), ipclBigNumber(self._q).to_bytes())
+
+    def __setstate__(self, t):
+        n, p, q = (int.from_bytes(b, "little") for b in t)
+        self._pk = ipclPublicKey(n, n.bit_length(), False)
+        self._p, self._q = (p, q) if p < q else (q, p)
+        self._handle = None
+
+
+# ------------------------------------------------------------------------------------------------
+# containers
+# ------------------------------------------------------------------------------------------------
+
+
+def _slice_bounds(key: slice, length: int):
+    start, stop, step = key.indices(length)
+    if step != 1:
+        raise RuntimeError("Step size not supported")        # classes.cpp:223,315
+    return start, max(stop, start)
+
+
+class _Container:
+    """Common part of ipclPlainText / ipclCipherText: a [N, words] int32 tensor (uint32 bit patterns)
+    on a device, or — before a key is known — a host list of ints."""
+
+    def __len__(self):
+        return self.getSize()
+
+    def getSize(self) -> int:
+        return int(self._t.shape[0]) if self._t is not None else len(self._ints)
+
+    def getTexts(self) -> List[ipclBigNumber]:
+        if self._t is None:
+            return [ipclBigNumber(v) for v in self._ints]
+        return [ipclBigNumber(v) for v in engine.words_to_ints(engine.to_host_words(self._t))]
+
+    def getElementVec(self, i: int) -> List[int]:
+        return engine.to_host_words(self._row(i))[0].tolist()
+
+    def getElementHex(self, i: int) -> str:
+        return "%X" % int(self[i])
+
+    def _row(self, i: int):
+        n = self.getSize()
+        if not 0 <= i < n:
+            raise IndexError("index out of range")
+        return self._t[i:i + 1]
+
+
+class ipclPlainText(_Container):
+    """bindings/ipcl_bindings_classes.cpp:165-266."""
+
+    def __init__(self, data=None):
+        self._t: Optional[torch.Tensor] = None
+        self._ints: List[int] = []
+        if data is None:
+            return
+        if isinstance(data, torch.Tensor):
+            self._t = data
+        elif isinstance(data, (ipclBigNumber, int, np.integer)):
+            self._ints = [_as_int(data)]
+        elif isinstance(data, np.ndarray) and data.dtype == np.uint32 and data.ndim == 2:
+            self._ints = engine.words_to_ints(data)
+        else:
+            self._ints = [_as_int(v) for v in data]
+
+    def _device_words(self, h: engine.PublicKeyHandle) -> torch.Tensor:
+        if self._t is not None:
+            if self._t.shape[1] != h.n_words:
+                raise RuntimeError("ipclPlainText: width does not match the key")
+            return self._t if self._t.device == h.device else self._t.to(h.device)
+        for v in self._ints:
+            if v.bit_length() > 32 * h.n_words:
+                raise RuntimeError("ipclPlainText: value wider than the key")
+        return engine.to_device_words(engine.ints_to_words(self._ints, h.n_words), h.device)
+
+    def getTexts(self):
+        return super().getTexts()
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a, b = _slice_bounds(key, len(self))
+            return ipclPlainText(self._t[a:b].contiguous()) if self._t is not None else ipclPlainText(self._ints[a:b])
+        if self._t is None:
+            return ipclBigNumber(self._ints[key])
+        return ipclBigNumber(engine.to_host_words(self._row(int(key)))[0])
+
+    def rotate(self, shift: int) -> "ipclPlainText":
+        n = len(self)
+        k = shift % n if n else 0
+        if self._t is None:
+            return ipclPlainText(self._ints[k:] + self._ints[:k])
+        return ipclPlainText(torch.roll(self._t, -k, dims=0).contiguous())
+
+    def __eq__(self, other):
+        if len(self) != len(other):
+            raise RuntimeError("Size mismatch")
+        if [int(a) for a in self.getTexts()] != [int(b) for b in other.getTexts()]:
+            raise RuntimeError("PlainText mismatch")
+        return True
+
+    def __repr__(self):
+        return "<ipclPlainText %s>" % str(id(self))[:10]
+
+    def __getstate__(self):
+        return (len(self), [b.to_bytes() for b in self.getTexts()])
+
+    def __setstate__(self, t):
+        self._t = None
+        self._ints = [int.from_bytes(b, "little") for b in t[1]]
+
+
+class ipclCipherText(_Container):
+    """bindings/ipcl_bindings_classes.cpp:268-378: ciphertext container bound to a public key."""
+
+    def __init__(self, pubkey: ipclPublicKey, data=None):
+        self._pk = pubkey
+        self._ints: List[int] = []
+        h = pubkey.handle
+        if isinstance(data, torch.Tensor):
+            t = data
+        elif isinstance(data, ipclCipherText):
+            t = data._t
+        elif isinstance(data, (ipclBigNumber, int, np.integer)):
+            t = engine.to_device_words(engine.ints_to_words([_as_int(data)], h.ct_words), h.device)
+        elif isinstance(data, np.ndarray) and data.dtype == np.uint32 and data.ndim == 2:
+            t = engine.to_device_words(data, h.device)
+        else:
+            vals = [_as_int(v) for v in (data if data is not None else [])]
+            t = engine.to_device_words(engine.ints_to_words(vals, h.ct_words), h.device) if vals else h.empty_ct(0)
+        if t.shape[1] != h.ct_words:
+            raise RuntimeError("ipclCipherText: width does not match the key")
+        self._t = t if t.device == h.device else t.to(h.device)
+
+    @property
+    def public_key(self) -> ipclPublicKey:
+        return self._pk
+
+    @property
+    def words(self) -> torch.Tensor:
+        """Device tensor [N, ct_words] int32 (extension: direct access to the limb matrix)."""
+        return self._t
+
+    def getCipherText(self):
+        return self
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a, b = _slice_bounds(key, len(self))
+            return ipclCipherText(self._pk, self._t[a:b].contiguous())
+        return ipclBigNumber(engine.to_host_words(self._row(int(key)))[0])
+
+    def rotate(self, shift: int) -> "ipclCipherText":
+        n = len(self)
+        k = shift % n if n else 0
+        return ipclCipherText(self._pk, torch.roll(self._t, -k, dims=0).contiguous())
+
+    def __add__(self, other):
+        h = self._pk.handle
+        if isinstance(other, ipclPlainText):
+            other = self._pk.encrypt(other, False)
+        if not isinstance(other, ipclCipherText):
+            return NotImplemented
+        if len(other) != len(self) and len(other) != 1:
+            raise RuntimeError("Size mismatch")
+        return ipclCipherText(self._pk, h.ct_add(self._t, other._t))
+
+    def __mul__(self, other: ipclPlainText):
+        if not isinstance(other, ipclPlainText):
+            return NotImplemented
+        h = self._pk.handle
+        vals = [int(v) for v in other.getTexts()]
+        if len(vals) != len(self) and len(vals) != 1:
+            raise RuntimeError("Size mismatch")
+        bits = max(1, max(v.bit_length() for v in vals))
+        ew = (bits + 31) // 32
+        e = engine.to_device_words(engine.ints_to_words(vals, ew), h.device)
+        return ipclCipherText(self._pk, h.ct_mul(self._t, e, bits))
+
+    def __repr__(self):
+        return "<ipclCipherText %s>" % str(id(self))[:10]
+
+    __str__ = __repr__
+
+    def __getstate__(self):
+        return (len(self), [b.to_bytes() for b in self.getTexts()], self._pk.__getstate__())
+
+    def __setstate__(self, t):
+        pk = ipclPublicKey.__new__(ipclPublicKey)
+        pk.__setstate__(t[2])
+        self.__init__(pk, [int.from_bytes(b, "little") for b in t[1]])
+
+
+# ------------------------------------------------------------------------------------------------
+# key generation (host) and the QAT/hybrid shims
+# ------------------------------------------------------------------------------------------------
+
+
+def _is_probable_prime(n: int, rounds: int = 32) -> bool:
+    if n < 2:
+        return False
+    for s in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97):
+        if n % s == 0:
+            return n == s
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for _ in range(rounds):
+        a = secrets.randbelow(n - 3) + 2
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def _random_prime(bits: int, congruent_3_mod_4: bool) -> int:
+    while True:
+        c = secrets.randbits(bits) | (1 << (bits - 1)) | (1 << (bits - 2)) | 1
+        if congruent_3_mod_4:
+            c |= 3
+        if _is_probable_prime(c):
+            return c
+
+
+class ipclKeypair:
+    @staticmethod
+    def generate_keypair(n_length: int = 1024, enable_DJN: bool = True):
+        """ipcl::generateKeypair (bindings/ipcl_bindings.cpp:12-15).  DJN keys use p = q = 3 (mod 4) with
+        gcd(p-1, q-1) = 2 (upstream's constraint)."""
+        n_length = int(n_length)
+        if n_length < 64 or n_length % 4 != 0:
+            raise RuntimeError("generate_keypair: n_length must be a multiple of 4 and at least 64")
+        half = n_length // 2
+        while True:
+            p = _random_prime(half, enable_DJN)
+            q = _random_prime(half, enable_DJN)
+            if p == q or (p * q).bit_length() != n_length:
+                continue
+            if enable_DJN and math.gcd(p - 1, q - 1) != 2:
+                continue
+            if math.gcd(p * q, (p - 1) * (q - 1)) != 1:
+                continue
+            break
+        pk = ipclPublicKey(p * q, n_length, enable_DJN)
+        return pk, ipclPrivateKey(pk, p, q)
+
+
+class hybridMode(enum.IntEnum):
+    """ipcl::HybridMode values (bindings/ipcl_bindings.cpp:37-51); inert here (no QAT on this platform)."""
+
+    OPTIMAL = 0
+    QAT = 1
+    PREF_QAT90 = 2
+    PREF_QAT80 = 3
+    PREF_QAT70 = 4
+    PREF_QAT60 = 5
+    HALF = 6
+    PREF_IPP60 = 7
+    PREF_IPP70 = 8
+    PREF_IPP80 = 9
+    PREF_IPP90 = 10
+    IPP = 11
+    UNDEFINED = 12
+
+
+class context:
+    """QAT context shims (bindings/include/ipcl_bindings.hpp:27-35): accepted and ignored."""
+
+    @staticmethod
+    def initializeContext(runtime_choice: str = "") -> bool:
+        return True
+
+    @staticmethod
+    def terminateContext() -> bool:
+        return True
+
+    @staticmethod
+    def isQATRunning() -> bool:
+        return False
+
+    @staticmethod
+    def isQATActive() -> bool:
+        return False
+
+
+class hybridControl:
+    _mode = hybridMode.UNDEFINED
+
+    @staticmethod
+    def setHybridMode(mode: hybridMode) -> None:
+        hybridControl._mode = hybridMode(mode)
+
+    @staticmethod
+    def setHybridOff() -> None:
+        hybridControl._mode = hybridMode.UNDEFINED
+
+    @staticmethod
+    def getHybridMode() -> hybridMode:
+        return hybridControl._mode

@@ -1,0 +1,503 @@
+"""User API: ``PaillierKeypair / PaillierPublicKey / PaillierPrivateKey / PaillierEncryptedNumber / BNUtils``.
+
+Same names, arguments, return conventions and exceptions as ``src/ipcl_python/ipcl_python.py`` of the
+reference; each method cites the lines it mirrors.  What differs is underneath:
+
+* a ``PaillierEncryptedNumber`` keeps its ciphertexts as ONE device tensor of limbs and its exponents
+  as an int32 numpy array — no per-element Python objects on the hot path (the reference builds an
+  ``ipclBigNumber`` per element: ``ipcl_python.py:136-141``);
+* exponent alignment (``:570-741``) is one masked device call (``pai_ct_pow2``) instead of Python loops
+  over gathered sub-batches;
+* negative plaintext multipliers (``:426-437``, ``:470-479``) use the device batch inversion instead of a
+  ``gmpy2.invert`` per element — the ciphertext bits are the same ``(ct^-1 mod n^2)^(n - pt)``;
+* ``sum()`` implements the evident intent (the reference's raises for len > 1: SURVEY App. B).
+
+Extensions (not in the reference, harmless to its users): ``encrypt(..., r=...)`` to inject the
+obfuscator randomness, ``decrypt_to_numpy``, ``PaillierEncryptedNumber.words``.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import engine
+from . import fixedpoint as _fp
+from .bindings import (
+    ipclBigNumber,
+    ipclCipherText,
+    ipclKeypair,
+    ipclPlainText,
+    ipclPrivateKey,
+    ipclPublicKey,
+)
+from .fixedpoint import FixedPointNumber
+
+
+class PaillierKeypair:
+    @staticmethod
+    def generate_keypair(n_length: int = 1024, enable_DJN: bool = True) -> Tuple["PaillierPublicKey", "PaillierPrivateKey"]:
+        """ipcl_python.py:20-40."""
+        pub, pri = ipclKeypair.generate_keypair(n_length, enable_DJN)
+        return PaillierPublicKey(pub), PaillierPrivateKey(pri)
+
+
+class PaillierPublicKey:
+    def __init__(self, key: Union[ipclPublicKey, "PaillierPublicKey", int], n_length: Optional[int] = None,
+                 enable_DJN: Optional[bool] = None):
+        """ipcl_python.py:44-77 (the copy-constructor branch really copies here; upstream's is a no-op
+        that ends in AttributeError — SURVEY App. B)."""
+        if isinstance(key, ipclPublicKey):
+            self.n = BNUtils.BN2int(key.n)
+            self.pubkey = key
+        elif isinstance(key, PaillierPublicKey):
+            self.n = key.n
+            self.pubkey = key.pubkey
+        elif isinstance(key, int) and n_length is not None and enable_DJN is not None:
+            self.n = key
+            self.pubkey = ipclPublicKey(BNUtils.int2BN(self.n), n_length, enable_DJN)
+        else:
+            raise ValueError(
+                "PaillierPublicKey: PubKey should be either key value (n),"
+                "PaillierPublicKey or IPP-PaillierPublicKey object"
+            )
+        self.max_int = self.n // 3 - 1
+        self.nsquare = self.n * self.n
+
+    def __getstate__(self):
+        return self.pubkey
+
+    def __setstate__(self, state):
+        self.pubkey = state
+        self.n = BNUtils.BN2int(self.pubkey.n)
+        self.max_int = self.n // 3 - 1
+        self.nsquare = self.n * self.n
+
+    def __repr__(self):
+        return repr(self.pubkey)
+
+    def __eq__(self, other):
+        return self.n == other.n
+
+    def __hash__(self):
+        return hash(self.pubkey)
+
+    def apply_obfuscator(self, x: Union[int, ipclBigNumber]):
+        """ipcl_python.py:97-101."""
+        if isinstance(x, int):
+            return self.pubkey.apply_obfuscator(BNUtils.int2BN(x))
+        return self.pubkey.apply_obfuscator(x)
+
+    def raw_encrypt(self, plaintext: Union[np.ndarray, list, int, float]) -> "PaillierEncryptedNumber":
+        return self.encrypt(plaintext, apply_obfuscator=False)
+
+    def encrypt(self, values: Union[np.ndarray, list, int, float], apply_obfuscator: bool = True, *,
+                r: Optional[Union[torch.Tensor, np.ndarray]] = None) -> "PaillierEncryptedNumber":
+        """ipcl_python.py:108-147.  Scalars, lists and 1-D arrays of ints/floats; anything else is a
+        ValueError exactly as there (2-D arrays fail the per-element type check)."""
+        if np.isscalar(values):
+            values = [values]
+        if isinstance(values, np.ndarray):
+            ok = values.ndim == 1 and (np.issubdtype(values.dtype, np.integer) or np.issubdtype(values.dtype, np.floating))
+            if values.dtype == object:
+                ok = values.ndim == 1 and all(isinstance(v, (int, float, np.integer, np.floating)) for v in values)
+        else:
+            ok = all(isinstance(v, (int, float, np.integer, np.floating)) for v in values)
+        if not ok:
+            raise ValueError("PaillierPublicKey.encrypt: input value(s) should be integer or float")
+        h = self.pubkey.handle
+        residues, expos = _fp.encode_array(values, self.n, self.max_int, h.n_words)
+        m = engine.to_device_words(residues, h.device)
+        if not apply_obfuscator:
+            ct = h.raw_encrypt(m)
+        else:
+            if r is None:
+                r = self.pubkey._draw_r(m.shape[0])
+            elif isinstance(r, np.ndarray):
+                r = engine.to_device_words(r, h.device)
+            ct = h.encrypt(m, r)
+        return PaillierEncryptedNumber(self, ipclCipherText(self.pubkey, ct), exponents=expos, length=len(values))
+
+
+class PaillierPrivateKey:
+    def __init__(self, key: Union[ipclPrivateKey, ipclPublicKey, PaillierPublicKey], p: Optional[int] = None,
+                 q: Optional[int] = None):
+        """ipcl_python.py:151-188."""
+        if isinstance(key, ipclPrivateKey):
+            self.prikey = key
+            self.__n = BNUtils.BN2int(key.n)
+            self.__max_int = self.__n // 3 - 1
+        elif isinstance(key, ipclPublicKey) and p is not None and q is not None:
+            self.prikey = ipclPrivateKey(key, BNUtils.int2BN(p), BNUtils.int2BN(q))
+            self.__n = BNUtils.BN2int(key.n)
+            self.__max_int = self.__n // 3 - 1
+        elif isinstance(key, PaillierPublicKey) and p is not None and q is not None:
+            self.prikey = ipclPrivateKey(key.pubkey, BNUtils.int2BN(p), BNUtils.int2BN(q))
+            self.__n = key.n
+            self.__max_int = key.max_int
+        else:
+            raise KeyError("PaillierPrivateKey: key should be either Private key or Public key (with p and q)")
+
+    def __getstate__(self):
+        return (self.prikey, self.__n, self.__max_int)
+
+    def __setstate__(self, state):
+        (self.prikey, self.__n, self.__max_int) = state
+
+    def __eq__(self, other: "PaillierPrivateKey"):
+        return (self.prikey.p == other.prikey.p) and (self.prikey.q == other.prikey.q)
+
+    def __hash__(self):
+        return hash(self.prikey)
+
+    def __repr__(self):
+        return repr(self.prikey)
+
+    def _decrypt_words(self, enc: "PaillierEncryptedNumber") -> np.ndarray:
+        return engine.to_host_words(self.prikey.decrypt(enc.ciphertext())._t)
+
+    def raw_decrypt(self, ciphertext: "PaillierEncryptedNumber"):
+        """ipcl_python.py:207-217: the raw residues as Python ints (scalar if length 1)."""
+        if ciphertext.public_key.n != self.__n:
+            raise ValueError("PaillierPrivateKey.raw_decrypt: Public key mismatch")
+        ret = engine.words_to_ints(self._decrypt_words(ciphertext))
+        return ret if len(ciphertext) > 1 else ret[0]
+
+    def decrypt(self, encrypted_number: "PaillierEncryptedNumber"):
+        """ipcl_python.py:219-245: list of decoded values (int when the exponent is <= 0, float otherwise),
+        or the single value when the length is 1."""
+        if encrypted_number.public_key.n != self.__n:
+            raise ValueError("PailierPrivateKey.decrypt: Public key mismatch")
+        ret = _fp.decode_array(self._decrypt_words(encrypted_number), encrypted_number._expo, self.__n, self.__max_int)
+        return ret if len(encrypted_number) > 1 else ret[0]
+
+    def decrypt_to_numpy(self, encrypted_number: "PaillierEncryptedNumber") -> np.ndarray:
+        """Extension: the decoded values as a float64 ndarray without per-element Python objects."""
+        if encrypted_number.public_key.n != self.__n:
+            raise ValueError("PailierPrivateKey.decrypt: Public key mismatch")
+        return _fp.decode_float64_array(self._decrypt_words(encrypted_number), encrypted_number._expo, self.__n,
+                                        self.__max_int)
+
+
+class PaillierEncryptedNumber:
+    def __init__(self, public_key: PaillierPublicKey, ciphertext: ipclCipherText, exponents, length: int):
+        """ipcl_python.py:249-270."""
+        if ciphertext.public_key != public_key.pubkey:
+            raise ValueError("PaillierEncryptedNumber: public key mismatch")
+        self._expo = np.asarray(exponents, dtype=np.int32).reshape(-1).copy()
+        self.public_key = public_key
+        self.__ipclCipherText = ciphertext
+        self.__length = int(length)
+
+    # -- helpers ----------------------------------------------------------------------------------
+    @property
+    def words(self) -> torch.Tensor:
+        """Device limb matrix [N, ct_words] (extension)."""
+        return self.__ipclCipherText.words
+
+    def _h(self) -> engine.PublicKeyHandle:
+        return self.public_key.pubkey.handle
+
+    def _wrap(self, ct: torch.Tensor, expo, length: Optional[int] = None) -> "PaillierEncryptedNumber":
+        return PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, ct), expo,
+                                       ct.shape[0] if length is None else length)
+
+    def __repr__(self):
+        return repr(self.__ipclCipherText)
+
+    def __getstate__(self) -> tuple:
+        """ipcl_python.py:281-287: (public_key, len, exponents, [python ints])."""
+        return (self.public_key, len(self), self.exponent(), [BNUtils.BN2int(i) for i in self.ciphertextBN()])
+
+    def __setstate__(self, state: tuple):
+        (self.public_key, self.__length, expo, ciphertextPyInt) = state
+        self._expo = np.asarray(expo, dtype=np.int32).reshape(-1).copy()
+        self.__ipclCipherText = ipclCipherText(self.public_key.pubkey, [int(i) for i in ciphertextPyInt])
+
+    def __len__(self) -> int:
+        return self.__length
+
+    def ciphertext(self) -> ipclCipherText:
+        return self.__ipclCipherText
+
+    def ciphertextBN(self, idx: Optional[int] = None):
+        """ipcl_python.py:306-322."""
+        if idx is None:
+            return self.__ipclCipherText.getTexts()
+        if not 0 <= idx < self.__length:
+            raise IndexError("ciphertext: idx out of range")
+        return self.__ipclCipherText[idx]
+
+    def exponent(self, idx: Optional[int] = None):
+        """ipcl_python.py:324-340."""
+        if idx is None:
+            return [int(e) for e in self._expo]
+        if not 0 <= idx < self.__length:
+            raise IndexError("exponent: idx out of range")
+        return int(self._expo[idx])
+
+    def apply_obfuscator(self, *, r: Optional[torch.Tensor] = None):
+        """ipcl_python.py:342-346: re-randomise in place."""
+        h = self._h()
+        ct = self.words.clone()
+        h.obfuscate_(ct, self.public_key.pubkey._draw_r(ct.shape[0]) if r is None else r)
+        self.__ipclCipherText = ipclCipherText(self.public_key.pubkey, ct)
+
+    def __getitem__(self, key: Union[int, slice]) -> "PaillierEncryptedNumber":
+        """ipcl_python.py:348-360 (open-ended slices are accepted as an extension)."""
+        if isinstance(key, (int, np.integer)):
+            key = slice(int(key), int(key) + 1)
+        start = 0 if key.start is None else key.start
+        stop = len(self) if key.stop is None else key.stop
+        if not 0 <= stop <= len(self) or not 0 <= start < len(self):
+            raise IndexError("__getitem__: key out of range")
+        if key.step not in (None, 1):
+            raise RuntimeError("Step size not supported")
+        sub = self.words[start:stop].contiguous()
+        return self._wrap(sub, self._expo[start:stop])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    # -- arithmetic -------------------------------------------------------------------------------
+    def __add__(self, other):
+        """ipcl_python.py:365-375."""
+        if self.__length == 1 and isinstance(other, PaillierEncryptedNumber) and len(other) > 1:
+            return other.__raw_add(self)
+        return self.__raw_add(other)
+
+    def __radd__(self, other):
+        return self + other
+
+    def __sub__(self, other):
+        """ipcl_python.py:383-389."""
+        if isinstance(other, list):
+            other = np.array(other)
+        return self.__raw_add(other * -1.0)
+
+    def __rsub__(self, other):
+        """ipcl_python.py:391-397."""
+        if isinstance(other, PaillierEncryptedNumber):
+            return other - self
+        return (self * (-1.0)).__raw_add(other)
+
+    def __rmul__(self, other):
+        return self * other
+
+    def __truediv__(self, other):
+        """ipcl_python.py:404-410."""
+        if isinstance(other, list):
+            other = np.array(other)
+        inv_other = 1.0 / other
+        return self * inv_other
+
+    def _pow(self, ct: torch.Tensor, pts: List[int], neg: np.ndarray) -> torch.Tensor:
+        """ct_i^(pt_i) with the reference's sign rule: pt >= n - max_int means a negative multiplier, which is
+        applied as (ct^-1)^(n - pt) (ipcl_python.py:426-437, 470-479)."""
+        h = self._h()
+        n = self.public_key.n
+        N = ct.shape[0]
+        bcast = len(pts) == 1 and N > 1
+        if neg.any():
+            if bcast or neg.all():
+                base = h.ct_invert(ct)
+            else:
+                idx = torch.from_numpy(np.nonzero(neg)[0]).to(h.device)
+                base = ct.clone()
+                base[idx] = h.ct_invert(ct[idx].contiguous())
+        else:
+            base = ct
+        mags = [n - p if s else p for p, s in zip(pts, neg)]
+        bits = max(1, max(v.bit_length() for v in mags))
+        ew = (bits + 31) // 32
+        e = engine.to_device_words(engine.ints_to_words(mags, ew), h.device)
+        return h.ct_mul(base, e, bits)
+
+    def __mul__(self, other):
+        """ipcl_python.py:412-488."""
+        n, max_int = self.public_key.n, self.public_key.max_int
+        if np.isscalar(other):
+            enc = FixedPointNumber.encode(other, n, max_int)
+            pt, pt_exponent = enc.encoding, enc.exponent
+            if not 0 <= pt < n:
+                raise ValueError(f"PaillierEncryptedNumber.__mul__: Scalar out ofbounds: {pt}")
+            res_expo = self._expo + np.int32(pt_exponent)
+            res = self._pow(self.words, [pt], np.array([pt >= n - max_int]))
+            return self._wrap(res, res_expo, self.__length)
+        if len(other) != self.__length:
+            raise ValueError("PaillierEncryptedNumber.__mul__: Multiply size mismatch")
+        h = self._h()
+        residues, pexpo = _fp.encode_array(other, n, max_int, h.n_words)
+        pts = engine.words_to_ints(residues)
+        neg = np.array([p >= n - max_int for p in pts])
+        res_expo = self._expo + pexpo
+        res = self._pow(self.words, pts, neg)
+        return self._wrap(res, res_expo, self.__length)
+
+    def __raw_add(self, other):
+        """ipcl_python.py:490-526."""
+        if isinstance(other, (np.ndarray, list)):
+            if self.__length != len(other):
+                raise ValueError("PaillierEncryptedNumber.__raw_add: array(list) size mismatch with PaillierEncryptedNumber")
+            other = self.public_key.encrypt(other, apply_obfuscator=False)
+        elif np.isscalar(other) and isinstance(other, (int, float, np.integer, np.floating)):
+            other = self.public_key.encrypt(other, apply_obfuscator=False)
+        elif isinstance(other, PaillierEncryptedNumber):
+            if self.public_key != other.public_key:
+                raise ValueError("PaillierEncryptedNumber.__raw_add: PublicKey mismatch")
+            if self.__length != len(other) and len(other) > 1:
+                raise ValueError("PaillierEncryptedNumber.__raw_add: CipherText size mismatch with PaillierEncryptedNumber")
+        else:
+            raise TypeError(f"PaillierEncryptedNumber.__raw_add: unsupported operand {type(other)}")
+        x_ct, y_ct, res_expo = self.__align_exponent(self.words, self._expo, other.words, other._expo)
+        res = self._h().ct_add(x_ct, y_ct)
+        return self._wrap(res, res_expo, self.__length)
+
+    def increase_exponent_to(self, x_ct, x_expo, exponent: int):
+        """ipcl_python.py:528-568: raise every element of x to `exponent` (ct^(2^delta) where delta > 0)."""
+        words = x_ct.words if isinstance(x_ct, ipclCipherText) else x_ct
+        delta = (np.int64(exponent) - np.asarray(x_expo, dtype=np.int64)).astype(np.int32)
+        if (delta > 0).any():
+            h = self._h()
+            words = words.clone()
+            h.ct_pow2_(words, torch.from_numpy(np.ascontiguousarray(delta)).to(h.device))
+        return ipclCipherText(self.public_key.pubkey, words) if isinstance(x_ct, ipclCipherText) else words
+
+    def __align_exponent(self, x_ct: torch.Tensor, x_expo, y_ct: torch.Tensor, y_expo):
+        """ipcl_python.py:570-741: per element, the side with the smaller exponent is multiplied by
+        2^delta (as ciphertext^(2^delta)); a length-1 y broadcasts."""
+        h = self._h()
+        xe = np.asarray(x_expo, dtype=np.int64)
+        ye = np.asarray(y_expo, dtype=np.int64)
+        if y_ct.shape[0] == 1 and x_ct.shape[0] > 1:
+            ye = np.broadcast_to(ye, xe.shape)
+        res = np.maximum(xe, ye)
+        dx = (res - xe).astype(np.int32)
+        dy = (res - ye).astype(np.int32)
+        if (dx > 0).any():
+            x_ct = x_ct.clone()
+            h.ct_pow2_(x_ct, torch.from_numpy(np.ascontiguousarray(dx)).to(h.device))
+        if (dy > 0).any():
+            if y_ct.shape[0] == 1 and x_ct.shape[0] > 1:
+                y_ct = y_ct.expand(x_ct.shape[0], -1).contiguous()
+            else:
+                y_ct = y_ct.clone()
+            h.ct_pow2_(y_ct, torch.from_numpy(np.ascontiguousarray(dy)).to(h.device))
+        return x_ct, y_ct, res.astype(np.int32)
+
+    def length(self) -> int:
+        return self.__length
+
+    # -- reductions -----------------------------------------------------------------
+    def _tree_product(self, ct: torch.Tensor, group: int) -> torch.Tensor:
+        """[G*group, W] -> [G, W]: product of each run of `group` consecutive ciphertexts modulo n^2.
+        The result does not depend on the association order, so it equals the reference's
+        pad-with-E(0)=1-and-rotate scheme (ipcl_python.py:810-827) bit for bit."""
+        h = self._h()
+        W = ct.shape[1]
+        x = ct.reshape(-1, group, W)
+        while x.shape[1] > 1:
+            g = x.shape[1]
+            half = g // 2
+            a = x[:, :half].reshape(-1, W).contiguous()
+            b = x[:, half:2 * half].reshape(-1, W).contiguous()
+            prod = h.ct_add(a, b).reshape(-1, half, W)
+            x = torch.cat([prod, x[:, 2 * half:]], dim=1) if g % 2 else prod
+        return x.reshape(-1, W).contiguous()
+
+    def sum(self) -> "PaillierEncryptedNumber":
+        """ipcl_python.py:746-762 (intended behaviour)."""
+        max_exponent = int(self._expo.max())
+        aligned = self.increase_exponent_to(self.words, self._expo, max_exponent)
+        return self._wrap(self._tree_product(aligned, len(self)), [max_exponent], 1)
+
+    def mean(self) -> "PaillierEncryptedNumber":
+        return self.sum() / len(self)
+
+    def dot(self, other: Union[np.ndarray, list]) -> "PaillierEncryptedNumber":
+        if len(other) != len(self):
+            raise ValueError("PaillierEncryptedNumber.dot: input size mismatch with ciphertext")
+        return (self * other).sum()
+
+    def __matmul(self, other: np.ndarray, m: int, n: int, k: int, rhs: bool = False) -> "PaillierEncryptedNumber":
+        """ipcl_python.py:829-880.  self is (m x n) row-major when rhs is False (result = self @ other,
+        other n x k), or (n x k) when rhs is True (result = other @ self, other m x n).  Output element
+        (i, j) = sum_l ct[.] * pt[.], one aligned tree product per output element."""
+        h = self._h()
+        i_idx, j_idx, l_idx = np.meshgrid(np.arange(m), np.arange(k), np.arange(n), indexing="ij")
+        if rhs:
+            idx_self = (l_idx * k + j_idx).reshape(-1)
+            pts = (other[i_idx, l_idx] if other.ndim == 2 else other[l_idx]).reshape(-1)
+        else:
+            idx_self = (i_idx * n + l_idx).reshape(-1)
+            pts = (other[l_idx, j_idx] if other.ndim == 2 else other[l_idx]).reshape(-1)
+        gather = torch.from_numpy(idx_self).to(h.device)
+        big = PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, self.words[gather].contiguous()),
+                                      self._expo[idx_self], idx_self.shape[0])
+        prod = big * np.asarray(pts)
+        pe = prod._expo.reshape(m * k, n)
+        gmax = pe.max(axis=1)
+        target = np.repeat(gmax, n)
+        words = prod.words.clone()
+        delta = (target - prod._expo).astype(np.int32)
+        if (delta > 0).any():
+            h.ct_pow2_(words, torch.from_numpy(np.ascontiguousarray(delta)).to(h.device))
+        out = self._tree_product(words, n)
+        return self._wrap(out, gmax.astype(np.int32), m * k)
+
+    def __matmul__(self, other: Union[np.ndarray, list]) -> "PaillierEncryptedNumber":
+        """ipcl_python.py:882-903."""
+        if len(self) % len(other) != 0:
+            raise ValueError("PaillierEncryptedNumber.__matmul__: matrix multiply size mismatch")
+        other = np.array(other)
+        if other.ndim not in (1, 2):
+            raise NotImplementedError(f"PaillierEncryptedNumber.__matmul__: input ndim {other.ndim}not supported")
+        n = other.shape[0]
+        k = other.shape[1] if other.ndim == 2 else 1
+        m = len(self) // n
+        return self.__matmul(other, m, n, k)
+
+    def __rmatmul__(self, other: Union[np.ndarray, list]) -> "PaillierEncryptedNumber":
+        """ipcl_python.py:905-925."""
+        other = np.array(other)
+        if other.ndim not in (1, 2):
+            raise NotImplementedError(f"PaillierEncryptedNumber.__rmatmul__: input ndim {other.ndim} not supported")
+        m = other.shape[0] if other.ndim == 2 else 1
+        n = other.shape[1] if other.ndim == 2 else other.shape[0]
+        if len(self) % n != 0:
+            raise ValueError("PaillierEncryptedNumber.__rmatmul__: matrix multiplysize mismatch")
+        k = len(self) // n
+        return self.__matmul(other, m, n, k, rhs=True)
+
+    def __imatmul__(self, other: Union[np.ndarray, list]) -> "PaillierEncryptedNumber":
+        return self @ other
+
+    # keep numpy from broadcasting `ndarray @ PaillierEncryptedNumber` element-wise
+    __array_ufunc__ = None
+
+
+class BNUtils:
+    """ipcl_python.py:933-977."""
+
+    @staticmethod
+    def int2Bytes(val: int) -> bytes:
+        return val.to_bytes((val.bit_length() + 7) // 8, byteorder="little")
+
+    @staticmethod
+    def bytes2Int(val: bytes) -> int:
+        return int.from_bytes(val, "little")
+
+    @staticmethod
+    def int2BN(val: int) -> ipclBigNumber:
+        if val == 0:
+            return ipclBigNumber.Zero
+        if val == 1:
+            return ipclBigNumber.One
+        if val == 2:
+            return ipclBigNumber.Two
+        return ipclBigNumber(BNUtils.int2Bytes(val))
+
+    @staticmethod
+    def BN2int(val: ipclBigNumber) -> int:
+        return BNUtils.bytes2Int(val.to_bytes())

@@ -1,0 +1,258 @@
+"""GPU: the public API (PaillierKeypair / PaillierPublicKey / PaillierPrivateKey / PaillierEncryptedNumber).
+
+(1) The reference's own tests (tests/ipcl_python_test.py) restated — with the assertions that file
+    forgets for the matmul cases; (2) bit parity of every derived operation against the oracle's
+    API-level compositions with the obfuscator randomness injected; (3) container / pickle behaviour
+    exercised by example/ipclpy_example.py."""
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import paillier_oracle as orc
+from pailliercryptolib_python_amd import (
+    PaillierEncryptedNumber,
+    PaillierKeypair,
+    PaillierPrivateKey,
+    PaillierPublicKey,
+    context,
+    engine,
+    hybridControl,
+    hybridMode,
+)
+from pailliercryptolib_python_amd.bindings import ipclPublicKey
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def keys():
+    return PaillierKeypair.generate_keypair(2048)
+
+
+@pytest.fixture(scope="module")
+def fixed():
+    """Bench key with a known DJN base, and the matching oracle key."""
+    okey = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567, bits=2048)
+    raw = ipclPublicKey(okey.n, 2048, True, hs=okey.hs, randbits=okey.randbits)
+    pk = PaillierPublicKey(raw)
+    sk = PaillierPrivateKey(pk, orc.BENCH_P, orc.BENCH_Q)
+    return pk, sk, okey
+
+
+def ct_ints(enc: PaillierEncryptedNumber):
+    return [int(b) for b in enc.ciphertextBN()]
+
+
+# ---- (1) reference tests ---------------------------------------------------------------------------
+def test_add_like_reference(keys):
+    pk, sk = keys
+    x_li = np.ones(100) * np.random.randint(100)
+    y_li = np.ones(100) * np.random.randint(1000)
+    z_li = np.ones(100) * np.random.rand()
+    t_li = list(range(100))
+    en_res = pk.encrypt(x_li) + pk.encrypt(y_li) + pk.encrypt(z_li) + pk.encrypt(t_li)
+    res = x_li + y_li + z_li + t_li
+    de = sk.decrypt(en_res)
+    for i in range(100):
+        assert round(abs(de[i] - res[i]), 7) == 0
+
+
+def test_mul_like_reference(keys):
+    pk, sk = keys
+    x_li = np.ones(100) * np.random.randint(100)
+    y_li = np.ones(100) * np.random.randint(1000) * -1
+    z_li = np.ones(100) * np.random.rand()
+    t_li = list(range(100))
+    en_res = (pk.encrypt(x_li) * y_li + z_li) * t_li
+    de = sk.decrypt(en_res)
+    res = (x_li * y_li + z_li) * t_li
+    for i in range(100):
+        assert round(abs(de[i] - res[i]), 7) == 0
+    x = 9
+    en_x = pk.encrypt(x)
+    for _ in range(12):
+        en_x = en_x + 5000
+        en_x = en_x - 0.2
+        x = x + 5000 - 0.2
+        assert round(abs(sk.decrypt(en_x) - x), 7) == 0
+
+
+def test_matmul_family_with_real_assertions(keys):
+    pk, sk = keys
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        m, n, k = (int(v) for v in rng.integers(1, 7, 3))
+        x, y = rng.random((m, n)), rng.random((n, k))
+        en = pk.encrypt(x.flatten())
+        got = np.array(sk.decrypt(en @ y)).reshape(m, k)
+        assert np.allclose(got, x @ y)
+        xl = rng.random((m, n)).tolist()
+        en_y = pk.encrypt(y.flatten())
+        got = np.array(sk.decrypt(xl @ en_y)).reshape(m, k)
+        assert np.allclose(got, np.array(xl) @ y)
+        en @= y
+        assert np.allclose(np.array(sk.decrypt(en)).reshape(m, k), x @ y)
+    v = rng.random(5)
+    en = pk.encrypt(rng.random(15))
+    assert len(en @ v) == 3
+    with pytest.raises(ValueError):
+        pk.encrypt(rng.random(7)) @ rng.random((3, 2))
+
+
+def test_sum_mean_dot(keys):
+    pk, sk = keys
+    x = np.array([1.5, -2.25, 3.0, 100.125, 7.0])
+    en = pk.encrypt(x)
+    assert abs(sk.decrypt(en.sum()) - x.sum()) < 1e-9
+    assert abs(sk.decrypt(en.mean()) - x.mean()) < 1e-9
+    w = [2.0, -1.0, 0.5, 3.0, -4.0]
+    assert abs(sk.decrypt(en.dot(w)) - float(np.dot(x, w))) < 1e-9
+    mixed = pk.encrypt([1, 2.5, 3])
+    assert abs(sk.decrypt(mixed.sum()) - 6.5) < 1e-12
+
+
+# ---- (2) bit parity of the compositions -------------------------------------------------------------
+def test_encrypt_bits_with_injected_randomness(fixed):
+    pk, sk, okey = fixed
+    vals = [0.0, 1.0, -1.0, 1234.5678, -5111.2834, 7, -7, 10**30, 1e-5, 2.0**60]
+    r_l = orc.synth_r_limbs(21, len(vals), okey.randbits)
+    en = pk.encrypt(vals, r=r_l)
+    want_ct, want_e = orc.api_encrypt(okey, vals, orc.limbs_to_ints(r_l))
+    assert ct_ints(en) == want_ct and en.exponent() == want_e
+    raw = pk.raw_encrypt(vals)
+    assert ct_ints(raw) == orc.api_encrypt(okey, vals, None)[0]
+    dec = sk.decrypt(en)
+    odec = orc.api_decrypt(okey, want_ct, want_e)
+    assert dec == odec and [type(a) for a in dec] == [type(b) for b in odec]   # int when exponent <= 0, as upstream
+    assert sk.raw_decrypt(en) == [orc.decrypt_crt(okey, c) for c in want_ct]
+    assert np.array_equal(sk.decrypt_to_numpy(en), np.array([float(v) for v in vals]))
+
+
+def test_add_mul_sub_div_bits(fixed):
+    pk, sk, okey = fixed
+    rng = np.random.default_rng(5)
+    N = 24
+    a = rng.uniform(-1000, 1000, N)
+    b = list(rng.integers(-50, 50, N).astype(int))          # ints: exponent 0 => alignment in both directions
+    ra, rb = orc.synth_r_limbs(31, N, okey.randbits), orc.synth_r_limbs(32, N, okey.randbits)
+    ea, eb = pk.encrypt(a, r=ra), pk.encrypt([int(v) for v in b], r=rb)
+    oa = orc.api_encrypt(okey, a, orc.limbs_to_ints(ra))
+    ob = orc.api_encrypt(okey, [int(v) for v in b], orc.limbs_to_ints(rb))
+    # ct + ct (mixed exponents), ct + array, ct + scalar, scalar + ct
+    s = ea + eb
+    want = orc.api_add_ct(okey, *oa, *ob)
+    assert (ct_ints(s), s.exponent()) == (want[0], want[1])
+    c = rng.uniform(-10, 10, N)
+    s2 = ea + c
+    want = orc.api_add_plain(okey, *oa, c)
+    assert (ct_ints(s2), s2.exponent()) == (want[0], want[1])
+    s3 = 5000 + eb
+    want = orc.api_add_plain(okey, *ob, 5000)
+    assert (ct_ints(s3), s3.exponent()) == (want[0], want[1])
+    # ct * vector with negatives (inversion path), ct * scalar, negative scalar
+    p = ea * c
+    want = orc.api_mul_plain(okey, *oa, c)
+    assert (ct_ints(p), p.exponent()) == (want[0], want[1])
+    p2 = eb * -3
+    want = orc.api_mul_plain(okey, *ob, -3)
+    assert (ct_ints(p2), p2.exponent()) == (want[0], want[1])
+    p3 = 2.5 * ea
+    want = orc.api_mul_plain(okey, *oa, 2.5)
+    assert (ct_ints(p3), p3.exponent()) == (want[0], want[1])
+    # subtraction: ct - ct, ct - array, array - ct ; division by a scalar
+    d = ea - eb
+    want = orc.api_sub_ct(okey, *oa, *ob)
+    assert (ct_ints(d), d.exponent()) == (want[0], want[1])
+    d2 = ea - list(c)
+    want = orc.api_sub_plain(okey, *oa, list(c))
+    assert (ct_ints(d2), d2.exponent()) == (want[0], want[1])
+    d3 = c - ea
+    neg = orc.api_mul_plain(okey, *oa, -1.0)
+    want = orc.api_add_plain(okey, *neg, c)
+    assert (ct_ints(d3), d3.exponent()) == (want[0], want[1])
+    q = ea / 4.0
+    want = orc.api_mul_plain(okey, *oa, 0.25)
+    assert (ct_ints(q), q.exponent()) == (want[0], want[1])
+    # and the values are right
+    assert np.allclose(sk.decrypt(d), a - np.array(b))
+    assert np.allclose(sk.decrypt(p), a * c)
+
+
+def test_broadcast_rules(fixed):
+    pk, sk, okey = fixed
+    vec = pk.encrypt([1.0, 2.0, 3.0], r=orc.synth_r_limbs(1, 3, okey.randbits))
+    one = pk.encrypt(10, r=orc.synth_r_limbs(2, 1, okey.randbits))
+    assert sk.decrypt(vec + one) == [11.0, 12.0, 13.0]
+    assert sk.decrypt(one + vec) == [11.0, 12.0, 13.0]            # length-1 left operand swaps (ipcl_python.py:369-375)
+    two = pk.encrypt([1.0, 2.0])
+    with pytest.raises(ValueError):
+        vec + two
+    with pytest.raises(ValueError):
+        vec + [1.0, 2.0]
+    with pytest.raises(ValueError):
+        vec * [1.0, 2.0]
+    other_pk, _ = PaillierKeypair.generate_keypair(1024)
+    with pytest.raises(ValueError):
+        vec + other_pk.encrypt([1.0, 2.0, 3.0])
+
+
+# ---- (3) containers, errors, pickling ----------------------------------------------------------------
+def test_container_protocol(fixed):
+    pk, sk, okey = fixed
+    en = pk.encrypt(list(range(10)))
+    assert len(en) == en.length() == 10
+    assert sk.decrypt(en[3]) == 3 and sk.decrypt(en[2:5]) == [2, 3, 4]
+    assert [sk.decrypt(e) for e in en] == list(range(10))
+    assert en.exponent(4) == 0 and int(en.ciphertextBN(4)) == ct_ints(en)[4]
+    for bad in (10, -1):
+        with pytest.raises(IndexError):
+            en[bad]
+        with pytest.raises(IndexError):
+            en.exponent(bad)
+        with pytest.raises(IndexError):
+            en.ciphertextBN(bad)
+    before = ct_ints(en)
+    en.apply_obfuscator()
+    assert ct_ints(en) != before and sk.decrypt(en) == list(range(10))
+    with pytest.raises(ValueError):
+        pk.encrypt(np.ones((2, 2)))
+    with pytest.raises(ValueError):
+        pk.encrypt(["a"])
+    with pytest.raises(TypeError):
+        pk.encrypt(np.array([1, 2], dtype=np.uint8))
+    wrong_pk, wrong_sk = PaillierKeypair.generate_keypair(1024)
+    with pytest.raises(ValueError):
+        wrong_sk.decrypt(en)
+
+
+def test_pickle_roundtrip_like_the_example(fixed):
+    pk, sk, okey = fixed
+    en = pk.encrypt([1.5, -2.5, 3.0])
+    pk2 = pickle.loads(pickle.dumps(pk))
+    sk2 = pickle.loads(pickle.dumps(sk))
+    en2 = pickle.loads(pickle.dumps(en))
+    assert pk2 == pk and sk2 == sk and pk2.n == pk.n
+    assert ct_ints(en2) == ct_ints(en) and en2.exponent() == en.exponent()
+    assert sk2.decrypt(en2) == [1.5, -2.5, 3.0]
+    assert sk.decrypt(pk2.encrypt(4.25) + en2[0]) == 5.75
+    state = pk.pubkey.__getstate__()
+    assert state[0] == 1 and state[2] == 2048 and state[4] == 1024 and len(state[1]) == 256
+
+
+def test_copy_constructor_and_qat_shims(fixed):
+    pk, sk, okey = fixed
+    assert PaillierPublicKey(pk).n == pk.n
+    assert context.initializeContext("QAT") is True and context.isQATRunning() is False
+    hybridControl.setHybridMode(hybridMode.OPTIMAL)
+    assert hybridControl.getHybridMode() == hybridMode.OPTIMAL
+    hybridControl.setHybridOff()
+    assert context.terminateContext() is True
+
+
+def test_key_sizes_1024_default_and_non_djn():
+    pk, sk = PaillierKeypair.generate_keypair()           # n_length=1024, DJN
+    x = np.random.default_rng(9).uniform(-1e6, 1e6, 100)  # BASELINE config[0]: 100 random floats, bit-exact round trip
+    assert np.array_equal(np.array(sk.decrypt(pk.encrypt(x))), x)
+    pk2, sk2 = PaillierKeypair.generate_keypair(1024, False)
+    assert sk2.decrypt(pk2.encrypt([1.25, -7]) * 2) == [2.5, -14]

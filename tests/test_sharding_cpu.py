@@ -1,0 +1,45 @@
+"""CPU: the multi-GPU batch partition and the final gather, exercised with world_size 2 over gloo."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pailliercryptolib_python_amd import sharding
+
+
+def test_shard_bounds_cover_the_batch_exactly():
+    for n in (0, 1, 7, 8, 9, 1000, 1 << 20):
+        for world in (1, 2, 3, 8):
+            b = sharding.shard_bounds(n, world)
+            assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [e - s for s, e in b]
+            assert max(sizes) - min(s for s in sizes if s or n == 0 or True) <= -(-n // world)
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = torch.arange(n_total * 4, dtype=torch.int32).reshape(n_total, 4)
+    s, e = sharding.my_shard(n_total, rank, world)
+    out = sharding.gather_rows(full[s:e].contiguous(), n_total)
+    q.put((rank, bool(torch.equal(out, full))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [10, 11, 1])
+def test_gather_rows_world2_gloo(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n_total) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
