@@ -54,16 +54,27 @@ struct MontCtx {
 // ---- lane-group helpers -------------------------------------------------------------------------
 template <int T> PAI_DEV int group_lane() { return (int)(threadIdx.x & (T - 1)); }
 
+// Cross-lane moves inside a lane group.  T = 2 and 4 use DPP (a VALU move, no LDS pipe, short
+// latency); T = 8 falls back to ds_bpermute through __shfl.
+//   quad_perm control = p0 | p1<<2 | p2<<4 | p3<<6 ; row_shl:1 = 0x101 ; row_shr:1 = 0x111
+template <int CTRL> PAI_DEV uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);   // bound_ctrl: missing source -> 0
+}
 // value held by lane 0 of the caller's group
 template <int T> PAI_DEV uint32_t bcast0(uint32_t v) {
     if constexpr (T == 1) return v;
+    else if constexpr (T == 2) return dpp_mov<0xA0>(v);          // quad_perm [0,0,2,2]
+    else if constexpr (T == 4) return dpp_mov<0x00>(v);          // quad_perm [0,0,0,0]
     else return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63) & ~(T - 1)), 64);
 }
 // value held by the next lane of the group (lane T-1 receives 0)
 template <int T> PAI_DEV uint32_t from_next(uint32_t v) {
     if constexpr (T == 1) return 0u;
     else {
-        uint32_t r = (uint32_t)__shfl_down((int)v, 1, 64);
+        uint32_t r;
+        if constexpr (T == 2) r = dpp_mov<0xF5>(v);              // quad_perm [1,1,3,3]
+        else if constexpr (T == 4) r = dpp_mov<0x101>(v);        // row_shl:1  (lane i <- lane i+1)
+        else r = (uint32_t)__shfl_down((int)v, 1, 64);
         return (group_lane<T>() == T - 1) ? 0u : r;
     }
 }
@@ -71,7 +82,10 @@ template <int T> PAI_DEV uint32_t from_next(uint32_t v) {
 template <int T> PAI_DEV uint32_t from_prev(uint32_t v) {
     if constexpr (T == 1) return 0u;
     else {
-        uint32_t r = (uint32_t)__shfl_up((int)v, 1, 64);
+        uint32_t r;
+        if constexpr (T == 2) r = dpp_mov<0xA0>(v);              // quad_perm [0,0,2,2]
+        else if constexpr (T == 4) r = dpp_mov<0x111>(v);        // row_shr:1  (lane i <- lane i-1)
+        else r = (uint32_t)__shfl_up((int)v, 1, 64);
         return (group_lane<T>() == 0) ? 0u : r;
     }
 }
@@ -154,11 +168,17 @@ struct Rows {
             uint64_t cin = ((uint64_t)cin_hi << 32) | cin_lo;
             while (__any(cin != 0)) {
                 uint64_t cc = cin;
+                // the incoming carry (< 2^36) normally dies within the first two limbs: ripple in
+                // groups of four limbs and stop as soon as no lane of the wave has a carry left
 #pragma unroll
-                for (int j = 0; j < NLL; ++j) {
-                    uint64_t t = (uint64_t)r[j] + cc;
-                    r[j] = (uint32_t)t & RMASK;
-                    cc = t >> RB;
+                for (int j0 = 0; j0 < NLL; j0 += 4) {
+#pragma unroll
+                    for (int j = j0; j < j0 + 4 && j < NLL; ++j) {
+                        uint64_t t = (uint64_t)r[j] + cc;
+                        r[j] = (uint32_t)t & RMASK;
+                        cc = t >> RB;
+                    }
+                    if (!__any(cc != 0)) break;
                 }
                 cin = (uint64_t)from_prev<T>((uint32_t)cc);   // 0 or 1 now
             }
@@ -246,7 +266,7 @@ PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32
         for (int u = 0; u < U; ++u) bv[u] = b_ptr[(blk * U + u) * bstride];
         uint32_t low[U];
         RW::template block<true, true>(acc, a, bv, nm, n0inv, low);
-        if (++since == NORM_BLOCKS) { RW::normalize(acc); since = 0; }
+        if (++since == NORM_BLOCKS && blk != NB - 1) { RW::normalize(acc); since = 0; }   // finish() takes lazy columns
     }
     RW::finish(acc, r);
 }
@@ -278,7 +298,7 @@ PAI_DEV void mul_plain(uint32_t (&hi)[NLL], const uint32_t (&init)[NLL], const u
 #pragma unroll
             for (int u = 0; u < U; ++u) lo_ptr[(blk * U + u) * lstride] = low[u];
         }
-        if (++since == NORM_BLOCKS) { RW::normalize(acc); since = 0; }
+        if (++since == NORM_BLOCKS && blk != NB - 1) { RW::normalize(acc); since = 0; }   // finish() takes lazy columns
     }
     RW::finish(acc, hi);
 }
@@ -312,7 +332,7 @@ PAI_DEV void mont_redc(uint32_t (&r)[NLL], const uint32_t (&lo)[NLL], const uint
         }
         uint32_t low[U];
         RW::template block<false, true>(acc, lo, bv, nm, n0inv, low);
-        if (++since == NORM_BLOCKS) { RW::normalize(acc); since = 0; }
+        if (++since == NORM_BLOCKS && blk != NB - 1) { RW::normalize(acc); since = 0; }   // finish() takes lazy columns
     }
     RW::finish(acc, r);
 }
