@@ -152,12 +152,13 @@ def main() -> None:
         enc = ck.gmp_encrypt_djn if use_gmp else ck.encrypt_djn
         dec = ck.gmp_decrypt_crt if use_gmp else ck.decrypt_crt
         threads = co.max_threads()
-        r_host = engine.to_host_words(r[: 64 * threads])
+        cap = min(B, 4096 * threads)
+        r_host = engine.to_host_words(r[:cap])
         probe = 4 * threads
         t1 = time.perf_counter()
         dec(enc(res[:probe], r_host[:probe]))
         t_probe = time.perf_counter() - t1
-        sample = int(min(64 * threads, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-3))))
+        sample = int(min(cap, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-3))))
         t1 = time.perf_counter()
         c_ct = enc(res[:sample], r_host[:sample])
         c_m = dec(c_ct)

@@ -29,6 +29,7 @@ SOURCES = [
     "geo_28x8.hip",
     "geo_36x8.hip",
     "inv_eea.hip",
+    "wide_kernels.hip",
     "paillier_capi.hip",
 ]
 

@@ -47,6 +47,13 @@ const GeoOps* geo_ops_36x8();
 // smallest geometry whose capacity covers a modulus of `bits` bits (R = 2^(29 NL) > 4 M), or nullptr
 const GeoOps* geo_for_bits(int bits);
 
+// Wide engine (one integer per lane, mont_wide.hpp): limb count serving a modulus of `bits` bits (0 = none),
+// table scratch words, and the stage-A decrypt launcher (grid = gridx x 2 primes, 256 elements per block).
+int wide_nl_for_bits(int bits);
+size_t wide_table_words(int nl, size_t blocks);
+bool launch_dec_a_wide(int nl, hipStream_t s, int gridx, const DecAParams& P, const uint32_t* ct, uint32_t* u_out, int n,
+                       uint32_t* table);
+
 // x = a^-1 mod M for `count` values of `words` 32-bit words each (words in {64,128,192,256}); *fail counts
 // non-invertible inputs.  Returns false if `words` has no instantiation.
 bool launch_inv_eea(hipStream_t s, int words, const uint32_t* mod, const uint32_t* a, uint32_t* out, int count,

@@ -118,14 +118,16 @@ struct ModSetup {
     const GeoOps* geo = nullptr;
     MontCtx* d_ctx = nullptr;
     int bits = 0, w32 = 0;
-    void init(const Limbs& mod_) {
+    int nl = 0;       // radix-29 limbs of the Montgomery representation (R = 2^(29 nl))
+    // nl_override != 0: constants for the wide engine's limb count instead of the lane-group geometry's
+    void init(const Limbs& mod_, int nl_override = 0) {
         M = mod_;
         require(hbn::is_odd(M), "modulus must be odd");
         bits = hbn::bitlen(M);
         w32 = words_for_bits(bits);
         geo = geo_for_bits(bits);
         if (!geo) throw PaiError(PAI_E_UNSUPPORTED, "modulus wider than 8192 bits is not supported");
-        const int nl = geo->nl;
+        nl = nl_override ? nl_override : geo->nl;
         R = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * nl), M);
         R2 = hbn::mulmod(R, R, M);
         R3 = hbn::mulmod(R2, R, M);
@@ -250,6 +252,7 @@ struct pai_privkey {
     uint32_t* d_hR[2] = {nullptr, nullptr};
     uint32_t* d_pinvqR = nullptr;
     int u_words = 0;
+    int wide_nl = 0;              // != 0: stage A runs on the wide engine with this many limbs
     DevBuf table, ubuf;
     std::mutex mu;
 };
@@ -397,7 +400,7 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         pk->ct_words = 2 * pk->n_words;
         pk->nsq = hbn::mul(pk->n, pk->n);
         pk->msq.init(pk->nsq);
-        const int nl = pk->msq.geo->nl;
+        const int nl = pk->msq.nl;
         pk->d_nR = upload_r29(hbn::mulmod(pk->n, pk->msq.R, pk->nsq), nl);
         pk->d_nexp = upload_words(pk->n, pk->n_words);
         pk->d_nsq_words = upload_words(pk->nsq, pk->ct_words);
@@ -625,10 +628,13 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
         const Limbs g = hbn::add(pk->n, one);
         const Limbs prime[2] = {p, q};
         // both primes share the geometry of the wider one
+        Limbs q2 = hbn::mul(q, q);
+        sk->wide_nl = wide_nl_for_bits(hbn::bitlen(q2));       // 0: fall back to the lane-group kernel
+        if (const char* env = std::getenv("PAI_DISABLE_WIDE")) { if (env[0] == '1') sk->wide_nl = 0; }
         for (int w = 0; w < 2; ++w) {
             const Limbs& s = prime[w];
             Limbs s2 = hbn::mul(s, s);
-            sk->sq[w].init(s2);
+            sk->sq[w].init(s2, sk->wide_nl);
             sk->pr[w].init(s);
         }
         require(sk->sq[0].geo == sk->sq[1].geo && sk->pr[0].geo == sk->pr[1].geo,
@@ -637,7 +643,7 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
         for (int w = 0; w < 2; ++w) {
             const Limbs& s = prime[w];
             const Limbs& s2 = sk->sq[w].M;
-            sk->d_r3[w] = upload_r29(sk->sq[w].R3, sk->sq[w].geo->nl);
+            sk->d_r3[w] = upload_r29(sk->sq[w].R3, sk->sq[w].nl);
             Limbs e = hbn::sub(s, one);
             sk->ebits[w] = hbn::bitlen(e);
             sk->ewords[w] = words_for_bits(sk->ebits[w]);
@@ -693,8 +699,14 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         hipStream_t s = (hipStream_t)stream;
         const GeoOps* ga = sk->sq[0].geo;
         const GeoOps* gb = sk->pr[0].geo;
-        const int gridx = grid_for(ga, N, dev.ncu, 1);          // x2 primes => 2 workgroups per CU
-        sk->table.ensure(ga->table_words((size_t)gridx * 2) * 4);
+        int gridx = grid_for(ga, N, dev.ncu, 1);          // x2 primes => 2 workgroups per CU
+        if (sk->wide_nl) {
+            const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
+            gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)dev.ncu / 2));   // x2 primes => one workgroup per CU
+            sk->table.ensure(wide_table_words(sk->wide_nl, (size_t)gridx * 2) * 4);
+        } else {
+            sk->table.ensure(ga->table_words((size_t)gridx * 2) * 4);
+        }
         sk->ubuf.ensure(2 * N * (size_t)sk->u_words * 4);
         DecAParams A;
         for (int w = 0; w < 2; ++w) {
@@ -709,7 +721,12 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         g_last_times.clear();
         {
             ScopedKernelTimer t("k_dec_a", s);
-            ga->dec_a(s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>());
+            if (sk->wide_nl) {
+                if (!launch_dec_a_wide(sk->wide_nl, s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))
+                    throw PaiError(PAI_E_INTERNAL, "no wide kernel for this limb count");
+            } else {
+                ga->dec_a(s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>());
+            }
             t.stop();
         }
         HIP_CHECK(hipGetLastError());
