@@ -46,6 +46,19 @@ CANON_MAC_ENC, CANON_MAC_DEC = 41.52e6, 20.86e6
 BYTES_ENC, BYTES_DEC = 648, 520   # algorithmic bytes per op
 
 
+def executed_macs_decrypt(prime_bits: int = 1024, nl: int = 36, window: int = 5, ct_bits: int = 4096) -> float:
+    """29x29-bit MACs actually issued per decrypted element by k_dec_a_padic (both primes): the p-adic digit
+    engine does a squaring in (12*36+12*24+12*12) + 36^2 + 2*36^2 MACs and a multiplication in 5*36^2."""
+    sq = (12 * nl + 12 * (nl - 12) + 12 * (nl - 24)) + nl * nl + 2 * nl * nl
+    mul = 5 * nl * nl
+    nwin = -(-prime_bits // window)
+    n_sq = window * (nwin - 1)
+    n_mul = (nwin - 1) * (1 - 2.0 ** -window) + (2 ** window - 2) + 1          # windows + table + leaving Montgomery form
+    nd = -(-ct_bits // (29 * nl))
+    conv = nd * 4 * nl * nl
+    return 2.0 * (n_sq * sq + n_mul * mul + conv)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +191,7 @@ def main() -> None:
         t_deca = kern.get("k_dec_a", 0.0) * 1e-3
         t_enc = kern.get("k_encrypt(djn)", 0.0) * 1e-3
         achieved = (CANON_MAC_DEC * B / t_deca) if t_deca > 0 else None
+        executed = (executed_macs_decrypt() * B / t_deca) if t_deca > 0 else None
         line = {
             "metric": "Paillier encrypt+decrypt ops/sec, 2048-bit key",
             "value": value,
@@ -198,11 +212,16 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "valu_int",
-                "kernel": "k_dec_a (CRT half-size modexps)",
+                "kernel": "k_dec_a_padic (CRT-decrypt stage A: (ct mod s^2)^(s-1) for both primes)",
                 "achieved": (achieved / 1e12) if achieved else None,
                 "peak": PEAK_MAC32_PER_S / 1e12,
                 "unit": "T MAC32/s (canonical 32x32->64 multiply-accumulates, SURVEY §8d)",
                 "frac": (achieved / PEAK_MAC32_PER_S) if achieved else None,
+                "note": "achieved/frac price the kernel at the CANONICAL algorithm's work (SURVEY §8d); the kernel runs an "
+                        "asymptotically cheaper algorithm (arithmetic mod s on base-s digit pairs instead of mod s^2), "
+                        "so the canonical fraction can exceed 1 — executed_* is the issue-rate view of kernel quality",
+                "executed_T_MAC_s": (executed / 1e12) if executed else None,
+                "executed_frac": (executed / PEAK_MAC32_PER_S) if executed else None,
                 "kernel_ms": kern,
                 "traffic": None,
                 "hbm": {

@@ -54,6 +54,13 @@ size_t wide_table_words(int nl, size_t blocks);
 bool launch_dec_a_wide(int nl, hipStream_t s, int gridx, const DecAParams& P, const uint32_t* ct, uint32_t* u_out, int n,
                        uint32_t* table);
 
+// p-adic digit engine for CRT-decrypt stage A (mont_padic.hpp / kernels_padic.hpp)
+struct DecPadicParams;
+int padic_nl_for_prime_bits(int bits);
+size_t padic_table_words(int nl, size_t blocks);
+bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out,
+                        int n, uint32_t* table);
+
 // x = a^-1 mod M for `count` values of `words` 32-bit words each (words in {64,128,192,256}); *fail counts
 // non-invertible inputs.  Returns false if `words` has no instantiation.
 bool launch_inv_eea(hipStream_t s, int words, const uint32_t* mod, const uint32_t* a, uint32_t* out, int count,

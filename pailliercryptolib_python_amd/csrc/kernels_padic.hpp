@@ -1,0 +1,186 @@
+// CRT-decrypt stage A on the p-adic digit engine (mont_padic.hpp):
+//   for s in {p, q} (blockIdx.y):  L_s = L_s( ct^(s-1) mod s^2 ) = ((ct^(s-1) mod s^2) - 1) / s      (< s)
+// written as packed words into u_out[which][i][0 .. u_words) (upper words zero).  Stage B then only has
+// to multiply by h_s and recombine (DecBParams::u_is_L).  Replaces, for keys whose primes fit NL limbs,
+// the modexp modulo s^2 of k_dec_a / k_dec_a_wide with arithmetic modulo s on digit pairs.
+#pragma once
+#include "kernels_wide.hpp"
+#include "mont_padic.hpp"
+
+namespace pai {
+
+struct DecPadicParams {
+    const MontCtx* pr[2];        // moduli p, q (NL limbs, R = 2^(29 NL))
+    const uint32_t* pm1[2];      // p - 1, q - 1 as radix-29 limbs (NLMAX padded)
+    const uint32_t* kdig[2];     // [ND][2][NL]: digit pairs of R^(i+2) mod s^2, i = 0 .. ND-1
+    const uint32_t* expo[2];     // s - 1, packed u32 words
+    int ewords[2], ebits[2];
+    int nd;                      // base-R digits of a ciphertext
+    int ct_words, u_words;
+};
+
+template <int NL, int U, int WB>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n,
+              uint4* __restrict__ table) {
+    using E = Padic<NL, U>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int which = blockIdx.y;
+    const MontCtx* ctx = P.pr[which];
+    const uint32_t* __restrict__ nm = ctx->n;
+    const uint32_t n0inv = ctx->n0inv;
+    const uint32_t* __restrict__ pm1 = P.pm1[which];
+    const uint32_t* __restrict__ kdig = P.kdig[which];
+    const uint32_t* __restrict__ expo = P.expo[which];
+    const int ewords = P.ewords[which], ebits = P.ebits[which];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* A = reinterpret_cast<uint4*>(lds + wave * 3 * E::DIGIT_WORDS) + lane;
+    uint4* B = A + E::NC * 64;
+    uint4* M = B + E::NC * 64;        // quotient digits of the first half of the product rule
+    const size_t nslots = (size_t)gridDim.x * gridDim.y * BLOCK_THREADS;
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK_THREADS + threadIdx.x;
+    // table entry e: digit d (0 = first, 1 = second), chunk c
+    auto tbl = [&](int e, int d, int c) -> uint4& { return table[(((size_t)e * 2 + d) * E::NC + c) * nslots + slot]; };
+    const int nwin = (ebits + WB - 1) / WB;
+    const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        const uint32_t* row = ct + (size_t)es * P.ct_words;
+        // ---- digit form of ct:  sum_i  (c_i, 0) * digits(R^(i+2) mod s^2) -----------------------------
+        {
+            uint32_t sw[NL], sv[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { sw[j] = 0; sv[j] = 0; }
+#pragma unroll 1
+            for (int i = 0; i < P.nd; ++i) {
+                wave_lds_fence();
+#pragma unroll 1
+                for (int c = 0; c < E::NC; ++c) {
+                    uint32_t t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = row_limb(row, P.ct_words, NL * i + 4 * c + k);
+                    E::st(A, c, make_uint4(t[0], t[1], t[2], t[3]));
+                }
+                wave_lds_fence();
+                const uint32_t* __restrict__ ka = kdig + (size_t)(2 * i) * NL;
+                const uint32_t* __restrict__ kb = ka + NL;
+                uint32_t w[NL], v[NL];
+                E::mm1_mul(w, M, A, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(ka, blk, xv); }, nm, n0inv);
+                {   // v = (c_i * kb - m + R p + m' p) / R   (the element's second digit is zero)
+                    uint64_t acc[E::NW];
+                    E::mm2_init(acc, M);
+                    uint32_t dummy[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+                    for (int blk = 0; blk < E::NB; ++blk) {
+                        uint32_t xv[U], q[U];
+                        E::digits_uniform(kb, blk, xv);
+                        E::template block<true, 0, NL, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);
+                        if (blk != E::NB - 1) E::normalize(acc);
+                    }
+                    E::finish(acc, v);
+                }
+#pragma unroll
+                for (int j = 0; j < NL; ++j) { sw[j] += w[j]; sv[j] += v[j]; }
+            }
+            // limb sums (< 2^32) back to 29-bit limbs
+            uint32_t cw = 0, cv = 0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const uint64_t tw = (uint64_t)sw[j] + cw, tv = (uint64_t)sv[j] + cv;
+                sw[j] = (uint32_t)tw & RMASK; cw = (uint32_t)(tw >> RB);
+                sv[j] = (uint32_t)tv & RMASK; cv = (uint32_t)(tv >> RB);
+            }
+            wave_lds_fence();
+            E::store_digit(A, sw);
+            E::store_digit(B, sv);
+            wave_lds_fence();
+        }
+        // ---- table[k] = base^k, k = 1 .. 2^WB - 1 ---------------------------------------------------
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) { tbl(1, 0, c) = E::ld(A, c); tbl(1, 1, c) = E::ld(B, c); }
+        auto from_table = [&](int e, int d) {
+            return [&, e, d](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int c = 0; c < E::UC; ++c) {
+                    const uint4 t = tbl(e, d, E::UC * blk + c);
+                    xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                }
+            };
+        };
+#pragma unroll 1
+        for (int k = 2; k < (1 << WB); ++k) {
+            E::mul(A, B, M, from_table(1, 0), from_table(1, 1), nm, pm1, n0inv);
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
+        }
+        // ---- left-to-right fixed windows; the top window of s - 1 is never zero -----------------------
+        {
+            const int wv = (int)exp_bits(expo, ewords, (nwin - 1) * WB, WB);
+            wave_lds_fence();
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { E::st(A, c, tbl(wv, 0, c)); E::st(B, c, tbl(wv, 1, c)); }
+            wave_lds_fence();
+        }
+#pragma unroll 1
+        for (int wi = nwin - 2; wi >= 0; --wi) {
+            const int wv = (int)exp_bits(expo, ewords, wi * WB, WB);
+#pragma unroll 1
+            for (int s = 0; s < WB; ++s) E::sqr(A, B, M, nm, pm1, n0inv);
+            if (wv != 0) E::mul(A, B, M, from_table(wv, 0), from_table(wv, 1), nm, pm1, n0inv);
+        }
+        // ---- leave Montgomery form: multiply by the plain element 1 = (1, 0) ----------------------------
+        uint32_t w[NL], v[NL];
+        {
+            auto one = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = 0;
+                if (blk == 0) xv[0] = 1;
+            };
+            auto zero = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = 0;
+            };
+            E::mm1_mul(w, M, A, one, nm, n0inv);
+            E::mm2_mul(v, M, A, B, zero, one, nm, pm1, n0inv);
+        }
+        // u = w + v s with w == 1 (mod s), w < 2s: L = v (+1 if w = s + 1), reduced into [0, s)
+        {
+            uint32_t wc[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) wc[j] = w[j];
+            E::cond_sub(wc, nm);
+            bool same = true;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) same = same && (wc[j] == w[j]);
+            uint32_t carry = same ? 0u : 1u;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const uint32_t t = v[j] + carry;
+                v[j] = t & RMASK;
+                carry = t >> RB;
+            }
+            E::cond_sub(v, nm);
+            E::cond_sub(v, nm);
+        }
+        if (live) {
+            uint32_t* orow = u_out + ((size_t)which * n + ei) * P.u_words;
+            constexpr int MAXW = (RB * NL + 31) / 32;
+#pragma unroll
+            for (int k = 0; k < MAXW; ++k) {
+                const int j0 = (32 * k) / RB, s0 = 32 * k - RB * j0;
+                uint64_t t = (uint64_t)v[j0] >> s0;
+                if (j0 + 1 < NL) t |= (uint64_t)v[j0 + 1] << (RB - s0);
+                if (j0 + 2 < NL) t |= (uint64_t)v[j0 + 2] << (2 * RB - s0);
+                if (k < P.u_words) orow[k] = (uint32_t)t;
+            }
+            for (int k = MAXW; k < P.u_words; ++k) orow[k] = 0;
+        }
+        wave_lds_fence();
+    }
+}
+
+}  // namespace pai

@@ -224,6 +224,7 @@ struct DecBParams {
     const uint32_t* hR[2];       // hp R mod p, hq R mod q
     const uint32_t* pinvqR;      // (p^-1 mod q) R mod q
     int u_words, pt_words;
+    int u_is_L;                  // stage A already produced L_s(u_s) (p-adic engine) instead of u_s
 };
 
 template <class G>
@@ -248,11 +249,15 @@ k_dec_b(DecBParams P, const uint32_t* __restrict__ u_in /*[2][n][u_words]*/, uin
             // L = (u - 1) / s = low half of (u_low * sinv2 + nsinv2)
             uint32_t ulo[G::NLL], c[G::NLL], init[G::NLL], hi[G::NLL];
             load_elem_off<G>(ulo, u_in + ((size_t)which * n + es) * P.u_words, P.u_words, 0);
-            stage_b<G>(ulo, ldsA);
-            load_const_slice<G>(c, P.sinv2[which]);
-            load_const_slice<G>(init, P.nsinv2[which]);
-            mul_plain<G::NLL, G::U, G::T>(hi, init, c, ldsA + e, G::EPB, ldsB + e, G::EPB);
-            wave_lds_fence();
+            if (P.u_is_L) {
+                stage_b<G>(ulo, ldsB);                                   // the input already is L
+            } else {
+                stage_b<G>(ulo, ldsA);
+                load_const_slice<G>(c, P.sinv2[which]);
+                load_const_slice<G>(init, P.nsinv2[which]);
+                mul_plain<G::NLL, G::U, G::T>(hi, init, c, ldsA + e, G::EPB, ldsB + e, G::EPB);
+                wave_lds_fence();
+            }
             // ms = L * h mod s  with L read back from LDS as the multiplier
             load_const_slice<G>(c, P.hR[which]);
             mont_mul<G::NLL, G::U, G::T>(ms[which], c, ldsB + e, G::EPB, nm, n0inv);

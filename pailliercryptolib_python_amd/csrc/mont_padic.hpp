@@ -1,0 +1,297 @@
+// Arithmetic modulo p^2 on base-p digit pairs — the engine behind CRT-decrypt stage A.
+//
+// An element x of Z/p^2 is kept in "Montgomery digit form": two integers (a, b), each of NL limbs of
+// 29 bits (lazy: < 2p + eps, never canonicalised inside the exponentiation), with
+//        a + b p  ==  x R   (mod p^2),        R = 2^(29 NL)  >>  p   (R/p >= 2^20).
+// Product rule.  For (a, b) ~ x and (c, d) ~ y let
+//        w  = (a c + m p) / R                     -- Montgomery product mod p, quotient digits m
+//        v  = (a d + b c - m + R p + m' p) / R    -- second Montgomery reduction mod p, quotient m'
+// then  w + v p == (a + b p)(c + d p) R^-1 (mod p^2), i.e. (w, v) ~ x y.   Proof: a c = R w - m p and
+// R v = a d + b c - m + (R + m') p, hence (a + b p)(c + d p) == a c + (a d + b c) p == R w + R v p.
+// The b d p^2 term vanishes and every reduction is modulo p (NL limbs) instead of p^2 (2 NL limbs):
+// a multiplication costs 5 NL^2 limb products instead of 8 NL^2, a squaring (a^2 symmetric by limb
+// classes, 2 a b once) ~3.7 NL^2 instead of ~6.7 NL^2.  There is no division anywhere: the input is
+// brought into digit form by applying the rule to its base-R digits and host-precomputed digit
+// pairs of R^(i+2) mod p^2, and at the end the second digit of x^(p-1) IS Paillier's L function.
+//
+// Layout: one element per lane; the digit pair lives in LDS (chunk-major, see mont_wide.hpp); the
+// accumulator window (NL + U lazy 64-bit columns, U = 12), the quotient digits m and the first
+// result digit w live in VGPRs; p and p - 1 are wave-uniform (scalar loads).
+#pragma once
+#include "mont_dev.hpp"
+
+namespace pai {
+
+template <int NL, int U>
+struct Padic {
+    static_assert(NL % 4 == 0 && U % 4 == 0 && NL % U == 0 && U <= 16, "geometry");
+    static constexpr int NC = NL / 4;        // four-limb chunks per digit
+    static constexpr int UC = U / 4;         // chunks per row block
+    static constexpr int NB = NL / U;        // row blocks
+    static constexpr int NW = NL + U;        // accumulator window
+    static constexpr int DIGIT_WORDS = NL * 64;   // LDS words of one digit for one wave
+
+    PAI_DEV static uint4 ld(const uint4* x, int c) { return x[c * 64]; }
+    PAI_DEV static void st(uint4* x, int c, uint4 v) { x[c * 64] = v; }
+
+    PAI_DEV static void zero(uint64_t (&acc)[NW]) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc[j] = 0;
+    }
+    PAI_DEV static void normalize(uint64_t (&acc)[NW]) {
+#pragma unroll
+        for (int j = NW - 1; j >= 1; --j) {
+            uint64_t keep = (j == NW - 1) ? acc[j] : (acc[j] & RMASK);
+            acc[j] = keep + (acc[j - 1] >> RB);
+        }
+        acc[0] &= RMASK;
+    }
+    PAI_DEV static void slide(uint64_t (&acc)[NW]) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) acc[j] = acc[j + U];
+#pragma unroll
+        for (int j = NL; j < NW; ++j) acc[j] = 0;
+    }
+    // U digits of an LDS operand for row block `blk`
+    PAI_DEV static void digits(const uint4* x, int blk, uint32_t (&v)[U]) {
+#pragma unroll
+        for (int c = 0; c < UC; ++c) {
+            const uint4 t = ld(x, UC * blk + c);
+            v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+        }
+    }
+    PAI_DEV static void digits_uniform(const uint32_t* __restrict__ k, int blk, uint32_t (&v)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = k[U * blk + u];
+    }
+
+    // One block of U rows:  acc += X * xv  (limbs of X below LO skipped, limbs >= HI taken twice)
+    //                           (+ Y * yv)  + p * q ,  then the window slides by U columns.
+    // q receives the block's quotient digits.  FEED: U limbs of a constant enter at the window top.
+    template <bool HAS_X, int LO, int HI, bool HAS_Y, bool FEED>
+    PAI_DEV static void block(uint64_t (&acc)[NW], const uint4* X, const uint32_t (&xv)[U], const uint4* Y,
+                              const uint32_t (&yv)[U], const uint32_t* __restrict__ nm, uint32_t n0inv,
+                              const uint32_t* __restrict__ feed, int blk, uint32_t (&q)[U]) {
+        uint32_t xv2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv2[u] = xv[u] << 1;
+        if constexpr (FEED) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[NL + u] += feed[U * blk + u];
+        }
+        // low U limbs of the operands (the quotient chain needs them)
+        uint32_t x0[U], y0[U];
+#pragma unroll
+        for (int c = 0; c < UC; ++c) {
+            if (HAS_X && LO < 4 * (c + 1)) {
+                const uint4 t = ld(X, c);
+                x0[4 * c] = t.x; x0[4 * c + 1] = t.y; x0[4 * c + 2] = t.z; x0[4 * c + 3] = t.w;
+            } else {
+                x0[4 * c] = x0[4 * c + 1] = x0[4 * c + 2] = x0[4 * c + 3] = 0;
+            }
+            if constexpr (HAS_Y) {
+                const uint4 t = ld(Y, c);
+                y0[4 * c] = t.x; y0[4 * c + 1] = t.y; y0[4 * c + 2] = t.z; y0[4 * c + 3] = t.w;
+            } else {
+                y0[4 * c] = y0[4 * c + 1] = y0[4 * c + 2] = y0[4 * c + 3] = 0;
+            }
+        }
+        auto xterm = [&](int j, int u) -> uint64_t {           // contribution of limb j of X in row u
+            if (!HAS_X || j < LO) return 0;
+            return (uint64_t)x0[j] * (j >= HI ? xv2[u] : xv[u]);
+        };
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j <= u; ++j) {
+                if (HAS_X && j >= LO) acc[u] += xterm(j, u - j);
+                if constexpr (HAS_Y) acc[u] += (uint64_t)y0[j] * yv[u - j];
+            }
+#pragma unroll
+            for (int j = 1; j <= u; ++j) acc[u] += (uint64_t)nm[j] * q[u - j];
+            q[u] = ((uint32_t)acc[u] * n0inv) & RMASK;
+            acc[u] += (uint64_t)nm[0] * q[u];
+            acc[u + 1] += acc[u] >> RB;
+        }
+#pragma unroll
+        for (int j = 1; j < U; ++j) {
+#pragma unroll
+            for (int u = U - j; u < U; ++u) {
+                if (HAS_X && j >= LO) acc[j + u] += xterm(j, u);
+                if constexpr (HAS_Y) acc[j + u] += (uint64_t)y0[j] * yv[u];
+                acc[j + u] += (uint64_t)nm[j] * q[u];
+            }
+        }
+        // remaining chunks: a pure rank-(2U or 3U) update
+#pragma unroll
+        for (int c = UC; c < NC; ++c) {
+            uint32_t xa[4] = {0, 0, 0, 0}, ya[4] = {0, 0, 0, 0};
+            if constexpr (HAS_X) {
+                if (4 * c >= LO) { const uint4 t = ld(X, c); xa[0] = t.x; xa[1] = t.y; xa[2] = t.z; xa[3] = t.w; }
+            }
+            if constexpr (HAS_Y) { const uint4 t = ld(Y, c); ya[0] = t.x; ya[1] = t.y; ya[2] = t.z; ya[3] = t.w; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (HAS_X && 4 * c >= LO) acc[4 * c + k + u] += (uint64_t)xa[k] * (4 * c >= HI ? xv2[u] : xv[u]);
+                    if constexpr (HAS_Y) acc[4 * c + k + u] += (uint64_t)ya[k] * yv[u];
+                    acc[4 * c + k + u] += (uint64_t)nm[4 * c + k] * q[u];
+                }
+            }
+        }
+        slide(acc);
+    }
+
+    // carry-propagate the low NL columns into canonical 29-bit limbs (registers)
+    PAI_DEV static void finish(const uint64_t (&acc)[NW], uint32_t (&r)[NL]) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const uint64_t t = acc[j] + c;
+            r[j] = (uint32_t)t & RMASK;
+            c = t >> RB;
+        }
+    }
+    PAI_DEV static void store_digit(uint4* x, const uint32_t (&r)[NL]) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) st(x, c, make_uint4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]));
+    }
+
+    // ---- first half of the product rule: w = (X * C + m p) / R, quotient digits m -----------------
+    // CSrc: functor (blk, xv) giving the U digits of C for a row block.
+    // The quotient digits m are parked in LDS (digit buffer M) so that the row-block loop can stay rolled
+    // (a rolled loop cannot index a register array) — the hot loop must fit the 64 KB instruction cache.
+    PAI_DEV static void store_q(uint4* M, int blk, const uint32_t (&q)[U]) {
+#pragma unroll
+        for (int c = 0; c < UC; ++c) st(M, UC * blk + c, make_uint4(q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]));
+    }
+    template <class CSrc>
+    PAI_DEV static void mm1_mul(uint32_t (&w)[NL], uint4* M, const uint4* X, CSrc&& csrc,
+                                const uint32_t* __restrict__ nm, uint32_t n0inv) {
+        uint64_t acc[NW];
+        zero(acc);
+        uint32_t dummy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t xv[U], q[U];
+            csrc(blk, xv);
+            block<true, 0, NL, false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, blk, q);
+            store_q(M, blk, q);
+            if (blk != NB - 1 && ((blk + 1) * U) % 24 == 0) normalize(acc);    // 2^59 per row: every 24 rows
+        }
+        finish(acc, w);
+    }
+    // squaring: C = X, symmetric by limb classes of U limbs (row block b multiplies limbs >= U b)
+    template <int B>
+    PAI_DEV static void mm1_sqr_blocks(uint64_t (&acc)[NW], uint4* M, const uint4* X,
+                                       const uint32_t* __restrict__ nm, uint32_t n0inv) {
+        if constexpr (B < NB) {
+            uint32_t xv[U], q[U], dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+            digits(X, B, xv);
+            block<true, U * B, U * (B + 1), false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, B, q);
+            store_q(M, B, q);
+            if (B != NB - 1) normalize(acc);                                    // doubled products: every block
+            mm1_sqr_blocks<B + 1>(acc, M, X, nm, n0inv);
+        }
+    }
+    PAI_DEV static void mm1_sqr(uint32_t (&w)[NL], uint4* M, const uint4* X,
+                                const uint32_t* __restrict__ nm, uint32_t n0inv) {
+        uint64_t acc[NW];
+        zero(acc);
+        mm1_sqr_blocks<0>(acc, M, X, nm, n0inv);
+        finish(acc, w);
+    }
+
+    // ---- second half: v = (X * D + Y * C - m + R p + m' p) / R --------------------------------------
+    // initial window = (R - 1 - m) + 1 in the low NL columns; p - 1 enters at the top (pm1 = limbs of p - 1)
+    PAI_DEV static void mm2_init(uint64_t (&acc)[NW], const uint4* M) {
+        wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const uint4 t = ld(M, c);
+            acc[4 * c] = (uint64_t)(RMASK - t.x); acc[4 * c + 1] = (uint64_t)(RMASK - t.y);
+            acc[4 * c + 2] = (uint64_t)(RMASK - t.z); acc[4 * c + 3] = (uint64_t)(RMASK - t.w);
+        }
+        acc[0] += 1;
+#pragma unroll
+        for (int j = NL; j < NW; ++j) acc[j] = 0;
+    }
+    template <class DSrc, class CSrc>
+    PAI_DEV static void mm2_mul(uint32_t (&v)[NL], const uint4* M, const uint4* X, const uint4* Y, DSrc&& dsrc,
+                                CSrc&& csrc, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        uint64_t acc[NW];
+        mm2_init(acc, M);
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t xv[U], yv[U], q[U];
+            dsrc(blk, xv);
+            csrc(blk, yv);
+            block<true, 0, NL, true, true>(acc, X, xv, Y, yv, nm, n0inv, pm1, blk, q);
+            if (blk != NB - 1) normalize(acc);                                  // 1.5 * 2^59 per row
+        }
+        finish(acc, v);
+    }
+    // squaring: v = (2 X * Y - m + R p + m' p) / R   (X = first digit, Y = second digit of the same element)
+    PAI_DEV static void mm2_sqr(uint32_t (&v)[NL], const uint4* M, const uint4* X, const uint4* Y,
+                                const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        uint64_t acc[NW];
+        mm2_init(acc, M);
+        uint32_t dummy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t xv[U], q[U];
+            digits(Y, blk, xv);
+            block<true, 0, 0, false, true>(acc, X, xv, X, dummy, nm, n0inv, pm1, blk, q);   // HI = 0: every limb doubled
+            if (blk != NB - 1) normalize(acc);
+        }
+        finish(acc, v);
+    }
+
+    // (A, B) <- (A, B)^2
+    PAI_DEV static void sqr(uint4* A, uint4* B, uint4* M, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
+                            uint32_t n0inv) {
+        uint32_t w[NL], v[NL];
+        mm1_sqr(w, M, A, nm, n0inv);
+        mm2_sqr(v, M, A, B, nm, pm1, n0inv);
+        wave_lds_fence();
+        store_digit(A, w);
+        store_digit(B, v);
+        wave_lds_fence();
+    }
+    // (A, B) <- (A, B) * (C, D), the second operand's digits supplied per row block
+    template <class CSrc, class DSrc>
+    PAI_DEV static void mul(uint4* A, uint4* B, uint4* M, CSrc&& csrc, DSrc&& dsrc, const uint32_t* __restrict__ nm,
+                            const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        uint32_t w[NL], v[NL];
+        mm1_mul(w, M, A, csrc, nm, n0inv);
+        mm2_mul(v, M, A, B, dsrc, csrc, nm, pm1, n0inv);
+        wave_lds_fence();
+        store_digit(A, w);
+        store_digit(B, v);
+        wave_lds_fence();
+    }
+
+    // x (NL limbs, < 4p say) -> canonical [0, p) by up to `times` conditional subtractions, in registers
+    PAI_DEV static void cond_sub(uint32_t (&x)[NL], const uint32_t* __restrict__ nm) {
+        uint32_t d[NL];
+        int32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int32_t t = (int32_t)x[j] - (int32_t)nm[j] + borrow;
+            d[j] = (uint32_t)t & RMASK;
+            borrow = t >> RB;
+        }
+        const bool ge = (borrow == 0);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) x[j] = ge ? d[j] : x[j];
+    }
+};
+
+}  // namespace pai

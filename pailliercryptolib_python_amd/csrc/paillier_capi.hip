@@ -13,6 +13,7 @@
 
 #include "geo_ops.hpp"
 #include "hostbn.hpp"
+#include "kernels_padic.hpp"
 
 using namespace pai;
 using hbn::Limbs;
@@ -253,6 +254,10 @@ struct pai_privkey {
     uint32_t* d_pinvqR = nullptr;
     int u_words = 0;
     int wide_nl = 0;              // != 0: stage A runs on the wide engine with this many limbs
+    int padic_nl = 0;             // != 0: stage A runs on the p-adic digit engine (takes precedence)
+    uint32_t* d_pm1[2] = {nullptr, nullptr};
+    uint32_t* d_kdig[2] = {nullptr, nullptr};
+    int padic_nd = 0;
     DevBuf table, ubuf;
     std::mutex mu;
 };
@@ -664,6 +669,32 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
             sk->d_sinv2[w] = upload_r29(sinv2, nl);
             sk->d_nsinv2[w] = upload_r29(hbn::sub(hbn::shl(one, k), sinv2), nl);
         }
+        // p-adic digit engine: digit pairs of R^(i+2) mod s^2 and s - 1 as limbs
+        sk->padic_nl = padic_nl_for_prime_bits(hbn::bitlen(q));
+        if (sk->pr[0].nl != sk->padic_nl || sk->pr[1].nl != sk->padic_nl) sk->padic_nl = 0;
+        if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') sk->padic_nl = 0; }
+        if (sk->padic_nl) {
+            const int nl = sk->padic_nl;
+            sk->padic_nd = (32 * pk->ct_words + hbn::RB * nl - 1) / (hbn::RB * nl);
+            for (int w = 0; w < 2; ++w) {
+                const Limbs& s = prime[w];
+                const Limbs& s2 = sk->sq[w].M;
+                sk->d_pm1[w] = upload_r29(hbn::sub(s, one), nl);
+                Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * nl), s2);
+                Limbs K = hbn::mulmod(Rm, Rm, s2);                       // R^2
+                std::vector<uint32_t> host((size_t)sk->padic_nd * 2 * nl, 0);
+                for (int i = 0; i < sk->padic_nd; ++i) {
+                    Limbs rem;
+                    Limbs quo = hbn::divq(K, s, &rem);
+                    auto ra = hbn::to_r29(rem, nl), rb = hbn::to_r29(quo, nl);
+                    std::memcpy(&host[(size_t)(2 * i) * nl], ra.data(), (size_t)nl * 4);
+                    std::memcpy(&host[(size_t)(2 * i + 1) * nl], rb.data(), (size_t)nl * 4);
+                    K = hbn::mulmod(K, Rm, s2);
+                }
+                HIP_CHECK(hipMalloc((void**)&sk->d_kdig[w], host.size() * 4));
+                HIP_CHECK(hipMemcpy(sk->d_kdig[w], host.data(), host.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
         Limbs pinvq = hbn::inv_mod_prime(hbn::mod(p, q), q);
         require(hbn::cmp(hbn::mulmod(pinvq, p, q), one) == 0, "q is not prime (inverse check failed)");
         sk->d_pinvqR = upload_r29(hbn::mulmod(pinvq, sk->pr[1].R, q), sk->pr[1].geo->nl);
@@ -682,6 +713,8 @@ void pai_privkey_destroy(pai_privkey* sk) {
         if (sk->d_sinv2[w]) (void)hipFree(sk->d_sinv2[w]);
         if (sk->d_nsinv2[w]) (void)hipFree(sk->d_nsinv2[w]);
         if (sk->d_hR[w]) (void)hipFree(sk->d_hR[w]);
+        if (sk->d_pm1[w]) (void)hipFree(sk->d_pm1[w]);
+        if (sk->d_kdig[w]) (void)hipFree(sk->d_kdig[w]);
     }
     if (sk->d_pinvqR) (void)hipFree(sk->d_pinvqR);
     sk->table.release();
@@ -700,7 +733,11 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         const GeoOps* ga = sk->sq[0].geo;
         const GeoOps* gb = sk->pr[0].geo;
         int gridx = grid_for(ga, N, dev.ncu, 1);          // x2 primes => 2 workgroups per CU
-        if (sk->wide_nl) {
+        if (sk->padic_nl) {
+            const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
+            gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)dev.ncu / 2));   // x2 primes => one workgroup per CU
+            sk->table.ensure(padic_table_words(sk->padic_nl, (size_t)gridx * 2) * 4);
+        } else if (sk->wide_nl) {
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
             gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)dev.ncu / 2));   // x2 primes => one workgroup per CU
             sk->table.ensure(wide_table_words(sk->wide_nl, (size_t)gridx * 2) * 4);
@@ -721,7 +758,22 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         g_last_times.clear();
         {
             ScopedKernelTimer t("k_dec_a", s);
-            if (sk->wide_nl) {
+            if (sk->padic_nl) {
+                DecPadicParams Q;
+                for (int w = 0; w < 2; ++w) {
+                    Q.pr[w] = sk->pr[w].d_ctx;
+                    Q.pm1[w] = sk->d_pm1[w];
+                    Q.kdig[w] = sk->d_kdig[w];
+                    Q.expo[w] = sk->d_expo[w];
+                    Q.ewords[w] = sk->ewords[w];
+                    Q.ebits[w] = sk->ebits[w];
+                }
+                Q.nd = sk->padic_nd;
+                Q.ct_words = pk->ct_words;
+                Q.u_words = sk->u_words;
+                if (!launch_dec_a_padic(sk->padic_nl, s, gridx, Q, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))
+                    throw PaiError(PAI_E_INTERNAL, "no p-adic kernel for this limb count");
+            } else if (sk->wide_nl) {
                 if (!launch_dec_a_wide(sk->wide_nl, s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))
                     throw PaiError(PAI_E_INTERNAL, "no wide kernel for this limb count");
             } else {
@@ -740,6 +792,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         B.pinvqR = sk->d_pinvqR;
         B.u_words = sk->u_words;
         B.pt_words = pk->n_words;
+        B.u_is_L = sk->padic_nl ? 1 : 0;
         {
             ScopedKernelTimer t("k_dec_b", s);
             gb->dec_b(s, grid_for(gb, N, dev.ncu), B, sk->ubuf.as<uint32_t>(), d_m, (int)N);

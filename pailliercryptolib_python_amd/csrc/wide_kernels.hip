@@ -1,6 +1,7 @@
 // Instantiations of the wide-engine kernels (kernels_wide.hpp): CRT-decrypt stage A for s^2 of up to
 // 1158 bits (40 limbs) and up to 2086 bits (72 limbs).
 #include "geo_ops.hpp"
+#include "kernels_padic.hpp"
 #include "kernels_wide.hpp"
 
 namespace pai {
@@ -28,6 +29,19 @@ bool launch_dec_a_wide(int nl, hipStream_t s, int gridx, const DecAParams& P, co
         case 72: launch_a<72>(s, gridx, P, ct, u_out, n, table); return true;
         default: return false;
     }
+}
+
+// ---- p-adic digit engine (kernels_padic.hpp): primes of 700..1024 bits, 36 limbs, 12-row blocks -----
+int padic_nl_for_prime_bits(int bits) { return (bits >= 700 && RB * 36 >= bits + 20) ? 36 : 0; }
+size_t padic_table_words(int nl, size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * 2 * nl * blocks * BLOCK_THREADS; }
+bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out,
+                        int n, uint32_t* table) {
+    if (nl != 36) return false;
+    constexpr int bytes = 3 * 36 * BLOCK_THREADS * 4;
+    (void)hipFuncSetAttribute((const void*)k_dec_a_padic<36, 12, MODEXP_WINDOW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((k_dec_a_padic<36, 12, MODEXP_WINDOW>), dim3(gridx, 2), dim3(BLOCK_THREADS), bytes, s, P, ct, u_out, n,
+                       reinterpret_cast<uint4*>(table));
+    return true;
 }
 
 }  // namespace pai
