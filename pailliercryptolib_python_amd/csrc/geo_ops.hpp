@@ -61,6 +61,14 @@ size_t padic_table_words(int nl, size_t blocks);
 bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out,
                         int n, uint32_t* table);
 
+// digit engine with base n for raw/DJN encryption (kernels_padic_enc.hpp)
+struct EncPadicParams;
+int padic_enc_nl_for_n_bits(int bits);
+bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
+                           const uint32_t* one_dig, uint32_t* table, int J);
+bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
+                          uint32_t* ct_out, int n, int mode);
+
 // x = a^-1 mod M for `count` values of `words` 32-bit words each (words in {64,128,192,256}); *fail counts
 // non-invertible inputs.  Returns false if `words` has no instantiation.
 bool launch_inv_eea(hipStream_t s, int words, const uint32_t* mod, const uint32_t* a, uint32_t* out, int count,

@@ -27,16 +27,20 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int which = blockIdx.y;
     const MontCtx* ctx = P.pr[which];
-    const uint32_t* __restrict__ nm = ctx->n;
+    // modulus and s - 1 from LDS (see kernels_padic_enc.hpp)
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 3 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = ctx->n[i]; ldsn[NL + i] = P.pm1[which][i]; }
+    __syncthreads();
+    const uint32_t* nm = ldsn;
+    const uint32_t* pm1 = ldsn + NL;
     const uint32_t n0inv = ctx->n0inv;
-    const uint32_t* __restrict__ pm1 = P.pm1[which];
     const uint32_t* __restrict__ kdig = P.kdig[which];
     const uint32_t* __restrict__ expo = P.expo[which];
     const int ewords = P.ewords[which], ebits = P.ebits[which];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint4* A = reinterpret_cast<uint4*>(lds + wave * 3 * E::DIGIT_WORDS) + lane;
     uint4* B = A + E::NC * 64;
-    uint4* M = B + E::NC * 64;        // quotient digits of the first half of the product rule
+    const typename E::MBuf M{B + E::NC * 64, 64};   // quotient digits of the first half of the product rule (LDS)
     const size_t nslots = (size_t)gridDim.x * gridDim.y * BLOCK_THREADS;
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK_THREADS + threadIdx.x;
     // table entry e: digit d (0 = first, 1 = second), chunk c

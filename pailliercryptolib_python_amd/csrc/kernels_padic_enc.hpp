@@ -1,0 +1,236 @@
+// Encryption on the digit engine (mont_padic.hpp) with the public modulus n as the digit base:
+// an element of Z/n^2 is a pair (a, b), a + b n == x R (mod n^2), and every reduction is modulo n.
+//   k_fb_table_padic   per-key fixed-base table T[j][d] = digits( hs^(d 2^(8 j)) R mod n^2 )
+//   k_encrypt_padic    mode 0: ct = 1 + m n                (raw_encrypt: the plain digit pair (1, m) itself)
+//                      mode 1: ct = (1 + m n) hs^r          (DJN encrypt: prod_j T[j][r_j], then * (1, m))
+//                      (apply_obfuscator on existing ciphertexts stays on the lane-group kernel k_encrypt)
+// Same contracts as k_encrypt (kernels_paillier.hpp); ciphertexts are returned as canonical packed words.
+#pragma once
+#include "kernels_wide.hpp"
+#include "mont_padic.hpp"
+
+namespace pai {
+
+struct EncPadicParams {
+    const MontCtx* nctx;         // modulus n (NL limbs, R = 2^(29 NL))
+    const uint32_t* nm1;         // n - 1 limbs
+    const uint32_t* nsq;         // n^2 limbs (2 NL, radix 29)
+    const uint4* fb_table;       // [J][256][2][NC] uint4
+    uint4* mscratch;             // [2 NC][nslots]: quotient digits, then the parked first result digit
+    int fb_windows;
+    int pt_words, ct_words, r_words;
+};
+
+// ---- table construction: one lane per window j ------------------------------------------------------
+template <int NL, int U>
+__global__ void __launch_bounds__(64, 1)
+k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const uint32_t* __restrict__ hs_dig,
+                 const uint32_t* __restrict__ one_dig, uint4* __restrict__ table, int J) {
+    using E = Padic<NL, U>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* ldsn = lds + 3 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += 64) { ldsn[i] = nctx->n[i]; ldsn[NL + i] = nm1[i]; }
+    __syncthreads();
+    const uint32_t* nm = ldsn;
+    nm1 = ldsn + NL;
+    const uint32_t n0inv = nctx->n0inv;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 64 + lane;
+    const int js = j < J ? j : J - 1;
+    uint4* A = reinterpret_cast<uint4*>(lds) + lane;
+    uint4* B = A + E::NC * 64;
+    const typename E::MBuf M{B + E::NC * 64, 64};
+    auto ent = [&](int d, int dg, int c) -> uint4& { return table[(((size_t)js * 256 + d) * 2 + dg) * E::NC + c]; };
+    auto self = [&](const uint4* X) {
+        return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); };
+    };
+    // B_j = hs^(2^(8 j)): every lane walks the same squaring chain and snapshots its own window base
+#pragma unroll 1
+    for (int c = 0; c < E::NC; ++c) {
+        E::st(A, c, make_uint4(hs_dig[4 * c], hs_dig[4 * c + 1], hs_dig[4 * c + 2], hs_dig[4 * c + 3]));
+        E::st(B, c, make_uint4(hs_dig[NL + 4 * c], hs_dig[NL + 4 * c + 1], hs_dig[NL + 4 * c + 2], hs_dig[NL + 4 * c + 3]));
+    }
+    wave_lds_fence();
+    const int jmax = min(J - 1, blockIdx.x * 64 + 63);
+#pragma unroll 1
+    for (int s = 0;; ++s) {
+        if (s == 8 * js) {
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { ent(1, 0, c) = E::ld(A, c); ent(1, 1, c) = E::ld(B, c); }
+        }
+        if (s == 8 * jmax) break;
+        E::mul(A, B, M, self(A), self(B), nm, nm1, n0inv);            // x <- x^2
+    }
+    __threadfence();
+    // T[j][0] = 1 (Montgomery digit form), T[j][d] = T[j][d-1] * B_j
+#pragma unroll 1
+    for (int c = 0; c < E::NC; ++c) {
+        ent(0, 0, c) = make_uint4(one_dig[4 * c], one_dig[4 * c + 1], one_dig[4 * c + 2], one_dig[4 * c + 3]);
+        ent(0, 1, c) = make_uint4(one_dig[NL + 4 * c], one_dig[NL + 4 * c + 1], one_dig[NL + 4 * c + 2], one_dig[NL + 4 * c + 3]);
+    }
+    wave_lds_fence();
+#pragma unroll 1
+    for (int c = 0; c < E::NC; ++c) { E::st(A, c, ent(1, 0, c)); E::st(B, c, ent(1, 1, c)); }
+    wave_lds_fence();
+    auto from_ent = [&](int dg) {
+        return [&, dg](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+            for (int c = 0; c < E::UC; ++c) {
+                const uint4 t = ent(1, dg, E::UC * blk + c);
+                xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+            }
+        };
+    };
+#pragma unroll 1
+    for (int d = 2; d < 256; ++d) {
+        E::mul(A, B, M, from_ent(0), from_ent(1), nm, nm1, n0inv);
+        if (j < J) {
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { ent(d, 0, c) = E::ld(A, c); ent(d, 1, c) = E::ld(B, c); }
+        }
+    }
+}
+
+// ---- (lo in LDS digit A, hi in LDS digit B) as one 2 NL-limb integer: conditional subtraction of n^2 ----
+template <class E>
+PAI_DEV void cond_sub_2nl(uint4* A, uint4* B, const uint32_t* __restrict__ nsq) {
+    int32_t borrow = 0;
+#pragma unroll 1
+    for (int c = 0; c < 2 * E::NC; ++c) {
+        const uint4 t = c < E::NC ? E::ld(A, c) : E::ld(B, c - E::NC);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) borrow = ((int32_t)w[k] - (int32_t)nsq[4 * c + k] + borrow) >> RB;
+    }
+    const bool ge = borrow == 0;
+    int32_t b2 = 0;
+#pragma unroll 1
+    for (int c = 0; c < 2 * E::NC; ++c) {
+        uint4* dst = c < E::NC ? A : B;
+        const int cc = c < E::NC ? c : c - E::NC;
+        const uint4 t = E::ld(dst, cc);
+        uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int32_t d = (int32_t)w[k] - (int32_t)nsq[4 * c + k] + b2;
+            b2 = d >> RB;
+            w[k] = ge ? ((uint32_t)d & RMASK) : w[k];
+        }
+        E::st(dst, cc, make_uint4(w[0], w[1], w[2], w[3]));
+    }
+    wave_lds_fence();
+}
+
+// limb J of the 2 NL-limb integer held in the LDS digit buffers (A = low half, B = high half)
+template <class E>
+PAI_DEV uint32_t lds_limb(const uint4* A, const uint4* B, int J) {
+    if (J >= 2 * E::NC * 4) return 0u;
+    const uint4* base = J < 4 * E::NC ? A : B;
+    const int jj = J < 4 * E::NC ? J : J - 4 * E::NC;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (jj >> 2) * 64);
+    return p[jj & 3];
+}
+
+template <int NL, int U>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
+                const uint32_t* __restrict__ ct_in, uint32_t* __restrict__ ct_out, int n, int mode) {
+    using E = Padic<NL, U>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // the modulus and n - 1 are read from LDS (broadcast reads): through the kernel-argument struct the
+    // compiler cannot prove them unclobbered and would fetch them with vector global loads inside the loops
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
+    __syncthreads();
+    const uint32_t* nm = ldsn;
+    const uint32_t* nm1 = ldsn + NL;
+    const uint32_t n0inv = P.nctx->n0inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* A = reinterpret_cast<uint4*>(lds + wave * 2 * E::DIGIT_WORDS) + lane;
+    uint4* B = A + E::NC * 64;
+    const size_t nslots = (size_t)gridDim.x * BLOCK_THREADS;
+    const size_t slot = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const typename E::MBuf M{P.mscratch + slot, nslots};
+    const typename E::MBuf Wb{P.mscratch + (size_t)E::NC * nslots + slot, nslots};
+    auto one = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = 0;
+        if (blk == 0) xv[0] = 1;
+    };
+    const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        uint32_t w[NL], v[NL];
+        if (mode == 0) {
+            // the plain digit pair of 1 + m n is (1, m)
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { w[j] = 0; v[j] = row_limb(m + (size_t)es * P.pt_words, P.pt_words, j); }
+            w[0] = 1;
+        } else {
+            // x = prod_j T[j][r_j]  (Montgomery digit form of hs^r)
+            const uint32_t* rrow = r + (size_t)es * P.r_words;
+#pragma unroll 1
+            for (int jw = 0; jw < P.fb_windows; ++jw) {
+                const int bit = jw * FB_WBITS;
+                const uint32_t d = (rrow[bit >> 5] >> (bit & 31)) & (FB_ENTRIES - 1);
+                const uint4* ent = P.fb_table + ((size_t)jw * FB_ENTRIES + d) * 2 * E::NC;
+                if (jw == 0) {
+                    wave_lds_fence();
+#pragma unroll 1
+                    for (int c = 0; c < E::NC; ++c) { E::st(A, c, ent[c]); E::st(B, c, ent[E::NC + c]); }
+                    wave_lds_fence();
+                } else {
+                    auto from_ent = [&](int dg) {
+                        return [&, dg](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                            for (int c = 0; c < E::UC; ++c) {
+                                const uint4 t = ent[dg * E::NC + E::UC * blk + c];
+                                xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                            }
+                        };
+                    };
+                    E::mul_wbuf(A, B, M, Wb, from_ent(0), from_ent(1), nm, nm1, n0inv);
+                }
+            }
+            // times the plain digit pair (1, m) of 1 + m n  => plain digit pair of the ciphertext
+            {
+                const uint32_t* mrow = m + (size_t)es * P.pt_words;
+                auto mdig = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) xv[u] = row_limb(mrow, P.pt_words, U * blk + u);
+                };
+                E::mm1_mul(w, M, A, one, nm, n0inv);
+                E::mm2_mul(v, M, A, B, mdig, one, nm, nm1, n0inv);
+            }
+        }
+        // ct = w + v n  (w, v lazy < 2n + eps)  ->  canonical residue modulo n^2, packed words
+        wave_lds_fence();
+        E::store_digit(B, v);
+        wave_lds_fence();
+        uint32_t hi[NL];
+        E::mul_plain(hi, A, w, B, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(nm, blk, xv); });
+        wave_lds_fence();
+        E::store_digit(B, hi);
+        wave_lds_fence();
+        if (mode != 0) {
+            cond_sub_2nl<E>(A, B, P.nsq);
+            cond_sub_2nl<E>(A, B, P.nsq);
+        }
+        if (live) {
+            uint32_t* orow = ct_out + (size_t)ei * P.ct_words;
+#pragma unroll 1
+            for (int k = 0; k < P.ct_words; ++k) {
+                const int j0 = (32 * k) / RB, s0 = 32 * k - RB * j0;
+                uint64_t t = (uint64_t)lds_limb<E>(A, B, j0) >> s0;
+                t |= (uint64_t)lds_limb<E>(A, B, j0 + 1) << (RB - s0);
+                t |= (uint64_t)lds_limb<E>(A, B, j0 + 2) << (2 * RB - s0);
+                orow[k] = (uint32_t)t;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+}  // namespace pai

@@ -52,7 +52,8 @@ struct EncParams {
     const MontCtx* nsq;          // modulus n^2
     const uint32_t* nR;          // n * R mod n^2, radix-29, NLMAX-padded (for 1 + m n)
     const uint32_t* fb_table;    // [J][256][NL] radix-29 limbs, Montgomery form (DJN) or NULL
-    int fb_windows;              // J
+    int fb_windows;              // J = ceil(randbits / fb_wbits)
+    int fb_wbits;                // window width (table has 2^fb_wbits entries per window)
     int pt_words, ct_words, r_words;
 };
 
@@ -95,9 +96,11 @@ k_encrypt(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restric
             uint32_t x[G::NLL];
 #pragma unroll 1
             for (int jw = 0; jw < P.fb_windows; ++jw) {
-                const int bit = jw * FB_WBITS;
-                const uint32_t d = (rrow[bit >> 5] >> (bit & 31)) & (FB_ENTRIES - 1);   // 8-bit windows never straddle words
-                const uint32_t* ent = P.fb_table + ((size_t)jw * FB_ENTRIES + d) * G::NL + G::NLL * t;
+                const int bit = jw * P.fb_wbits, k = bit >> 5;
+                uint64_t bits2 = rrow[k];
+                if (k + 1 < P.r_words) bits2 |= (uint64_t)rrow[k + 1] << 32;
+                const uint32_t d = (uint32_t)(bits2 >> (bit & 31)) & ((1u << P.fb_wbits) - 1u);
+                const uint32_t* ent = P.fb_table + ((((size_t)jw << P.fb_wbits) + d) * G::NL) + G::NLL * t;
                 if (jw == 0) {
 #pragma unroll
                     for (int j = 0; j < G::NLL; ++j) x[j] = ent[j];

@@ -30,6 +30,8 @@ struct Padic {
     static constexpr int NB = NL / U;        // row blocks
     static constexpr int NW = NL + U;        // accumulator window
     static constexpr int DIGIT_WORDS = NL * 64;   // LDS words of one digit for one wave
+    static constexpr int P1 = (24 / U) * U;       // rows between normalisations at 2^59 per row
+    static constexpr int P2 = (16 / U) * U;       // ... at 1.5 * 2^59 per row (doubled or three products)
 
     PAI_DEV static uint4 ld(const uint4* x, int c) { return x[c * 64]; }
     PAI_DEV static void st(uint4* x, int c, uint4 v) { x[c * 64] = v; }
@@ -123,21 +125,51 @@ struct Padic {
             }
         }
         // remaining chunks: a pure rank-(2U or 3U) update
+        if constexpr (NL <= 48) {
 #pragma unroll
-        for (int c = UC; c < NC; ++c) {
-            uint32_t xa[4] = {0, 0, 0, 0}, ya[4] = {0, 0, 0, 0};
-            if constexpr (HAS_X) {
-                if (4 * c >= LO) { const uint4 t = ld(X, c); xa[0] = t.x; xa[1] = t.y; xa[2] = t.z; xa[3] = t.w; }
-            }
-            if constexpr (HAS_Y) { const uint4 t = ld(Y, c); ya[0] = t.x; ya[1] = t.y; ya[2] = t.z; ya[3] = t.w; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (HAS_X && 4 * c >= LO) acc[4 * c + k + u] += (uint64_t)xa[k] * (4 * c >= HI ? xv2[u] : xv[u]);
-                    if constexpr (HAS_Y) acc[4 * c + k + u] += (uint64_t)ya[k] * yv[u];
-                    acc[4 * c + k + u] += (uint64_t)nm[4 * c + k] * q[u];
+            for (int c = UC; c < NC; ++c) {
+                uint32_t xa[4] = {0, 0, 0, 0}, ya[4] = {0, 0, 0, 0};
+                if constexpr (HAS_X) {
+                    if (4 * c >= LO) { const uint4 t = ld(X, c); xa[0] = t.x; xa[1] = t.y; xa[2] = t.z; xa[3] = t.w; }
                 }
+                if constexpr (HAS_Y) { const uint4 t = ld(Y, c); ya[0] = t.x; ya[1] = t.y; ya[2] = t.z; ya[3] = t.w; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (HAS_X && 4 * c >= LO) acc[4 * c + k + u] += (uint64_t)xa[k] * (4 * c >= HI ? xv2[u] : xv[u]);
+                        if constexpr (HAS_Y) acc[4 * c + k + u] += (uint64_t)ya[k] * yv[u];
+                        acc[4 * c + k + u] += (uint64_t)nm[4 * c + k] * q[u];
+                    }
+                }
+            }
+        } else {
+            // wide windows (NL = 72): stream the operands one chunk ahead and fence the scheduler per chunk so
+            // that the chunk loads are not all hoisted to the top (which would spill the accumulator window)
+            __builtin_amdgcn_sched_barrier(0);
+            uint4 x_cur = ld(X, UC), y_cur = ld(Y, UC);
+            uint32_t n_cur[4] = {nm[4 * UC], nm[4 * UC + 1], nm[4 * UC + 2], nm[4 * UC + 3]};
+#pragma unroll
+            for (int c = UC; c < NC; ++c) {
+                const int cn = (c + 1 < NC) ? c + 1 : c;
+                const uint4 x_nxt = ld(X, cn), y_nxt = ld(Y, cn);
+                const uint32_t n_nxt[4] = {nm[4 * cn], nm[4 * cn + 1], nm[4 * cn + 2], nm[4 * cn + 3]};
+                const uint32_t xa[4] = {x_cur.x, x_cur.y, x_cur.z, x_cur.w};
+                const uint32_t ya[4] = {y_cur.x, y_cur.y, y_cur.z, y_cur.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (HAS_X && 4 * c >= LO) acc[4 * c + k + u] += (uint64_t)xa[k] * (4 * c >= HI ? xv2[u] : xv[u]);
+                        if constexpr (HAS_Y) acc[4 * c + k + u] += (uint64_t)ya[k] * yv[u];
+                        acc[4 * c + k + u] += (uint64_t)n_cur[k] * q[u];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                x_cur = x_nxt;
+                y_cur = y_nxt;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) n_cur[k] = n_nxt[k];
             }
         }
         slide(acc);
@@ -162,31 +194,43 @@ struct Padic {
     // CSrc: functor (blk, xv) giving the U digits of C for a row block.
     // The quotient digits m are parked in LDS (digit buffer M) so that the row-block loop can stay rolled
     // (a rolled loop cannot index a register array) — the hot loop must fit the 64 KB instruction cache.
-    PAI_DEV static void store_q(uint4* M, int blk, const uint32_t (&q)[U]) {
+    // M may be an LDS digit buffer (stride 64 uint4) or a global scratch column (stride = number of slots)
+    struct MBuf {
+        uint4* p;
+        size_t stride;
+    };
+    PAI_DEV static void store_q(MBuf M, int blk, const uint32_t (&q)[U]) {
 #pragma unroll
-        for (int c = 0; c < UC; ++c) st(M, UC * blk + c, make_uint4(q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]));
+        for (int c = 0; c < UC; ++c)
+            M.p[(size_t)(UC * blk + c) * M.stride] = make_uint4(q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]);
     }
     template <class CSrc>
-    PAI_DEV static void mm1_mul(uint32_t (&w)[NL], uint4* M, const uint4* X, CSrc&& csrc,
+    PAI_DEV static void mm1_mul(uint32_t (&w)[NL], MBuf M, const uint4* X, CSrc&& csrc,
                                 const uint32_t* __restrict__ nm, uint32_t n0inv) {
         uint64_t acc[NW];
         zero(acc);
         uint32_t dummy[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) dummy[u] = 0;
+        // the digits of the next row block are fetched while the current block is computed (they may come
+        // from global memory: table entries)
+        uint32_t xn[U];
+        csrc(0, xn);
 #pragma unroll 1
         for (int blk = 0; blk < NB; ++blk) {
             uint32_t xv[U], q[U];
-            csrc(blk, xv);
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = xn[u];
+            csrc(blk + 1 < NB ? blk + 1 : blk, xn);
             block<true, 0, NL, false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, blk, q);
             store_q(M, blk, q);
-            if (blk != NB - 1 && ((blk + 1) * U) % 24 == 0) normalize(acc);    // 2^59 per row: every 24 rows
+            if (blk != NB - 1 && ((blk + 1) * U) % P1 == 0) normalize(acc);    // 2^59 per row: at most 24 rows
         }
         finish(acc, w);
     }
     // squaring: C = X, symmetric by limb classes of U limbs (row block b multiplies limbs >= U b)
     template <int B>
-    PAI_DEV static void mm1_sqr_blocks(uint64_t (&acc)[NW], uint4* M, const uint4* X,
+    PAI_DEV static void mm1_sqr_blocks(uint64_t (&acc)[NW], MBuf M, const uint4* X,
                                        const uint32_t* __restrict__ nm, uint32_t n0inv) {
         if constexpr (B < NB) {
             uint32_t xv[U], q[U], dummy[U];
@@ -195,11 +239,11 @@ struct Padic {
             digits(X, B, xv);
             block<true, U * B, U * (B + 1), false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, B, q);
             store_q(M, B, q);
-            if (B != NB - 1) normalize(acc);                                    // doubled products: every block
+            if (B != NB - 1 && ((B + 1) * U) % P2 == 0) normalize(acc);         // doubled products: at most 16 rows
             mm1_sqr_blocks<B + 1>(acc, M, X, nm, n0inv);
         }
     }
-    PAI_DEV static void mm1_sqr(uint32_t (&w)[NL], uint4* M, const uint4* X,
+    PAI_DEV static void mm1_sqr(uint32_t (&w)[NL], MBuf M, const uint4* X,
                                 const uint32_t* __restrict__ nm, uint32_t n0inv) {
         uint64_t acc[NW];
         zero(acc);
@@ -209,11 +253,11 @@ struct Padic {
 
     // ---- second half: v = (X * D + Y * C - m + R p + m' p) / R --------------------------------------
     // initial window = (R - 1 - m) + 1 in the low NL columns; p - 1 enters at the top (pm1 = limbs of p - 1)
-    PAI_DEV static void mm2_init(uint64_t (&acc)[NW], const uint4* M) {
+    PAI_DEV static void mm2_init(uint64_t (&acc)[NW], MBuf M) {
         wave_lds_fence();
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const uint4 t = ld(M, c);
+            const uint4 t = M.p[(size_t)c * M.stride];
             acc[4 * c] = (uint64_t)(RMASK - t.x); acc[4 * c + 1] = (uint64_t)(RMASK - t.y);
             acc[4 * c + 2] = (uint64_t)(RMASK - t.z); acc[4 * c + 3] = (uint64_t)(RMASK - t.w);
         }
@@ -222,22 +266,27 @@ struct Padic {
         for (int j = NL; j < NW; ++j) acc[j] = 0;
     }
     template <class DSrc, class CSrc>
-    PAI_DEV static void mm2_mul(uint32_t (&v)[NL], const uint4* M, const uint4* X, const uint4* Y, DSrc&& dsrc,
+    PAI_DEV static void mm2_mul(uint32_t (&v)[NL], MBuf M, const uint4* X, const uint4* Y, DSrc&& dsrc,
                                 CSrc&& csrc, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1, uint32_t n0inv) {
         uint64_t acc[NW];
+        uint32_t xn[U], yn[U];
+        dsrc(0, xn);
+        csrc(0, yn);
         mm2_init(acc, M);
 #pragma unroll 1
         for (int blk = 0; blk < NB; ++blk) {
             uint32_t xv[U], yv[U], q[U];
-            dsrc(blk, xv);
-            csrc(blk, yv);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { xv[u] = xn[u]; yv[u] = yn[u]; }
+            dsrc(blk + 1 < NB ? blk + 1 : blk, xn);
+            csrc(blk + 1 < NB ? blk + 1 : blk, yn);
             block<true, 0, NL, true, true>(acc, X, xv, Y, yv, nm, n0inv, pm1, blk, q);
-            if (blk != NB - 1) normalize(acc);                                  // 1.5 * 2^59 per row
+            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);     // 1.5 * 2^59 per row: at most 16 rows
         }
         finish(acc, v);
     }
     // squaring: v = (2 X * Y - m + R p + m' p) / R   (X = first digit, Y = second digit of the same element)
-    PAI_DEV static void mm2_sqr(uint32_t (&v)[NL], const uint4* M, const uint4* X, const uint4* Y,
+    PAI_DEV static void mm2_sqr(uint32_t (&v)[NL], MBuf M, const uint4* X, const uint4* Y,
                                 const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1, uint32_t n0inv) {
         uint64_t acc[NW];
         mm2_init(acc, M);
@@ -249,13 +298,87 @@ struct Padic {
             uint32_t xv[U], q[U];
             digits(Y, blk, xv);
             block<true, 0, 0, false, true>(acc, X, xv, X, dummy, nm, n0inv, pm1, blk, q);   // HI = 0: every limb doubled
-            if (blk != NB - 1) normalize(acc);
+            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
         }
         finish(acc, v);
     }
 
+    // Variant for wide digits (NL = 72): the first result digit w is parked in a strided scratch buffer (same
+    // shape as M) instead of 72 registers, so that nothing but the accumulator window is live inside the loops.
+    PAI_DEV static void finish_to_buf(const uint64_t (&acc)[NW], MBuf Wb) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t t = acc[4 * ch + k] + c;
+                w[k] = (uint32_t)t & RMASK;
+                c = t >> RB;
+            }
+            Wb.p[(size_t)ch * Wb.stride] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    template <class CSrc, class DSrc>
+    PAI_DEV static void mul_wbuf(uint4* A, uint4* B, MBuf M, MBuf Wb, CSrc&& csrc, DSrc&& dsrc,
+                                 const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        {   // first half: w -> Wb, quotient digits -> M
+            uint64_t acc[NW];
+            zero(acc);
+            uint32_t dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+            uint32_t xn[U];
+            csrc(0, xn);
+#pragma unroll 1
+            for (int blk = 0; blk < NB; ++blk) {
+                uint32_t xv[U], q[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = xn[u];
+                csrc(blk + 1 < NB ? blk + 1 : blk, xn);
+                block<true, 0, NL, false, false>(acc, A, xv, A, dummy, nm, n0inv, nm, blk, q);
+                store_q(M, blk, q);
+                if (blk != NB - 1 && ((blk + 1) * U) % P1 == 0) normalize(acc);
+            }
+            finish_to_buf(acc, Wb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {   // second half: v -> B (after the last read of B), then w -> A
+            uint64_t acc[NW];
+            uint32_t xn[U], yn[U];
+            dsrc(0, xn);
+            csrc(0, yn);
+            mm2_init(acc, M);
+#pragma unroll 1
+            for (int blk = 0; blk < NB; ++blk) {
+                uint32_t xv[U], yv[U], q[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { xv[u] = xn[u]; yv[u] = yn[u]; }
+                dsrc(blk + 1 < NB ? blk + 1 : blk, xn);
+                csrc(blk + 1 < NB ? blk + 1 : blk, yn);
+                block<true, 0, NL, true, true>(acc, A, xv, B, yv, nm, n0inv, pm1, blk, q);
+                if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
+            }
+            wave_lds_fence();
+            uint64_t c = 0;
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                uint32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint64_t t = acc[4 * ch + k] + c;
+                    w[k] = (uint32_t)t & RMASK;
+                    c = t >> RB;
+                }
+                st(B, ch, make_uint4(w[0], w[1], w[2], w[3]));
+                st(A, ch, Wb.p[(size_t)ch * Wb.stride]);
+            }
+            wave_lds_fence();
+        }
+    }
+
     // (A, B) <- (A, B)^2
-    PAI_DEV static void sqr(uint4* A, uint4* B, uint4* M, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
+    PAI_DEV static void sqr(uint4* A, uint4* B, MBuf M, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
                             uint32_t n0inv) {
         uint32_t w[NL], v[NL];
         mm1_sqr(w, M, A, nm, n0inv);
@@ -267,7 +390,7 @@ struct Padic {
     }
     // (A, B) <- (A, B) * (C, D), the second operand's digits supplied per row block
     template <class CSrc, class DSrc>
-    PAI_DEV static void mul(uint4* A, uint4* B, uint4* M, CSrc&& csrc, DSrc&& dsrc, const uint32_t* __restrict__ nm,
+    PAI_DEV static void mul(uint4* A, uint4* B, MBuf M, CSrc&& csrc, DSrc&& dsrc, const uint32_t* __restrict__ nm,
                             const uint32_t* __restrict__ pm1, uint32_t n0inv) {
         uint32_t w[NL], v[NL];
         mm1_mul(w, M, A, csrc, nm, n0inv);
@@ -276,6 +399,43 @@ struct Padic {
         store_digit(A, w);
         store_digit(B, v);
         wave_lds_fence();
+    }
+
+    // Plain product with addend, no reduction:  X * D + W  (X in LDS, D digits per block, W < 2^(29 NL) in registers).
+    // The low NL limbs are written to the LDS digit buffer LO (chunk-major), the high NL limbs returned in hi.
+    template <class DSrc>
+    PAI_DEV static void mul_plain(uint32_t (&hi)[NL], uint4* LO, const uint32_t (&W)[NL], const uint4* X, DSrc&& dsrc) {
+        uint64_t acc[NW];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) acc[j] = W[j];
+#pragma unroll
+        for (int j = NL; j < NW; ++j) acc[j] = 0;
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t xv[U], low[U];
+            dsrc(blk, xv);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const uint4 t = ld(X, c);
+                const uint32_t xa[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[4 * c + k + u] += (uint64_t)xa[k] * xv[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                low[u] = (uint32_t)acc[u] & RMASK;
+                acc[u + 1] += acc[u] >> RB;
+            }
+#pragma unroll
+            for (int c = 0; c < UC; ++c)
+                st(LO, UC * blk + c, make_uint4(low[4 * c], low[4 * c + 1], low[4 * c + 2], low[4 * c + 3]));
+            slide(acc);
+            if (blk != NB - 1 && ((blk + 1) * U) % P1 == 0) normalize(acc);
+        }
+        finish(acc, hi);
     }
 
     // x (NL limbs, < 4p say) -> canonical [0, p) by up to `times` conditional subtractions, in registers

@@ -14,6 +14,7 @@
 #include "geo_ops.hpp"
 #include "hostbn.hpp"
 #include "kernels_padic.hpp"
+#include "kernels_padic_enc.hpp"
 
 using namespace pai;
 using hbn::Limbs;
@@ -222,7 +223,14 @@ struct pai_pubkey {
     uint32_t* d_nR = nullptr;     // n * R mod n^2 (radix 29)
     uint32_t* d_fb = nullptr;     // fixed-base table [J][256][NL]
     uint32_t* d_nexp = nullptr;   // n as packed words (exponent of the standard obfuscator)
-    int fb_windows = 0;
+    int fb_windows = 0, fb_wbits = 8;
+    // digit engine with base n (raw / DJN encryption): modulus n, n - 1, n^2 limbs, digit-form table, scratch
+    int penc_nl = 0;
+    ModSetup nmod;
+    uint32_t* d_nm1 = nullptr;
+    uint32_t* d_nsq29 = nullptr;
+    uint32_t* d_fb_dig = nullptr;
+    uint32_t* d_mscratch = nullptr;
     uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
     mutable DevBuf inv_prefix, inv_tot, inv_totinv, inv_fail;
@@ -233,6 +241,7 @@ struct pai_pubkey {
         P.nR = d_nR;
         P.fb_table = d_fb;
         P.fb_windows = fb_windows;
+        P.fb_wbits = fb_wbits;
         P.pt_words = n_words;
         P.ct_words = ct_words;
         P.r_words = r_words;
@@ -410,13 +419,20 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         pk->d_nexp = upload_words(pk->n, pk->n_words);
         pk->d_nsq_words = upload_words(pk->nsq, pk->ct_words);
         if (h_hs) {
-            require(hs_words > 0 && randbits > 0 && randbits % FB_WBITS == 0, "DJN key needs hs and randbits (multiple of 8)");
+            require(hs_words > 0 && randbits > 0, "DJN key needs hs and randbits");
+            // fixed-base window width: the widest (<= 12 bits) whose table stays within 256 MiB
+            // (2048-bit keys: 12 bits => 86 windows x 4096 entries x 576 B = 203 MB, resident in the Infinity Cache)
+            int wb = 12;
+            while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > 256.0 * 1048576.0) --wb;
+            if (const char* env = std::getenv("PAI_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 14) wb = v; }
+            pk->fb_wbits = wb;
             pk->djn = true;
             pk->hs = hbn::from_u32(h_hs, (size_t)hs_words);
             require(hbn::cmp(pk->hs, pk->nsq) < 0 && !hbn::is_zero(pk->hs), "hs must lie in (0, n^2)");
             pk->randbits = randbits;
             pk->r_words = words_for_bits(randbits);
-            const int J = randbits / FB_WBITS;
+            const int J = (randbits + wb - 1) / wb;
+            const size_t ENT = (size_t)1 << wb;
             pk->fb_windows = J;
             // window bases B_j = hs^(2^(8 j)) on the host, then T[j][d] = B_j^d on the device
             hbn::Mont32 mt(pk->nsq);
@@ -425,11 +441,11 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             for (int j = 0; j < J; ++j) {
                 Limbs plain = mt.from_mont(b);
                 std::memcpy(&bases[(size_t)j * pk->ct_words], plain.data(), plain.size() * 4);
-                for (int s = 0; s < FB_WBITS; ++s) b = mt.mmul(b, b);
+                for (int s = 0; s < wb; ++s) b = mt.mmul(b, b);
             }
-            const size_t NE = (size_t)J * FB_ENTRIES;
+            const size_t NE = (size_t)J * ENT;
             std::vector<uint32_t> expo(NE);
-            for (size_t i = 0; i < NE; ++i) expo[i] = (uint32_t)(i & (FB_ENTRIES - 1));
+            for (size_t i = 0; i < NE; ++i) expo[i] = (uint32_t)(i & (ENT - 1));
             uint32_t *d_bases = nullptr, *d_expo = nullptr;
             HIP_CHECK(hipMalloc((void**)&d_bases, bases.size() * 4));
             HIP_CHECK(hipMalloc((void**)&d_expo, NE * 4));
@@ -437,12 +453,47 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             HIP_CHECK(hipMemcpy(d_expo, expo.data(), NE * 4, hipMemcpyHostToDevice));
             HIP_CHECK(hipMalloc((void**)&pk->d_fb, NE * (size_t)nl * 4));
             const GeoOps* g = pk->msq.geo;
-            g->modexp_var(nullptr, grid_for(g, NE, pk->dev.ncu), pk->msq.d_ctx, d_bases, pk->ct_words, 8 /* base = i>>8 */,
-                          d_expo, 1, FB_WBITS, 0, pk->d_fb, 0, (int)NE, 1 /*keep_mont*/, 1 /*out_raw*/);
+            g->modexp_var(nullptr, grid_for(g, NE, pk->dev.ncu), pk->msq.d_ctx, d_bases, pk->ct_words, wb /* base = i >> wb */,
+                          d_expo, 1, wb, 0, pk->d_fb, 0, (int)NE, 1 /*keep_mont*/, 1 /*out_raw*/);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipDeviceSynchronize());
             HIP_CHECK(hipFree(d_bases));
             HIP_CHECK(hipFree(d_expo));
+            // digit-form table for the base-n digit engine
+            // EXPERIMENTAL, off by default: the base-n digit engine is bit-exact but currently slower than the
+            // lane-group kernel for encryption (memory-latency bound at one wave per SIMD); PAI_ENABLE_PADIC_ENC=1 enables it
+            pk->penc_nl = 0;
+            if (const char* env = std::getenv("PAI_ENABLE_PADIC_ENC")) { if (env[0] == '1' && wb == 8) pk->penc_nl = padic_enc_nl_for_n_bits(hbn::bitlen(pk->n)); }
+            if (pk->penc_nl) {
+                const int pnl = pk->penc_nl;
+                pk->nmod.init(pk->n, pnl);
+                const Limbs one{1u};
+                pk->d_nm1 = upload_r29(hbn::sub(pk->n, one), pnl);
+                pk->d_nsq29 = upload_r29(pk->nsq, 2 * pnl);
+                Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * pnl), pk->nsq);
+                auto digits_of = [&](const Limbs& v) {
+                    Limbs rem;
+                    Limbs quo = hbn::divq(v, pk->n, &rem);
+                    std::vector<uint32_t> h(2 * (size_t)pnl, 0);
+                    auto ra = hbn::to_r29(rem, pnl), rb = hbn::to_r29(quo, pnl);
+                    std::memcpy(h.data(), ra.data(), (size_t)pnl * 4);
+                    std::memcpy(h.data() + pnl, rb.data(), (size_t)pnl * 4);
+                    uint32_t* d = nullptr;
+                    HIP_CHECK(hipMalloc((void**)&d, h.size() * 4));
+                    HIP_CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+                    return d;
+                };
+                uint32_t* d_one = digits_of(Rm);
+                uint32_t* d_hs = digits_of(hbn::mulmod(pk->hs, Rm, pk->nsq));
+                HIP_CHECK(hipMalloc((void**)&pk->d_fb_dig, NE * 2 * (size_t)pnl * 4));
+                if (!launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs, d_one, pk->d_fb_dig, J))
+                    throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipDeviceSynchronize());
+                HIP_CHECK(hipFree(d_one));
+                HIP_CHECK(hipFree(d_hs));
+                HIP_CHECK(hipMalloc((void**)&pk->d_mscratch, 2 * (size_t)pk->dev.ncu * BLOCK_THREADS * (size_t)pnl * 4));
+            }
         } else {
             pk->djn = false;
             pk->randbits = 0;
@@ -459,6 +510,11 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_nR) (void)hipFree(pk->d_nR);
     if (pk->d_fb) (void)hipFree(pk->d_fb);
     if (pk->d_nexp) (void)hipFree(pk->d_nexp);
+    pk->nmod.release();
+    if (pk->d_nm1) (void)hipFree(pk->d_nm1);
+    if (pk->d_nsq29) (void)hipFree(pk->d_nsq29);
+    if (pk->d_fb_dig) (void)hipFree(pk->d_fb_dig);
+    if (pk->d_mscratch) (void)hipFree(pk->d_mscratch);
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
     pk->inv_prefix.release();
     pk->inv_tot.release();
@@ -491,7 +547,25 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
     const int grid = grid_for(g, N, pk->dev.ncu);
     EncParams P = pk->enc_params();
     g_last_times.clear();
-    if (d_r == nullptr) {
+    if (pk->penc_nl && from_plain && (d_r == nullptr || pk->djn)) {
+        // raw / DJN encryption on the base-n digit engine: one workgroup per CU
+        EncPadicParams Q;
+        Q.nctx = pk->nmod.d_ctx;
+        Q.nm1 = pk->d_nm1;
+        Q.nsq = pk->d_nsq29;
+        Q.fb_table = reinterpret_cast<const uint4*>(pk->d_fb_dig);
+        Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
+        Q.fb_windows = pk->fb_windows;
+        Q.pt_words = pk->n_words;
+        Q.ct_words = pk->ct_words;
+        Q.r_words = pk->r_words;
+        const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
+        const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+        ScopedKernelTimer t(d_r ? "k_encrypt(djn)" : "k_encrypt(raw)", s);
+        if (!launch_encrypt_padic(pk->penc_nl, s, pgrid, Q, d_m, d_r, d_ct_out, (int)N, d_r ? 1 : 0))
+            throw PaiError(PAI_E_INTERNAL, "no digit-engine encrypt kernel for this limb count");
+        t.stop();
+    } else if (d_r == nullptr) {
         require(from_plain, "obfuscation needs randomness");
         ScopedKernelTimer t("k_encrypt(raw)", s);
         g->encrypt(s, grid, P, d_m, nullptr, nullptr, d_ct_out, (int)N, 0);

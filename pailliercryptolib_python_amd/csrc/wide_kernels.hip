@@ -2,6 +2,7 @@
 // 1158 bits (40 limbs) and up to 2086 bits (72 limbs).
 #include "geo_ops.hpp"
 #include "kernels_padic.hpp"
+#include "kernels_padic_enc.hpp"
 #include "kernels_wide.hpp"
 
 namespace pai {
@@ -37,10 +38,30 @@ size_t padic_table_words(int nl, size_t blocks) { return (size_t)(1u << MODEXP_W
 bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out,
                         int n, uint32_t* table) {
     if (nl != 36) return false;
-    constexpr int bytes = 3 * 36 * BLOCK_THREADS * 4;
+    constexpr int bytes = 3 * 36 * BLOCK_THREADS * 4 + 2 * 36 * 4;
     (void)hipFuncSetAttribute((const void*)k_dec_a_padic<36, 12, MODEXP_WINDOW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     hipLaunchKernelGGL((k_dec_a_padic<36, 12, MODEXP_WINDOW>), dim3(gridx, 2), dim3(BLOCK_THREADS), bytes, s, P, ct, u_out, n,
                        reinterpret_cast<uint4*>(table));
+    return true;
+}
+
+// ---- digit engine with base n for encryption (kernels_padic_enc.hpp): 1400..2048-bit n, 72 limbs -------
+int padic_enc_nl_for_n_bits(int bits) { return (bits >= 1400 && RB * 72 >= bits + 20) ? 72 : 0; }
+bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
+                           const uint32_t* one_dig, uint32_t* table, int J) {
+    if (nl != 72) return false;
+    constexpr int bytes = 3 * 72 * 64 * 4 + 2 * 72 * 4;
+    (void)hipFuncSetAttribute((const void*)k_fb_table_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((k_fb_table_padic<72, 8>), dim3((J + 63) / 64), dim3(64), bytes, s, nctx, nm1, hs_dig, one_dig,
+                       reinterpret_cast<uint4*>(table), J);
+    return true;
+}
+bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
+                          uint32_t* ct_out, int n, int mode) {
+    if (nl != 72) return false;
+    constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
+    (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((k_encrypt_padic<72, 8>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, nullptr, ct_out, n, mode);
     return true;
 }
 

@@ -1,0 +1,12 @@
+import time, sys, os
+sys.path.insert(0, '/root/repo')
+import torch
+from oracle import paillier_oracle as orc
+from pailliercryptolib_python_amd import engine
+key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567, bits=2048)
+for w in (8, 10, 11, 12):
+    os.environ["PAI_FB_WBITS"] = str(w)
+    torch.cuda.synchronize(); t = time.time()
+    pub = engine.PublicKeyHandle(key.n, 2048, key.hs, key.randbits, device="cuda:0")
+    torch.cuda.synchronize(); print("w", w, "pubkey create s", round(time.time() - t, 3), flush=True)
+    del pub
