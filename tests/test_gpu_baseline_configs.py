@@ -1,0 +1,110 @@
+"""GPU: the BASELINE.json configurations at their full sizes, checked through size-independent properties
+(round trips, homomorphic identities evaluated with Python big ints on the residues) plus bit parity
+against the C oracle on a sample.  One GPU runs one rank's shard of the 8-GPU configurations."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import paillier_oracle as orc
+from pailliercryptolib_python_amd import PaillierKeypair, engine, fixedpoint, sharding
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def key2048():
+    return orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567, bits=2048)
+
+
+def fixture_key(bits):
+    fx = json.loads((Path(__file__).parent / "golden" / "fixture_keys.json").read_text())[str(bits)]
+    return orc.make_key(int(fx["p"], 16), int(fx["q"], 16), djn_x=(1 << 70) + 12345, bits=bits)
+
+
+def handles(key):
+    pub = engine.PublicKeyHandle(key.n, key.bits, key.hs, key.randbits, device=DEV)
+    return pub, engine.PrivateKeyHandle(pub, key.p, key.q)
+
+
+def test_config0_1024bit_100_floats_roundtrip_bit_exact():
+    pk, sk = PaillierKeypair.generate_keypair(1024)
+    x = np.random.default_rng(1000).uniform(-1000, 1000, 100)
+    assert np.array_equal(np.array(sk.decrypt(pk.encrypt(x))), x)
+
+
+def test_config1_2048bit_batch_65536_encrypt_decrypt():
+    key = key2048()
+    pub, priv = handles(key)
+    N = 65536
+    x = np.random.default_rng(1001).uniform(-1000, 1000, N)
+    res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
+    r_l = orc.synth_r_limbs(4001, N, key.randbits)
+    m, r = engine.to_device_words(res, pub.device), engine.to_device_words(r_l, pub.device)
+    ct = pub.encrypt(m, r)
+    back = priv.decrypt(ct)
+    torch.cuda.synchronize()
+    assert torch.equal(back, m)                                              # every element round-trips
+    assert np.array_equal(fixedpoint.decode_float64_array(engine.to_host_words(back), expo, key.n, key.max_int), x)
+    # ciphertext bits against the C oracle on a 512-element sample spread over the batch
+    idx = np.linspace(0, N - 1, 512).astype(np.int64)
+    ck = co.COracleKey(key)
+    want = ck.encrypt_djn(res[idx], r_l[idx])
+    got = engine.to_host_words(ct[torch.from_numpy(idx).to(pub.device)])
+    assert np.array_equal(got, want)
+    assert np.array_equal(ck.decrypt_crt(want), res[idx])
+
+
+def test_config2_2048bit_batch_1M_add_and_mul():
+    key = key2048()
+    pub, priv = handles(key)
+    N = 1 << 20
+    rng = np.random.default_rng(1002)
+    a = rng.uniform(-1000, 1000, N)
+    b = np.random.default_rng(3003).uniform(-1000, 1000, N)
+    ra, ea = fixedpoint.encode_float64_array(a, key.n, pub.n_words)
+    rb, eb = fixedpoint.encode_float64_array(b, key.n, pub.n_words)
+    ca = pub.raw_encrypt(engine.to_device_words(ra, pub.device))
+    cb = pub.raw_encrypt(engine.to_device_words(rb, pub.device))
+    # ct + ct: D(E(a) E(b)) = a + b mod n  (same exponent classes only: compare residues, no alignment here)
+    s = priv.decrypt(pub.ct_add(ca, cb))
+    # ct * k: D(E(a)^k) = k a mod n with 53-bit multipliers
+    k = rng.integers(1, 1 << 53, size=N, dtype=np.uint64)
+    kw = np.stack([(k & 0xFFFFFFFF).astype(np.uint32), (k >> np.uint64(32)).astype(np.uint32)], axis=1)
+    p = priv.decrypt(pub.ct_mul(ca, engine.to_device_words(kw, pub.device), 53))
+    torch.cuda.synchronize()
+    sh, ph = engine.to_host_words(s), engine.to_host_words(p)
+    idx = np.concatenate([np.arange(0, 2048), np.linspace(2048, N - 1, 2048).astype(np.int64)])
+    ai, bi = engine.words_to_ints(ra[idx]), engine.words_to_ints(rb[idx])
+    assert engine.words_to_ints(sh[idx]) == [(x + y) % key.n for x, y in zip(ai, bi)]
+    assert engine.words_to_ints(ph[idx]) == [int(kk) * x % key.n for kk, x in zip(k[idx], ai)]
+    # whole-batch checksum: the sum of all decrypted residues is linear too (mod n)
+    def total(words):
+        acc = 0
+        for col in range(words.shape[1] - 1, -1, -1):
+            acc = (acc << 32) + int(words[:, col].astype(np.uint64).sum())
+        return acc % key.n
+    assert total(sh) == (total(ra) + total(rb)) % key.n
+
+
+@pytest.mark.parametrize("bits,total_n", [(3072, 1 << 20), (4096, 1 << 18)])
+def test_config3_4_one_rank_shard_roundtrip(bits, total_n):
+    """Configs 4/5 shard the batch over 8 GPUs; one GPU runs rank 0's shard."""
+    key = fixture_key(bits)
+    pub, priv = handles(key)
+    s0, e0 = sharding.my_shard(total_n, 0, 8)
+    N = e0 - s0
+    x = np.random.default_rng(1000 + bits).uniform(-1000, 1000, total_n)[s0:e0]
+    res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
+    m = engine.to_device_words(res, pub.device)
+    ct = pub.encrypt(m, pub.random_r(N))
+    back = priv.decrypt(ct)
+    torch.cuda.synchronize()
+    assert torch.equal(back, m)
+    # and a handful of ciphertexts decrypt correctly under the oracle's CRT definition
+    for i in (0, N // 2, N - 1):
+        c = engine.words_to_ints(engine.to_host_words(ct[i:i + 1]))[0]
+        assert orc.decrypt_crt(key, c) == engine.words_to_ints(res[i:i + 1])[0]
