@@ -46,17 +46,39 @@ CANON_MAC_ENC, CANON_MAC_DEC = 41.52e6, 20.86e6
 BYTES_ENC, BYTES_DEC = 648, 520   # algorithmic bytes per op
 
 
-def executed_macs_decrypt(prime_bits: int = 1024, nl: int = 36, window: int = 5, ct_bits: int = 4096) -> float:
-    """29x29-bit MACs actually issued per decrypted element by k_dec_a_padic (both primes): the p-adic digit
-    engine does a squaring in (12*36+12*24+12*12) + 36^2 + 2*36^2 MACs and a multiplication in 5*36^2."""
+def _sliding_counts(e: int, w: int = 6):
+    """(#squarings, #multiplications) of the left-to-right sliding-window schedule the library compiles for the
+    exponent e (csrc/paillier_capi.hip): windows of at most w bits that end in a 1."""
+    i, nsq, nmul, first, pending = e.bit_length() - 1, 0, 0, True, 0
+    while i >= 0:
+        if not (e >> i) & 1:
+            pending += 1
+            i -= 1
+            continue
+        l = min(w, i + 1)
+        while not (e >> (i - l + 1)) & 1:
+            l -= 1
+        if not first:
+            nsq += pending + l
+            nmul += 1
+        first, pending = False, 0
+        i -= l
+    return nsq + pending, nmul
+
+
+def executed_macs_decrypt(p: int, q: int, nl: int = 36, w: int = 6, ct_bits: int = 4096) -> float:
+    """29x29-bit MACs actually issued per decrypted element by k_dec_a_padic (both primes): on base-s digit
+    pairs a squaring takes (12*36+12*24+12*12) + 36^2 + 2*36^2 MACs and a multiplication 5*36^2."""
     sq = (12 * nl + 12 * (nl - 12) + 12 * (nl - 24)) + nl * nl + 2 * nl * nl
     mul = 5 * nl * nl
-    nwin = -(-prime_bits // window)
-    n_sq = window * (nwin - 1)
-    n_mul = (nwin - 1) * (1 - 2.0 ** -window) + (2 ** window - 2) + 1          # windows + table + leaving Montgomery form
     nd = -(-ct_bits // (29 * nl))
-    conv = nd * 4 * nl * nl
-    return 2.0 * (n_sq * sq + n_mul * mul + conv)
+    total = 0.0
+    for s_ in (p, q):
+        n_sq, n_mul = _sliding_counts(s_ - 1, w)
+        n_sq += 1                                   # base^2 for the odd-power table
+        n_mul += (1 << (w - 1)) - 1 + 1             # table of odd powers + leaving Montgomery form
+        total += n_sq * sq + n_mul * mul + nd * 4 * nl * nl
+    return total
 
 
 def main() -> None:
@@ -191,7 +213,7 @@ def main() -> None:
         t_deca = kern.get("k_dec_a", 0.0) * 1e-3
         t_enc = kern.get("k_encrypt(djn)", 0.0) * 1e-3
         achieved = (CANON_MAC_DEC * B / t_deca) if t_deca > 0 else None
-        executed = (executed_macs_decrypt() * B / t_deca) if t_deca > 0 else None
+        executed = (executed_macs_decrypt(orc.BENCH_P, orc.BENCH_Q) * B / t_deca) if t_deca > 0 else None
         line = {
             "metric": "Paillier encrypt+decrypt ops/sec, 2048-bit key",
             "value": value,

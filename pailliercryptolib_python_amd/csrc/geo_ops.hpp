@@ -56,6 +56,8 @@ bool launch_dec_a_wide(int nl, hipStream_t s, int gridx, const DecAParams& P, co
 
 // p-adic digit engine for CRT-decrypt stage A (mont_padic.hpp / kernels_padic.hpp)
 struct DecPadicParams;
+constexpr int PADIC_SLIDE_BITS = 6;                              // sliding-window width of the decrypt schedule
+constexpr int PADIC_TBL_ENTRIES = 1 << (PADIC_SLIDE_BITS - 1);    // odd powers
 int padic_nl_for_prime_bits(int bits);
 size_t padic_table_words(int nl, size_t blocks);
 bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out,

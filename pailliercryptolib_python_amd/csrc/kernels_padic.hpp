@@ -13,8 +13,9 @@ struct DecPadicParams {
     const MontCtx* pr[2];        // moduli p, q (NL limbs, R = 2^(29 NL))
     const uint32_t* pm1[2];      // p - 1, q - 1 as radix-29 limbs (NLMAX padded)
     const uint32_t* kdig[2];     // [ND][2][NL]: digit pairs of R^(i+2) mod s^2, i = 0 .. ND-1
-    const uint32_t* expo[2];     // s - 1, packed u32 words
-    int ewords[2], ebits[2];
+    const uint16_t* ops[2];      // sliding-window schedule of s - 1: entries (squarings | table index << 8), 0xFF = no multiply
+    int nops[2];
+    int tbl_entries;             // odd powers base^(2i+1), i < tbl_entries; slot tbl_entries holds base^2
     int nd;                      // base-R digits of a ciphertext
     int ct_words, u_words;
 };
@@ -35,8 +36,8 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const uint32_t* pm1 = ldsn + NL;
     const uint32_t n0inv = ctx->n0inv;
     const uint32_t* __restrict__ kdig = P.kdig[which];
-    const uint32_t* __restrict__ expo = P.expo[which];
-    const int ewords = P.ewords[which], ebits = P.ebits[which];
+    const uint16_t* __restrict__ ops = P.ops[which];
+    const int nops = P.nops[which];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint4* A = reinterpret_cast<uint4*>(lds + wave * 3 * E::DIGIT_WORDS) + lane;
     uint4* B = A + E::NC * 64;
@@ -45,7 +46,6 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK_THREADS + threadIdx.x;
     // table entry e: digit d (0 = first, 1 = second), chunk c
     auto tbl = [&](int e, int d, int c) -> uint4& { return table[(((size_t)e * 2 + d) * E::NC + c) * nslots + slot]; };
-    const int nwin = (ebits + WB - 1) / WB;
     const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int ei = tile * BLOCK_THREADS + threadIdx.x;
@@ -103,9 +103,10 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
             E::store_digit(B, sv);
             wave_lds_fence();
         }
-        // ---- table[k] = base^k, k = 1 .. 2^WB - 1 ---------------------------------------------------
+        // ---- table of odd powers: T[i] = base^(2i+1); slot `tbl_entries` keeps base^2 -----------------------
+        const int NT = P.tbl_entries;
 #pragma unroll 1
-        for (int c = 0; c < E::NC; ++c) { tbl(1, 0, c) = E::ld(A, c); tbl(1, 1, c) = E::ld(B, c); }
+        for (int c = 0; c < E::NC; ++c) { tbl(0, 0, c) = E::ld(A, c); tbl(0, 1, c) = E::ld(B, c); }
         auto from_table = [&](int e, int d) {
             return [&, e, d](int blk, uint32_t (&xv)[U]) {
 #pragma unroll
@@ -115,26 +116,34 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
                 }
             };
         };
+        E::sqr(A, B, M, nm, pm1, n0inv);
 #pragma unroll 1
-        for (int k = 2; k < (1 << WB); ++k) {
-            E::mul(A, B, M, from_table(1, 0), from_table(1, 1), nm, pm1, n0inv);
+        for (int c = 0; c < E::NC; ++c) { tbl(NT, 0, c) = E::ld(A, c); tbl(NT, 1, c) = E::ld(B, c); }
+        wave_lds_fence();
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) { E::st(A, c, tbl(0, 0, c)); E::st(B, c, tbl(0, 1, c)); }
+        wave_lds_fence();
+#pragma unroll 1
+        for (int k = 1; k < NT; ++k) {
+            E::mul(A, B, M, from_table(NT, 0), from_table(NT, 1), nm, pm1, n0inv);
 #pragma unroll 1
             for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
         }
-        // ---- left-to-right fixed windows; the top window of s - 1 is never zero -----------------------
+        // ---- sliding-window schedule (wave-uniform, compiled on the host from s - 1) --------------------
         {
-            const int wv = (int)exp_bits(expo, ewords, (nwin - 1) * WB, WB);
+            const int i0 = (int)(ops[0] >> 8);
             wave_lds_fence();
 #pragma unroll 1
-            for (int c = 0; c < E::NC; ++c) { E::st(A, c, tbl(wv, 0, c)); E::st(B, c, tbl(wv, 1, c)); }
+            for (int c = 0; c < E::NC; ++c) { E::st(A, c, tbl(i0, 0, c)); E::st(B, c, tbl(i0, 1, c)); }
             wave_lds_fence();
         }
 #pragma unroll 1
-        for (int wi = nwin - 2; wi >= 0; --wi) {
-            const int wv = (int)exp_bits(expo, ewords, wi * WB, WB);
+        for (int k = 1; k < nops; ++k) {
+            const int op = (int)ops[k];
+            const int nsq = op & 0xFF, idx = op >> 8;
 #pragma unroll 1
-            for (int s = 0; s < WB; ++s) E::sqr(A, B, M, nm, pm1, n0inv);
-            if (wv != 0) E::mul(A, B, M, from_table(wv, 0), from_table(wv, 1), nm, pm1, n0inv);
+            for (int s = 0; s < nsq; ++s) E::sqr(A, B, M, nm, pm1, n0inv);
+            if (idx != 0xFF) E::mul(A, B, M, from_table(idx, 0), from_table(idx, 1), nm, pm1, n0inv);
         }
         // ---- leave Montgomery form: multiply by the plain element 1 = (1, 0) ----------------------------
         uint32_t w[NL], v[NL];

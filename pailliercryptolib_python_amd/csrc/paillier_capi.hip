@@ -266,6 +266,8 @@ struct pai_privkey {
     int padic_nl = 0;             // != 0: stage A runs on the p-adic digit engine (takes precedence)
     uint32_t* d_pm1[2] = {nullptr, nullptr};
     uint32_t* d_kdig[2] = {nullptr, nullptr};
+    uint16_t* d_ops[2] = {nullptr, nullptr};
+    int nops[2] = {0, 0};
     int padic_nd = 0;
     DevBuf table, ubuf;
     std::mutex mu;
@@ -767,6 +769,34 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
                 }
                 HIP_CHECK(hipMalloc((void**)&sk->d_kdig[w], host.size() * 4));
                 HIP_CHECK(hipMemcpy(sk->d_kdig[w], host.data(), host.size() * 4, hipMemcpyHostToDevice));
+                // sliding-window schedule of the exponent s - 1 (MSB first): each entry = (#squarings, table index of
+                // the odd window value) applied as "square nsq times, then multiply by base^(2 idx + 1)"
+                {
+                    const Limbs e = hbn::sub(s, one);
+                    auto bit = [&](int i) { return i >= 0 && ((e[i / 32] >> (i % 32)) & 1u); };
+                    std::vector<uint16_t> ops;
+                    int i = hbn::bitlen(e) - 1;
+                    int pending_sq = 0;
+                    bool first = true;
+                    while (i >= 0) {
+                        if (!bit(i)) { ++pending_sq; --i; continue; }
+                        int l = std::min(PADIC_SLIDE_BITS, i + 1);
+                        while (!bit(i - l + 1)) --l;                          // window must end in a 1
+                        uint32_t val = 0;
+                        for (int k = 0; k < l; ++k) val = (val << 1) | (bit(i - k) ? 1u : 0u);
+                        const int idx = (int)(val >> 1);                      // odd value 2 idx + 1
+                        int nsq = first ? 0 : pending_sq + l;
+                        while (nsq > 255) { ops.push_back((uint16_t)(255 | (0xFF << 8))); nsq -= 255; }
+                        ops.push_back((uint16_t)(nsq | (idx << 8)));
+                        first = false;
+                        pending_sq = 0;
+                        i -= l;
+                    }
+                    while (pending_sq > 0) { int c = std::min(pending_sq, 255); ops.push_back((uint16_t)(c | (0xFF << 8))); pending_sq -= c; }
+                    sk->nops[w] = (int)ops.size();
+                    HIP_CHECK(hipMalloc((void**)&sk->d_ops[w], ops.size() * 2));
+                    HIP_CHECK(hipMemcpy(sk->d_ops[w], ops.data(), ops.size() * 2, hipMemcpyHostToDevice));
+                }
             }
         }
         Limbs pinvq = hbn::inv_mod_prime(hbn::mod(p, q), q);
@@ -789,6 +819,7 @@ void pai_privkey_destroy(pai_privkey* sk) {
         if (sk->d_hR[w]) (void)hipFree(sk->d_hR[w]);
         if (sk->d_pm1[w]) (void)hipFree(sk->d_pm1[w]);
         if (sk->d_kdig[w]) (void)hipFree(sk->d_kdig[w]);
+        if (sk->d_ops[w]) (void)hipFree(sk->d_ops[w]);
     }
     if (sk->d_pinvqR) (void)hipFree(sk->d_pinvqR);
     sk->table.release();
@@ -838,10 +869,10 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                     Q.pr[w] = sk->pr[w].d_ctx;
                     Q.pm1[w] = sk->d_pm1[w];
                     Q.kdig[w] = sk->d_kdig[w];
-                    Q.expo[w] = sk->d_expo[w];
-                    Q.ewords[w] = sk->ewords[w];
-                    Q.ebits[w] = sk->ebits[w];
+                    Q.ops[w] = sk->d_ops[w];
+                    Q.nops[w] = sk->nops[w];
                 }
+                Q.tbl_entries = PADIC_TBL_ENTRIES;
                 Q.nd = sk->padic_nd;
                 Q.ct_words = pk->ct_words;
                 Q.u_words = sk->u_words;

@@ -34,7 +34,7 @@ bool launch_dec_a_wide(int nl, hipStream_t s, int gridx, const DecAParams& P, co
 
 // ---- p-adic digit engine (kernels_padic.hpp): primes of 700..1024 bits, 36 limbs, 12-row blocks -----
 int padic_nl_for_prime_bits(int bits) { return (bits >= 700 && RB * 36 >= bits + 20) ? 36 : 0; }
-size_t padic_table_words(int nl, size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * 2 * nl * blocks * BLOCK_THREADS; }
+size_t padic_table_words(int nl, size_t blocks) { return (size_t)(PADIC_TBL_ENTRIES + 1) * 2 * nl * blocks * BLOCK_THREADS; }
 bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out,
                         int n, uint32_t* table) {
     if (nl != 36) return false;
