@@ -50,7 +50,11 @@ def _compile(src: str) -> None:
     obj = OBJ / (Path(src).stem + ".o")
     if obj.exists() and obj.stat().st_mtime >= _deps_mtime():
         return
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(CSRC / src), "-o", str(obj)]
+    # the row engines rely on full unrolling of loops with thousands of multiply-accumulates (register-resident
+    # accumulator windows need compile-time indices); clang's default pragma-unroll budget silently falls back to a
+    # partial unroll there, which demotes the window to scratch memory (4x slower)
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1048576",
+           "-c", str(CSRC / src), "-o", str(obj)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")

@@ -60,14 +60,14 @@ constexpr int PADIC_SLIDE_BITS = 6;                              // sliding-wind
 constexpr int PADIC_TBL_ENTRIES = 1 << (PADIC_SLIDE_BITS - 1);    // odd powers
 int padic_nl_for_prime_bits(int bits);
 size_t padic_table_words(int nl, size_t blocks);
-bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out,
-                        int n, uint32_t* table);
+bool launch_dec_a_padic(int nl, bool lean, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
+                        uint32_t* u_out, int n, uint32_t* table);
 
 // digit engine with base n for raw/DJN encryption (kernels_padic_enc.hpp)
 struct EncPadicParams;
 int padic_enc_nl_for_n_bits(int bits);
 bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
-                           const uint32_t* one_dig, uint32_t* table, int J);
+                           const uint32_t* one_dig, uint32_t* table, int J, int wb);
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
                           uint32_t* ct_out, int n, int mode);
 

@@ -17,11 +17,14 @@ struct DecPadicParams {
     int nops[2];
     int tbl_entries;             // odd powers base^(2i+1), i < tbl_entries; slot tbl_entries holds base^2
     int nd;                      // base-R digits of a ciphertext
+    uint4* wscratch;             // LEAN variant: [NC][nslots] parking space for the first result digit
     int ct_words, u_words;
 };
 
-template <int NL, int U, int WB>
-__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+// LEAN = true: two waves per SIMD (quotient digits in registers, first result digit parked in global scratch,
+// LDS holds only the digit pair); LEAN = false: one wave per SIMD with everything in LDS/registers.
+template <int NL, int U, int WB, bool LEAN>
+__global__ void __launch_bounds__(BLOCK_THREADS, LEAN ? 2 : 1)
 k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n,
               uint4* __restrict__ table) {
     using E = Padic<NL, U>;
@@ -29,7 +32,8 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const int which = blockIdx.y;
     const MontCtx* ctx = P.pr[which];
     // modulus and s - 1 from LDS (see kernels_padic_enc.hpp)
-    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 3 * E::DIGIT_WORDS;
+    constexpr int LDS_DIGITS = LEAN ? 2 : 3;
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * LDS_DIGITS * E::DIGIT_WORDS;
     for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = ctx->n[i]; ldsn[NL + i] = P.pm1[which][i]; }
     __syncthreads();
     const uint32_t* nm = ldsn;
@@ -39,11 +43,13 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const uint16_t* __restrict__ ops = P.ops[which];
     const int nops = P.nops[which];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint4* A = reinterpret_cast<uint4*>(lds + wave * 3 * E::DIGIT_WORDS) + lane;
+    uint4* A = reinterpret_cast<uint4*>(lds + wave * LDS_DIGITS * E::DIGIT_WORDS) + lane;
     uint4* B = A + E::NC * 64;
-    const typename E::MBuf M{B + E::NC * 64, 64};   // quotient digits of the first half of the product rule (LDS)
     const size_t nslots = (size_t)gridDim.x * gridDim.y * BLOCK_THREADS;
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK_THREADS + threadIdx.x;
+    // M: quotient digits of the first half of the product rule (LDS) — or, LEAN, the global parking column
+    const typename E::MBuf M = LEAN ? typename E::MBuf{P.wscratch + slot, nslots} : typename E::MBuf{B + E::NC * 64, 64};
+    auto SQR = [&]() { if constexpr (LEAN) E::sqr_lean(A, B, M, nm, pm1, n0inv); else E::sqr(A, B, M, nm, pm1, n0inv); };
     // table entry e: digit d (0 = first, 1 = second), chunk c
     auto tbl = [&](int e, int d, int c) -> uint4& { return table[(((size_t)e * 2 + d) * E::NC + c) * nslots + slot]; };
     const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
@@ -116,7 +122,7 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
                 }
             };
         };
-        E::sqr(A, B, M, nm, pm1, n0inv);
+        SQR();
 #pragma unroll 1
         for (int c = 0; c < E::NC; ++c) { tbl(NT, 0, c) = E::ld(A, c); tbl(NT, 1, c) = E::ld(B, c); }
         wave_lds_fence();
@@ -125,7 +131,8 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
         wave_lds_fence();
 #pragma unroll 1
         for (int k = 1; k < NT; ++k) {
-            E::mul(A, B, M, from_table(NT, 0), from_table(NT, 1), nm, pm1, n0inv);
+            if constexpr (LEAN) E::mul_lean(A, B, M, from_table(NT, 0), from_table(NT, 1), nm, pm1, n0inv);
+            else E::mul(A, B, M, from_table(NT, 0), from_table(NT, 1), nm, pm1, n0inv);
 #pragma unroll 1
             for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
         }
@@ -142,8 +149,11 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
             const int op = (int)ops[k];
             const int nsq = op & 0xFF, idx = op >> 8;
 #pragma unroll 1
-            for (int s = 0; s < nsq; ++s) E::sqr(A, B, M, nm, pm1, n0inv);
-            if (idx != 0xFF) E::mul(A, B, M, from_table(idx, 0), from_table(idx, 1), nm, pm1, n0inv);
+            for (int s = 0; s < nsq; ++s) SQR();
+            if (idx != 0xFF) {
+                if constexpr (LEAN) E::mul_lean(A, B, M, from_table(idx, 0), from_table(idx, 1), nm, pm1, n0inv);
+                else E::mul(A, B, M, from_table(idx, 0), from_table(idx, 1), nm, pm1, n0inv);
+            }
         }
         // ---- leave Montgomery form: multiply by the plain element 1 = (1, 0) ----------------------------
         uint32_t w[NL], v[NL];

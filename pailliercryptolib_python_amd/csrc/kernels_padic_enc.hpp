@@ -17,7 +17,7 @@ struct EncPadicParams {
     const uint32_t* nsq;         // n^2 limbs (2 NL, radix 29)
     const uint4* fb_table;       // [J][256][2][NC] uint4
     uint4* mscratch;             // [2 NC][nslots]: quotient digits, then the parked first result digit
-    int fb_windows;
+    int fb_windows, fb_wbits;
     int pt_words, ct_words, r_words;
 };
 
@@ -25,7 +25,7 @@ struct EncPadicParams {
 template <int NL, int U>
 __global__ void __launch_bounds__(64, 1)
 k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const uint32_t* __restrict__ hs_dig,
-                 const uint32_t* __restrict__ one_dig, uint4* __restrict__ table, int J) {
+                 const uint32_t* __restrict__ one_dig, uint4* __restrict__ table, int J, int wb) {
     using E = Padic<NL, U>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* ldsn = lds + 3 * E::DIGIT_WORDS;
@@ -40,11 +40,12 @@ k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const ui
     uint4* A = reinterpret_cast<uint4*>(lds) + lane;
     uint4* B = A + E::NC * 64;
     const typename E::MBuf M{B + E::NC * 64, 64};
-    auto ent = [&](int d, int dg, int c) -> uint4& { return table[(((size_t)js * 256 + d) * 2 + dg) * E::NC + c]; };
+    const int ENT = 1 << wb;
+    auto ent = [&](int d, int dg, int c) -> uint4& { return table[((((size_t)js << wb) + d) * 2 + dg) * E::NC + c]; };
     auto self = [&](const uint4* X) {
         return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); };
     };
-    // B_j = hs^(2^(8 j)): every lane walks the same squaring chain and snapshots its own window base
+    // B_j = hs^(2^(wb j)): every lane walks the same squaring chain and snapshots its own window base
 #pragma unroll 1
     for (int c = 0; c < E::NC; ++c) {
         E::st(A, c, make_uint4(hs_dig[4 * c], hs_dig[4 * c + 1], hs_dig[4 * c + 2], hs_dig[4 * c + 3]));
@@ -54,11 +55,11 @@ k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const ui
     const int jmax = min(J - 1, blockIdx.x * 64 + 63);
 #pragma unroll 1
     for (int s = 0;; ++s) {
-        if (s == 8 * js) {
+        if (s == wb * js) {
 #pragma unroll 1
             for (int c = 0; c < E::NC; ++c) { ent(1, 0, c) = E::ld(A, c); ent(1, 1, c) = E::ld(B, c); }
         }
-        if (s == 8 * jmax) break;
+        if (s == wb * jmax) break;
         E::mul(A, B, M, self(A), self(B), nm, nm1, n0inv);            // x <- x^2
     }
     __threadfence();
@@ -82,7 +83,7 @@ k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const ui
         };
     };
 #pragma unroll 1
-    for (int d = 2; d < 256; ++d) {
+    for (int d = 2; d < ENT; ++d) {
         E::mul(A, B, M, from_ent(0), from_ent(1), nm, nm1, n0inv);
         if (j < J) {
 #pragma unroll 1
@@ -173,9 +174,11 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
             const uint32_t* rrow = r + (size_t)es * P.r_words;
 #pragma unroll 1
             for (int jw = 0; jw < P.fb_windows; ++jw) {
-                const int bit = jw * FB_WBITS;
-                const uint32_t d = (rrow[bit >> 5] >> (bit & 31)) & (FB_ENTRIES - 1);
-                const uint4* ent = P.fb_table + ((size_t)jw * FB_ENTRIES + d) * 2 * E::NC;
+                const int bit = jw * P.fb_wbits, k = bit >> 5;
+                uint64_t bits2 = rrow[k];
+                if (k + 1 < P.r_words) bits2 |= (uint64_t)rrow[k + 1] << 32;
+                const uint32_t d = (uint32_t)(bits2 >> (bit & 31)) & ((1u << P.fb_wbits) - 1u);
+                const uint4* ent = P.fb_table + (((size_t)jw << P.fb_wbits) + d) * 2 * E::NC;
                 if (jw == 0) {
                     wave_lds_fence();
 #pragma unroll 1

@@ -377,6 +377,108 @@ struct Padic {
         }
     }
 
+    // ---- register-lean variant (two waves per SIMD): quotient digits m stay in VGPRs (the first half is fully
+    // unrolled so that they can be indexed statically), the first result digit is parked in a global scratch
+    // column Wb while the second half runs, and the second digit is written straight over B.  LDS then holds
+    // only the digit pair itself (2 x NL limbs per lane).
+    template <int B_, bool SQR, class CSrc>
+    PAI_DEV static void mm1_unrolled(uint64_t (&acc)[NW], uint32_t (&m)[NL], const uint4* X, CSrc& csrc,
+                                     const uint32_t* __restrict__ nm, uint32_t n0inv) {
+        if constexpr (B_ < NB) {
+            uint32_t xv[U], q[U], dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+            if constexpr (SQR) {
+                digits(X, B_, xv);
+                block<true, U * B_, U * (B_ + 1), false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, B_, q);
+            } else {
+                csrc(B_, xv);
+                block<true, 0, NL, false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, B_, q);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) m[U * B_ + u] = q[u];
+            if (B_ != NB - 1 && ((B_ + 1) * U) % (SQR ? P2 : P1) == 0) normalize(acc);
+            mm1_unrolled<B_ + 1, SQR>(acc, m, X, csrc, nm, n0inv);
+        }
+    }
+    PAI_DEV static void init_from_m(uint64_t (&acc)[NW], const uint32_t (&m)[NL]) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) acc[j] = (uint64_t)(RMASK - m[j]);
+        acc[0] += 1;
+#pragma unroll
+        for (int j = NL; j < NW; ++j) acc[j] = 0;
+    }
+    PAI_DEV static void finish_into(const uint64_t (&acc)[NW], uint4* Bdst, uint4* Adst, MBuf Wb) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t t = acc[4 * ch + k] + c;
+                w[k] = (uint32_t)t & RMASK;
+                c = t >> RB;
+            }
+            st(Bdst, ch, make_uint4(w[0], w[1], w[2], w[3]));
+            st(Adst, ch, Wb.p[(size_t)ch * Wb.stride]);
+        }
+    }
+    PAI_DEV static void sqr_lean(uint4* A, uint4* B, MBuf Wb, const uint32_t* __restrict__ nm,
+                                 const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        uint32_t m[NL];
+        {
+            uint64_t acc[NW];
+            zero(acc);
+            int none = 0;
+            mm1_unrolled<0, true>(acc, m, A, none, nm, n0inv);
+            finish_to_buf(acc, Wb);
+        }
+        uint64_t acc[NW];
+        init_from_m(acc, m);
+        uint32_t dummy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t xv[U], q[U];
+            digits(B, blk, xv);
+            block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);
+            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
+        }
+        wave_lds_fence();
+        finish_into(acc, B, A, Wb);
+        wave_lds_fence();
+    }
+    template <class CSrc, class DSrc>
+    PAI_DEV static void mul_lean(uint4* A, uint4* B, MBuf Wb, CSrc&& csrc, DSrc&& dsrc, const uint32_t* __restrict__ nm,
+                                 const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        uint32_t m[NL];
+        {
+            uint64_t acc[NW];
+            zero(acc);
+            mm1_unrolled<0, false>(acc, m, A, csrc, nm, n0inv);
+            finish_to_buf(acc, Wb);
+        }
+        uint64_t acc[NW];
+        init_from_m(acc, m);
+        uint32_t xn[U], yn[U];
+        dsrc(0, xn);
+        csrc(0, yn);
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t xv[U], yv[U], q[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { xv[u] = xn[u]; yv[u] = yn[u]; }
+            dsrc(blk + 1 < NB ? blk + 1 : blk, xn);
+            csrc(blk + 1 < NB ? blk + 1 : blk, yn);
+            block<true, 0, NL, true, true>(acc, A, xv, B, yv, nm, n0inv, pm1, blk, q);
+            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
+        }
+        wave_lds_fence();
+        finish_into(acc, B, A, Wb);
+        wave_lds_fence();
+    }
+
     // (A, B) <- (A, B)^2
     PAI_DEV static void sqr(uint4* A, uint4* B, MBuf M, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
                             uint32_t n0inv) {

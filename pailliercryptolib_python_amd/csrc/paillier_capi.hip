@@ -261,6 +261,8 @@ struct pai_privkey {
     uint32_t* d_nsinv2[2] = {nullptr, nullptr};
     uint32_t* d_hR[2] = {nullptr, nullptr};
     uint32_t* d_pinvqR = nullptr;
+    bool padic_lean = false;      // two-waves-per-SIMD variant of the digit kernel (PAI_PADIC_LEAN=1)
+    DevBuf wscratch;
     int u_words = 0;
     int wide_nl = 0;              // != 0: stage A runs on the wide engine with this many limbs
     int padic_nl = 0;             // != 0: stage A runs on the p-adic digit engine (takes precedence)
@@ -462,10 +464,10 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             HIP_CHECK(hipFree(d_bases));
             HIP_CHECK(hipFree(d_expo));
             // digit-form table for the base-n digit engine
-            // EXPERIMENTAL, off by default: the base-n digit engine is bit-exact but currently slower than the
-            // lane-group kernel for encryption (memory-latency bound at one wave per SIMD); PAI_ENABLE_PADIC_ENC=1 enables it
-            pk->penc_nl = 0;
-            if (const char* env = std::getenv("PAI_ENABLE_PADIC_ENC")) { if (env[0] == '1' && wb == 8) pk->penc_nl = padic_enc_nl_for_n_bits(hbn::bitlen(pk->n)); }
+            // raw / DJN encryption run on the base-n digit engine when n fits 72 limbs (PAI_DISABLE_PADIC=1 falls
+            // back to the lane-group kernel, which also serves apply_obfuscator and every other key size)
+            pk->penc_nl = padic_enc_nl_for_n_bits(hbn::bitlen(pk->n));
+            if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') pk->penc_nl = 0; }
             if (pk->penc_nl) {
                 const int pnl = pk->penc_nl;
                 pk->nmod.init(pk->n, pnl);
@@ -488,7 +490,7 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
                 uint32_t* d_one = digits_of(Rm);
                 uint32_t* d_hs = digits_of(hbn::mulmod(pk->hs, Rm, pk->nsq));
                 HIP_CHECK(hipMalloc((void**)&pk->d_fb_dig, NE * 2 * (size_t)pnl * 4));
-                if (!launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs, d_one, pk->d_fb_dig, J))
+                if (!launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs, d_one, pk->d_fb_dig, J, wb))
                     throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipDeviceSynchronize());
@@ -558,6 +560,7 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         Q.fb_table = reinterpret_cast<const uint4*>(pk->d_fb_dig);
         Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
         Q.fb_windows = pk->fb_windows;
+        Q.fb_wbits = pk->fb_wbits;
         Q.pt_words = pk->n_words;
         Q.ct_words = pk->ct_words;
         Q.r_words = pk->r_words;
@@ -749,6 +752,7 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
         sk->padic_nl = padic_nl_for_prime_bits(hbn::bitlen(q));
         if (sk->pr[0].nl != sk->padic_nl || sk->pr[1].nl != sk->padic_nl) sk->padic_nl = 0;
         if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') sk->padic_nl = 0; }
+        if (const char* env = std::getenv("PAI_PADIC_LEAN")) sk->padic_lean = env[0] == '1';
         if (sk->padic_nl) {
             const int nl = sk->padic_nl;
             sk->padic_nd = (32 * pk->ct_words + hbn::RB * nl - 1) / (hbn::RB * nl);
@@ -823,6 +827,7 @@ void pai_privkey_destroy(pai_privkey* sk) {
     }
     if (sk->d_pinvqR) (void)hipFree(sk->d_pinvqR);
     sk->table.release();
+    sk->wscratch.release();
     sk->ubuf.release();
     delete sk;
 }
@@ -840,8 +845,10 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         int gridx = grid_for(ga, N, dev.ncu, 1);          // x2 primes => 2 workgroups per CU
         if (sk->padic_nl) {
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
-            gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)dev.ncu / 2));   // x2 primes => one workgroup per CU
+            const size_t per_prime = sk->padic_lean ? (size_t)dev.ncu : (size_t)dev.ncu / 2;   // x2 primes => 2 or 1 workgroups per CU
+            gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, per_prime));
             sk->table.ensure(padic_table_words(sk->padic_nl, (size_t)gridx * 2) * 4);
+            if (sk->padic_lean) sk->wscratch.ensure((size_t)gridx * 2 * BLOCK_THREADS * sk->padic_nl * 4);
         } else if (sk->wide_nl) {
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
             gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)dev.ncu / 2));   // x2 primes => one workgroup per CU
@@ -874,9 +881,10 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 }
                 Q.tbl_entries = PADIC_TBL_ENTRIES;
                 Q.nd = sk->padic_nd;
+                Q.wscratch = sk->wscratch.as<uint4>();
                 Q.ct_words = pk->ct_words;
                 Q.u_words = sk->u_words;
-                if (!launch_dec_a_padic(sk->padic_nl, s, gridx, Q, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))
+                if (!launch_dec_a_padic(sk->padic_nl, sk->padic_lean, s, gridx, Q, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))
                     throw PaiError(PAI_E_INTERNAL, "no p-adic kernel for this limb count");
             } else if (sk->wide_nl) {
                 if (!launch_dec_a_wide(sk->wide_nl, s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))

@@ -35,25 +35,32 @@ bool launch_dec_a_wide(int nl, hipStream_t s, int gridx, const DecAParams& P, co
 // ---- p-adic digit engine (kernels_padic.hpp): primes of 700..1024 bits, 36 limbs, 12-row blocks -----
 int padic_nl_for_prime_bits(int bits) { return (bits >= 700 && RB * 36 >= bits + 20) ? 36 : 0; }
 size_t padic_table_words(int nl, size_t blocks) { return (size_t)(PADIC_TBL_ENTRIES + 1) * 2 * nl * blocks * BLOCK_THREADS; }
-bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out,
-                        int n, uint32_t* table) {
+bool launch_dec_a_padic(int nl, bool lean, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
+                        uint32_t* u_out, int n, uint32_t* table) {
     if (nl != 36) return false;
-    constexpr int bytes = 3 * 36 * BLOCK_THREADS * 4 + 2 * 36 * 4;
-    (void)hipFuncSetAttribute((const void*)k_dec_a_padic<36, 12, MODEXP_WINDOW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_dec_a_padic<36, 12, MODEXP_WINDOW>), dim3(gridx, 2), dim3(BLOCK_THREADS), bytes, s, P, ct, u_out, n,
-                       reinterpret_cast<uint4*>(table));
+    if (lean) {
+        constexpr int bytes = 2 * 36 * BLOCK_THREADS * 4 + 2 * 36 * 4;
+        (void)hipFuncSetAttribute((const void*)k_dec_a_padic<36, 12, MODEXP_WINDOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        hipLaunchKernelGGL((k_dec_a_padic<36, 12, MODEXP_WINDOW, true>), dim3(gridx, 2), dim3(BLOCK_THREADS), bytes, s, P, ct,
+                           u_out, n, reinterpret_cast<uint4*>(table));
+    } else {
+        constexpr int bytes = 3 * 36 * BLOCK_THREADS * 4 + 2 * 36 * 4;
+        (void)hipFuncSetAttribute((const void*)k_dec_a_padic<36, 12, MODEXP_WINDOW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        hipLaunchKernelGGL((k_dec_a_padic<36, 12, MODEXP_WINDOW, false>), dim3(gridx, 2), dim3(BLOCK_THREADS), bytes, s, P, ct,
+                           u_out, n, reinterpret_cast<uint4*>(table));
+    }
     return true;
 }
 
 // ---- digit engine with base n for encryption (kernels_padic_enc.hpp): 1400..2048-bit n, 72 limbs -------
 int padic_enc_nl_for_n_bits(int bits) { return (bits >= 1400 && RB * 72 >= bits + 20) ? 72 : 0; }
 bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
-                           const uint32_t* one_dig, uint32_t* table, int J) {
+                           const uint32_t* one_dig, uint32_t* table, int J, int wb) {
     if (nl != 72) return false;
     constexpr int bytes = 3 * 72 * 64 * 4 + 2 * 72 * 4;
     (void)hipFuncSetAttribute((const void*)k_fb_table_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     hipLaunchKernelGGL((k_fb_table_padic<72, 8>), dim3((J + 63) / 64), dim3(64), bytes, s, nctx, nm1, hs_dig, one_dig,
-                       reinterpret_cast<uint4*>(table), J);
+                       reinterpret_cast<uint4*>(table), J, wb);
     return true;
 }
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
