@@ -70,6 +70,15 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not LIB_PATH.exists():
+        # not built yet (fresh checkout): compile it in-tree with hipcc; this is a build step, not a fallback
+        try:
+            from . import build as _build
+
+            if _build.LIB == LIB_PATH:
+                _build.build_native()
+        except Exception:      # noqa: BLE001 - reported below
+            pass
+    if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m pailliercryptolib_python_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."

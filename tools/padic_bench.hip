@@ -89,5 +89,9 @@ int main(int argc, char** argv) {
     run<36, 12, 0>("mul <36,12> M in LDS", iters, ncu);
     run<36, 12, 2>("sqr <36,12> M in LDS", iters, ncu);
     run<72, 8, 1>("mul_wbuf <72,8> M,W global", iters, ncu);
+    run<72, 12, 1>("mul_wbuf <72,12> M,W global", iters, ncu);
+    run<72, 4, 1>("mul_wbuf <72,4> M,W global", iters, ncu);
+    run<36, 4, 0>("mul <36,4> M in LDS", iters, ncu);
+    run<36, 4, 2>("sqr <36,4> M in LDS", iters, ncu);
     return 0;
 }
