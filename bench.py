@@ -68,8 +68,9 @@ def _sliding_counts(e: int, w: int = 6):
 
 def executed_macs_decrypt(p: int, q: int, nl: int = 36, w: int = 6, ct_bits: int = 4096) -> float:
     """29x29-bit MACs actually issued per decrypted element by k_dec_a_padic (both primes): on base-s digit
-    pairs a squaring takes (12*36+12*24+12*12) + 36^2 + 2*36^2 MACs and a multiplication 5*36^2."""
-    sq = (12 * nl + 12 * (nl - 12) + 12 * (nl - 24)) + nl * nl + 2 * nl * nl
+    pairs a squaring takes 36*37/2 (a^2, every limb pair once) + 36^2 (its reduction) + 2*36^2 (2ab and
+    its reduction) MACs and a multiplication 5*36^2."""
+    sq = nl * (nl + 1) // 2 + nl * nl + 2 * nl * nl
     mul = 5 * nl * nl
     nd = -(-ct_bits // (29 * nl))
     total = 0.0

@@ -41,9 +41,12 @@ struct Padic {
         for (int j = 0; j < NW; ++j) acc[j] = 0;
     }
     PAI_DEV static void normalize(uint64_t (&acc)[NW]) {
+#ifdef PADIC_X_NONORM
+        return;
+#endif
 #pragma unroll
         for (int j = NW - 1; j >= 1; --j) {
-            uint64_t keep = (j == NW - 1) ? acc[j] : (acc[j] & RMASK);
+            const uint64_t keep = (j == NW - 1) ? acc[j] : (acc[j] & RMASK);
             acc[j] = keep + (acc[j - 1] >> RB);
         }
         acc[0] &= RMASK;
@@ -70,7 +73,9 @@ struct Padic {
     // One block of U rows:  acc += X * xv  (limbs of X below LO skipped, limbs >= HI taken twice)
     //                           (+ Y * yv)  + p * q ,  then the window slides by U columns.
     // q receives the block's quotient digits.  FEED: U limbs of a constant enter at the window top.
-    template <bool HAS_X, int LO, int HI, bool HAS_Y, bool FEED>
+    // SYM (squaring, xv = limbs LO .. HI-1 of X itself): inside the diagonal class [LO, HI) the pair
+    // (limb LO + d, row u) is taken once — skipped for d < u, single for d == u, doubled for d > u.
+    template <bool HAS_X, int LO, int HI, bool HAS_Y, bool FEED, bool SYM = false>
     PAI_DEV static void block(uint64_t (&acc)[NW], const uint4* X, const uint32_t (&xv)[U], const uint4* Y,
                               const uint32_t (&yv)[U], const uint32_t* __restrict__ nm, uint32_t n0inv,
                               const uint32_t* __restrict__ feed, int blk, uint32_t (&q)[U]) {
@@ -98,28 +103,40 @@ struct Padic {
                 y0[4 * c] = y0[4 * c + 1] = y0[4 * c + 2] = y0[4 * c + 3] = 0;
             }
         }
-        auto xterm = [&](int j, int u) -> uint64_t {           // contribution of limb j of X in row u
+        // multiplicity of the product (limb j of X) * (row u): 0, 1 or 2
+        auto xmult = [](int j, int u) -> int {
             if (!HAS_X || j < LO) return 0;
-            return (uint64_t)x0[j] * (j >= HI ? xv2[u] : xv[u]);
+            if (j >= HI) return 2;
+            if (!SYM) return 1;
+            return (j - LO < u) ? 0 : (j - LO == u ? 1 : 2);
+        };
+        auto xterm = [&](int j, int u) -> uint64_t {           // contribution of limb j (< U) of X in row u
+            const int k = xmult(j, u);
+            return k == 0 ? 0 : (uint64_t)x0[j] * (k == 2 ? xv2[u] : xv[u]);
         };
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int j = 0; j <= u; ++j) {
-                if (HAS_X && j >= LO) acc[u] += xterm(j, u - j);
+                if (xmult(j, u - j)) acc[u] += xterm(j, u - j);
                 if constexpr (HAS_Y) acc[u] += (uint64_t)y0[j] * yv[u - j];
             }
 #pragma unroll
             for (int j = 1; j <= u; ++j) acc[u] += (uint64_t)nm[j] * q[u - j];
+#ifdef PADIC_X_NOQ
+            q[u] = (uint32_t)acc[u];
+            acc[u] += (uint64_t)nm[0] * q[u];
+#else
             q[u] = ((uint32_t)acc[u] * n0inv) & RMASK;
             acc[u] += (uint64_t)nm[0] * q[u];
             acc[u + 1] += acc[u] >> RB;
+#endif
         }
 #pragma unroll
         for (int j = 1; j < U; ++j) {
 #pragma unroll
             for (int u = U - j; u < U; ++u) {
-                if (HAS_X && j >= LO) acc[j + u] += xterm(j, u);
+                if (xmult(j, u)) acc[j + u] += xterm(j, u);
                 if constexpr (HAS_Y) acc[j + u] += (uint64_t)y0[j] * yv[u];
                 acc[j + u] += (uint64_t)nm[j] * q[u];
             }
@@ -137,7 +154,8 @@ struct Padic {
                 for (int k = 0; k < 4; ++k) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        if (HAS_X && 4 * c >= LO) acc[4 * c + k + u] += (uint64_t)xa[k] * (4 * c >= HI ? xv2[u] : xv[u]);
+                        const int mult = xmult(4 * c + k, u);
+                        if (mult) acc[4 * c + k + u] += (uint64_t)xa[k] * (mult == 2 ? xv2[u] : xv[u]);
                         if constexpr (HAS_Y) acc[4 * c + k + u] += (uint64_t)ya[k] * yv[u];
                         acc[4 * c + k + u] += (uint64_t)nm[4 * c + k] * q[u];
                     }
@@ -160,7 +178,8 @@ struct Padic {
                 for (int k = 0; k < 4; ++k) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        if (HAS_X && 4 * c >= LO) acc[4 * c + k + u] += (uint64_t)xa[k] * (4 * c >= HI ? xv2[u] : xv[u]);
+                        const int mult = xmult(4 * c + k, u);
+                        if (mult) acc[4 * c + k + u] += (uint64_t)xa[k] * (mult == 2 ? xv2[u] : xv[u]);
                         if constexpr (HAS_Y) acc[4 * c + k + u] += (uint64_t)ya[k] * yv[u];
                         acc[4 * c + k + u] += (uint64_t)n_cur[k] * q[u];
                     }
@@ -177,6 +196,11 @@ struct Padic {
 
     // carry-propagate the low NL columns into canonical 29-bit limbs (registers)
     PAI_DEV static void finish(const uint64_t (&acc)[NW], uint32_t (&r)[NL]) {
+#ifdef PADIC_X_NOFINISH
+#pragma unroll
+        for (int j = 0; j < NL; ++j) r[j] = (uint32_t)acc[j];
+        return;
+#endif
         uint64_t c = 0;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
@@ -229,6 +253,15 @@ struct Padic {
         finish(acc, w);
     }
     // squaring: C = X, symmetric by limb classes of U limbs (row block b multiplies limbs >= U b)
+    // Column bound: a column of X^2 holds at most NL/2 doubled pairs (2^59 each) and one square over the WHOLE
+    // pass, plus one p*q product (2^58) per row.  For NL <= 40 a single normalisation after about half the rows
+    // keeps both halves below 2^64: (NL/2 + 1/2) 2^59 + r 2^58 < 2^64 for r <= 24.  Wider digits use the
+    // per-row rule (1.5 * 2^59 per row, at most 16 rows).
+    PAI_DEV static constexpr bool sqr1_normalize_after(int B) {
+        if (B == NB - 1) return false;
+        if (NL <= 40) return (B + 1) * U <= 24 && (B + 2) * U > 24;
+        return ((B + 1) * U) % P2 == 0;
+    }
     template <int B>
     PAI_DEV static void mm1_sqr_blocks(uint64_t (&acc)[NW], MBuf M, const uint4* X,
                                        const uint32_t* __restrict__ nm, uint32_t n0inv) {
@@ -237,9 +270,9 @@ struct Padic {
 #pragma unroll
             for (int u = 0; u < U; ++u) dummy[u] = 0;
             digits(X, B, xv);
-            block<true, U * B, U * (B + 1), false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, B, q);
+            block<true, U * B, U * (B + 1), false, false, true>(acc, X, xv, X, dummy, nm, n0inv, nm, B, q);
             store_q(M, B, q);
-            if (B != NB - 1 && ((B + 1) * U) % P2 == 0) normalize(acc);         // doubled products: at most 16 rows
+            if (sqr1_normalize_after(B)) normalize(acc);
             mm1_sqr_blocks<B + 1>(acc, M, X, nm, n0inv);
         }
     }
@@ -390,14 +423,14 @@ struct Padic {
             for (int u = 0; u < U; ++u) dummy[u] = 0;
             if constexpr (SQR) {
                 digits(X, B_, xv);
-                block<true, U * B_, U * (B_ + 1), false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, B_, q);
+                block<true, U * B_, U * (B_ + 1), false, false, true>(acc, X, xv, X, dummy, nm, n0inv, nm, B_, q);
             } else {
                 csrc(B_, xv);
                 block<true, 0, NL, false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, B_, q);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) m[U * B_ + u] = q[u];
-            if (B_ != NB - 1 && ((B_ + 1) * U) % (SQR ? P2 : P1) == 0) normalize(acc);
+            if (SQR ? sqr1_normalize_after(B_) : (B_ != NB - 1 && ((B_ + 1) * U) % P1 == 0)) normalize(acc);
             mm1_unrolled<B_ + 1, SQR>(acc, m, X, csrc, nm, n0inv);
         }
     }
