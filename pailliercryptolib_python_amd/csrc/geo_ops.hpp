@@ -68,6 +68,8 @@ struct EncPadicParams;
 int padic_enc_nl_for_n_bits(int bits);
 bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
                            const uint32_t* one_dig, uint32_t* table, int J, int wb);
+bool launch_fb_expand_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
+                            uint32_t* T, int J, int h, uint32_t* mscratch);
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
                           uint32_t* ct_out, int n, int mode);
 

@@ -15,7 +15,7 @@ struct EncPadicParams {
     const MontCtx* nctx;         // modulus n (NL limbs, R = 2^(29 NL))
     const uint32_t* nm1;         // n - 1 limbs
     const uint32_t* nsq;         // n^2 limbs (2 NL, radix 29)
-    const uint4* fb_table;       // [J][256][2][NC] uint4
+    const uint4* fb_table;       // [J][2^fb_wbits][2][NC] uint4
     uint4* mscratch;             // [2 NC][nslots]: quotient digits, then the parked first result digit
     int fb_windows, fb_wbits;
     int pt_words, ct_words, r_words;
@@ -88,6 +88,62 @@ k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const ui
         if (j < J) {
 #pragma unroll 1
             for (int c = 0; c < E::NC; ++c) { ent(d, 0, c) = E::ld(A, c); ent(d, 1, c) = E::ld(B, c); }
+        }
+    }
+}
+
+// ---- wide windows (2 h bits): T[j][d1 2^h + d0] = S[2 j + 1][d1] * S[2 j][d0] ----------------------------
+// S is a table of h-bit windows at twice the density (k_fb_table_padic with 2 J windows of h bits), so that
+// S[2 j] covers the low half and S[2 j + 1] the high half of window j.  One lane per output entry: the
+// J 2^(2 h) products are independent, which turns the sequential d -> d + 1 chain (2^(2 h) steps per lane)
+// into one parallel pass.
+template <int NL, int U>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_fb_expand_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1g, const uint4* __restrict__ S,
+                  uint4* __restrict__ T, int J, int h, uint4* __restrict__ mscratch) {
+    using E = Padic<NL, U>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = nctx->n[i]; ldsn[NL + i] = nm1g[i]; }
+    __syncthreads();
+    const uint32_t* nm = ldsn;
+    const uint32_t* nm1 = ldsn + NL;
+    const uint32_t n0inv = nctx->n0inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* A = reinterpret_cast<uint4*>(lds + wave * 2 * E::DIGIT_WORDS) + lane;
+    uint4* B = A + E::NC * 64;
+    const size_t nslots = (size_t)gridDim.x * BLOCK_THREADS;
+    const size_t slot = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const typename E::MBuf M{mscratch + slot, nslots};
+    const typename E::MBuf Wb{mscratch + (size_t)E::NC * nslots + slot, nslots};
+    const size_t total = (size_t)J << (2 * h);
+    const size_t tiles = (total + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t idx = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = idx < total;
+        const size_t is = live ? idx : total - 1;
+        const size_t j = is >> (2 * h);
+        const uint32_t d = (uint32_t)(is & (((size_t)1 << (2 * h)) - 1));
+        const uint4* lo = S + ((((2 * j) << h) + (d & ((1u << h) - 1u))) * 2) * E::NC;
+        const uint4* hi = S + ((((2 * j + 1) << h) + (d >> h)) * 2) * E::NC;
+        wave_lds_fence();
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) { E::st(A, c, lo[c]); E::st(B, c, lo[E::NC + c]); }
+        wave_lds_fence();
+        auto from_hi = [&](int dg) {
+            return [&, dg](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int c = 0; c < E::UC; ++c) {
+                    const uint4 t = hi[dg * E::NC + E::UC * blk + c];
+                    xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                }
+            };
+        };
+        E::mul_wbuf(A, B, M, Wb, from_hi(0), from_hi(1), nm, nm1, n0inv);
+        if (live) {
+            uint4* out = T + is * 2 * E::NC;
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { out[c] = E::ld(A, c); out[E::NC + c] = E::ld(B, c); }
         }
     }
 }

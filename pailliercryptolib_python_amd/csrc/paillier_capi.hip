@@ -224,6 +224,7 @@ struct pai_pubkey {
     uint32_t* d_fb = nullptr;     // fixed-base table [J][256][NL]
     uint32_t* d_nexp = nullptr;   // n as packed words (exponent of the standard obfuscator)
     int fb_windows = 0, fb_wbits = 8;
+    int fbd_windows = 0, fbd_wbits = 8;   // window geometry of the digit-form table (may be wider: see pai_pubkey_create)
     // digit engine with base n (raw / DJN encryption): modulus n, n - 1, n^2 limbs, digit-form table, scratch
     int penc_nl = 0;
     ModSetup nmod;
@@ -489,14 +490,51 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
                 };
                 uint32_t* d_one = digits_of(Rm);
                 uint32_t* d_hs = digits_of(hbn::mulmod(pk->hs, Rm, pk->nsq));
-                HIP_CHECK(hipMalloc((void**)&pk->d_fb_dig, NE * 2 * (size_t)pnl * 4));
-                if (!launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs, d_one, pk->d_fb_dig, J, wb))
-                    throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
+                HIP_CHECK(hipMalloc((void**)&pk->d_mscratch, 2 * (size_t)pk->dev.ncu * BLOCK_THREADS * (size_t)pnl * 4));
+                // Window width of the digit-form table.  Every window costs one multiplication mod n^2 per
+                // ciphertext, and HBM is plentiful: take the widest even width (<= 20 bits) whose table fits the
+                // budget — 1/32 of the device memory unless PAI_FB_TABLE_MB says otherwise (MI355X, 288 GB:
+                // 9 GB => 2048-bit keys get 18 bits, 57 windows x 262144 entries x 576 B = 8.6 GB; measured
+                // k_encrypt per 2^20: 109 / 95 / 84 / 75 / 70 ms at 12 / 14 / 16 / 18 / 20 bits).
+                // PAI_FB_DIGIT_WBITS pins the width (<= 12, or an even value up to 20).
+                const size_t ent_bytes = 2 * (size_t)pnl * 4;
+                auto table_bytes = [&](int w) { return (double)((randbits + w - 1) / w) * (double)((size_t)1 << w) * (double)ent_bytes; };
+                size_t mem_free = 0, mem_total = 0;
+                HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
+                double budget = (double)mem_total / 32.0;
+                if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) budget = v * 1048576.0; }
+                int dwb = wb;
+                for (int cand = 20; cand > 12; cand -= 2)
+                    if (table_bytes(cand) <= budget) { dwb = cand; break; }
+                if (const char* env = std::getenv("PAI_FB_DIGIT_WBITS")) {
+                    int v = std::atoi(env);
+                    if ((v >= 4 && v <= 12) || (v > 12 && v <= 20 && v % 2 == 0)) dwb = v;
+                }
+                const int DJ = (randbits + dwb - 1) / dwb;
+                pk->fbd_wbits = dwb;
+                pk->fbd_windows = DJ;
+                HIP_CHECK(hipMalloc((void**)&pk->d_fb_dig, ((size_t)DJ << dwb) * ent_bytes));
+                if (dwb <= 12) {
+                    if (!launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs, d_one, pk->d_fb_dig, DJ, dwb))
+                        throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
+                } else {
+                    // two levels: half-width windows at twice the density (sequential chains of 2^h entries), then
+                    // one parallel pass of DJ * 2^dwb independent products
+                    const int h = dwb / 2;
+                    uint32_t* d_half = nullptr;
+                    HIP_CHECK(hipMalloc((void**)&d_half, ((size_t)(2 * DJ) << h) * ent_bytes));
+                    if (!launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs, d_one, d_half, 2 * DJ, h) ||
+                        !launch_fb_expand_padic(pnl, nullptr, pk->dev.ncu, pk->nmod.d_ctx, pk->d_nm1, d_half, pk->d_fb_dig, DJ, h,
+                                                pk->d_mscratch))
+                        throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
+                    HIP_CHECK(hipGetLastError());
+                    HIP_CHECK(hipDeviceSynchronize());
+                    HIP_CHECK(hipFree(d_half));
+                }
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipDeviceSynchronize());
                 HIP_CHECK(hipFree(d_one));
                 HIP_CHECK(hipFree(d_hs));
-                HIP_CHECK(hipMalloc((void**)&pk->d_mscratch, 2 * (size_t)pk->dev.ncu * BLOCK_THREADS * (size_t)pnl * 4));
             }
         } else {
             pk->djn = false;
@@ -559,8 +597,8 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         Q.nsq = pk->d_nsq29;
         Q.fb_table = reinterpret_cast<const uint4*>(pk->d_fb_dig);
         Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
-        Q.fb_windows = pk->fb_windows;
-        Q.fb_wbits = pk->fb_wbits;
+        Q.fb_windows = pk->fbd_windows;
+        Q.fb_wbits = pk->fbd_wbits;
         Q.pt_words = pk->n_words;
         Q.ct_words = pk->ct_words;
         Q.r_words = pk->r_words;

@@ -63,6 +63,15 @@ bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uin
                        reinterpret_cast<uint4*>(table), J, wb);
     return true;
 }
+bool launch_fb_expand_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
+                            uint32_t* T, int J, int h, uint32_t* mscratch) {
+    if (nl != 72) return false;
+    constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
+    (void)hipFuncSetAttribute((const void*)k_fb_expand_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((k_fb_expand_padic<72, 8>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, nctx, nm1,
+                       reinterpret_cast<const uint4*>(S), reinterpret_cast<uint4*>(T), J, h, reinterpret_cast<uint4*>(mscratch));
+    return true;
+}
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
                           uint32_t* ct_out, int n, int mode) {
     if (nl != 72) return false;
