@@ -105,6 +105,24 @@ def test_djn_encrypt_bits_and_roundtrip_2048(k2048):
     assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, limbs_to_ints(r2_l))]
 
 
+@pytest.mark.parametrize("wbits", ["5", "12", "14", "16"])
+def test_djn_encrypt_every_table_geometry_2048(wbits, monkeypatch):
+    """The digit-form fixed-base table is built directly (<= 12 bits, odd widths included) or in two levels
+    (even widths above 12; the default picks 18 bits on a 288 GB device): the ciphertext bits must not
+    depend on the geometry."""
+    monkeypatch.setenv("PAI_FB_DIGIT_WBITS", wbits)
+    nk = NativeKey(bench_key())
+    key, N = nk.key, 130
+    m = plaintexts(key, N, 21)
+    r_l = orc.synth_r_limbs(4021, N, key.randbits)
+    r_l[0] = 0
+    r_l[1] = 0xFFFFFFFF
+    dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r_l)
+    ct = DevArray(shape=(N, nk.cw))
+    _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+    assert limbs_to_ints(ct.get()) == [orc.encrypt(key, x, rr) for x, rr in zip(m, limbs_to_ints(r_l))]
+
+
 def test_ct_add_mul_pow2_2048(k2048):
     key, N = k2048.key, 200
     rng = np.random.default_rng(7)
