@@ -36,7 +36,13 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * LDS_DIGITS * E::DIGIT_WORDS;
     for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = ctx->n[i]; ldsn[NL + i] = P.pm1[which][i]; }
     __syncthreads();
-    const uint32_t* nm = ldsn;
+    // the modulus limbs are wave-uniform multiplier operands: pin them in SGPRs (every use is statically
+    // indexed, so the array never leaves the register file) instead of letting the compiler hoist LDS
+    // loads into 36 VGPRs/AGPRs
+    uint32_t sn[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
+    const uint32_t* nm = sn;
     const uint32_t* pm1 = ldsn + NL;
     const uint32_t n0inv = ctx->n0inv;
     const uint32_t* __restrict__ kdig = P.kdig[which];

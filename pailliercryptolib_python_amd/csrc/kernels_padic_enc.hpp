@@ -199,7 +199,13 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
     uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
     for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
     __syncthreads();
-    const uint32_t* nm = ldsn;
+    // modulus limbs pinned in SGPRs for the statically indexed uses (see kernels_padic.hpp); the rolled
+    // loop of mul_plain indexes them dynamically and keeps reading the LDS copy
+    uint32_t sn[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
+    const uint32_t* nm = sn;
+    const uint32_t* nm_lds = ldsn;
     const uint32_t* nm1 = ldsn + NL;
     const uint32_t n0inv = P.nctx->n0inv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -269,7 +275,7 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
         E::store_digit(B, v);
         wave_lds_fence();
         uint32_t hi[NL];
-        E::mul_plain(hi, A, w, B, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(nm, blk, xv); });
+        E::mul_plain(hi, A, w, B, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(nm_lds, blk, xv); });
         wave_lds_fence();
         E::store_digit(B, hi);
         wave_lds_fence();
