@@ -60,6 +60,7 @@ constexpr int PADIC_SLIDE_BITS = 6;                              // sliding-wind
 constexpr int PADIC_TBL_ENTRIES = 1 << (PADIC_SLIDE_BITS - 1);    // odd powers
 int padic_nl_for_prime_bits(int bits);
 size_t padic_table_words(int nl, size_t blocks);
+size_t padic_scratch_words(int nl, bool lean, size_t blocks);
 bool launch_dec_a_padic(int nl, bool lean, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
                         uint32_t* u_out, int n, uint32_t* table);
 

@@ -410,6 +410,35 @@ struct Padic {
         }
     }
 
+    // squaring counterpart of mul_wbuf: quotient digits and the first result digit in strided scratch
+    PAI_DEV static void sqr_wbuf(uint4* A, uint4* B, MBuf M, MBuf Wb, const uint32_t* __restrict__ nm,
+                                 const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        {
+            uint64_t acc[NW];
+            zero(acc);
+            mm1_sqr_blocks<0>(acc, M, A, nm, n0inv);
+            finish_to_buf(acc, Wb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            uint64_t acc[NW];
+            mm2_init(acc, M);
+            uint32_t dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+            for (int blk = 0; blk < NB; ++blk) {
+                uint32_t xv[U], q[U];
+                digits(B, blk, xv);
+                block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);
+                if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
+            }
+            wave_lds_fence();
+            finish_into(acc, B, A, Wb);
+            wave_lds_fence();
+        }
+    }
+
     // ---- register-lean variant (two waves per SIMD): quotient digits m stay in VGPRs (the first half is fully
     // unrolled so that they can be indexed statically), the first result digit is parked in a global scratch
     // column Wb while the second half runs, and the second digit is written straight over B.  LDS then holds

@@ -255,6 +255,7 @@ struct pai_privkey {
     Limbs p, q;
     ModSetup sq[2];               // p^2, q^2
     ModSetup pr[2];               // p, q
+    ModSetup pdig[2];             // p, q at the digit engine's limb count (stage A on digit pairs)
     uint32_t* d_r3[2] = {nullptr, nullptr};
     uint32_t* d_expo[2] = {nullptr, nullptr};
     int ewords[2] = {0, 0}, ebits[2] = {0, 0};
@@ -787,8 +788,7 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
             sk->d_nsinv2[w] = upload_r29(hbn::sub(hbn::shl(one, k), sinv2), nl);
         }
         // p-adic digit engine: digit pairs of R^(i+2) mod s^2 and s - 1 as limbs
-        sk->padic_nl = padic_nl_for_prime_bits(hbn::bitlen(q));
-        if (sk->pr[0].nl != sk->padic_nl || sk->pr[1].nl != sk->padic_nl) sk->padic_nl = 0;
+        sk->padic_nl = padic_nl_for_prime_bits(std::max(hbn::bitlen(p), hbn::bitlen(q)));
         if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') sk->padic_nl = 0; }
         if (const char* env = std::getenv("PAI_PADIC_LEAN")) sk->padic_lean = env[0] == '1';
         if (sk->padic_nl) {
@@ -797,6 +797,7 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
             for (int w = 0; w < 2; ++w) {
                 const Limbs& s = prime[w];
                 const Limbs& s2 = sk->sq[w].M;
+                sk->pdig[w].init(s, nl);                                  // modulus context at the digit engine's limb count
                 sk->d_pm1[w] = upload_r29(hbn::sub(s, one), nl);
                 Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * nl), s2);
                 Limbs K = hbn::mulmod(Rm, Rm, s2);                       // R^2
@@ -854,6 +855,7 @@ void pai_privkey_destroy(pai_privkey* sk) {
     for (int w = 0; w < 2; ++w) {
         sk->sq[w].release();
         sk->pr[w].release();
+        sk->pdig[w].release();
         if (sk->d_r3[w]) (void)hipFree(sk->d_r3[w]);
         if (sk->d_expo[w]) (void)hipFree(sk->d_expo[w]);
         if (sk->d_sinv2[w]) (void)hipFree(sk->d_sinv2[w]);
@@ -886,7 +888,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
             const size_t per_prime = sk->padic_lean ? (size_t)dev.ncu : (size_t)dev.ncu / 2;   // x2 primes => 2 or 1 workgroups per CU
             gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, per_prime));
             sk->table.ensure(padic_table_words(sk->padic_nl, (size_t)gridx * 2) * 4);
-            if (sk->padic_lean) sk->wscratch.ensure((size_t)gridx * 2 * BLOCK_THREADS * sk->padic_nl * 4);
+            if (const size_t sw = padic_scratch_words(sk->padic_nl, sk->padic_lean, (size_t)gridx * 2)) sk->wscratch.ensure(sw * 4);
         } else if (sk->wide_nl) {
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
             gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)dev.ncu / 2));   // x2 primes => one workgroup per CU
@@ -911,7 +913,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
             if (sk->padic_nl) {
                 DecPadicParams Q;
                 for (int w = 0; w < 2; ++w) {
-                    Q.pr[w] = sk->pr[w].d_ctx;
+                    Q.pr[w] = sk->pdig[w].d_ctx;
                     Q.pm1[w] = sk->d_pm1[w];
                     Q.kdig[w] = sk->d_kdig[w];
                     Q.ops[w] = sk->d_ops[w];

@@ -50,7 +50,9 @@ k_chain(const uint32_t* __restrict__ mod, const uint32_t* __restrict__ in, uint3
         else if constexpr (MODE == 1) E::mul_wbuf(A, B, Mg, Wg, self(A), self(B), nm, pm1, n0inv);
         else if constexpr (MODE == 2) E::sqr(A, B, Ml, nm, pm1, n0inv);
         else if constexpr (MODE == 3) E::sqr_lean(A, B, Wg, nm, pm1, n0inv);
-        else E::mul_lean(A, B, Wg, self(A), self(B), nm, pm1, n0inv);
+        else if constexpr (MODE == 4) E::mul_lean(A, B, Wg, self(A), self(B), nm, pm1, n0inv);
+        else if constexpr (MODE == 5) E::sqr_wbuf(A, B, Mg, Wg, nm, pm1, n0inv);
+        else E::mul_wbuf(A, B, Mg, Wg, self(A), self(B), nm, pm1, n0inv);
     }
     for (int c = 0; c < E::NC; ++c) {
         const uint4 a = E::ld(A, c), b = E::ld(B, c);
@@ -85,7 +87,7 @@ static void run(const char* name, int iters, int ncu) {
     hipLaunchKernelGGL((k_chain<NL, U, MODE>), dim3(grid), dim3(BLOCK_THREADS), bytes, 0, dmod, din, dout, dscr, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    const double macs = (MODE == 2 || MODE == 3) ? (0.5 * NL * (NL + 1) + 3.0 * NL * NL) : 5.0 * NL * NL;
+    const double macs = (MODE == 2 || MODE == 3 || MODE == 5) ? (0.5 * NL * (NL + 1) + 3.0 * NL * NL) : 5.0 * NL * NL;
     printf("{\"probe\": \"%s\", \"NL\": %d, \"U\": %d, \"elements\": %d, \"iters\": %d, \"ms\": %.3f, \"ns_per_product_per_elem\": %.4f, "
            "\"exec_TMAC_s\": %.2f}\n", name, NL, U, n, iters, ms, ms * 1e6 / ((double)n * iters), macs * n * iters / (ms * 1e-3) / 1e12);
     fflush(stdout);
@@ -101,5 +103,7 @@ int main(int argc, char** argv) {
     run<72, 8, 1>("mul_wbuf <72,8> M,W global", iters, ncu);
     run<36, 12, 3>("sqr_lean <36,12> 2 waves/SIMD", iters, ncu);
     run<36, 12, 4>("mul_lean <36,12> 2 waves/SIMD", iters, ncu);
+    run<36, 12, 5>("sqr_wbuf <36,12> 2 waves/SIMD", iters, ncu);
+    run<36, 12, 6>("mul_wbuf <36,12> 2 waves/SIMD", iters, ncu);
     return 0;
 }
