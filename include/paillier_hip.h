@@ -112,6 +112,23 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
 int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N,
                 void* stream);
 
+/* ---- data formats either side of the path --------------------------------------------------------------
+ * Fixed-point codec of bindings/fixedpoint.py:54-115 for float64 arrays (the hot Python loops of
+ * ipcl_python.py:136-140 and :229-243), on the device so that 8 B instead of 256 B per element cross PCIe.
+ * Both need n > 2^66 (any real key).  encode: d_x[N] finite doubles (the caller rejects NaN/Inf like the
+ * reference's int()) -> residues d_m[N][n_words] and base-2 exponents d_expo[N].  decode: residues ->
+ * signed mantissas d_mant[N] with d_flag[i] = 0, or d_flag[i] = 1 when element i needs the exact big-integer
+ * path (|mantissa| >= 2^63, overflow zone or corrupt residue: the host path raises the reference's errors). */
+int pai_fp_encode_f64(const pai_pubkey* pk, const double* d_x, size_t N, uint32_t* d_m, int32_t* d_expo, void* stream);
+int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64_t* d_mant, int32_t* d_flag, void* stream);
+
+/* Obfuscator randomness for DJN keys, replacing upstream ipcl's per-element getRandomBN inside
+ * PublicKey::encrypt (called at classes.cpp:57): d_r[N][r_words] <- ChaCha20 key stream (RFC 8439 block
+ * function; h_key8 = 256-bit key from the OS CSPRNG, h_nonce3 = 96-bit nonce, 32-bit block counter starting
+ * at counter0, carried into nonce word 0), top word of every row masked to randbits. */
+int pai_draw_r(const pai_pubkey* pk, const uint32_t* h_key8, const uint32_t* h_nonce3, uint32_t counter0, size_t N,
+               uint32_t* d_r, void* stream);
+
 /* ---- generic modular building blocks (arbitrary odd modulus up to 8192 bits) ------------------- */
 int pai_modulus_create(const uint32_t* h_m, int m_words, int device, pai_modulus** out);
 void pai_modulus_destroy(pai_modulus* m);

@@ -216,11 +216,8 @@ class ipclPublicKey:
     def _draw_r(self, count: int) -> torch.Tensor:
         h = self.handle
         if self._djn:
-            raw = np.frombuffer(secrets.token_bytes(4 * h.r_words * count), dtype="<u4").reshape(count, h.r_words).copy()
-            top = self._randbits - 32 * (h.r_words - 1)
-            if top < 32:
-                raw[:, -1] &= np.uint32((1 << top) - 1)
-            return engine.to_device_words(raw, h.device)
+            # fresh 256-bit key + 96-bit nonce from the OS CSPRNG, expanded on the device (ChaCha20, RFC 8439)
+            return h.draw_r(count, secrets.token_bytes(32), secrets.token_bytes(12))
         vals = [secrets.randbelow(self._n - 1) + 1 for _ in range(count)]
         return engine.to_device_words(engine.ints_to_words(vals, h.n_words), h.device)
 

@@ -1,0 +1,113 @@
+// Data-format kernels either side of the Paillier hot path (HBM-bound, one row per lane):
+//   k_fp_encode_f64   float64 -> (residue mod n as packed words, base-2 exponent)     fixedpoint.py:54-96
+//   k_fp_decode_i64   residue mod n -> signed 64-bit mantissa (+ "needs the exact host path" flag)  fixedpoint.py:98-115
+//   k_draw_r          obfuscator randomness r < 2^randbits for DJN keys: ChaCha20 key stream (RFC 8439 block
+//                     function, 256-bit key drawn from the OS CSPRNG by the caller), one 64-byte block per lane
+// They move 8 B instead of 256 B per element over PCIe on the way in and out of the device.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace pai {
+
+// Encoding of a finite double x (the caller rejects NaN/Inf as the reference's int() would):
+//   |x| < 1e-200 (zeros and subnormals included)  ->  mantissa 0, exponent 0            (fixedpoint.py:64-65,72-74)
+//   otherwise  exponent = 53 - frexp(x).exp,  mantissa = x * 2^exponent = +-(2^52 | fraction bits), exactly
+//   residue = mantissa mod n  (n > 2^66, so |mantissa| <= max_int always holds)
+__global__ void __launch_bounds__(256)
+k_fp_encode_f64(const double* __restrict__ x, const uint32_t* __restrict__ n_words_ptr, int nw, uint32_t* __restrict__ out,
+                int32_t* __restrict__ expo, size_t N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double v = x[i];
+    const uint64_t bits = (uint64_t)__double_as_longlong(v);
+    const bool tiny = fabs(v) < 1e-200;
+    const int e = (int)((bits >> 52) & 0x7FF);
+    const uint64_t mant = tiny ? 0ull : ((bits & 0xFFFFFFFFFFFFFull) | (1ull << 52));
+    const bool neg = !tiny && (bits >> 63);
+    expo[i] = tiny ? 0 : (1075 - e);
+    uint32_t* row = out + i * (size_t)nw;
+    if (!neg) {
+        row[0] = (uint32_t)mant;
+        row[1] = (uint32_t)(mant >> 32);
+        for (int k = 2; k < nw; ++k) row[k] = 0;
+    } else {
+        // n - mant, mant < 2^53: 64-bit subtract, then a single borrow ripples through the upper words
+        const uint64_t n_lo = (uint64_t)n_words_ptr[0] | ((uint64_t)n_words_ptr[1] << 32);
+        const uint64_t lo = n_lo - mant;
+        uint32_t borrow = mant > n_lo ? 1u : 0u;
+        row[0] = (uint32_t)lo;
+        row[1] = (uint32_t)(lo >> 32);
+        for (int k = 2; k < nw; ++k) {
+            const uint32_t w = n_words_ptr[k];
+            row[k] = w - borrow;
+            borrow = (borrow && w == 0) ? 1u : 0u;
+        }
+    }
+}
+
+// flag 0: mantissa in (-2^63, 2^63) returned; flag 1: anything else (|mantissa| >= 2^63, overflow zone, corrupt
+// residue >= n) — the host then runs the exact big-integer path, which also raises the reference's exceptions.
+__global__ void __launch_bounds__(256)
+k_fp_decode_i64(const uint32_t* __restrict__ res, const uint32_t* __restrict__ n_words_ptr, int nw, int64_t* __restrict__ mant,
+                int32_t* __restrict__ flag, size_t N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t* row = res + i * (size_t)nw;
+    const uint64_t lo = (uint64_t)row[0] | ((uint64_t)row[1] << 32);
+    uint32_t hi_or = 0;
+    // d = n - row (multiword); the negative branch needs 0 < d < 2^63
+    const uint64_t n_lo = (uint64_t)n_words_ptr[0] | ((uint64_t)n_words_ptr[1] << 32);
+    const uint64_t d_lo = n_lo - lo;
+    uint32_t borrow = lo > n_lo ? 1u : 0u;
+    uint32_t d_hi_or = 0;
+    for (int k = 2; k < nw; ++k) {
+        const uint32_t r = row[k], w = n_words_ptr[k];
+        hi_or |= r;
+        const uint64_t t = (uint64_t)w - r - borrow;
+        d_hi_or |= (uint32_t)t;
+        borrow = (uint32_t)(t >> 63);       // 1 when the subtraction wrapped
+    }
+    const bool pos = hi_or == 0 && lo < (1ull << 63);
+    const bool negv = !pos && borrow == 0 && d_hi_or == 0 && d_lo < (1ull << 63) && d_lo != 0;
+    mant[i] = pos ? (int64_t)lo : (negv ? -(int64_t)d_lo : 0);
+    flag[i] = (pos || negv) ? 0 : 1;
+}
+
+// ---- ChaCha20 block function, RFC 8439 section 2.3 -----------------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+#define PAI_CHACHA_QR(a, b, c, d) \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+
+struct ChaChaKey { uint32_t k[8]; uint32_t nonce[3]; uint32_t counter0; };
+
+// word w of the key stream (block = w / 16) goes to out[w]; rows of r_words words get their top word masked to
+// randbits.  The stream is the RFC's: state = constants | key | counter | nonce, 20 rounds, feed-forward.
+__global__ void __launch_bounds__(256)
+k_draw_r(ChaChaKey K, uint32_t* __restrict__ out, size_t total_words, int r_words, uint32_t top_mask) {
+    const size_t blk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk * 16 >= total_words) return;
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, K.k[0], K.k[1], K.k[2], K.k[3], K.k[4], K.k[5], K.k[6], K.k[7],
+                      K.counter0 + (uint32_t)blk, K.nonce[0] + (uint32_t)(blk >> 32), K.nonce[1], K.nonce[2]};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = s[i];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        PAI_CHACHA_QR(x[0], x[4], x[8], x[12]) PAI_CHACHA_QR(x[1], x[5], x[9], x[13])
+        PAI_CHACHA_QR(x[2], x[6], x[10], x[14]) PAI_CHACHA_QR(x[3], x[7], x[11], x[15])
+        PAI_CHACHA_QR(x[0], x[5], x[10], x[15]) PAI_CHACHA_QR(x[1], x[6], x[11], x[12])
+        PAI_CHACHA_QR(x[2], x[7], x[8], x[13]) PAI_CHACHA_QR(x[3], x[4], x[9], x[14])
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const size_t w = blk * 16 + i;
+        if (w < total_words) {
+            uint32_t v = x[i] + s[i];
+            if ((int)(w % (size_t)r_words) == r_words - 1) v &= top_mask;
+            out[w] = v;
+        }
+    }
+}
+
+}  // namespace pai

@@ -15,6 +15,7 @@
 #include "hostbn.hpp"
 #include "kernels_padic.hpp"
 #include "kernels_padic_enc.hpp"
+#include "kernels_codec.hpp"
 
 using namespace pai;
 using hbn::Limbs;
@@ -630,6 +631,52 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         HIP_CHECK(hipStreamSynchronize(s));     // scratch is shared between calls
     }
     HIP_CHECK(hipGetLastError());
+}
+
+// ---- data formats either side of the path (kernels_codec.hpp) ---------------------------------------------
+int pai_fp_encode_f64(const pai_pubkey* pk, const double* d_x, size_t N, uint32_t* d_m, int32_t* d_expo, void* stream) {
+    return guarded([&] {
+        require(pk && d_x && d_m && d_expo, "NULL argument");
+        require(hbn::bitlen(pk->n) > 66, "device encode needs a modulus of more than 66 bits");
+        if (N == 0) return;
+        use_device(pk->device);
+        hipLaunchKernelGGL(k_fp_encode_f64, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, pk->d_nexp,
+                           pk->n_words, d_m, d_expo, N);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64_t* d_mant, int32_t* d_flag, void* stream) {
+    return guarded([&] {
+        require(pk && d_m && d_mant && d_flag, "NULL argument");
+        require(hbn::bitlen(pk->n) > 66, "device decode needs a modulus of more than 66 bits");
+        if (N == 0) return;
+        use_device(pk->device);
+        hipLaunchKernelGGL(k_fp_decode_i64, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_m, pk->d_nexp,
+                           pk->n_words, d_mant, d_flag, N);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int pai_draw_r(const pai_pubkey* pk, const uint32_t* h_key8, const uint32_t* h_nonce3, uint32_t counter0, size_t N,
+               uint32_t* d_r, void* stream) {
+    return guarded([&] {
+        require(pk && h_key8 && h_nonce3 && d_r, "NULL argument");
+        require(pk->djn, "pai_draw_r serves DJN keys (r < 2^randbits); the standard scheme draws r in [1, n) on the host");
+        if (N == 0) return;
+        use_device(pk->device);
+        ChaChaKey K;
+        std::memcpy(K.k, h_key8, 32);
+        std::memcpy(K.nonce, h_nonce3, 12);
+        K.counter0 = counter0;
+        const size_t total = N * (size_t)pk->r_words;
+        const size_t blocks = (total + 15) / 16;
+        const int top = pk->randbits - 32 * (pk->r_words - 1);
+        const uint32_t mask = top >= 32 ? 0xFFFFFFFFu : ((1u << top) - 1u);
+        hipLaunchKernelGGL(k_draw_r, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, d_r, total,
+                           pk->r_words, mask);
+        HIP_CHECK(hipGetLastError());
+    });
 }
 
 int pai_raw_encrypt(const pai_pubkey* pk, const uint32_t* d_m, size_t N, uint32_t* d_ct, void* stream) {

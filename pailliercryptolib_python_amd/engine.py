@@ -170,6 +170,39 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_ct_pow2(self.h, _ptr(ct), _ptr(delta), bcast, ct.shape[0], _stream(self.device)))
         return ct
 
+    # -- data formats either side of the path (device codec, obfuscator randomness) ----------------
+    def fp_encode_f64(self, x: torch.Tensor):
+        """float64[N] on the device -> (residues int32[N, n_words], exponents int32[N]); fixedpoint.py:54-96.
+        The caller has rejected NaN/Inf."""
+        if x.dtype != torch.float64 or x.dim() != 1 or not x.is_contiguous() or x.device != self.device:
+            raise ValueError("x: expected contiguous float64 [N] on %s" % self.device)
+        m = self.empty_pt(x.shape[0])
+        expo = torch.empty((x.shape[0],), dtype=torch.int32, device=self.device)
+        _native.check(self.lib.pai_fp_encode_f64(self.h, _ptr(x), x.shape[0], _ptr(m), _ptr(expo), _stream(self.device)))
+        return m, expo
+
+    def fp_decode_i64(self, m: torch.Tensor):
+        """residues -> (mantissas int64[N], flags int32[N]); flag 1 = element needs the exact host path."""
+        self._chk(m, self.n_words, "m")
+        mant = torch.empty((m.shape[0],), dtype=torch.int64, device=self.device)
+        flag = torch.empty((m.shape[0],), dtype=torch.int32, device=self.device)
+        _native.check(self.lib.pai_fp_decode_i64(self.h, _ptr(m), m.shape[0], _ptr(mant), _ptr(flag), _stream(self.device)))
+        return mant, flag
+
+    def draw_r(self, n: int, key: bytes, nonce: bytes, counter0: int = 0) -> torch.Tensor:
+        """DJN obfuscator randomness r < 2^randbits: ChaCha20 key stream under ``key`` (32 bytes, from the OS
+        CSPRNG) and ``nonce`` (12 bytes), generated on the device."""
+        if self.hs is None:
+            raise NotImplementedError("draw_r serves DJN keys")
+        if len(key) != 32 or len(nonce) != 12:
+            raise ValueError("ChaCha20 needs a 32-byte key and a 12-byte nonce")
+        k = np.frombuffer(key, dtype="<u4").copy()
+        nn = np.frombuffer(nonce, dtype="<u4").copy()
+        r = torch.empty((n, self.r_words), dtype=torch.int32, device=self.device)
+        _native.check(self.lib.pai_draw_r(self.h, k.ctypes.data_as(C.c_void_p), nn.ctypes.data_as(C.c_void_p),
+                                          int(counter0) & 0xFFFFFFFF, n, _ptr(r), _stream(self.device)))
+        return r
+
     def random_r(self, n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """Device-side randomness of the right shape for throughput runs (NOT cryptographic: torch's
         Philox generator).  The Python API draws from the OS CSPRNG instead (paillier.py)."""

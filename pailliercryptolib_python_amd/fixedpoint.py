@@ -82,6 +82,37 @@ def _words_of(v: int, words: int) -> np.ndarray:
     return np.frombuffer(int(v).to_bytes(4 * words, "little"), dtype="<u4").copy()
 
 
+def is_float_batch(values) -> bool:
+    """True for what the vectorised / device float paths accept: 1-D float ndarrays and non-empty lists of
+    Python floats."""
+    if isinstance(values, np.ndarray):
+        return values.dtype in (np.float64, np.float32, np.float16) and values.ndim == 1 and values.shape[0] > 0
+    return isinstance(values, (list, tuple)) and len(values) > 0 and all(type(v) is float for v in values)
+
+
+def checked_float64(values) -> np.ndarray:
+    """Contiguous float64 copy of a float batch; NaN / infinity raise what the reference's int(round(..)) raises
+    (fixedpoint.py:89)."""
+    x = np.ascontiguousarray(np.asarray(values, dtype=np.float64))
+    if not np.all(np.isfinite(x)):
+        bad = x[~np.isfinite(x)][0]
+        if np.isnan(bad):
+            raise ValueError("cannot convert float NaN to integer")
+        raise OverflowError("cannot convert float infinity to integer")
+    return x
+
+
+def decode_mantissas(mant: np.ndarray, exponents) -> List:
+    """int64 mantissas + exponents -> list with the reference's element types (fixedpoint.py:115
+    ``mantissa * pow(2, -exponent)``): Python int when exponent <= 0, float otherwise."""
+    e = np.asarray(exponents, dtype=np.int64)
+    fl = mant.astype(np.float64) * np.ldexp(1.0, (-e).clip(-2000, 2000).astype(np.int32))     # == float(m) * 2.0**-e
+    out = fl.tolist()
+    for i in np.nonzero(e <= 0)[0].tolist():
+        out[i] = int(mant[i]) * (1 << int(-e[i]))
+    return out
+
+
 def encode_float64_array(x: np.ndarray, n: int, n_words: int) -> Tuple[np.ndarray, np.ndarray]:
     """float64[N] -> (residues uint32[N][n_words], exponents int32[N]); requires n > 2^66."""
     x = np.ascontiguousarray(x, dtype=np.float64)

@@ -107,8 +107,14 @@ class PaillierPublicKey:
         if not ok:
             raise ValueError("PaillierPublicKey.encrypt: input value(s) should be integer or float")
         h = self.pubkey.handle
-        residues, expos = _fp.encode_array(values, self.n, self.max_int, h.n_words)
-        m = engine.to_device_words(residues, h.device)
+        if _fp.is_float_batch(values) and self.n.bit_length() > 66:
+            # float arrays: 8 B per element cross PCIe and the codec runs on the device (pai_fp_encode_f64)
+            x = _fp.checked_float64(values)
+            m, expo_d = h.fp_encode_f64(torch.from_numpy(x).to(h.device))
+            expos = expo_d.cpu().numpy()
+        else:
+            residues, expos = _fp.encode_array(values, self.n, self.max_int, h.n_words)
+            m = engine.to_device_words(residues, h.device)
         if not apply_obfuscator:
             ct = h.raw_encrypt(m)
         else:
@@ -157,6 +163,16 @@ class PaillierPrivateKey:
     def _decrypt_words(self, enc: "PaillierEncryptedNumber") -> np.ndarray:
         return engine.to_host_words(self.prikey.decrypt(enc.ciphertext())._t)
 
+    def _decrypt_mantissas(self, enc: "PaillierEncryptedNumber"):
+        """(int64 mantissas, None) through the device decoder, or (None, residue words) when some element
+        needs the exact big-integer path (|mantissa| >= 2^63, overflow zone, corrupt residue)."""
+        t = self.prikey.decrypt(enc.ciphertext())._t
+        if self.__n.bit_length() > 66:
+            mant, flag = enc.public_key.pubkey.handle.fp_decode_i64(t)
+            if not bool(flag.any()):
+                return mant.cpu().numpy(), None
+        return None, engine.to_host_words(t)
+
     def raw_decrypt(self, ciphertext: "PaillierEncryptedNumber"):
         """ipcl_python.py:207-217: the raw residues as Python ints (scalar if length 1)."""
         if ciphertext.public_key.n != self.__n:
@@ -169,15 +185,21 @@ class PaillierPrivateKey:
         or the single value when the length is 1."""
         if encrypted_number.public_key.n != self.__n:
             raise ValueError("PailierPrivateKey.decrypt: Public key mismatch")
-        ret = _fp.decode_array(self._decrypt_words(encrypted_number), encrypted_number._expo, self.__n, self.__max_int)
+        mant, words = self._decrypt_mantissas(encrypted_number)
+        if mant is not None:
+            ret = _fp.decode_mantissas(mant, encrypted_number._expo)
+        else:
+            ret = _fp.decode_array(words, encrypted_number._expo, self.__n, self.__max_int)
         return ret if len(encrypted_number) > 1 else ret[0]
 
     def decrypt_to_numpy(self, encrypted_number: "PaillierEncryptedNumber") -> np.ndarray:
         """Extension: the decoded values as a float64 ndarray without per-element Python objects."""
         if encrypted_number.public_key.n != self.__n:
             raise ValueError("PailierPrivateKey.decrypt: Public key mismatch")
-        return _fp.decode_float64_array(self._decrypt_words(encrypted_number), encrypted_number._expo, self.__n,
-                                        self.__max_int)
+        mant, words = self._decrypt_mantissas(encrypted_number)
+        if mant is not None:
+            return np.ldexp(mant.astype(np.float64), -np.asarray(encrypted_number._expo, dtype=np.int64).astype(np.int32))
+        return _fp.decode_float64_array(words, encrypted_number._expo, self.__n, self.__max_int)
 
 
 class PaillierEncryptedNumber:

@@ -1,0 +1,111 @@
+"""GPU parity of the data-format kernels either side of the hot path (include/paillier_hip.h: pai_fp_encode_f64,
+pai_fp_decode_i64, pai_draw_r) against the oracle's restatement of fixedpoint.py:54-115 and of the RFC 8439
+key stream, through the C ABI — plus the public API paths that now use them."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import chacha20 as cc
+from oracle import paillier_oracle as orc
+from pailliercryptolib_python_amd import _native
+from tests._util import DevArray, host_ptr, ints_to_limbs, limbs_to_ints
+from tests.test_gpu_paillier_abi import NativeKey, bench_key, seeded_key
+
+pytestmark = pytest.mark.gpu
+
+EDGE = [0.0, -0.0, 1.0, -1.0, 0.5, -0.75, 1e-200, -1e-200, 9.9e-201, 5e-324, -5e-324, 2.2250738585072014e-308,
+        1e-199, 123456.789, -98765.4321, 2.0**52, 2.0**53 - 1, -(2.0**53), 2.0**1023, -1.7976931348623157e308,
+        1e300, -1e-150, 3.141592653589793, 1 / 3, -2 / 3, 1e16 + 2, 4.9406564584124654e-200]
+
+
+@pytest.fixture(scope="module", params=[2048, 1024])
+def nk(request):
+    return NativeKey(bench_key() if request.param == 2048 else seeded_key(1024))
+
+
+def test_device_encode_matches_the_reference_codec(nk):
+    key = nk.key
+    rng = np.random.default_rng(11)
+    x = np.concatenate([np.array(EDGE), rng.uniform(-1e3, 1e3, 3000), rng.standard_normal(1500) * 1e-30,
+                        np.ldexp(rng.uniform(-1, 1, 1500), rng.integers(-600, 1000, 1500))])
+    N = x.shape[0]
+    dx = DevArray(x)
+    dm = DevArray(shape=(N, nk.nw))
+    de = DevArray(shape=(N,), dtype=np.int32)
+    _native.check(nk.lib.pai_fp_encode_f64(nk.pk, dx.ptr, N, dm.ptr, de.ptr, None))
+    want = [orc.fp_encode(float(v), key.n, key.n // 3 - 1) for v in x]
+    assert limbs_to_ints(dm.get()) == [w[0] for w in want]
+    assert de.get().tolist() == [w[1] for w in want]
+
+
+def test_device_decode_flags_and_mantissas(nk):
+    key = nk.key
+    n, max_int = key.n, key.n // 3 - 1
+    rng = np.random.default_rng(12)
+    small = [int(v) for v in rng.integers(-(2**62), 2**62, 2000)]
+    mants = [0, 1, -1, 2**63 - 1, -(2**63) + 1, 2**53, -(2**53)] + small
+    hard = [2**63, -(2**63), 2**64 + 5, -(2**70), max_int, -max_int, max_int + 1, n - max_int - 1, n // 2]
+    enc = [m % n for m in mants] + [h % n for h in hard] + [n, n + 1, (1 << (32 * nk.nw)) - 1]
+    N = len(enc)
+    dm = DevArray(ints_to_limbs(enc, nk.nw))
+    dmant = DevArray(shape=(N,), dtype=np.int64)
+    dflag = DevArray(shape=(N,), dtype=np.int32)
+    _native.check(nk.lib.pai_fp_decode_i64(nk.pk, dm.ptr, N, dmant.ptr, dflag.ptr, None))
+    mant, flag = dmant.get(), dflag.get()
+    assert flag[:len(mants)].tolist() == [0] * len(mants)
+    assert mant[:len(mants)].tolist() == mants
+    assert flag[len(mants):].tolist() == [1] * (N - len(mants))
+    # wherever the flag is clear the mantissa is the reference's (fixedpoint.py:100-113)
+    for e, m in zip(enc[:len(mants)], mants):
+        assert orc.fp_decode(e, 0, n, max_int) == m
+
+
+@pytest.mark.parametrize("N,counter0", [(1, 0), (257, 7), (64, 0xFFFFFFF0)])
+def test_draw_r_is_the_rfc8439_key_stream(N, counter0):
+    nk_ = NativeKey(bench_key())
+    key = bytes(range(100, 132))
+    nonce = bytes([0xF0, 0xFF, 0xFF, 0xFF, 1, 2, 3, 4, 5, 6, 7, 8])       # nonce word 0 close to wrapping as well
+    k = np.frombuffer(key, dtype="<u4").copy()
+    nn = np.frombuffer(nonce, dtype="<u4").copy()
+    dr = DevArray(shape=(N, nk_.rw))
+    _native.check(nk_.lib.pai_draw_r(nk_.pk, host_ptr(k), host_ptr(nn), counter0, N, dr.ptr, None))
+    want = cc.draw_r_words(key, nonce, counter0, N, nk_.rw, nk_.key.randbits)
+    assert np.array_equal(dr.get(), want)
+    assert all(r < (1 << nk_.key.randbits) for r in limbs_to_ints(dr.get()))
+
+
+def test_draw_r_rejects_standard_scheme_keys():
+    nk_ = NativeKey(bench_key(djn=False))
+    k = np.zeros(8, dtype=np.uint32)
+    dr = DevArray(shape=(4, nk_.rw))
+    assert nk_.lib.pai_draw_r(nk_.pk, host_ptr(k), host_ptr(k), 0, 4, dr.ptr, None) == _native.PAI_E_INVALID
+
+
+def test_api_float_arrays_use_the_device_codec_and_keep_reference_semantics():
+    from pailliercryptolib_python_amd import PaillierKeypair
+
+    pk, sk = PaillierKeypair.generate_keypair(2048, True)
+    x = np.concatenate([np.array(EDGE), np.random.default_rng(5).uniform(-50, 50, 500)])
+    ct = pk.encrypt(x)
+    want_e = [orc.fp_encode(float(v), pk.n, pk.max_int)[1] for v in x]
+    assert np.asarray(ct.exponent()).tolist() == want_e
+    got = sk.decrypt(ct)
+    want = [orc.fp_decode(*orc.fp_encode(float(v), pk.n, pk.max_int), pk.n, pk.max_int) for v in x]
+    assert got == want and [type(g) for g in got] == [type(w) for w in want]
+    assert np.array_equal(sk.decrypt_to_numpy(ct), np.where(np.abs(x) < 1e-200, 0.0, x))
+    # lists of Python floats and float32 arrays take the same path
+    assert sk.decrypt(pk.encrypt([1.5, -2.25])) == [1.5, -2.25]
+    assert sk.decrypt(pk.encrypt(np.array([1.5, -2.25], dtype=np.float32))) == [1.5, -2.25]
+    # the reference's errors for non-finite input (int(round(nan)) / int(round(inf)))
+    with pytest.raises(ValueError):
+        pk.encrypt(np.array([1.0, math.nan]))
+    with pytest.raises(OverflowError):
+        pk.encrypt(np.array([math.inf]))
+    # big integers still decode exactly through the host path (device decoder flags them)
+    big = [2**70 + 3, -(2**90) - 1, 5]
+    assert sk.decrypt(pk.encrypt(big)) == big
+    # two encryptions of the same values draw different randomness
+    a, b = pk.encrypt(x[:4]), pk.encrypt(x[:4])
+    assert a.ciphertextBN(0) != b.ciphertextBN(0)

@@ -112,3 +112,35 @@ def test_c_oracle_modexp_modmul():
     al, bl = orc.ints_to_limbs(a, 64), orc.ints_to_limbs(b, 64)
     assert orc.limbs_to_ints(co.modexp(M, al, e)) == [pow(x, e, M) for x in a]
     assert orc.limbs_to_ints(co.modmul(M, al, bl)) == [x * y % M for x, y in zip(a, b)]
+
+
+def test_chacha20_oracle_reproduces_the_rfc8439_vectors():
+    """RFC 8439 section 2.1.1 (quarter round) and 2.3.2 (block function) known answers pin oracle/chacha20.py."""
+    from oracle import chacha20 as cc
+
+    assert cc.quarter_round(0x11111111, 0x01020304, 0x9B8D6F43, 0x01234567) == (0xEA2A92F4, 0xCB1CF8CE, 0x4581472E, 0x5881C4BB)
+    key = [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)]
+    out = cc.block(key, 1, [0x09000000, 0x4A000000, 0])
+    assert b"".join(v.to_bytes(4, "little") for v in out).hex() == (
+        "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+        "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    # row layout helper: rows are consecutive stream words, top word masked
+    r = cc.draw_r_words(bytes(range(32)), bytes([0, 0, 0, 9, 0, 0, 0, 0x4A, 0, 0, 0, 0]), 1, 3, 5, 150)
+    flat = cc.block(key, 1, [0x09000000, 0x4A000000, 0])[:15]
+    flat[4] &= (1 << 22) - 1; flat[9] &= (1 << 22) - 1; flat[14] &= (1 << 22) - 1
+    assert r.reshape(-1).tolist() == flat
+
+
+def test_decode_mantissas_matches_the_scalar_codec():
+    """The list builder behind the device decoder returns what fixedpoint.py:115 returns, element types included."""
+    import numpy as np
+    from pailliercryptolib_python_amd import fixedpoint as fp
+
+    n = orc.BENCH_P * orc.BENCH_Q
+    max_int = n // 3 - 1
+    mant = np.array([0, 1, -1, 3, -(2**62), 2**62 + 12345, 2**53 + 1, -(2**53) - 1, 7, 5], dtype=np.int64)
+    expo = np.array([0, 0, -3, 5, 40, 1074, 60, 1100, -70, 1022], dtype=np.int64)
+    got = fp.decode_mantissas(mant, expo)
+    want = [orc.fp_decode(int(m) % n, int(e), n, max_int) for m, e in zip(mant, expo)]
+    assert got == want
+    assert [type(g) for g in got] == [type(w) for w in want]
