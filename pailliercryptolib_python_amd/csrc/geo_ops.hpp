@@ -60,8 +60,8 @@ constexpr int PADIC_SLIDE_BITS = 6;                              // sliding-wind
 constexpr int PADIC_TBL_ENTRIES = 1 << (PADIC_SLIDE_BITS - 1);    // odd powers
 int padic_nl_for_prime_bits(int bits);
 size_t padic_table_words(int nl, size_t blocks);
-size_t padic_scratch_words(int nl, bool lean, size_t blocks);
-bool launch_dec_a_padic(int nl, bool lean, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
+size_t padic_scratch_words(int nl, size_t blocks);
+bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
                         uint32_t* u_out, int n, uint32_t* table);
 
 // digit engine with base n for raw/DJN encryption (kernels_padic_enc.hpp)

@@ -17,21 +17,20 @@ struct DecPadicParams {
     int nops[2];
     int tbl_entries;             // odd powers base^(2i+1), i < tbl_entries; slot tbl_entries holds base^2
     int nd;                      // base-R digits of a ciphertext
-    uint4* wscratch;             // MODE 1: [NC][nslots] parked first result digit; MODE 2: [2 NC][nslots] quotient digits + parked digit
+    uint4* wscratch;             // PADIC_WBUF: [2 NC][nslots] quotient digits + parked first result digit
     int ct_words, u_words;
 };
 
-// MODE 0: one wave per SIMD, digit pair + quotient digits in LDS (36-limb primes: 3 x 36 KB per workgroup).
-// MODE 1 ("lean"): two waves per SIMD (quotient digits in registers, first result digit parked in global
-//         scratch, LDS holds only the digit pair) — experimental, no faster than MODE 0.
-// MODE 2: one wave per SIMD, LDS holds only the digit pair; quotient digits and the parked first result
-//         digit live in strided global scratch (wider primes: 2 x 56 / 2 x 72 KB per workgroup).
+// MODE PADIC_LDS_M: digit pair + quotient digits in LDS (36-limb primes: 3 x 36 KB per workgroup).
+// MODE PADIC_WBUF:  LDS holds only the digit pair; quotient digits and the parked first result digit live in
+//                   strided global scratch (wider primes: 2 x 56 / 2 x 72 KB per workgroup).
+// Both run one wave per SIMD (a two-waves-per-SIMD variant was measured and dropped: DESIGN.md section 2).
 #ifndef PADIC_SGPR_MODULUS
 #define PADIC_SGPR_MODULUS(NL) ((NL) <= 36)
 #endif
-constexpr int PADIC_LDS_M = 0, PADIC_LEAN = 1, PADIC_WBUF = 2;
+constexpr int PADIC_LDS_M = 0, PADIC_WBUF = 2;
 template <int NL, int U, int WB, int MODE>
-__global__ void __launch_bounds__(BLOCK_THREADS, MODE == PADIC_LEAN ? 2 : 1)
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n,
               uint4* __restrict__ table) {
     using E = Padic<NL, U>;
@@ -39,7 +38,6 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const int which = blockIdx.y;
     const MontCtx* ctx = P.pr[which];
     // modulus and s - 1 from LDS (see kernels_padic_enc.hpp)
-    constexpr bool LEAN = MODE == PADIC_LEAN;
     constexpr int LDS_DIGITS = MODE == PADIC_LDS_M ? 3 : 2;
     uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * LDS_DIGITS * E::DIGIT_WORDS;
     for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = ctx->n[i]; ldsn[NL + i] = P.pm1[which][i]; }
@@ -61,12 +59,11 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     uint4* B = A + E::NC * 64;
     const size_t nslots = (size_t)gridDim.x * gridDim.y * BLOCK_THREADS;
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK_THREADS + threadIdx.x;
-    // M: quotient digits of the first half of the product rule (LDS) — or, LEAN, the global parking column
+    // M: quotient digits of the first half of the product rule: an LDS digit buffer, or (PADIC_WBUF) a strided global column
     const typename E::MBuf M = MODE != PADIC_LDS_M ? typename E::MBuf{P.wscratch + slot, nslots} : typename E::MBuf{B + E::NC * 64, 64};
     const typename E::MBuf Wb{P.wscratch + (size_t)E::NC * nslots + slot, nslots};      // MODE 2 only
     auto SQR = [&]() {
-        if constexpr (MODE == PADIC_LEAN) E::sqr_lean(A, B, M, nm, pm1, n0inv);
-        else if constexpr (MODE == PADIC_WBUF && NL > 56) {
+        if constexpr (MODE == PADIC_WBUF && NL > 56) {
             // the limb-class symmetric squaring is fully unrolled (62 KB of code at 72 limbs: it would thrash the
             // 64 KB instruction cache); squaring as a rolled-loop product costs 14 % more multiplies and fits
             auto self = [&](const uint4* X) { return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); }; };
@@ -75,8 +72,7 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
         else E::sqr(A, B, M, nm, pm1, n0inv);
     };
     auto MUL = [&](auto&& csrc, auto&& dsrc) {
-        if constexpr (MODE == PADIC_LEAN) E::mul_lean(A, B, M, csrc, dsrc, nm, pm1, n0inv);
-        else if constexpr (MODE == PADIC_WBUF) E::mul_wbuf(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);
+        if constexpr (MODE == PADIC_WBUF) E::mul_wbuf(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);
         else E::mul(A, B, M, csrc, dsrc, nm, pm1, n0inv);
     };
     // table entry e: digit d (0 = first, 1 = second), chunk c

@@ -41,9 +41,6 @@ struct Padic {
         for (int j = 0; j < NW; ++j) acc[j] = 0;
     }
     PAI_DEV static void normalize(uint64_t (&acc)[NW]) {
-#ifdef PADIC_X_NONORM
-        return;
-#endif
 #pragma unroll
         for (int j = NW - 1; j >= 1; --j) {
             const uint64_t keep = (j == NW - 1) ? acc[j] : (acc[j] & RMASK);
@@ -123,14 +120,9 @@ struct Padic {
             }
 #pragma unroll
             for (int j = 1; j <= u; ++j) acc[u] += (uint64_t)nm[j] * q[u - j];
-#ifdef PADIC_X_NOQ
-            q[u] = (uint32_t)acc[u];
-            acc[u] += (uint64_t)nm[0] * q[u];
-#else
             q[u] = ((uint32_t)acc[u] * n0inv) & RMASK;
             acc[u] += (uint64_t)nm[0] * q[u];
             acc[u + 1] += acc[u] >> RB;
-#endif
         }
 #pragma unroll
         for (int j = 1; j < U; ++j) {
@@ -196,11 +188,6 @@ struct Padic {
 
     // carry-propagate the low NL columns into canonical 29-bit limbs (registers)
     PAI_DEV static void finish(const uint64_t (&acc)[NW], uint32_t (&r)[NL]) {
-#ifdef PADIC_X_NOFINISH
-#pragma unroll
-        for (int j = 0; j < NL; ++j) r[j] = (uint32_t)acc[j];
-        return;
-#endif
         uint64_t c = 0;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
@@ -439,7 +426,8 @@ struct Padic {
         }
     }
 
-    // ---- register-lean variant (two waves per SIMD): quotient digits m stay in VGPRs (the first half is fully
+    // ---- register-lean variant (two waves per SIMD; EXPERIMENTAL — exercised by tools/padic_bench.hip only: it gains
+    // 10 % in isolation and nothing inside the decrypt kernel): quotient digits m stay in VGPRs (the first half is fully
     // unrolled so that they can be indexed statically), the first result digit is parked in a global scratch
     // column Wb while the second half runs, and the second digit is written straight over B.  LDS then holds
     // only the digit pair itself (2 x NL limbs per lane).

@@ -264,7 +264,6 @@ struct pai_privkey {
     uint32_t* d_nsinv2[2] = {nullptr, nullptr};
     uint32_t* d_hR[2] = {nullptr, nullptr};
     uint32_t* d_pinvqR = nullptr;
-    bool padic_lean = false;      // two-waves-per-SIMD variant of the digit kernel (PAI_PADIC_LEAN=1)
     DevBuf wscratch;
     int u_words = 0;
     int wide_nl = 0;              // != 0: stage A runs on the wide engine with this many limbs
@@ -837,7 +836,6 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
         // p-adic digit engine: digit pairs of R^(i+2) mod s^2 and s - 1 as limbs
         sk->padic_nl = padic_nl_for_prime_bits(std::max(hbn::bitlen(p), hbn::bitlen(q)));
         if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') sk->padic_nl = 0; }
-        if (const char* env = std::getenv("PAI_PADIC_LEAN")) sk->padic_lean = env[0] == '1';
         if (sk->padic_nl) {
             const int nl = sk->padic_nl;
             sk->padic_nd = (32 * pk->ct_words + hbn::RB * nl - 1) / (hbn::RB * nl);
@@ -932,10 +930,10 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         int gridx = grid_for(ga, N, dev.ncu, 1);          // x2 primes => 2 workgroups per CU
         if (sk->padic_nl) {
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
-            const size_t per_prime = sk->padic_lean ? (size_t)dev.ncu : (size_t)dev.ncu / 2;   // x2 primes => 2 or 1 workgroups per CU
+            const size_t per_prime = (size_t)dev.ncu / 2;                                         // x2 primes => one workgroup per CU
             gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, per_prime));
             sk->table.ensure(padic_table_words(sk->padic_nl, (size_t)gridx * 2) * 4);
-            if (const size_t sw = padic_scratch_words(sk->padic_nl, sk->padic_lean, (size_t)gridx * 2)) sk->wscratch.ensure(sw * 4);
+            if (const size_t sw = padic_scratch_words(sk->padic_nl, (size_t)gridx * 2)) sk->wscratch.ensure(sw * 4);
         } else if (sk->wide_nl) {
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
             gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)dev.ncu / 2));   // x2 primes => one workgroup per CU
@@ -971,7 +969,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 Q.wscratch = sk->wscratch.as<uint4>();
                 Q.ct_words = pk->ct_words;
                 Q.u_words = sk->u_words;
-                if (!launch_dec_a_padic(sk->padic_nl, sk->padic_lean, s, gridx, Q, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))
+                if (!launch_dec_a_padic(sk->padic_nl, s, gridx, Q, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))
                     throw PaiError(PAI_E_INTERNAL, "no p-adic kernel for this limb count");
             } else if (sk->wide_nl) {
                 if (!launch_dec_a_wide(sk->wide_nl, s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, sk->table.as<uint32_t>()))

@@ -42,10 +42,7 @@ int padic_nl_for_prime_bits(int bits) {
     return 0;
 }
 size_t padic_table_words(int nl, size_t blocks) { return (size_t)(PADIC_TBL_ENTRIES + 1) * 2 * nl * blocks * BLOCK_THREADS; }
-size_t padic_scratch_words(int nl, bool lean, size_t blocks) {
-    if (nl == 36) return lean ? (size_t)nl * blocks * BLOCK_THREADS : 0;
-    return 2 * (size_t)nl * blocks * BLOCK_THREADS;
-}
+size_t padic_scratch_words(int nl, size_t blocks) { return nl == 36 ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS; }
 template <int NL, int U, int MODE>
 static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table) {
     constexpr int bytes = (MODE == PADIC_LDS_M ? 3 : 2) * NL * BLOCK_THREADS * 4 + 2 * NL * 4;
@@ -53,13 +50,10 @@ static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, cons
     hipLaunchKernelGGL((k_dec_a_padic<NL, U, MODEXP_WINDOW, MODE>), dim3(gridx, 2), dim3(BLOCK_THREADS), bytes, s, P, ct, u_out, n,
                        reinterpret_cast<uint4*>(table));
 }
-bool launch_dec_a_padic(int nl, bool lean, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
+bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
                         uint32_t* u_out, int n, uint32_t* table) {
     switch (nl) {
-        case 36:
-            if (lean) launch_padic<36, 12, PADIC_LEAN>(s, gridx, P, ct, u_out, n, table);
-            else launch_padic<36, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table);
-            return true;
+        case 36: launch_padic<36, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
         case 56: launch_padic<56, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
         case 72: launch_padic<72, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
         default: return false;
