@@ -50,22 +50,11 @@ struct GeoInst {
         set_lds((const void*)k_pow2<G>, G::LDS_BYTES);
         hipLaunchKernelGGL(k_pow2<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, ct, delta, delta_bcast, n, w32);
     }
-    static void inv_prefix(hipStream_t s, int grid, const MontCtx* c, const uint32_t* ct, int w32, int n, int K,
-                           uint32_t* prefix, uint32_t* tot) {
-        set_lds((const void*)k_inv_prefix<G>, G::LDS_BYTES);
-        hipLaunchKernelGGL(k_inv_prefix<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, ct, w32, n, K, prefix, tot);
-    }
-    static void inv_back(hipStream_t s, int grid, const MontCtx* c, const uint32_t* ct, int w32, int n, int K,
-                         const uint32_t* prefix, const uint32_t* tot_inv, uint32_t* out) {
-        set_lds((const void*)k_inv_back<G>, G::LDS_BYTES);
-        hipLaunchKernelGGL(k_inv_back<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, ct, w32, n, K, prefix,
-                           tot_inv, out);
-    }
     static size_t table_words(size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * G::NL * blocks * G::EPB; }
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &encrypt, &dec_a, &dec_b, &pow2, &inv_prefix, &inv_back, &table_words};
+                                 &modmul, &modexp_fixed, &modexp_var, &encrypt, &dec_a, &dec_b, &pow2, &table_words};
         return &o;
     }
 };

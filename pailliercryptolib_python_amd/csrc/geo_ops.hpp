@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
-#include "kernels_invert.hpp"
 #include "kernels_paillier.hpp"
 
 namespace pai {
@@ -29,10 +28,6 @@ struct GeoOps {
     void (*dec_b)(hipStream_t, int grid, DecBParams, const uint32_t* u_in, uint32_t* m_out, int n);
     void (*pow2)(hipStream_t, int grid, const MontCtx*, uint32_t* ct, const int32_t* delta, int delta_bcast, int n,
                  int w32);
-    void (*inv_prefix)(hipStream_t, int grid, const MontCtx*, const uint32_t* ct, int w32, int n, int K,
-                       uint32_t* prefix, uint32_t* tot);
-    void (*inv_back)(hipStream_t, int grid, const MontCtx*, const uint32_t* ct, int w32, int n, int K,
-                     const uint32_t* prefix, const uint32_t* tot_inv, uint32_t* out);
     // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups
     size_t (*table_words)(size_t blocks);
 };

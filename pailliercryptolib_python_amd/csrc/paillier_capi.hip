@@ -235,7 +235,7 @@ struct pai_pubkey {
     uint32_t* d_mscratch = nullptr;
     uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
-    mutable DevBuf inv_prefix, inv_tot, inv_totinv, inv_fail;
+    mutable DevBuf inv_prod, inv_inv, inv_fail;
     mutable std::mutex mu;
     EncParams enc_params() const {
         EncParams P;
@@ -559,9 +559,8 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_fb_dig) (void)hipFree(pk->d_fb_dig);
     if (pk->d_mscratch) (void)hipFree(pk->d_mscratch);
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
-    pk->inv_prefix.release();
-    pk->inv_tot.release();
-    pk->inv_totinv.release();
+    pk->inv_prod.release();
+    pk->inv_inv.release();
     pk->inv_fail.release();
     pk->table.release();
     pk->tmp.release();
@@ -747,30 +746,61 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
         use_device(pk->device);
         const GeoOps* g = pk->msq.geo;
         hipStream_t s = (hipStream_t)stream;
-        // chunk length: long enough to amortise the extended GCD, short enough to keep every CU busy
-        int K = 32;
-        while (K > 1 && (N / (size_t)K) < (size_t)pk->dev.ncu * 2 * g->epb) K >>= 1;
-        if (const char* env = std::getenv("PAI_INVERT_CHUNK")) {     // test hook: force the chunk length
+        const size_t W = (size_t)pk->ct_words, ROW = W * 4;
+        // product tree over halves (kernels_invert.hpp): level k + 1 has ceil(count_k / 2) products; the tree stops
+        // at <= `top` values, each inverted by one wave's extended GCD
+        size_t top = 64;
+        if (const char* env = std::getenv("PAI_INVERT_CHUNK")) {     // test hook: where the tree stops
             int k = std::atoi(env);
-            if (k >= 1 && k <= 1024) K = k;
+            if (k >= 1 && k <= 65536) top = (size_t)k;
         }
-        const size_t nchunks = (N + K - 1) / K;
-        pk->inv_prefix.ensure(N * (size_t)g->nl * 4);
-        pk->inv_tot.ensure(nchunks * (size_t)pk->ct_words * 4);
-        pk->inv_totinv.ensure(nchunks * (size_t)pk->ct_words * 4);
+        std::vector<size_t> cnt{N};
+        while (cnt.back() > top) cnt.push_back((cnt.back() + 1) / 2);
+        const int L = (int)cnt.size() - 1;
+        size_t upper = 0;                                              // rows of all levels above the leaves
+        std::vector<size_t> off(L + 1, 0);
+        for (int k = 1; k <= L; ++k) { off[k] = upper; upper += cnt[k]; }
+        const bool alias = (d_out == d_ct);
+        pk->inv_prod.ensure(std::max<size_t>(1, upper + (alias ? N : 0)) * ROW);
+        pk->inv_inv.ensure(std::max<size_t>(1, upper + (L == 0 ? N : 0)) * ROW);
         pk->inv_fail.ensure(4);
         HIP_CHECK(hipMemsetAsync(pk->inv_fail.p, 0, 4, s));
-        const int grid = grid_for(g, nchunks, pk->dev.ncu);
-        g->inv_prefix(s, grid, pk->msq.d_ctx, d_ct, pk->ct_words, (int)N, K, pk->inv_prefix.as<uint32_t>(),
-                      pk->inv_tot.as<uint32_t>());
-        HIP_CHECK(hipGetLastError());
-        if (!launch_inv_eea(s, pk->ct_words, pk->d_nsq_words, pk->inv_tot.as<uint32_t>(), pk->inv_totinv.as<uint32_t>(),
-                            (int)nchunks, 2 * 32 * pk->ct_words + 64, pk->inv_fail.as<int>()))
+        uint32_t* prod = pk->inv_prod.as<uint32_t>();
+        uint32_t* inv = pk->inv_inv.as<uint32_t>();
+        const uint32_t* leaves = d_ct;
+        if (alias) {                                                    // the way down reads both halves after writing one
+            uint32_t* copy = prod + upper * W;
+            HIP_CHECK(hipMemcpyAsync(copy, d_ct, N * ROW, hipMemcpyDeviceToDevice, s));
+            leaves = copy;
+        }
+        auto level = [&](int k) -> const uint32_t* { return k == 0 ? leaves : prod + off[k] * W; };
+        auto mul = [&](const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+            if (n == 0) return;
+            g->modmul(s, grid_for(g, n, pk->dev.ncu), pk->msq.d_ctx, a, b, out, (int)n, (int)W, 0);
+            HIP_CHECK(hipGetLastError());
+        };
+        for (int k = 0; k < L; ++k) {                                   // up
+            const size_t h = cnt[k + 1], lo = cnt[k] - h;
+            const uint32_t* src = level(k);
+            uint32_t* dst = prod + off[k + 1] * W;
+            mul(src, src + h * W, dst, lo);
+            if (lo < h) HIP_CHECK(hipMemcpyAsync(dst + lo * W, src + lo * W, ROW, hipMemcpyDeviceToDevice, s));
+        }
+        uint32_t* top_out = (L == 0) ? d_out : inv + off[L] * W;
+        if (L == 0 && alias) top_out = inv;                             // in-place single level: stage, then copy back
+        if (!launch_inv_eea(s, (int)W, pk->d_nsq_words, level(L), top_out, (int)cnt[L], 2 * 32 * (int)W + 64, pk->inv_fail.as<int>()))
             throw PaiError(PAI_E_UNSUPPORTED, "ct_invert: key size without an extended-GCD instantiation");
         HIP_CHECK(hipGetLastError());
-        g->inv_back(s, grid, pk->msq.d_ctx, d_ct, pk->ct_words, (int)N, K, pk->inv_prefix.as<uint32_t>(),
-                    pk->inv_totinv.as<uint32_t>(), d_out);
-        HIP_CHECK(hipGetLastError());
+        if (L == 0 && alias) HIP_CHECK(hipMemcpyAsync(d_out, inv, N * ROW, hipMemcpyDeviceToDevice, s));
+        for (int k = L - 1; k >= 0; --k) {                              // down
+            const size_t h = cnt[k + 1], lo = cnt[k] - h;
+            const uint32_t* src = level(k);
+            const uint32_t* pinv = inv + off[k + 1] * W;
+            uint32_t* dst = (k == 0) ? d_out : inv + off[k] * W;
+            mul(pinv, src + h * W, dst, lo);                            // a[i]^-1     = P[i]^-1 a[i + h]
+            mul(pinv, src, dst + h * W, lo);                            // a[i + h]^-1 = P[i]^-1 a[i]
+            if (lo < h) HIP_CHECK(hipMemcpyAsync(dst + lo * W, pinv + lo * W, ROW, hipMemcpyDeviceToDevice, s));
+        }
         int fail = 0;
         HIP_CHECK(hipMemcpyAsync(&fail, pk->inv_fail.p, 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));

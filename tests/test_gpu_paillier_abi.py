@@ -182,7 +182,8 @@ def test_standard_scheme_2048():
 
 @pytest.mark.parametrize("chunk,N", [(None, 1), (None, 77), (8, 1000), (32, 4099), (5, 333)])
 def test_ct_invert_2048(k2048, chunk, N, monkeypatch):
-    """Batched inversion (simultaneous-inversion trick + device extended GCD) against pow(x, -1, n^2)."""
+    """Batched inversion (product tree + one wave-parallel extended GCD per top-level product; the env hook
+    moves the level at which the tree stops) against pow(x, -1, n^2)."""
     import os
 
     if chunk is None:
@@ -203,6 +204,24 @@ def test_ct_invert_2048(k2048, chunk, N, monkeypatch):
     for i in list(range(0, N, step)) + [N - 1]:
         assert got[i] == pow(a[i], -1, key.nsq), i
     assert all(0 < g < key.nsq for g in got)
+
+
+@pytest.mark.parametrize("N,top", [(3, None), (130, 7), (1025, None)])
+def test_ct_invert_in_place(k2048, N, top, monkeypatch):
+    """d_out == d_ct: the product tree reads both halves of a level after writing one of them, so the library
+    stages the leaves."""
+    if top is None:
+        monkeypatch.delenv("PAI_INVERT_CHUNK", raising=False)
+    else:
+        monkeypatch.setenv("PAI_INVERT_CHUNK", str(top))
+    key = k2048.key
+    a = rand_below(np.random.default_rng(77 + N), key.nsq, N)
+    da = DevArray(ints_to_limbs(a, k2048.cw))
+    _native.check(k2048.lib.pai_ct_invert(k2048.pk, da.ptr, N, da.ptr, None))
+    got = limbs_to_ints(da.get())
+    step = max(1, N // 100)
+    for i in list(range(0, N, step)) + [N - 1]:
+        assert got[i] == pow(a[i], -1, key.nsq), i
 
 
 def test_ct_invert_rejects_non_units(k2048):
