@@ -21,6 +21,64 @@ struct DecPadicParams {
     int ct_words, u_words;
 };
 
+// (A, B) <- Montgomery digit form of the packed integer `row` (row_words 32-bit words, any value < s^2 R-ish):
+// sum_i (c_i, 0) * digits(R^(i+2) mod s^2) over its base-R digits c_i (kdig = [nd][2][NL] host-precomputed pairs).
+// M is the quotient-digit buffer of the engine (LDS or strided scratch).
+template <class E>
+PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const uint32_t* __restrict__ row, int row_words,
+                                 const uint32_t* __restrict__ kdig, int nd, const uint32_t* __restrict__ nm,
+                                 const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+    constexpr int NL = E::NC * 4, U = E::UC * 4;
+    uint32_t sw[NL], sv[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { sw[j] = 0; sv[j] = 0; }
+#pragma unroll 1
+    for (int i = 0; i < nd; ++i) {
+        wave_lds_fence();
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) {
+            uint32_t t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = row_limb(row, row_words, NL * i + 4 * c + k);
+            E::st(A, c, make_uint4(t[0], t[1], t[2], t[3]));
+        }
+        wave_lds_fence();
+        const uint32_t* __restrict__ ka = kdig + (size_t)(2 * i) * NL;
+        const uint32_t* __restrict__ kb = ka + NL;
+        uint32_t w[NL], v[NL];
+        E::mm1_mul(w, M, A, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(ka, blk, xv); }, nm, n0inv);
+        {   // v = (c_i * kb - m + R p + m' p) / R   (the element's second digit is zero)
+            uint64_t acc[E::NW];
+            E::mm2_init(acc, M);
+            uint32_t dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+            for (int blk = 0; blk < E::NB; ++blk) {
+                uint32_t xv[U], q[U];
+                E::digits_uniform(kb, blk, xv);
+                E::template block<true, 0, NL, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);
+                if (blk != E::NB - 1) E::normalize(acc);
+            }
+            E::finish(acc, v);
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { sw[j] += w[j]; sv[j] += v[j]; }
+    }
+    // limb sums (< 2^32) back to 29-bit limbs
+    uint32_t cw = 0, cv = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const uint64_t tw = (uint64_t)sw[j] + cw, tv = (uint64_t)sv[j] + cv;
+        sw[j] = (uint32_t)tw & RMASK; cw = (uint32_t)(tw >> RB);
+        sv[j] = (uint32_t)tv & RMASK; cv = (uint32_t)(tv >> RB);
+    }
+    wave_lds_fence();
+    E::store_digit(A, sw);
+    E::store_digit(B, sv);
+    wave_lds_fence();
+}
+
 // MODE PADIC_LDS_M: digit pair + quotient digits in LDS (36-limb primes: 3 x 36 KB per workgroup).
 // MODE PADIC_WBUF:  LDS holds only the digit pair; quotient digits and the parked first result digit live in
 //                   strided global scratch (wider primes: 2 x 56 / 2 x 72 KB per workgroup).
@@ -84,56 +142,7 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
         const int es = live ? ei : n - 1;
         const uint32_t* row = ct + (size_t)es * P.ct_words;
         // ---- digit form of ct:  sum_i  (c_i, 0) * digits(R^(i+2) mod s^2) -----------------------------
-        {
-            uint32_t sw[NL], sv[NL];
-#pragma unroll
-            for (int j = 0; j < NL; ++j) { sw[j] = 0; sv[j] = 0; }
-#pragma unroll 1
-            for (int i = 0; i < P.nd; ++i) {
-                wave_lds_fence();
-#pragma unroll 1
-                for (int c = 0; c < E::NC; ++c) {
-                    uint32_t t[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) t[k] = row_limb(row, P.ct_words, NL * i + 4 * c + k);
-                    E::st(A, c, make_uint4(t[0], t[1], t[2], t[3]));
-                }
-                wave_lds_fence();
-                const uint32_t* __restrict__ ka = kdig + (size_t)(2 * i) * NL;
-                const uint32_t* __restrict__ kb = ka + NL;
-                uint32_t w[NL], v[NL];
-                E::mm1_mul(w, M, A, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(ka, blk, xv); }, nm, n0inv);
-                {   // v = (c_i * kb - m + R p + m' p) / R   (the element's second digit is zero)
-                    uint64_t acc[E::NW];
-                    E::mm2_init(acc, M);
-                    uint32_t dummy[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) dummy[u] = 0;
-#pragma unroll 1
-                    for (int blk = 0; blk < E::NB; ++blk) {
-                        uint32_t xv[U], q[U];
-                        E::digits_uniform(kb, blk, xv);
-                        E::template block<true, 0, NL, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);
-                        if (blk != E::NB - 1) E::normalize(acc);
-                    }
-                    E::finish(acc, v);
-                }
-#pragma unroll
-                for (int j = 0; j < NL; ++j) { sw[j] += w[j]; sv[j] += v[j]; }
-            }
-            // limb sums (< 2^32) back to 29-bit limbs
-            uint32_t cw = 0, cv = 0;
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const uint64_t tw = (uint64_t)sw[j] + cw, tv = (uint64_t)sv[j] + cv;
-                sw[j] = (uint32_t)tw & RMASK; cw = (uint32_t)(tw >> RB);
-                sv[j] = (uint32_t)tv & RMASK; cv = (uint32_t)(tv >> RB);
-            }
-            wave_lds_fence();
-            E::store_digit(A, sw);
-            E::store_digit(B, sv);
-            wave_lds_fence();
-        }
+        padic_to_digit_form<E>(A, B, M, row, P.ct_words, kdig, P.nd, nm, pm1, n0inv);
         // ---- table of odd powers: T[i] = base^(2i+1); slot `tbl_entries` keeps base^2 -----------------------
         const int NT = P.tbl_entries;
 #pragma unroll 1

@@ -4,10 +4,13 @@
 //   k_encrypt_padic    mode 0: ct = 1 + m n                (raw_encrypt: the plain digit pair (1, m) itself)
 //                      mode 1: ct = (1 + m n) hs^r          (DJN encrypt: prod_j T[j][r_j], then * (1, m))
 //                      (apply_obfuscator on existing ciphertexts stays on the lane-group kernel k_encrypt)
+//   k_ctmul_padic      ct^e mod n^2 with per-element (or broadcast) exponents: ciphertext * plaintext
+//                      (CipherText::operator*, classes.cpp:324-325), fixed windows over a per-slot table
 // Same contracts as k_encrypt (kernels_paillier.hpp); ciphertexts are returned as canonical packed words.
 #pragma once
 #include "kernels_wide.hpp"
 #include "mont_padic.hpp"
+#include "kernels_padic.hpp"
 
 namespace pai {
 
@@ -285,6 +288,139 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
         }
         if (live) {
             uint32_t* orow = ct_out + (size_t)ei * P.ct_words;
+#pragma unroll 1
+            for (int k = 0; k < P.ct_words; ++k) {
+                const int j0 = (32 * k) / RB, s0 = 32 * k - RB * j0;
+                uint64_t t = (uint64_t)lds_limb<E>(A, B, j0) >> s0;
+                t |= (uint64_t)lds_limb<E>(A, B, j0 + 1) << (RB - s0);
+                t |= (uint64_t)lds_limb<E>(A, B, j0 + 2) << (2 * RB - s0);
+                orow[k] = (uint32_t)t;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// ---- ciphertext * plaintext: out_i = ct_i ^ e_i mod n^2 on base-n digit pairs ------------------------------------------
+struct CtMulPadicParams {
+    const MontCtx* nctx;         // modulus n (NL limbs)
+    const uint32_t* nm1;         // n - 1 limbs
+    const uint32_t* nsq;         // n^2 limbs (2 NL, radix 29)
+    const uint32_t* kdig;        // [nd][2][NL] digit pairs of R^(i+2) mod n^2
+    const uint32_t* one_dig;     // [2][NL] digit pair of R mod n^2
+    uint4* mscratch;             // [2 NC][nslots]
+    uint4* table;                // [2^wbits][2][NC][nslots] per-slot powers x^0 .. x^(2^wbits - 1)
+    int nd, wbits;
+    int ct_words, e_words, ebits_max, e_bcast;
+};
+
+// Fixed windows of `wbits` bits, most significant first; every lane looks its own digit up in its own table column.
+// A window in which every lane's digit is zero is skipped (wave-uniform); otherwise lanes with a zero digit
+// multiply by the table's entry 0 (= 1).  Squarings run as products (see kernels_padic.hpp on the 72-limb squaring).
+template <int NL, int U>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ e, uint32_t* __restrict__ out, int n) {
+    using E = Padic<NL, U>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
+    __syncthreads();
+    uint32_t sn[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
+    const uint32_t* nm = sn;
+    const uint32_t* nm_lds = ldsn;
+    const uint32_t* nm1 = ldsn + NL;
+    const uint32_t n0inv = P.nctx->n0inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* A = reinterpret_cast<uint4*>(lds + wave * 2 * E::DIGIT_WORDS) + lane;
+    uint4* B = A + E::NC * 64;
+    const size_t nslots = (size_t)gridDim.x * BLOCK_THREADS;
+    const size_t slot = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const typename E::MBuf M{P.mscratch + slot, nslots};
+    const typename E::MBuf Wb{P.mscratch + (size_t)E::NC * nslots + slot, nslots};
+    auto tbl = [&](int ent, int d, int c) -> uint4& { return P.table[(((size_t)ent * 2 + d) * E::NC + c) * nslots + slot]; };
+    auto from_table = [&](int ent, int d) {
+        return [&, ent, d](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+            for (int c = 0; c < E::UC; ++c) {
+                const uint4 t = tbl(ent, d, E::UC * blk + c);
+                xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+            }
+        };
+    };
+    auto self = [&](const uint4* X) { return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); }; };
+    const int W = P.wbits, NT = 1 << W;
+    const int nwin = (P.ebits_max + W - 1) / W;
+    const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        const uint32_t* erow = e + (size_t)(P.e_bcast ? 0 : es) * P.e_words;
+        auto window = [&](int wi) -> uint32_t {
+            const int bit = wi * W, k = bit >> 5;
+            uint64_t bits2 = k < P.e_words ? erow[k] : 0u;
+            if (k + 1 < P.e_words) bits2 |= (uint64_t)erow[k + 1] << 32;
+            return (uint32_t)(bits2 >> (bit & 31)) & (uint32_t)(NT - 1);
+        };
+        // x in Montgomery digit form; table[d] = x^d
+        padic_to_digit_form<E>(A, B, M, ct + (size_t)es * P.ct_words, P.ct_words, P.kdig, P.nd, nm, nm1, n0inv);
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) {
+            tbl(0, 0, c) = make_uint4(P.one_dig[4 * c], P.one_dig[4 * c + 1], P.one_dig[4 * c + 2], P.one_dig[4 * c + 3]);
+            tbl(0, 1, c) = make_uint4(P.one_dig[NL + 4 * c], P.one_dig[NL + 4 * c + 1], P.one_dig[NL + 4 * c + 2], P.one_dig[NL + 4 * c + 3]);
+            tbl(1, 0, c) = E::ld(A, c);
+            tbl(1, 1, c) = E::ld(B, c);
+        }
+#pragma unroll 1
+        for (int k = 2; k < NT; ++k) {
+            E::mul_wbuf(A, B, M, Wb, from_table(1, 0), from_table(1, 1), nm, nm1, n0inv);
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
+        }
+        // top window
+        {
+            const int d0 = (int)window(nwin - 1);
+            wave_lds_fence();
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { E::st(A, c, tbl(d0, 0, c)); E::st(B, c, tbl(d0, 1, c)); }
+            wave_lds_fence();
+        }
+#pragma unroll 1
+        for (int wi = nwin - 2; wi >= 0; --wi) {
+#pragma unroll 1
+            for (int sq = 0; sq < W; ++sq) E::mul_wbuf(A, B, M, Wb, self(A), self(B), nm, nm1, n0inv);
+            const int d = (int)window(wi);
+            if (__any(d != 0)) E::mul_wbuf(A, B, M, Wb, from_table(d, 0), from_table(d, 1), nm, nm1, n0inv);
+        }
+        // leave Montgomery form (times the plain pair (1, 0)), then ct = w + v n as one integer, canonical
+        uint32_t w[NL], v[NL];
+        {
+            auto one = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = 0;
+                if (blk == 0) xv[0] = 1;
+            };
+            auto zero = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = 0;
+            };
+            E::mm1_mul(w, M, A, one, nm, n0inv);
+            E::mm2_mul(v, M, A, B, zero, one, nm, nm1, n0inv);
+        }
+        wave_lds_fence();
+        E::store_digit(B, v);
+        wave_lds_fence();
+        uint32_t hi[NL];
+        E::mul_plain(hi, A, w, B, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(nm_lds, blk, xv); });
+        wave_lds_fence();
+        E::store_digit(B, hi);
+        wave_lds_fence();
+        cond_sub_2nl<E>(A, B, P.nsq);
+        cond_sub_2nl<E>(A, B, P.nsq);
+        if (live) {
+            uint32_t* orow = out + (size_t)ei * P.ct_words;
 #pragma unroll 1
             for (int k = 0; k < P.ct_words; ++k) {
                 const int j0 = (32 * k) / RB, s0 = 32 * k - RB * j0;

@@ -233,6 +233,10 @@ struct pai_pubkey {
     uint32_t* d_nsq29 = nullptr;
     uint32_t* d_fb_dig = nullptr;
     uint32_t* d_mscratch = nullptr;
+    uint32_t* d_one_dig = nullptr;     // digit pair of R mod n^2 (the element 1 in Montgomery digit form)
+    uint32_t* d_ct_kdig = nullptr;     // [ct_nd][2][NL] digit pairs of R^(i+2) mod n^2
+    int ct_nd = 0;
+    mutable DevBuf ctmul_table;        // per-slot window tables of k_ctmul_padic
     uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
     mutable DevBuf inv_prod, inv_inv, inv_fail;
@@ -424,6 +428,47 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         pk->d_nR = upload_r29(hbn::mulmod(pk->n, pk->msq.R, pk->nsq), nl);
         pk->d_nexp = upload_words(pk->n, pk->n_words);
         pk->d_nsq_words = upload_words(pk->nsq, pk->ct_words);
+        // ---- base-n digit engine (kernels_padic_enc.hpp): raw / DJN encryption and ct * pt run on it when n fits 72
+        // limbs (PAI_DISABLE_PADIC=1 falls back to the lane-group kernels, which serve every other key size)
+        pk->penc_nl = padic_enc_nl_for_n_bits(hbn::bitlen(pk->n));
+        if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') pk->penc_nl = 0; }
+        Limbs Rm;
+        auto digits_of = [&](const Limbs& v) {
+            const int pnl = pk->penc_nl;
+            Limbs rem;
+            Limbs quo = hbn::divq(v, pk->n, &rem);
+            std::vector<uint32_t> h(2 * (size_t)pnl, 0);
+            auto ra = hbn::to_r29(rem, pnl), rb = hbn::to_r29(quo, pnl);
+            std::memcpy(h.data(), ra.data(), (size_t)pnl * 4);
+            std::memcpy(h.data() + pnl, rb.data(), (size_t)pnl * 4);
+            return h;
+        };
+        auto upload_vec = [&](const std::vector<uint32_t>& h) {
+            uint32_t* d = nullptr;
+            HIP_CHECK(hipMalloc((void**)&d, h.size() * 4));
+            HIP_CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            return d;
+        };
+        if (pk->penc_nl) {
+            const int pnl = pk->penc_nl;
+            pk->nmod.init(pk->n, pnl);
+            const Limbs one{1u};
+            pk->d_nm1 = upload_r29(hbn::sub(pk->n, one), pnl);
+            pk->d_nsq29 = upload_r29(pk->nsq, 2 * pnl);
+            Rm = hbn::mod(hbn::shl(one, hbn::RB * pnl), pk->nsq);
+            pk->d_one_dig = upload_vec(digits_of(Rm));
+            HIP_CHECK(hipMalloc((void**)&pk->d_mscratch, 2 * (size_t)pk->dev.ncu * BLOCK_THREADS * (size_t)pnl * 4));
+            // digit pairs of R^(i+2) mod n^2: a ciphertext enters digit form through its base-R digits (as in stage A)
+            pk->ct_nd = (32 * pk->ct_words + hbn::RB * pnl - 1) / (hbn::RB * pnl);
+            std::vector<uint32_t> kd;
+            Limbs K = hbn::mulmod(Rm, Rm, pk->nsq);
+            for (int i = 0; i < pk->ct_nd; ++i) {
+                auto h = digits_of(K);
+                kd.insert(kd.end(), h.begin(), h.end());
+                K = hbn::mulmod(K, Rm, pk->nsq);
+            }
+            pk->d_ct_kdig = upload_vec(kd);
+        }
         if (h_hs) {
             require(hs_words > 0 && randbits > 0, "DJN key needs hs and randbits");
             // fixed-base window width: the widest (<= 12 bits) whose table stays within 256 MiB
@@ -465,33 +510,11 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             HIP_CHECK(hipDeviceSynchronize());
             HIP_CHECK(hipFree(d_bases));
             HIP_CHECK(hipFree(d_expo));
-            // digit-form table for the base-n digit engine
-            // raw / DJN encryption run on the base-n digit engine when n fits 72 limbs (PAI_DISABLE_PADIC=1 falls
-            // back to the lane-group kernel, which also serves apply_obfuscator and every other key size)
-            pk->penc_nl = padic_enc_nl_for_n_bits(hbn::bitlen(pk->n));
-            if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') pk->penc_nl = 0; }
+            // digit-form fixed-base table for the base-n digit engine
             if (pk->penc_nl) {
                 const int pnl = pk->penc_nl;
-                pk->nmod.init(pk->n, pnl);
-                const Limbs one{1u};
-                pk->d_nm1 = upload_r29(hbn::sub(pk->n, one), pnl);
-                pk->d_nsq29 = upload_r29(pk->nsq, 2 * pnl);
-                Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * pnl), pk->nsq);
-                auto digits_of = [&](const Limbs& v) {
-                    Limbs rem;
-                    Limbs quo = hbn::divq(v, pk->n, &rem);
-                    std::vector<uint32_t> h(2 * (size_t)pnl, 0);
-                    auto ra = hbn::to_r29(rem, pnl), rb = hbn::to_r29(quo, pnl);
-                    std::memcpy(h.data(), ra.data(), (size_t)pnl * 4);
-                    std::memcpy(h.data() + pnl, rb.data(), (size_t)pnl * 4);
-                    uint32_t* d = nullptr;
-                    HIP_CHECK(hipMalloc((void**)&d, h.size() * 4));
-                    HIP_CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-                    return d;
-                };
-                uint32_t* d_one = digits_of(Rm);
-                uint32_t* d_hs = digits_of(hbn::mulmod(pk->hs, Rm, pk->nsq));
-                HIP_CHECK(hipMalloc((void**)&pk->d_mscratch, 2 * (size_t)pk->dev.ncu * BLOCK_THREADS * (size_t)pnl * 4));
+                uint32_t* d_one = pk->d_one_dig;
+                uint32_t* d_hs = upload_vec(digits_of(hbn::mulmod(pk->hs, Rm, pk->nsq)));
                 // Window width of the digit-form table.  Every window costs one multiplication mod n^2 per
                 // ciphertext, and HBM is plentiful: take the widest even width (<= 20 bits) whose table fits the
                 // budget — 1/32 of the device memory unless PAI_FB_TABLE_MB says otherwise (MI355X, 288 GB:
@@ -534,7 +557,6 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
                 }
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipDeviceSynchronize());
-                HIP_CHECK(hipFree(d_one));
                 HIP_CHECK(hipFree(d_hs));
             }
         } else {
@@ -558,6 +580,9 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_nsq29) (void)hipFree(pk->d_nsq29);
     if (pk->d_fb_dig) (void)hipFree(pk->d_fb_dig);
     if (pk->d_mscratch) (void)hipFree(pk->d_mscratch);
+    if (pk->d_one_dig) (void)hipFree(pk->d_one_dig);
+    if (pk->d_ct_kdig) (void)hipFree(pk->d_ct_kdig);
+    pk->ctmul_table.release();
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
     pk->inv_prod.release();
     pk->inv_inv.release();
@@ -719,6 +744,36 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         require(e_words > 0 && ebits_max > 0 && ebits_max <= 32 * e_words, "bad exponent shape");
         if (N == 0) return;
         use_device(pk->device);
+        g_last_times.clear();
+        if (pk->penc_nl) {
+            // base-n digit engine: fixed windows sized to the exponent width (table build 2^w - 2 products, then
+            // w squarings + 1 product per window)
+            std::lock_guard<std::mutex> lk(pk->mu);
+            const int wbits = ebits_max <= 24 ? 2 : (ebits_max <= 80 ? 3 : (ebits_max <= 240 ? 4 : 5));
+            const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
+            const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+            pk->ctmul_table.ensure(ctmul_padic_table_words(pk->penc_nl, wbits, (size_t)grid) * 4);
+            CtMulPadicParams Q;
+            Q.nctx = pk->nmod.d_ctx;
+            Q.nm1 = pk->d_nm1;
+            Q.nsq = pk->d_nsq29;
+            Q.kdig = pk->d_ct_kdig;
+            Q.one_dig = pk->d_one_dig;
+            Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
+            Q.table = pk->ctmul_table.as<uint4>();
+            Q.nd = pk->ct_nd;
+            Q.wbits = wbits;
+            Q.ct_words = pk->ct_words;
+            Q.e_words = e_words;
+            Q.ebits_max = ebits_max;
+            Q.e_bcast = e_bcast;
+            ScopedKernelTimer t("k_ctmul", (hipStream_t)stream);
+            if (!launch_ctmul_padic(pk->penc_nl, (hipStream_t)stream, grid, Q, d_ct, d_e, d_out, (int)N))
+                throw PaiError(PAI_E_INTERNAL, "no digit-engine ct*pt kernel for this limb count");
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         const GeoOps* g = pk->msq.geo;
         g->modexp_var((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, pk->ct_words, 0, d_e, e_words,
                       ebits_max, e_bcast, d_out, pk->ct_words, (int)N, 0, 0);

@@ -89,4 +89,14 @@ bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams&
     return true;
 }
 
+size_t ctmul_padic_table_words(int nl, int wbits, size_t blocks) { return ((size_t)1 << wbits) * 2 * nl * blocks * BLOCK_THREADS; }
+bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e,
+                        uint32_t* out, int n) {
+    if (nl != 72) return false;
+    constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
+    (void)hipFuncSetAttribute((const void*)k_ctmul_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((k_ctmul_padic<72, 8>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, ct, e, out, n);
+    return true;
+}
+
 }  // namespace pai

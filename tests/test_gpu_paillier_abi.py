@@ -146,6 +146,28 @@ def test_ct_add_mul_pow2_2048(k2048):
     assert limbs_to_ints(da.get()) == [orc.ct_mul(x, 2 ** int(d), key.nsq) if d > 0 else x for x, d in zip(a, delta)]
 
 
+@pytest.mark.parametrize("ebits", [1, 2, 24, 25, 80, 81, 240, 241, 2048, 4096])
+def test_ct_mul_every_window_width_and_exponent_shape(k2048, ebits):
+    """ct^e on the base-n digit engine: the window width follows ebits_max (2/3/4/5 bits), exponents of every
+    size up to a full ciphertext width, zero windows, e = 0, per-element and broadcast exponents, in place."""
+    key, N = k2048.key, 70
+    rng = np.random.default_rng(900 + ebits)
+    a = rand_below(rng, key.nsq, N)
+    a[0], a[1] = 1, key.nsq - 1
+    es = [int.from_bytes(rng.bytes(ebits // 8 + 1), "little") % (1 << ebits) for _ in range(N)]
+    es[0], es[1], es[2] = 0, (1 << ebits) - 1, 1 << (ebits - 1)
+    if ebits > 8:
+        es[3] = 1 << (ebits - 1) | 1                     # one long run of zero windows
+    ew = (ebits + 31) // 32
+    da, de = DevArray(ints_to_limbs(a, k2048.cw)), DevArray(ints_to_limbs(es, ew))
+    out = DevArray(shape=(N, k2048.cw))
+    _native.check(k2048.lib.pai_ct_mul(k2048.pk, da.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == [pow(x, e, key.nsq) for x, e in zip(a, es)]
+    db = DevArray(ints_to_limbs([es[3 if ebits > 8 else 1]], ew))
+    _native.check(k2048.lib.pai_ct_mul(k2048.pk, da.ptr, db.ptr, ew, ebits, 1, N, da.ptr, None))     # broadcast, in place
+    assert limbs_to_ints(da.get()) == [pow(x, es[3 if ebits > 8 else 1], key.nsq) for x in a]
+
+
 @pytest.mark.parametrize("bits", [1024, 3072, 4096])
 def test_other_key_sizes_roundtrip_and_bits(bits):
     nk = NativeKey(seeded_key(bits))
