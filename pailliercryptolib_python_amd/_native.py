@@ -2,15 +2,18 @@
 
 This module takes the place of ``from .bindings.ipcl_bindings import ...`` in the reference
 (``src/ipcl_python/ipcl_python.py:5-12``).  The library is loaded from ``pailliercryptolib_python_amd/lib``
-and nowhere else; if it is missing the import of any hot-path entry fails loudly — there is no CPU
+(or from the explicit path in ``PAI_NATIVE_LIB``: a variant build of the same sources); if it is missing the import of any hot-path entry fails loudly — there is no CPU
 fallback behind this boundary.
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpaillier_hip.so"
+if os.environ.get("PAI_NATIVE_LIB"):     # an explicitly built variant of the same library (A/B timing of compiler flags)
+    LIB_PATH = Path(os.environ["PAI_NATIVE_LIB"])
 
 PAI_OK = 0
 PAI_E_INVALID, PAI_E_NODEVICE, PAI_E_HIP, PAI_E_UNSUPPORTED, PAI_E_INTERNAL = -1, -2, -3, -4, -5

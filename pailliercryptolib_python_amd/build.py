@@ -30,8 +30,17 @@ SOURCES = [
     "geo_36x8.hip",
     "inv_eea.hip",
     "wide_kernels.hip",
+    "padic_dec_kernels.hip",
+    "padic_enc_kernels.hip",
     "paillier_capi.hip",
 ]
+
+# Per-translation-unit extra flags.  The digit-pair kernels run one wave per SIMD, so their speed is set by how the
+# compiler orders ~6000 instructions per product.  Scheduler strategies were A/B-timed on one MI355X box with
+# tools/build_variants.sh: -amdgpu-sched-strategy=max-ilp wins 5-11 % in the isolated probes of tools/padic_bench.hip
+# but LOSES 4 % inside k_dec_a_padic (508 vs 487 ms); -amdgpu-use-amdgpu-trackers and -amdgpu-schedule-metric-bias=0
+# are within noise (483-485 ms).  Hence: none.
+EXTRA_FLAGS: dict = {}
 
 
 def _hipcc() -> str:
@@ -54,7 +63,7 @@ def _compile(src: str) -> None:
     # accumulator windows need compile-time indices); clang's default pragma-unroll budget silently falls back to a
     # partial unroll there, which demotes the window to scratch memory (4x slower)
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1048576",
-           "-c", str(CSRC / src), "-o", str(obj)]
+           *EXTRA_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")

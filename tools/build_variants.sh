@@ -1,0 +1,25 @@
+#!/bin/bash
+# Builds variants of libpaillier_hip.so that differ only in the scheduler flags of the digit-pair kernels' translation
+# units, for same-box A/B timing (PAI_NATIVE_LIB=<variant> python bench.py).  Usage: bash tools/build_variants.sh
+set -e
+cd "$(dirname "$0")/.."
+python -m pailliercryptolib_python_amd.build > /dev/null
+C=pailliercryptolib_python_amd/csrc
+OUT=pailliercryptolib_python_amd/lib/alt
+mkdir -p $OUT
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1048576"
+OTHERS=$(ls $C/build/*.o | grep -v padic_dec_kernels | grep -v padic_enc_kernels)
+build() {  # tag, dec flags, enc flags
+  hipcc $BASE $2 -c $C/padic_dec_kernels.hip -o $OUT/dec_$1.o &
+  hipcc $BASE $3 -c $C/padic_enc_kernels.hip -o $OUT/enc_$1.o &
+  wait
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$1.so $OTHERS $OUT/dec_$1.o $OUT/enc_$1.o
+  rm -f $OUT/dec_$1.o $OUT/enc_$1.o
+}
+build plain "" "" &
+build ilp "-mllvm -amdgpu-sched-strategy=max-ilp" "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers" &
+wait
+build bias0 "-mllvm -amdgpu-schedule-metric-bias=0" "-mllvm -amdgpu-use-amdgpu-trackers" &
+build trk "-mllvm -amdgpu-use-amdgpu-trackers" "-mllvm -amdgpu-sched-strategy=max-ilp" &
+wait
+ls -la $OUT
