@@ -51,7 +51,10 @@ bool launch_dec_a_wide(int nl, hipStream_t s, int gridx, const DecAParams& P, co
 
 // p-adic digit engine for CRT-decrypt stage A (mont_padic.hpp / kernels_padic.hpp)
 struct DecPadicParams;
-constexpr int PADIC_SLIDE_BITS = 6;                              // sliding-window width of the decrypt schedule
+#ifndef PAI_PADIC_SLIDE_BITS
+#define PAI_PADIC_SLIDE_BITS 6
+#endif
+constexpr int PADIC_SLIDE_BITS = PAI_PADIC_SLIDE_BITS;    // sliding-window width of the decrypt exponent schedule (k_dec_a per 2^20: 486 / 478 / 489 ms at 5 / 6 / 7 bits)
 constexpr int PADIC_TBL_ENTRIES = 1 << (PADIC_SLIDE_BITS - 1);    // odd powers
 int padic_nl_for_prime_bits(int bits);
 size_t padic_table_words(int nl, size_t blocks);

@@ -313,7 +313,9 @@ struct Padic {
         uint32_t dummy[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) dummy[u] = 0;
-#pragma unroll 1
+        // unrolled (three 12-row blocks at 36 limbs): 2 % faster inside the decrypt kernel (476 vs 486 ms); unrolling the
+        // product's loops as well overflows the instruction cache (511 ms)
+#pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
             uint32_t xv[U], q[U];
             digits(Y, blk, xv);

@@ -9,17 +9,21 @@ OUT=pailliercryptolib_python_amd/lib/alt
 mkdir -p $OUT
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1048576"
 OTHERS=$(ls $C/build/*.o | grep -v padic_dec_kernels | grep -v padic_enc_kernels)
-build() {  # tag, dec flags, enc flags
+build() {  # tag, dec flags, enc flags, [1 = the flags also reach paillier_capi.hip (host constants)]
+  OTH="$OTHERS"
   hipcc $BASE $2 -c $C/padic_dec_kernels.hip -o $OUT/dec_$1.o &
   hipcc $BASE $3 -c $C/padic_enc_kernels.hip -o $OUT/enc_$1.o &
+  if [ "${4:-0}" = "1" ]; then
+    hipcc $BASE $2 -c $C/paillier_capi.hip -o $OUT/capi_$1.o &
+    OTH="$(echo $OTHERS | tr ' ' '\n' | grep -v paillier_capi) $OUT/capi_$1.o"
+  fi
   wait
-  hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$1.so $OTHERS $OUT/dec_$1.o $OUT/enc_$1.o
-  rm -f $OUT/dec_$1.o $OUT/enc_$1.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$1.so $OTH $OUT/dec_$1.o $OUT/enc_$1.o
+  rm -f $OUT/dec_$1.o $OUT/enc_$1.o $OUT/capi_$1.o
 }
 build plain "" "" &
-build ilp "-mllvm -amdgpu-sched-strategy=max-ilp" "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers" &
+build s5 "-DPAI_PADIC_SLIDE_BITS=5" "" 1 &
 wait
-build bias0 "-mllvm -amdgpu-schedule-metric-bias=0" "-mllvm -amdgpu-use-amdgpu-trackers" &
-build trk "-mllvm -amdgpu-use-amdgpu-trackers" "-mllvm -amdgpu-sched-strategy=max-ilp" &
+build s7 "-DPAI_PADIC_SLIDE_BITS=7" "" 1 &
 wait
 ls -la $OUT
