@@ -5,6 +5,11 @@
 
 namespace pai {
 
+#ifndef PAI_ENC_U
+#define PAI_ENC_U 8
+#endif
+constexpr int ENC_U = PAI_ENC_U;     // rows per block of the 72-limb products
+
 // ---- digit engine with base n for encryption (kernels_padic_enc.hpp): 1400..2048-bit n, 72 limbs -------
 int padic_enc_nl_for_n_bits(int bits) { return (bits >= 1400 && RB * 72 >= bits + 20) ? 72 : 0; }
 bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
@@ -29,8 +34,8 @@ bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams&
                           uint32_t* ct_out, int n, int mode) {
     if (nl != 72) return false;
     constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
-    (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_encrypt_padic<72, 8>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, nullptr, ct_out, n, mode);
+    (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, ENC_U>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((k_encrypt_padic<72, ENC_U>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, nullptr, ct_out, n, mode);
     return true;
 }
 
@@ -39,8 +44,8 @@ bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams&
                         uint32_t* out, int n) {
     if (nl != 72) return false;
     constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
-    (void)hipFuncSetAttribute((const void*)k_ctmul_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_ctmul_padic<72, 8>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, ct, e, out, n);
+    (void)hipFuncSetAttribute((const void*)k_ctmul_padic<72, ENC_U>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((k_ctmul_padic<72, ENC_U>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, ct, e, out, n);
     return true;
 }
 

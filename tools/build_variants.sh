@@ -21,9 +21,13 @@ build() {  # tag, dec flags, enc flags, [1 = the flags also reach paillier_capi.
   hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$1.so $OTH $OUT/dec_$1.o $OUT/enc_$1.o
   rm -f $OUT/dec_$1.o $OUT/enc_$1.o $OUT/capi_$1.o
 }
+# Edit the list below for the experiment at hand; every variant lands in lib/alt/lib_<tag>.so.  Then, in ONE gpurun
+# call (boxes differ by a few %):  for v in plain x plain; do PAI_NATIVE_LIB=$PWD/$OUT/lib_$v.so python bench.py ...; done
+# Results so far (k_dec_a / k_encrypt per 2^20, 2048-bit key, same box): scheduler strategy max-ilp 508 vs 487 ms;
+# trackers / metric-bias=0 within noise; modulus limbs from LDS instead of SGPRs 508 vs 488; second half of the
+# squaring unrolled 476 vs 486; product loops unrolled as well 511; sliding window 5 / 6 / 7 bits 486 / 478 / 489;
+# 12-row blocks for the 72-limb products 68.7 vs 67.4 ms (encrypt), 88.7 vs 90.0 ms (ct * pt).
 build plain "" "" &
-build s5 "-DPAI_PADIC_SLIDE_BITS=5" "" 1 &
-wait
-build s7 "-DPAI_PADIC_SLIDE_BITS=7" "" 1 &
+build trk "-mllvm -amdgpu-use-amdgpu-trackers" "-mllvm -amdgpu-use-amdgpu-trackers" &
 wait
 ls -la $OUT
