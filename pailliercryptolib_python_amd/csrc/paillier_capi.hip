@@ -471,10 +471,15 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         }
         if (h_hs) {
             require(hs_words > 0 && randbits > 0, "DJN key needs hs and randbits");
-            // fixed-base window width: the widest (<= 12 bits) whose table stays within 256 MiB
-            // (2048-bit keys: 12 bits => 86 windows x 4096 entries x 576 B = 203 MB, resident in the Infinity Cache)
-            int wb = 12;
-            while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > 256.0 * 1048576.0) --wb;
+            // Fixed-base window width of the lane-group table.  When the digit engine encrypts (its own, wider table
+            // below) this one only serves apply_obfuscator: the widest width <= 12 bits within 256 MiB (2048-bit keys:
+            // 86 windows x 4096 entries x 576 B = 203 MB).  Otherwise (3072/4096-bit keys) it IS the encryption table:
+            // up to 14 bits within 1/64 of device memory (4096-bit keys: 2.8 GB; k_encrypt 84 -> 61 ms per 65536).
+            size_t mem_free0 = 0, mem_total0 = 0;
+            HIP_CHECK(hipMemGetInfo(&mem_free0, &mem_total0));
+            const double lg_budget = pk->penc_nl ? 256.0 * 1048576.0 : std::max(256.0 * 1048576.0, (double)mem_total0 / 64.0);
+            int wb = pk->penc_nl ? 12 : 14;
+            while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > lg_budget) --wb;
             if (const char* env = std::getenv("PAI_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 14) wb = v; }
             pk->fb_wbits = wb;
             pk->djn = true;

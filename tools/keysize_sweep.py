@@ -54,16 +54,24 @@ def main() -> None:
             t_dec = dict(engine.profile_last())
         ok = bool(torch.equal(out, m))
         ct2 = pub.empty_ct(B)
-        pub.ct_add(ct, ct, out=ct2)
-        t_add = dict(engine.profile_last())
+
+        def wall(f):
+            f()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            f()
+            torch.cuda.synchronize()
+            return {"wall": (time.perf_counter() - t1) * 1e3}
+
+        t_add = wall(lambda: pub.ct_add(ct, ct, out=ct2))
         # 53-bit multipliers (what a float mantissa encodes to)
         e = torch.randint(1, 1 << 30, (B, 2), dtype=torch.int32, device=dev)
         e[:, 1] &= (1 << 21) - 1
-        pub.ct_mul(ct, e, 53, out=ct2)
-        t_mul = dict(engine.profile_last())
+        t_mul = wall(lambda: pub.ct_mul(ct, e, 53, out=ct2))
+        t_inv = wall(lambda: pub.ct_invert(ct, out=ct2))
         engine.profile_enable(False)
         times = {"encrypt_ms": sum(t_enc.values()), "decrypt_ms": sum(t_dec.values()), "ct_add_ms": sum(t_add.values()),
-                 "ct_mul53_ms": sum(t_mul.values())}
+                 "ct_mul53_ms": sum(t_mul.values()), "ct_invert_ms": sum(t_inv.values())}
         print(json.dumps({"key_bits": bits, "batch": B, "roundtrip_ok": ok, "key_setup_s": round(t_key, 3),
                           **{k: round(v, 3) for k, v in times.items()},
                           "enc_dec_ops_per_s": round(B / ((times["encrypt_ms"] + times["decrypt_ms"]) * 1e-3)),
