@@ -69,6 +69,8 @@ bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uin
                            const uint32_t* one_dig, uint32_t* table, int J, int wb);
 bool launch_fb_expand_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
                             uint32_t* T, int J, int h, uint32_t* mscratch);
+struct PowPadicParams;
+bool launch_pow_padic(int nl, hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n);
 struct CtMulPadicParams;
 size_t ctmul_padic_table_words(int nl, int wbits, size_t blocks);
 bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e,

@@ -4,6 +4,7 @@
 //   k_encrypt_padic    mode 0: ct = 1 + m n                (raw_encrypt: the plain digit pair (1, m) itself)
 //                      mode 1: ct = (1 + m n) hs^r          (DJN encrypt: prod_j T[j][r_j], then * (1, m))
 //                      (apply_obfuscator on existing ciphertexts stays on the lane-group kernel k_encrypt)
+//   k_pow_padic        base^E mod n^2 for a wave-uniform E (standard-scheme obfuscator r^n), sliding windows
 //   k_ctmul_padic      ct^e mod n^2 with per-element (or broadcast) exponents: ciphertext * plaintext
 //                      (CipherText::operator*, classes.cpp:324-325), fixed windows over a per-slot table
 // Same contracts as k_encrypt (kernels_paillier.hpp); ciphertexts are returned as canonical packed words.
@@ -395,6 +396,132 @@ k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_
             if (__any(d != 0)) E::mul_wbuf(A, B, M, Wb, from_table(d, 0), from_table(d, 1), nm, nm1, n0inv);
         }
         // leave Montgomery form (times the plain pair (1, 0)), then ct = w + v n as one integer, canonical
+        uint32_t w[NL], v[NL];
+        {
+            auto one = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = 0;
+                if (blk == 0) xv[0] = 1;
+            };
+            auto zero = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = 0;
+            };
+            E::mm1_mul(w, M, A, one, nm, n0inv);
+            E::mm2_mul(v, M, A, B, zero, one, nm, nm1, n0inv);
+        }
+        wave_lds_fence();
+        E::store_digit(B, v);
+        wave_lds_fence();
+        uint32_t hi[NL];
+        E::mul_plain(hi, A, w, B, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(nm_lds, blk, xv); });
+        wave_lds_fence();
+        E::store_digit(B, hi);
+        wave_lds_fence();
+        cond_sub_2nl<E>(A, B, P.nsq);
+        cond_sub_2nl<E>(A, B, P.nsq);
+        if (live) {
+            uint32_t* orow = out + (size_t)ei * P.ct_words;
+#pragma unroll 1
+            for (int k = 0; k < P.ct_words; ++k) {
+                const int j0 = (32 * k) / RB, s0 = 32 * k - RB * j0;
+                uint64_t t = (uint64_t)lds_limb<E>(A, B, j0) >> s0;
+                t |= (uint64_t)lds_limb<E>(A, B, j0 + 1) << (RB - s0);
+                t |= (uint64_t)lds_limb<E>(A, B, j0 + 2) << (2 * RB - s0);
+                orow[k] = (uint32_t)t;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// ---- out_i = base_i ^ E mod n^2 for a wave-uniform exponent E (the standard scheme's obfuscator r^n) --------------------
+struct PowPadicParams {
+    const MontCtx* nctx;
+    const uint32_t* nm1;
+    const uint32_t* nsq;
+    const uint32_t* kdig;        // [>= ceil(in bits / (29 NL))][2][NL]
+    const uint16_t* ops;         // sliding-window schedule of E (paillier_capi.hip: compile_sliding_schedule)
+    int nops, tbl_entries;
+    uint4* mscratch;
+    uint4* table;                // [tbl_entries + 1][2][NC][nslots]
+    int in_words, ct_words;
+};
+
+template <int NL, int U>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __restrict__ out, int n) {
+    using E = Padic<NL, U>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
+    __syncthreads();
+    uint32_t sn[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
+    const uint32_t* nm = sn;
+    const uint32_t* nm_lds = ldsn;
+    const uint32_t* nm1 = ldsn + NL;
+    const uint32_t n0inv = P.nctx->n0inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* A = reinterpret_cast<uint4*>(lds + wave * 2 * E::DIGIT_WORDS) + lane;
+    uint4* B = A + E::NC * 64;
+    const size_t nslots = (size_t)gridDim.x * BLOCK_THREADS;
+    const size_t slot = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const typename E::MBuf M{P.mscratch + slot, nslots};
+    const typename E::MBuf Wb{P.mscratch + (size_t)E::NC * nslots + slot, nslots};
+    auto tbl = [&](int ent, int d, int c) -> uint4& { return P.table[(((size_t)ent * 2 + d) * E::NC + c) * nslots + slot]; };
+    auto from_table = [&](int ent, int d) {
+        return [&, ent, d](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+            for (int c = 0; c < E::UC; ++c) {
+                const uint4 t = tbl(ent, d, E::UC * blk + c);
+                xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+            }
+        };
+    };
+    auto self = [&](const uint4* X) { return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); }; };
+    auto SQR = [&]() { E::mul_wbuf(A, B, M, Wb, self(A), self(B), nm, nm1, n0inv); };
+    const int NT = P.tbl_entries;
+    const int nd = (32 * P.in_words + RB * NL - 1) / (RB * NL);
+    const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        padic_to_digit_form<E>(A, B, M, base + (size_t)es * P.in_words, P.in_words, P.kdig, nd, nm, nm1, n0inv);
+        // table of odd powers T[i] = x^(2i+1); slot NT keeps x^2
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) { tbl(0, 0, c) = E::ld(A, c); tbl(0, 1, c) = E::ld(B, c); }
+        SQR();
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) { tbl(NT, 0, c) = E::ld(A, c); tbl(NT, 1, c) = E::ld(B, c); }
+        wave_lds_fence();
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) { E::st(A, c, tbl(0, 0, c)); E::st(B, c, tbl(0, 1, c)); }
+        wave_lds_fence();
+#pragma unroll 1
+        for (int k = 1; k < NT; ++k) {
+            E::mul_wbuf(A, B, M, Wb, from_table(NT, 0), from_table(NT, 1), nm, nm1, n0inv);
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
+        }
+        {
+            const int i0 = (int)(P.ops[0] >> 8);
+            wave_lds_fence();
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) { E::st(A, c, tbl(i0, 0, c)); E::st(B, c, tbl(i0, 1, c)); }
+            wave_lds_fence();
+        }
+#pragma unroll 1
+        for (int k = 1; k < P.nops; ++k) {
+            const int op = (int)P.ops[k];
+            const int nsq = op & 0xFF, idx = op >> 8;
+#pragma unroll 1
+            for (int s_ = 0; s_ < nsq; ++s_) SQR();
+            if (idx != 0xFF) E::mul_wbuf(A, B, M, Wb, from_table(idx, 0), from_table(idx, 1), nm, nm1, n0inv);
+        }
+        // leave Montgomery form, w + v n as one canonical integer, packed words (as in k_encrypt_padic)
         uint32_t w[NL], v[NL];
         {
             auto one = [&](int blk, uint32_t (&xv)[U]) {

@@ -49,4 +49,12 @@ bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams&
     return true;
 }
 
+bool launch_pow_padic(int nl, hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n) {
+    if (nl != 72) return false;
+    constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
+    (void)hipFuncSetAttribute((const void*)k_pow_padic<72, ENC_U>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL((k_pow_padic<72, ENC_U>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, base, out, n);
+    return true;
+}
+
 }  // namespace pai

@@ -236,6 +236,8 @@ struct pai_pubkey {
     uint32_t* d_one_dig = nullptr;     // digit pair of R mod n^2 (the element 1 in Montgomery digit form)
     uint32_t* d_ct_kdig = nullptr;     // [ct_nd][2][NL] digit pairs of R^(i+2) mod n^2
     int ct_nd = 0;
+    uint16_t* d_pow_ops = nullptr;     // sliding-window schedule of the exponent n (standard scheme)
+    int pow_nops = 0;
     mutable DevBuf ctmul_table;        // per-slot window tables of k_ctmul_padic
     uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
@@ -408,6 +410,33 @@ int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const
     });
 }
 
+// Sliding-window schedule (PADIC_SLIDE_BITS) of a wave-uniform exponent e, most significant bit first: each entry =
+// (#squarings | table index << 8), applied as "square nsq times, then multiply by base^(2 idx + 1)"; index 0xFF = no
+// multiplication (runs of more than 255 squarings, trailing zeros).  The first entry loads its table element.
+static std::vector<uint16_t> compile_sliding_schedule(const Limbs& e) {
+    auto bit = [&](int i) { return i >= 0 && ((e[i / 32] >> (i % 32)) & 1u); };
+    std::vector<uint16_t> ops;
+    int i = hbn::bitlen(e) - 1;
+    int pending_sq = 0;
+    bool first = true;
+    while (i >= 0) {
+        if (!bit(i)) { ++pending_sq; --i; continue; }
+        int l = std::min(PADIC_SLIDE_BITS, i + 1);
+        while (!bit(i - l + 1)) --l;                          // window must end in a 1
+        uint32_t val = 0;
+        for (int k = 0; k < l; ++k) val = (val << 1) | (bit(i - k) ? 1u : 0u);
+        const int idx = (int)(val >> 1);                      // odd value 2 idx + 1
+        int nsq = first ? 0 : pending_sq + l;
+        while (nsq > 255) { ops.push_back((uint16_t)(255 | (0xFF << 8))); nsq -= 255; }
+        ops.push_back((uint16_t)(nsq | (idx << 8)));
+        first = false;
+        pending_sq = 0;
+        i -= l;
+    }
+    while (pending_sq > 0) { int c = std::min(pending_sq, 255); ops.push_back((uint16_t)(c | (0xFF << 8))); pending_sq -= c; }
+    return ops;
+}
+
 // ---- public key -----------------------------------------------------------------------------------
 int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint32_t* h_hs, int hs_words,
                       int randbits, int device, pai_pubkey** out) {
@@ -568,6 +597,12 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             pk->djn = false;
             pk->randbits = 0;
             pk->r_words = pk->n_words;
+            if (pk->penc_nl) {        // standard-scheme obfuscator r^n on the base-n digit engine (k_pow_padic)
+                const std::vector<uint16_t> ops = compile_sliding_schedule(pk->n);
+                pk->pow_nops = (int)ops.size();
+                HIP_CHECK(hipMalloc((void**)&pk->d_pow_ops, ops.size() * 2));
+                HIP_CHECK(hipMemcpy(pk->d_pow_ops, ops.data(), ops.size() * 2, hipMemcpyHostToDevice));
+            }
         }
         *out = pk.release();
     });
@@ -587,6 +622,7 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_mscratch) (void)hipFree(pk->d_mscratch);
     if (pk->d_one_dig) (void)hipFree(pk->d_one_dig);
     if (pk->d_ct_kdig) (void)hipFree(pk->d_ct_kdig);
+    if (pk->d_pow_ops) (void)hipFree(pk->d_pow_ops);
     pk->ctmul_table.release();
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
     pk->inv_prod.release();
@@ -651,9 +687,31 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         // standard scheme: obf_i = r_i^n mod n^2 (uniform exponent), then one fused multiply
         std::lock_guard<std::mutex> lk(pk->mu);
         pk->tmp.ensure(N * (size_t)pk->ct_words * 4);
-        pk->table.ensure(g->table_words((size_t)grid) * 4);
-        g->modexp_fixed(s, grid, pk->msq.d_ctx, d_r, pk->n_words, pk->d_nexp, pk->n_words, hbn::bitlen(pk->n),
-                        pk->tmp.as<uint32_t>(), pk->ct_words, (int)N, pk->table.as<uint32_t>(), 0);
+        if (pk->penc_nl && pk->d_pow_ops) {
+            const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
+            const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+            pk->table.ensure(padic_table_words(pk->penc_nl, (size_t)pgrid) * 4);
+            PowPadicParams Q;
+            Q.nctx = pk->nmod.d_ctx;
+            Q.nm1 = pk->d_nm1;
+            Q.nsq = pk->d_nsq29;
+            Q.kdig = pk->d_ct_kdig;
+            Q.ops = pk->d_pow_ops;
+            Q.nops = pk->pow_nops;
+            Q.tbl_entries = PADIC_TBL_ENTRIES;
+            Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
+            Q.table = pk->table.as<uint4>();
+            Q.in_words = pk->n_words;
+            Q.ct_words = pk->ct_words;
+            ScopedKernelTimer t("k_pow(r^n)", s);
+            if (!launch_pow_padic(pk->penc_nl, s, pgrid, Q, d_r, pk->tmp.as<uint32_t>(), (int)N))
+                throw PaiError(PAI_E_INTERNAL, "no digit-engine power kernel for this limb count");
+            t.stop();
+        } else {
+            pk->table.ensure(g->table_words((size_t)grid) * 4);
+            g->modexp_fixed(s, grid, pk->msq.d_ctx, d_r, pk->n_words, pk->d_nexp, pk->n_words, hbn::bitlen(pk->n),
+                            pk->tmp.as<uint32_t>(), pk->ct_words, (int)N, pk->table.as<uint32_t>(), 0);
+        }
         g->encrypt(s, grid, P, d_m, pk->tmp.as<uint32_t>(), d_ct_in, d_ct_out, (int)N, from_plain ? 3 : 4);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(s));     // scratch is shared between calls
@@ -947,30 +1005,8 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
                 }
                 HIP_CHECK(hipMalloc((void**)&sk->d_kdig[w], host.size() * 4));
                 HIP_CHECK(hipMemcpy(sk->d_kdig[w], host.data(), host.size() * 4, hipMemcpyHostToDevice));
-                // sliding-window schedule of the exponent s - 1 (MSB first): each entry = (#squarings, table index of
-                // the odd window value) applied as "square nsq times, then multiply by base^(2 idx + 1)"
                 {
-                    const Limbs e = hbn::sub(s, one);
-                    auto bit = [&](int i) { return i >= 0 && ((e[i / 32] >> (i % 32)) & 1u); };
-                    std::vector<uint16_t> ops;
-                    int i = hbn::bitlen(e) - 1;
-                    int pending_sq = 0;
-                    bool first = true;
-                    while (i >= 0) {
-                        if (!bit(i)) { ++pending_sq; --i; continue; }
-                        int l = std::min(PADIC_SLIDE_BITS, i + 1);
-                        while (!bit(i - l + 1)) --l;                          // window must end in a 1
-                        uint32_t val = 0;
-                        for (int k = 0; k < l; ++k) val = (val << 1) | (bit(i - k) ? 1u : 0u);
-                        const int idx = (int)(val >> 1);                      // odd value 2 idx + 1
-                        int nsq = first ? 0 : pending_sq + l;
-                        while (nsq > 255) { ops.push_back((uint16_t)(255 | (0xFF << 8))); nsq -= 255; }
-                        ops.push_back((uint16_t)(nsq | (idx << 8)));
-                        first = false;
-                        pending_sq = 0;
-                        i -= l;
-                    }
-                    while (pending_sq > 0) { int c = std::min(pending_sq, 255); ops.push_back((uint16_t)(c | (0xFF << 8))); pending_sq -= c; }
+                    const std::vector<uint16_t> ops = compile_sliding_schedule(hbn::sub(s, one));
                     sk->nops[w] = (int)ops.size();
                     HIP_CHECK(hipMalloc((void**)&sk->d_ops[w], ops.size() * 2));
                     HIP_CHECK(hipMemcpy(sk->d_ops[w], ops.data(), ops.size() * 2, hipMemcpyHostToDevice));
