@@ -26,7 +26,8 @@ build() {  # tag, dec flags, enc flags, [1 = the flags also reach paillier_capi.
 # Results so far (k_dec_a / k_encrypt per 2^20, 2048-bit key, same box): scheduler strategy max-ilp 508 vs 487 ms;
 # trackers / metric-bias=0 within noise; modulus limbs from LDS instead of SGPRs 508 vs 488; second half of the
 # squaring unrolled 476 vs 486; product loops unrolled as well 511; sliding window 5 / 6 / 7 bits 486 / 478 / 489;
-# 12-row blocks for the 72-limb products 68.7 vs 67.4 ms (encrypt), 88.7 vs 90.0 ms (ct * pt).
+# 12-row blocks for the 72-limb products 68.7 vs 67.4 ms (encrypt), 88.7 vs 90.0 ms (ct * pt); touching the next
+# window's table lines one product ahead in k_encrypt_padic 72.1 vs 67.0 ms.
 build plain "" "" &
 build trk "-mllvm -amdgpu-use-amdgpu-trackers" "-mllvm -amdgpu-use-amdgpu-trackers" &
 wait
