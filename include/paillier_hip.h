@@ -120,6 +120,8 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
  * signed mantissas d_mant[N] with d_flag[i] = 0, or d_flag[i] = 1 when element i needs the exact big-integer
  * path (|mantissa| >= 2^63, overflow zone or corrupt residue: the host path raises the reference's errors). */
 int pai_fp_encode_f64(const pai_pubkey* pk, const double* d_x, size_t N, uint32_t* d_m, int32_t* d_expo, void* stream);
+/* the same for int64 arrays: exponent 0, residue = x mod n (fixedpoint.py:72-74,89-96) */
+int pai_fp_encode_i64(const pai_pubkey* pk, const int64_t* d_x, size_t N, uint32_t* d_m, int32_t* d_expo, void* stream);
 int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64_t* d_mant, int32_t* d_flag, void* stream);
 
 /* Obfuscator randomness for DJN keys, replacing upstream ipcl's per-element getRandomBN inside

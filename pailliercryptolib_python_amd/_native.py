@@ -58,6 +58,7 @@ PROTOTYPES = {
     "pai_ct_invert": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_pow2": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp]),
     "pai_fp_encode_f64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
+    "pai_fp_encode_i64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_fp_decode_i64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_draw_r": (C.c_int, [voidp, voidp, voidp, C.c_uint32, C.c_size_t, voidp, voidp]),
     "pai_modulus_create": (C.c_int, [voidp, C.c_int, C.c_int, C.POINTER(voidp)]),

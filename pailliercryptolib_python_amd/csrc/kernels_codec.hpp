@@ -1,5 +1,6 @@
 // Data-format kernels either side of the Paillier hot path (HBM-bound, one row per lane):
 //   k_fp_encode_f64   float64 -> (residue mod n as packed words, base-2 exponent)     fixedpoint.py:54-96
+//   k_fp_encode_i64   int64 -> residue mod n, exponent 0                                  fixedpoint.py:72-74,89-96
 //   k_fp_decode_i64   residue mod n -> signed 64-bit mantissa (+ "needs the exact host path" flag)  fixedpoint.py:98-115
 //   k_draw_r          obfuscator randomness r < 2^randbits for DJN keys: ChaCha20 key stream (RFC 8439 block
 //                     function, 256-bit key drawn from the OS CSPRNG by the caller), one 64-byte block per lane
@@ -33,6 +34,38 @@ k_fp_encode_f64(const double* __restrict__ x, const uint32_t* __restrict__ n_wor
         for (int k = 2; k < nw; ++k) row[k] = 0;
     } else {
         // n - mant, mant < 2^53: 64-bit subtract, then a single borrow ripples through the upper words
+        const uint64_t n_lo = (uint64_t)n_words_ptr[0] | ((uint64_t)n_words_ptr[1] << 32);
+        const uint64_t lo = n_lo - mant;
+        uint32_t borrow = mant > n_lo ? 1u : 0u;
+        row[0] = (uint32_t)lo;
+        row[1] = (uint32_t)(lo >> 32);
+        for (int k = 2; k < nw; ++k) {
+            const uint32_t w = n_words_ptr[k];
+            row[k] = w - borrow;
+            borrow = (borrow && w == 0) ? 1u : 0u;
+        }
+    }
+}
+
+// Encoding of an integer (fixedpoint.py:72-74,89-96): exponent 0, residue = x mod n.
+__global__ void __launch_bounds__(256)
+k_fp_encode_i64(const int64_t* __restrict__ x, const uint32_t* __restrict__ n_words_ptr, int nw, uint32_t* __restrict__ out,
+                int32_t* __restrict__ expo, size_t N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int64_t v = x[i];
+    // the reference's tiny-value test `np.abs(scalar) < 1e-200` (fixedpoint.py:64) wraps for -2^63 (int64 abs overflow:
+    // the "absolute value" is negative), so that one value encodes as 0 there — reproduced for parity
+    if (v == INT64_MIN) v = 0;
+    const bool neg = v < 0;
+    const uint64_t mant = neg ? (0ull - (uint64_t)v) : (uint64_t)v;
+    expo[i] = 0;
+    uint32_t* row = out + i * (size_t)nw;
+    if (!neg) {
+        row[0] = (uint32_t)mant;
+        row[1] = (uint32_t)(mant >> 32);
+        for (int k = 2; k < nw; ++k) row[k] = 0;
+    } else {
         const uint64_t n_lo = (uint64_t)n_words_ptr[0] | ((uint64_t)n_words_ptr[1] << 32);
         const uint64_t lo = n_lo - mant;
         uint32_t borrow = mant > n_lo ? 1u : 0u;

@@ -732,6 +732,18 @@ int pai_fp_encode_f64(const pai_pubkey* pk, const double* d_x, size_t N, uint32_
     });
 }
 
+int pai_fp_encode_i64(const pai_pubkey* pk, const int64_t* d_x, size_t N, uint32_t* d_m, int32_t* d_expo, void* stream) {
+    return guarded([&] {
+        require(pk && d_x && d_m && d_expo, "NULL argument");
+        require(hbn::bitlen(pk->n) > 66, "device encode needs a modulus of more than 66 bits");
+        if (N == 0) return;
+        use_device(pk->device);
+        hipLaunchKernelGGL(k_fp_encode_i64, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, pk->d_nexp,
+                           pk->n_words, d_m, d_expo, N);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64_t* d_mant, int32_t* d_flag, void* stream) {
     return guarded([&] {
         require(pk && d_m && d_mant && d_flag, "NULL argument");

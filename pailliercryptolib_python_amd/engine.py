@@ -181,6 +181,15 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_fp_encode_f64(self.h, _ptr(x), x.shape[0], _ptr(m), _ptr(expo), _stream(self.device)))
         return m, expo
 
+    def fp_encode_i64(self, x: torch.Tensor):
+        """int64[N] on the device -> (residues, exponents = 0); fixedpoint.py:72-74,89-96."""
+        if x.dtype != torch.int64 or x.dim() != 1 or not x.is_contiguous() or x.device != self.device:
+            raise ValueError("x: expected contiguous int64 [N] on %s" % self.device)
+        m = self.empty_pt(x.shape[0])
+        expo = torch.empty((x.shape[0],), dtype=torch.int32, device=self.device)
+        _native.check(self.lib.pai_fp_encode_i64(self.h, _ptr(x), x.shape[0], _ptr(m), _ptr(expo), _stream(self.device)))
+        return m, expo
+
     def fp_decode_i64(self, m: torch.Tensor):
         """residues -> (mantissas int64[N], flags int32[N]); flag 1 = element needs the exact host path."""
         self._chk(m, self.n_words, "m")

@@ -112,6 +112,11 @@ class PaillierPublicKey:
             x = _fp.checked_float64(values)
             m, expo_d = h.fp_encode_f64(torch.from_numpy(x).to(h.device))
             expos = expo_d.cpu().numpy()
+        elif (isinstance(values, np.ndarray) and values.dtype in (np.int16, np.int32, np.int64) and values.ndim == 1
+              and values.shape[0] > 0 and self.n.bit_length() > 66):
+            # the integer dtypes the reference's codec accepts (fixedpoint.py:72): exponent 0, residue = x mod n
+            m, expo_d = h.fp_encode_i64(torch.from_numpy(np.ascontiguousarray(values, dtype=np.int64)).to(h.device))
+            expos = np.zeros(values.shape[0], dtype=np.int32)
         else:
             residues, expos = _fp.encode_array(values, self.n, self.max_int, h.n_words)
             m = engine.to_device_words(residues, h.device)

@@ -56,7 +56,7 @@ scalars = [
     2.0**52, 2.0**53, 2.0**53 + 2, 2.0**60, -(2.0**70), 1e300, -1e300, sys.float_info.max, float("inf"), float("-inf"),
     float("nan"), 3.141592653589793, 1 / 3, -1 / 3, 1e-5, 123456789.125,
     0, 1, -1, 2, 255, 256, 2**32 - 1, 2**32, -(2**32), 2**63, 10**30, -(10**30), MAX_INT, -MAX_INT, MAX_INT + 1,
-    1 << 2046, True, False,
+    1 << 2046, True, False, -(2**63), -(2**63) + 1, -(2**63) - 1, np.int64(-(2**63)),
     np.float64(2.5), np.float64(-1e-3), np.float32(1.5), np.int64(-77), np.int32(12345), np.int16(-3), np.int8(5),
     np.uint8(5),
 ]

@@ -40,6 +40,22 @@ def test_device_encode_matches_the_reference_codec(nk):
     assert de.get().tolist() == [w[1] for w in want]
 
 
+def test_device_integer_encode_matches_the_reference_codec(nk):
+    key = nk.key
+    rng = np.random.default_rng(13)
+    x = np.concatenate([np.array([0, 1, -1, 2**63 - 1, -(2**63), 2**53, -(2**53) - 1, 12345, -987654321], dtype=np.int64),
+                        rng.integers(-(2**63), 2**63 - 1, 3000, dtype=np.int64), rng.integers(-1000, 1000, 500, dtype=np.int64)])
+    N = x.shape[0]
+    dx = DevArray(x)
+    dm = DevArray(shape=(N, nk.nw))
+    de = DevArray(shape=(N,), dtype=np.int32)
+    _native.check(nk.lib.pai_fp_encode_i64(nk.pk, dx.ptr, N, dm.ptr, de.ptr, None))
+    want = [orc.fp_encode(int(v), key.n, key.n // 3 - 1) for v in x]
+    assert limbs_to_ints(dm.get()) == [w[0] for w in want]
+    assert de.get().tolist() == [w[1] for w in want] == [0] * N
+    assert want[4][0] == 0          # -2^63 encodes as 0 in the reference (np.abs overflow in its tiny-value test)
+
+
 def test_device_decode_flags_and_mantissas(nk):
     key = nk.key
     n, max_int = key.n, key.n // 3 - 1
@@ -103,6 +119,11 @@ def test_api_float_arrays_use_the_device_codec_and_keep_reference_semantics():
         pk.encrypt(np.array([1.0, math.nan]))
     with pytest.raises(OverflowError):
         pk.encrypt(np.array([math.inf]))
+    # integer arrays of the dtypes the reference accepts: device encode, Python ints back
+    xi = np.array([0, 7, -7, 2**40, -(2**62)], dtype=np.int64)
+    got_i = sk.decrypt(pk.encrypt(xi))
+    assert got_i == xi.tolist() and all(type(g) is int for g in got_i)
+    assert sk.decrypt(pk.encrypt(np.array([3, -4], dtype=np.int32))) == [3, -4]
     # big integers still decode exactly through the host path (device decoder flags them)
     big = [2**70 + 3, -(2**90) - 1, 5]
     assert sk.decrypt(pk.encrypt(big)) == big
