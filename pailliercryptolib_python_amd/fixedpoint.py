@@ -113,6 +113,18 @@ def decode_mantissas(mant: np.ndarray, exponents) -> List:
     return out
 
 
+def float64_mantissas(x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(signed 53-bit mantissas int64[N], exponents int32[N]) of finite doubles: the integer the reference's
+    ``int(round(scalar * 2**exponent))`` yields (fixedpoint.py:75-89), before the reduction modulo n."""
+    tiny = np.abs(x) < 1e-200
+    man, ex = np.frexp(x)
+    expo = (_MANT - ex).astype(np.int32)
+    mant = np.ldexp(man, _MANT).astype(np.int64)          # exact: |mant| < 2^53
+    expo[tiny] = 0
+    mant[tiny] = 0
+    return mant, expo
+
+
 def encode_float64_array(x: np.ndarray, n: int, n_words: int) -> Tuple[np.ndarray, np.ndarray]:
     """float64[N] -> (residues uint32[N][n_words], exponents int32[N]); requires n > 2^66."""
     x = np.ascontiguousarray(x, dtype=np.float64)

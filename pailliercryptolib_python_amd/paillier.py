@@ -341,6 +341,27 @@ class PaillierEncryptedNumber:
         e = engine.to_device_words(engine.ints_to_words(mags, ew), h.device)
         return h.ct_mul(base, e, bits)
 
+    def _pow_small(self, ct: torch.Tensor, mant: np.ndarray) -> torch.Tensor:
+        """The same for a batch of signed 64-bit multipliers (float mantissas): no per-element Python objects."""
+        h = self._h()
+        neg = mant < 0
+        if neg.any():
+            if neg.all():
+                base = h.ct_invert(ct)
+            else:
+                idx = torch.from_numpy(np.nonzero(neg)[0]).to(h.device)
+                base = ct.clone()
+                base[idx] = h.ct_invert(ct[idx].contiguous())
+        else:
+            base = ct
+        mag = np.abs(mant).astype(np.uint64)
+        bits = max(1, int(mag.max()).bit_length())
+        e = np.empty((mant.shape[0], 2), dtype=np.uint32)
+        e[:, 0] = (mag & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        e[:, 1] = (mag >> np.uint64(32)).astype(np.uint32)
+        ew = (bits + 31) // 32
+        return h.ct_mul(base, engine.to_device_words(np.ascontiguousarray(e[:, :ew]), h.device), bits)
+
     def __mul__(self, other):
         """ipcl_python.py:412-488."""
         n, max_int = self.public_key.n, self.public_key.max_int
@@ -355,6 +376,9 @@ class PaillierEncryptedNumber:
         if len(other) != self.__length:
             raise ValueError("PaillierEncryptedNumber.__mul__: Multiply size mismatch")
         h = self._h()
+        if _fp.is_float_batch(other) and n.bit_length() > 66:
+            mant, pexpo = _fp.float64_mantissas(_fp.checked_float64(other))
+            return self._wrap(self._pow_small(self.words, mant), self._expo + pexpo, self.__length)
         residues, pexpo = _fp.encode_array(other, n, max_int, h.n_words)
         pts = engine.words_to_ints(residues)
         neg = np.array([p >= n - max_int for p in pts])
