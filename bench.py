@@ -208,6 +208,33 @@ def main() -> None:
                       + f", OpenMP over {threads} host threads, {t_cpu:.1f} s",
         }
 
+    # ---- the other operations of BASELINE configs[2] (ct+ct add, ct x pt mul), kernel-resident, rank 0, N = 1 ----
+    other = None
+    if rank == 0 and world == 1:
+        def wall(f, reps=2):
+            f()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                f()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / reps
+
+        ct2 = pub.empty_ct(B)
+        e53 = torch.randint(0, 1 << 30, (B, 2), dtype=torch.int32, device=device)     # 53-bit multipliers (float mantissas)
+        e53[:, 1] &= (1 << 21) - 1
+        e53[:, 1] |= 1 << 20
+        t_add = wall(lambda: pub.ct_add(ct, ct, out=ct2))
+        t_mul = wall(lambda: pub.ct_mul(ct, e53, 53, out=ct2))
+        t_inv = wall(lambda: pub.ct_invert(ct, out=ct2))
+        chk = [0, B - 1]
+        c_h = engine.words_to_ints(engine.to_host_words(ct[chk]))
+        i_h = engine.words_to_ints(engine.to_host_words(ct2[chk]))
+        if any((a * b) % key.nsq != 1 for a, b in zip(c_h, i_h)):
+            raise SystemExit("bench.py: ct_invert parity check failed")
+        other = {"ct_add_ops_per_s": B / t_add, "ct_mul_53bit_ops_per_s": B / t_mul, "ct_invert_ops_per_s": B / t_inv,
+                 "batch": B, "note": "BASELINE configs[2] operations on the same resident batch (wall clock around the C-ABI call)"}
+
     if rank == 0:
         total_ops = float(B) * world * args.steps
         value = total_ops / elapsed
@@ -260,6 +287,7 @@ def main() -> None:
                 "encrypt_canonical_T_MAC32_s": (CANON_MAC_ENC * B / t_enc / 1e12) if t_enc > 0 else None,
             },
             "cpu_baseline": cpu,
+            "other_ops": other,
             "parity_checked": True,
         }
         print(json.dumps(line), flush=True)
