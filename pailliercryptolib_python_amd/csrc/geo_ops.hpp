@@ -76,7 +76,7 @@ size_t ctmul_padic_table_words(int nl, int wbits, size_t blocks);
 bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e,
                         uint32_t* out, int n);
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
-                          uint32_t* ct_out, int n, int mode);
+                          const uint32_t* ct_in, uint32_t* ct_out, int n, int mode);
 
 // x = a^-1 mod M for `count` values of `words` 32-bit words each (words in {64,128,192,256}); *fail counts
 // non-invertible inputs.  Returns false if `words` has no instantiation.

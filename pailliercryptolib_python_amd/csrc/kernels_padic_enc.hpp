@@ -3,7 +3,7 @@
 //   k_fb_table_padic   per-key fixed-base table T[j][d] = digits( hs^(d 2^(8 j)) R mod n^2 )
 //   k_encrypt_padic    mode 0: ct = 1 + m n                (raw_encrypt: the plain digit pair (1, m) itself)
 //                      mode 1: ct = (1 + m n) hs^r          (DJN encrypt: prod_j T[j][r_j], then * (1, m))
-//                      (apply_obfuscator on existing ciphertexts stays on the lane-group kernel k_encrypt)
+//                      mode 2: ct <- ct hs^r               (apply_obfuscator: the ciphertext enters digit form as in stage A)
 //   k_pow_padic        base^E mod n^2 for a wave-uniform E (standard-scheme obfuscator r^n), sliding windows
 //   k_ctmul_padic      ct^e mod n^2 with per-element (or broadcast) exponents: ciphertext * plaintext
 //                      (CipherText::operator*, classes.cpp:324-325), fixed windows over a per-slot table
@@ -21,6 +21,8 @@ struct EncPadicParams {
     const uint32_t* nsq;         // n^2 limbs (2 NL, radix 29)
     const uint4* fb_table;       // [J][2^fb_wbits][2][NC] uint4
     uint4* mscratch;             // [2 NC][nslots]: quotient digits, then the parked first result digit
+    const uint32_t* kdig;        // mode 2: [nd][2][NL] digit pairs of R^(i+2) mod n^2
+    int nd;
     int fb_windows, fb_wbits;
     int pt_words, ct_words, r_words;
 };
@@ -238,6 +240,8 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
         } else {
             // x = prod_j T[j][r_j]  (Montgomery digit form of hs^r)
             const uint32_t* rrow = r + (size_t)es * P.r_words;
+            // mode 2 (apply_obfuscator): start from the existing ciphertext in digit form instead of the first entry
+            if (mode == 2) padic_to_digit_form<E>(A, B, M, ct_in + (size_t)es * P.ct_words, P.ct_words, P.kdig, P.nd, nm, nm1, n0inv);
 #pragma unroll 1
             for (int jw = 0; jw < P.fb_windows; ++jw) {
                 const int bit = jw * P.fb_wbits, k = bit >> 5;
@@ -245,7 +249,7 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
                 if (k + 1 < P.r_words) bits2 |= (uint64_t)rrow[k + 1] << 32;
                 const uint32_t d = (uint32_t)(bits2 >> (bit & 31)) & ((1u << P.fb_wbits) - 1u);
                 const uint4* ent = P.fb_table + (((size_t)jw << P.fb_wbits) + d) * 2 * E::NC;
-                if (jw == 0) {
+                if (jw == 0 && mode != 2) {
                     wave_lds_fence();
 #pragma unroll 1
                     for (int c = 0; c < E::NC; ++c) { E::st(A, c, ent[c]); E::st(B, c, ent[E::NC + c]); }
@@ -265,10 +269,11 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
             }
             // times the plain digit pair (1, m) of 1 + m n  => plain digit pair of the ciphertext
             {
-                const uint32_t* mrow = m + (size_t)es * P.pt_words;
+                // mode 2 leaves Montgomery form with the plain pair (1, 0)
+                const uint32_t* mrow = mode == 2 ? nullptr : m + (size_t)es * P.pt_words;
                 auto mdig = [&](int blk, uint32_t (&xv)[U]) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) xv[u] = row_limb(mrow, P.pt_words, U * blk + u);
+                    for (int u = 0; u < U; ++u) xv[u] = mrow ? row_limb(mrow, P.pt_words, U * blk + u) : 0u;
                 };
                 E::mm1_mul(w, M, A, one, nm, n0inv);
                 E::mm2_mul(v, M, A, B, mdig, one, nm, nm1, n0inv);

@@ -31,11 +31,11 @@ bool launch_fb_expand_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx
     return true;
 }
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
-                          uint32_t* ct_out, int n, int mode) {
+                          const uint32_t* ct_in, uint32_t* ct_out, int n, int mode) {
     if (nl != 72) return false;
     constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
     (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, ENC_U>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_encrypt_padic<72, ENC_U>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, nullptr, ct_out, n, mode);
+    hipLaunchKernelGGL((k_encrypt_padic<72, ENC_U>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, ct_in, ct_out, n, mode);
     return true;
 }
 

@@ -655,7 +655,7 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
     const int grid = grid_for(g, N, pk->dev.ncu);
     EncParams P = pk->enc_params();
     g_last_times.clear();
-    if (pk->penc_nl && from_plain && (d_r == nullptr || pk->djn)) {
+    if (pk->penc_nl && ((from_plain && (d_r == nullptr || pk->djn)) || (!from_plain && d_r && pk->djn))) {
         // raw / DJN encryption on the base-n digit engine: one workgroup per CU
         EncPadicParams Q;
         Q.nctx = pk->nmod.d_ctx;
@@ -663,6 +663,8 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         Q.nsq = pk->d_nsq29;
         Q.fb_table = reinterpret_cast<const uint4*>(pk->d_fb_dig);
         Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
+        Q.kdig = pk->d_ct_kdig;
+        Q.nd = pk->ct_nd;
         Q.fb_windows = pk->fbd_windows;
         Q.fb_wbits = pk->fbd_wbits;
         Q.pt_words = pk->n_words;
@@ -670,8 +672,8 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         Q.r_words = pk->r_words;
         const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
         const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
-        ScopedKernelTimer t(d_r ? "k_encrypt(djn)" : "k_encrypt(raw)", s);
-        if (!launch_encrypt_padic(pk->penc_nl, s, pgrid, Q, d_m, d_r, d_ct_out, (int)N, d_r ? 1 : 0))
+        ScopedKernelTimer t(!from_plain ? "k_encrypt(obfuscate)" : (d_r ? "k_encrypt(djn)" : "k_encrypt(raw)"), s);
+        if (!launch_encrypt_padic(pk->penc_nl, s, pgrid, Q, d_m, d_r, d_ct_in, d_ct_out, (int)N, !from_plain ? 2 : (d_r ? 1 : 0)))
             throw PaiError(PAI_E_INTERNAL, "no digit-engine encrypt kernel for this limb count");
         t.stop();
     } else if (d_r == nullptr) {
