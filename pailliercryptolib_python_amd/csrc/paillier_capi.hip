@@ -500,10 +500,9 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         }
         if (h_hs) {
             require(hs_words > 0 && randbits > 0, "DJN key needs hs and randbits");
-            // Fixed-base window width of the lane-group table.  When the digit engine encrypts (its own, wider table
-            // below) this one only serves apply_obfuscator: the widest width <= 12 bits within 256 MiB (2048-bit keys:
-            // 86 windows x 4096 entries x 576 B = 203 MB).  Otherwise (3072/4096-bit keys) it IS the encryption table:
-            // up to 14 bits within 1/64 of device memory (4096-bit keys: 2.8 GB; k_encrypt 84 -> 61 ms per 65536).
+            // Fixed-base window width of the lane-group table (built only when the digit engine does not serve this key
+            // size, i.e. 1024/3072/4096-bit keys): up to 14 bits within 1/64 of device memory (4096-bit keys: 2.8 GB;
+            // k_encrypt 84 -> 61 ms per 65536).
             size_t mem_free0 = 0, mem_total0 = 0;
             HIP_CHECK(hipMemGetInfo(&mem_free0, &mem_total0));
             const double lg_budget = pk->penc_nl ? 256.0 * 1048576.0 : std::max(256.0 * 1048576.0, (double)mem_total0 / 64.0);
@@ -519,7 +518,9 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             const int J = (randbits + wb - 1) / wb;
             const size_t ENT = (size_t)1 << wb;
             pk->fb_windows = J;
-            // window bases B_j = hs^(2^(8 j)) on the host, then T[j][d] = B_j^d on the device
+            // window bases B_j = hs^(2^(8 j)) on the host, then T[j][d] = B_j^d on the device — only when the lane-group
+            // kernel is the one that encrypts (the digit engine has its own table below)
+            if (!pk->penc_nl) {
             hbn::Mont32 mt(pk->nsq);
             std::vector<uint32_t> bases((size_t)J * pk->ct_words, 0);
             Limbs b = mt.to_mont(pk->hs);
@@ -544,6 +545,7 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             HIP_CHECK(hipDeviceSynchronize());
             HIP_CHECK(hipFree(d_bases));
             HIP_CHECK(hipFree(d_expo));
+            }
             // digit-form fixed-base table for the base-n digit engine
             if (pk->penc_nl) {
                 const int pnl = pk->penc_nl;
