@@ -505,7 +505,8 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             // k_encrypt 84 -> 61 ms per 65536).
             size_t mem_free0 = 0, mem_total0 = 0;
             HIP_CHECK(hipMemGetInfo(&mem_free0, &mem_total0));
-            const double lg_budget = pk->penc_nl ? 256.0 * 1048576.0 : std::max(256.0 * 1048576.0, (double)mem_total0 / 64.0);
+            const double lg_budget = pk->penc_nl ? 256.0 * 1048576.0
+                                                 : std::max(256.0 * 1048576.0, std::min((double)mem_total0 / 64.0, (double)mem_free0 / 8.0));
             int wb = pk->penc_nl ? 12 : 14;
             while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > lg_budget) --wb;
             if (const char* env = std::getenv("PAI_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 14) wb = v; }
@@ -561,7 +562,7 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
                 auto table_bytes = [&](int w) { return (double)((randbits + w - 1) / w) * (double)((size_t)1 << w) * (double)ent_bytes; };
                 size_t mem_free = 0, mem_total = 0;
                 HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
-                double budget = (double)mem_total / 32.0;
+                double budget = std::min((double)mem_total / 32.0, (double)mem_free / 4.0);   // never more than a quarter of what is free
                 if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) budget = v * 1048576.0; }
                 int dwb = wb;
                 for (int cand = 20; cand > 12; cand -= 2)
