@@ -45,6 +45,12 @@ struct GeoInst {
         set_lds((const void*)k_dec_b<G>, bytes);
         hipLaunchKernelGGL(k_dec_b<G>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, u_in, m_out, n);
     }
+    static void modexp_var_win(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32, const uint32_t* expo,
+                               int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits) {
+        set_lds((const void*)k_modexp_var_win<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_modexp_var_win<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, base, base_w32, expo, ew,
+                           ebits_max, exp_bcast, out, out_w32, n, table, wbits);
+    }
     static void pow2(hipStream_t s, int grid, const MontCtx* c, uint32_t* ct, const int32_t* delta, int delta_bcast,
                      int n, int w32) {
         set_lds((const void*)k_pow2<G>, G::LDS_BYTES);
@@ -54,7 +60,7 @@ struct GeoInst {
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &encrypt, &dec_a, &dec_b, &pow2, &table_words};
+                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &dec_a, &dec_b, &pow2, &table_words};
         return &o;
     }
 };

@@ -22,6 +22,9 @@ struct GeoOps {
     void (*modexp_var)(hipStream_t, int grid, const MontCtx*, const uint32_t* base, int base_w32, int base_shift,
                        const uint32_t* expo, int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32,
                        int n, int keep_mont, int out_raw);
+    // windowed variant: table scratch of var_table_words(blocks, wbits) words
+    void (*modexp_var_win)(hipStream_t, int grid, const MontCtx*, const uint32_t* base, int base_w32, const uint32_t* expo,
+                           int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits);
     void (*encrypt)(hipStream_t, int grid, EncParams, const uint32_t* m, const uint32_t* r, const uint32_t* ct_in,
                     uint32_t* ct_out, int n, int mode);
     void (*dec_a)(hipStream_t, int gridx, DecAParams, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table);

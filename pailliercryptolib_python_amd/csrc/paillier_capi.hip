@@ -397,6 +397,9 @@ int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e
         HIP_CHECK(hipStreamSynchronize(s));     // the staged exponent / table are reused by the next call
     });
 }
+// window width of the per-element-exponent kernels: table build 2^w - 2 products, then w squarings + 1 product per window
+static int var_window_bits(int ebits_max) { return ebits_max <= 24 ? 2 : (ebits_max <= 80 ? 3 : (ebits_max <= 240 ? 4 : 5)); }
+
 int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const uint32_t* d_e, int e_words,
                    int ebits_max, int e_bcast, size_t N, uint32_t* d_out, void* stream) {
     return guarded([&] {
@@ -404,7 +407,19 @@ int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const
         if (N == 0) return;
         use_device(m->device);
         const GeoOps* g = m->ms.geo;
-        g->modexp_var((hipStream_t)stream, grid_for(g, N, m->dev.ncu), m->ms.d_ctx, d_base, m->ms.w32, base_bcast ? 31 : 0,
+        const int grid = grid_for(g, N, m->dev.ncu);
+        if (!base_bcast && ebits_max > 8) {
+            // fixed windows sized to the exponent width over a per-slot table (kernels_modexp.hpp: k_modexp_var_win)
+            std::lock_guard<std::mutex> lk(m->mu);
+            const int wbits = var_window_bits(ebits_max);
+            m->table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
+            g->modexp_var_win((hipStream_t)stream, grid, m->ms.d_ctx, d_base, m->ms.w32, d_e, e_words, ebits_max, e_bcast, d_out,
+                              m->ms.w32, (int)N, m->table.as<uint32_t>(), wbits);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));     // the table is reused by the next call
+            return;
+        }
+        g->modexp_var((hipStream_t)stream, grid, m->ms.d_ctx, d_base, m->ms.w32, base_bcast ? 31 : 0,
                       d_e, e_words, ebits_max, e_bcast, d_out, m->ms.w32, (int)N, 0, 0);
         HIP_CHECK(hipGetLastError());
     });
@@ -829,7 +844,7 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
             // base-n digit engine: fixed windows sized to the exponent width (table build 2^w - 2 products, then
             // w squarings + 1 product per window)
             std::lock_guard<std::mutex> lk(pk->mu);
-            const int wbits = ebits_max <= 24 ? 2 : (ebits_max <= 80 ? 3 : (ebits_max <= 240 ? 4 : 5));
+            const int wbits = var_window_bits(ebits_max);
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
             const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
             pk->ctmul_table.ensure(ctmul_padic_table_words(pk->penc_nl, wbits, (size_t)grid) * 4);
@@ -855,7 +870,19 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
             return;
         }
         const GeoOps* g = pk->msq.geo;
-        g->modexp_var((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, pk->ct_words, 0, d_e, e_words,
+        const int grid = grid_for(g, N, pk->dev.ncu);
+        if (ebits_max > 8) {
+            std::lock_guard<std::mutex> lk(pk->mu);
+            const int wbits = var_window_bits(ebits_max);
+            pk->ctmul_table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
+            ScopedKernelTimer t("k_ctmul", (hipStream_t)stream);
+            g->modexp_var_win((hipStream_t)stream, grid, pk->msq.d_ctx, d_ct, pk->ct_words, d_e, e_words, ebits_max, e_bcast, d_out,
+                              pk->ct_words, (int)N, pk->ctmul_table.as<uint32_t>(), wbits);
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+        g->modexp_var((hipStream_t)stream, grid, pk->msq.d_ctx, d_ct, pk->ct_words, 0, d_e, e_words,
                       ebits_max, e_bcast, d_out, pk->ct_words, (int)N, 0, 0);
         HIP_CHECK(hipGetLastError());
     });
