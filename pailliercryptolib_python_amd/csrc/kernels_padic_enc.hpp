@@ -194,7 +194,9 @@ PAI_DEV uint32_t lds_limb(const uint4* A, const uint4* B, int J) {
     return p[jj & 3];
 }
 
-template <int NL, int U>
+// OBF = true is the apply_obfuscator instantiation (mode 2 only): kept out of the encryption kernel, whose register
+// allocation suffers from the extra digit-form conversion (k_encrypt 67 -> 78 ms per 2^20 when both shared one kernel)
+template <int NL, int U, bool OBF>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
                 const uint32_t* __restrict__ ct_in, uint32_t* __restrict__ ct_out, int n, int mode) {
@@ -241,7 +243,7 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
             // x = prod_j T[j][r_j]  (Montgomery digit form of hs^r)
             const uint32_t* rrow = r + (size_t)es * P.r_words;
             // mode 2 (apply_obfuscator): start from the existing ciphertext in digit form instead of the first entry
-            if (mode == 2) padic_to_digit_form<E>(A, B, M, ct_in + (size_t)es * P.ct_words, P.ct_words, P.kdig, P.nd, nm, nm1, n0inv);
+            if constexpr (OBF) padic_to_digit_form<E>(A, B, M, ct_in + (size_t)es * P.ct_words, P.ct_words, P.kdig, P.nd, nm, nm1, n0inv);
 #pragma unroll 1
             for (int jw = 0; jw < P.fb_windows; ++jw) {
                 const int bit = jw * P.fb_wbits, k = bit >> 5;
@@ -249,7 +251,7 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
                 if (k + 1 < P.r_words) bits2 |= (uint64_t)rrow[k + 1] << 32;
                 const uint32_t d = (uint32_t)(bits2 >> (bit & 31)) & ((1u << P.fb_wbits) - 1u);
                 const uint4* ent = P.fb_table + (((size_t)jw << P.fb_wbits) + d) * 2 * E::NC;
-                if (jw == 0 && mode != 2) {
+                if (jw == 0 && !OBF) {
                     wave_lds_fence();
 #pragma unroll 1
                     for (int c = 0; c < E::NC; ++c) { E::st(A, c, ent[c]); E::st(B, c, ent[E::NC + c]); }
@@ -270,10 +272,10 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
             // times the plain digit pair (1, m) of 1 + m n  => plain digit pair of the ciphertext
             {
                 // mode 2 leaves Montgomery form with the plain pair (1, 0)
-                const uint32_t* mrow = mode == 2 ? nullptr : m + (size_t)es * P.pt_words;
+                const uint32_t* mrow = OBF ? nullptr : m + (size_t)es * P.pt_words;
                 auto mdig = [&](int blk, uint32_t (&xv)[U]) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) xv[u] = mrow ? row_limb(mrow, P.pt_words, U * blk + u) : 0u;
+                    for (int u = 0; u < U; ++u) xv[u] = OBF ? 0u : row_limb(mrow, P.pt_words, U * blk + u);
                 };
                 E::mm1_mul(w, M, A, one, nm, n0inv);
                 E::mm2_mul(v, M, A, B, mdig, one, nm, nm1, n0inv);

@@ -34,8 +34,13 @@ bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams&
                           const uint32_t* ct_in, uint32_t* ct_out, int n, int mode) {
     if (nl != 72) return false;
     constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
-    (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, ENC_U>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_encrypt_padic<72, ENC_U>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, ct_in, ct_out, n, mode);
+    if (mode == 2) {
+        (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, ENC_U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        hipLaunchKernelGGL((k_encrypt_padic<72, ENC_U, true>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, ct_in, ct_out, n, mode);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, ENC_U, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        hipLaunchKernelGGL((k_encrypt_padic<72, ENC_U, false>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, ct_in, ct_out, n, mode);
+    }
     return true;
 }
 
