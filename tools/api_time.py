@@ -35,6 +35,7 @@ def main():
     _, out["  draw_r_s"] = t(pk.pubkey._draw_r, N)
     s, out["add_s"] = t(lambda: ct + ct)
     m, out["mul_scalar_s"] = t(lambda: ct * 3.5)
+    y, out["decrypt_to_numpy_first_s"] = t(sk.decrypt_to_numpy, ct)       # first call: grows the key's device scratch
     y, out["decrypt_to_numpy_s"] = t(sk.decrypt_to_numpy, ct)
     out["roundtrip_ok"] = bool(np.array_equal(y, x))
     if N <= (1 << 18):
