@@ -274,10 +274,10 @@ def main() -> None:
                 "executed_frac": (executed / PEAK_MAC32_PER_S) if executed else None,
                 "kernel_ms": kern,
                 # HBM bytes per launch of the dominant kernel at batch = 2^20 from the PMC passes committed in
-                # profiles/r01/pmc_bench_r01c.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE halving applied).
+                # profiles/r01/pmc_bench_r01d.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE halving applied).
                 # It is ~200x the algorithmic bytes because every resident element keeps its 33-entry window table in
                 # HBM scratch (19 GB written, 88 GB read per launch = 0.2 TB/s, 3 % of the HBM roof): compute bound.
-                "traffic": (2 * 43544208.0 + 19988539.5625) * 1024 * (B / float(1 << 20)),
+                "traffic": (2 * 43612792.0625 + 19988491.90625) * 1024 * (B / float(1 << 20)),
                 "traffic_unit": "bytes per k_dec_a_padic launch (PMC, scaled linearly from batch 2^20)",
                 "hbm": {
                     "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
