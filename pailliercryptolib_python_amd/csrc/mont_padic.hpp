@@ -9,8 +9,8 @@
 // then  w + v p == (a + b p)(c + d p) R^-1 (mod p^2), i.e. (w, v) ~ x y.   Proof: a c = R w - m p and
 // R v = a d + b c - m + (R + m') p, hence (a + b p)(c + d p) == a c + (a d + b c) p == R w + R v p.
 // The b d p^2 term vanishes and every reduction is modulo p (NL limbs) instead of p^2 (2 NL limbs):
-// a multiplication costs 5 NL^2 limb products instead of 8 NL^2, a squaring (a^2 symmetric by limb
-// classes, 2 a b once) ~3.7 NL^2 instead of ~6.7 NL^2.  There is no division anywhere: the input is
+// a multiplication costs 5 NL^2 limb products instead of 8 NL^2, a squaring (every limb pair of a^2
+// once, 2 a b once) 3.5 NL^2 instead of ~6.7 NL^2.  There is no division anywhere: the input is
 // brought into digit form by applying the rule to its base-R digits and host-precomputed digit
 // pairs of R^(i+2) mod p^2, and at the end the second digit of x^(p-1) IS Paillier's L function.
 //
