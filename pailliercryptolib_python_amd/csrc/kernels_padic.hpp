@@ -84,7 +84,8 @@ PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const u
 //                   strided global scratch (wider primes: 2 x 56 / 2 x 72 KB per workgroup).
 // Both run one wave per SIMD (a two-waves-per-SIMD variant was measured and dropped: DESIGN.md section 2).
 #ifndef PADIC_SGPR_MODULUS
-#define PADIC_SGPR_MODULUS(NL) ((NL) <= 36)
+// measured per 65 536 decryptions: 36 limbs 488 vs 508 ms (x16), 56 limbs 174 vs 166 ms (LDS wins), 72 limbs 364 vs 391 ms
+#define PADIC_SGPR_MODULUS(NL) ((NL) <= 36 || (NL) >= 72)
 #endif
 constexpr int PADIC_LDS_M = 0, PADIC_WBUF = 2;
 template <int NL, int U, int WB, int MODE>
