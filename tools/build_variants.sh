@@ -30,7 +30,8 @@ build() {  # tag, dec flags, enc flags, [1 = the flags also reach paillier_capi.
 # window's table lines one product ahead in k_encrypt_padic 72.1 vs 67.0 ms; first result digit written into the
 # quotient-digit buffer with the LDS buffers rotating (no 36 registers held across the second half) 488 vs 481 ms;
 # 56 / 72-limb decrypt (per 65536): modulus in SGPRs 174 vs 166 / 364 vs 391 ms; unpipelined chunk loop at 56 limbs 667 ms;
-# 12-row blocks in the 72-limb decrypt kernel 945 vs 366 ms (spills).
+# 12-row blocks in the 72-limb decrypt kernel 945 vs 366 ms (spills); -O2, gcn-iterative-ilp within noise, post-RA
+# scheduler off 501 vs 477 ms.
 build plain "" "" &
 build trk "-mllvm -amdgpu-use-amdgpu-trackers" "-mllvm -amdgpu-use-amdgpu-trackers" &
 wait
