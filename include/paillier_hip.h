@@ -12,6 +12,10 @@
  *  - pointers named d_* are DEVICE pointers on the key's device; h_* are HOST pointers;
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are asynchronous
  *    with respect to the host unless stated otherwise;
+ *  - a key handle owns device scratch (window tables, quotient-digit columns) that its operations reuse: issue
+ *    the operations of ONE key handle on one stream, or order them yourself; different handles (also of the same
+ *    key material) are independent.  pai_decrypt, pai_ct_invert, pai_modexp_fixed / pai_modexp_var (windowed)
+ *    and the standard-scheme pai_encrypt return after their stream work has completed;
  *  - there is NO CPU fallback: without a usable gfx950 device key creation fails with
  *    PAI_E_NODEVICE.
  *
