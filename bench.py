@@ -11,8 +11,8 @@ SURVEY.md §8d).  With N > 1 every rank runs the same per-GPU batch on its own d
 by independent elements, no data-path collective: "weak" scaling); the timed region is bracketed by a
 barrier + torch.cuda.synchronize() and the maximum over ranks is taken.
 
-Inputs: key = the reference's bench constants P, Q (bench/bench_ipcl_python.py:83-97) with a fixed
-DJN base; plaintexts = fixed-point encodings of default_rng(1002).uniform(-1000, 1000, B); randomness
+Inputs: key = the reference's bench constants P, Q (bench/bench_ipcl_python.py:83-97, stored in
+tests/golden/fixture_keys.json) with a fixed DJN base — built here from plain integers, the oracle only checks; plaintexts = fixed-point encodings of default_rng(1002).uniform(-1000, 1000, B); randomness
 r = seeded device generator (1024 random bits per element), all uploaded before the timed region.
 
 The JSON line also carries
@@ -31,6 +31,8 @@ import os
 import sys
 import time
 from pathlib import Path
+from types import SimpleNamespace
+from typing import Optional
 
 import numpy as np
 
@@ -64,6 +66,19 @@ def _sliding_counts(e: int, w: int = 6):
         first, pending = False, 0
         i -= l
     return nsq + pending, nmul
+
+
+def synthetic_key(bits: int = 2048, djn_x: Optional[int] = 0x1234567) -> SimpleNamespace:
+    """Synthetic key material for throughput runs: the prime pair of tests/golden/fixture_keys.json (2048 bits = the
+    reference's own bench constants, bench/bench_ipcl_python.py:83-97; other sizes seeded) and, for DJN, the
+    obfuscator base hs = (-x^2)^n mod n^2 with randbits = bits / 2.  Plain CPython integers."""
+    fx = json.loads((Path(__file__).resolve().parent / "tests" / "golden" / "fixture_keys.json").read_text())[str(bits)]
+    p, q = sorted((int(fx["p"], 16), int(fx["q"], 16)))
+    n = p * q
+    nsq = n * n
+    hs = pow((-djn_x * djn_x) % nsq, n, nsq) if djn_x is not None else None
+    return SimpleNamespace(bits=bits, p=p, q=q, n=n, nsq=nsq, hs=hs, randbits=bits // 2 if djn_x is not None else 0,
+                           max_int=n // 3 - 1, djn_x=djn_x)
 
 
 def executed_macs_decrypt(p: int, q: int, nl: int = 36, w: int = 6, ct_bits: int = 4096) -> float:
@@ -105,12 +120,15 @@ def main() -> None:
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
-    from oracle import paillier_oracle as orc          # checker + synthetic-input definitions only
     from pailliercryptolib_python_amd import engine, fixedpoint
 
-    key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=DJN_X, bits=KEY_BITS)
+    key = synthetic_key(KEY_BITS, DJN_X)
     pub = engine.PublicKeyHandle(key.n, KEY_BITS, key.hs, key.randbits, device=device)
-    priv = engine.PrivateKeyHandle(pub, orc.BENCH_P, orc.BENCH_Q)
+    priv = engine.PrivateKeyHandle(pub, key.p, key.q)
+    # the oracle enters only as the checker of what was timed and as the CPU baseline
+    from oracle import paillier_oracle as orc
+    okey = orc.make_key(key.p, key.q, djn_x=DJN_X, bits=KEY_BITS)
+    assert okey.n == key.n and okey.hs == key.hs and okey.randbits == key.randbits
 
     B = args.batch
     x = np.random.default_rng(1002 + rank).uniform(-1000.0, 1000.0, B)
@@ -154,7 +172,7 @@ def main() -> None:
     ct_h = engine.to_host_words(ct[idx])
     r_h = engine.words_to_ints(engine.to_host_words(r[idx]))
     m_h = engine.words_to_ints(res[idx])
-    ok = ok and engine.words_to_ints(ct_h) == [orc.encrypt(key, mm, rr) for mm, rr in zip(m_h, r_h)]
+    ok = ok and engine.words_to_ints(ct_h) == [orc.encrypt(okey, mm, rr) for mm, rr in zip(m_h, r_h)]
     if world > 1:
         flag = torch.tensor([1 if ok else 0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -183,7 +201,7 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle as co
 
-        ck = co.COracleKey(key)
+        ck = co.COracleKey(okey)
         use_gmp = co.gmp_available()
         enc = ck.gmp_encrypt_djn if use_gmp else ck.encrypt_djn
         dec = ck.gmp_decrypt_crt if use_gmp else ck.decrypt_crt
@@ -241,7 +259,7 @@ def main() -> None:
         t_deca = kern.get("k_dec_a", 0.0) * 1e-3
         t_enc = kern.get("k_encrypt(djn)", 0.0) * 1e-3
         achieved = (CANON_MAC_DEC * B / t_deca) if t_deca > 0 else None
-        executed = (executed_macs_decrypt(orc.BENCH_P, orc.BENCH_Q) * B / t_deca) if t_deca > 0 else None
+        executed = (executed_macs_decrypt(key.p, key.q) * B / t_deca) if t_deca > 0 else None
         line = {
             "metric": "Paillier encrypt+decrypt ops/sec, 2048-bit key",
             "value": value,

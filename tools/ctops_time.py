@@ -1,10 +1,10 @@
 import sys, time, json
 sys.path.insert(0, '.')
 import numpy as np, torch
-from oracle import paillier_oracle as orc
+from bench import synthetic_key
 from pailliercryptolib_python_amd import engine, fixedpoint
 dev = torch.device('cuda', 0)
-key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567, bits=2048)
+key = synthetic_key(2048, 0x1234567)
 pub = engine.PublicKeyHandle(key.n, 2048, key.hs, key.randbits, device=dev)
 B = 1 << 20
 x = np.random.default_rng(7).uniform(-1000.0, 1000.0, B)

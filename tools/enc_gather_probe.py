@@ -3,9 +3,9 @@ random r (every lane reads a different table entry) and with r = 0 (every lane r
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import paillier_oracle as orc
+from bench import synthetic_key
 from pailliercryptolib_python_amd import engine, fixedpoint
-key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567, bits=2048)
+key = synthetic_key(2048, 0x1234567)
 pub = engine.PublicKeyHandle(key.n, 2048, key.hs, key.randbits, device="cuda:0")
 B = 1 << 18
 x = np.random.default_rng(1).uniform(-1000, 1000, B)

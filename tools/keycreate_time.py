@@ -1,9 +1,9 @@
 import time, sys, os
 sys.path.insert(0, '/root/repo')
 import torch
-from oracle import paillier_oracle as orc
+from bench import synthetic_key
 from pailliercryptolib_python_amd import engine
-key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567, bits=2048)
+key = synthetic_key(2048, 0x1234567)
 for w in (8, 10, 11, 12):
     os.environ["PAI_FB_WBITS"] = str(w)
     torch.cuda.synchronize(); t = time.time()

@@ -15,7 +15,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-from oracle import paillier_oracle as orc            # noqa: E402  (synthetic keys / inputs only)
+from bench import synthetic_key                        # noqa: E402
 from pailliercryptolib_python_amd import engine, fixedpoint  # noqa: E402
 
 
@@ -25,13 +25,9 @@ def main() -> None:
     ap.add_argument("--bits", type=int, nargs="*", default=[1024, 2048, 3072, 4096])
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    fx = json.loads((ROOT / "tests" / "golden" / "fixture_keys.json").read_text())
     for bits in args.bits:
-        if bits == 2048:
-            p, q = orc.BENCH_P, orc.BENCH_Q
-        else:
-            p, q = int(fx[str(bits)]["p"], 16), int(fx[str(bits)]["q"], 16)
-        key = orc.make_key(p, q, djn_x=0x1234567, bits=bits)
+        key = synthetic_key(bits, 0x1234567)
+        p, q = key.p, key.q
         t0 = time.perf_counter()
         pub = engine.PublicKeyHandle(key.n, bits, key.hs, key.randbits, device=dev)
         priv = engine.PrivateKeyHandle(pub, p, q)
