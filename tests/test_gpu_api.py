@@ -179,6 +179,62 @@ def test_add_mul_sub_div_bits(fixed):
     assert np.allclose(sk.decrypt(p), a * c)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_expression_chains_match_the_oracle_bit_for_bit(fixed, seed):
+    """Differential run: random chains of + - * / between ciphertext vectors, float / int vectors and scalars of very
+    different magnitudes (so that exponents diverge and alignment runs in both directions), every intermediate
+    ciphertext compared with the oracle's composition of the reference's rules, every decryption with numpy."""
+    pk, sk, okey = fixed
+    rng = np.random.default_rng(9000 + seed)
+    N = int(rng.integers(1, 9))
+
+    def rand_plain():
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            return rng.uniform(-1e3, 1e3, N)
+        if kind == 1:
+            return np.ldexp(rng.uniform(-1, 1, N), rng.integers(-40, 40, N))
+        if kind == 2:
+            return [int(v) for v in rng.integers(-10**6, 10**6, N)]
+        return float(rng.uniform(-50, 50))
+
+    def as_np(v):
+        return np.asarray(v, dtype=np.float64)
+
+    r0 = orc.synth_r_limbs(100 + seed, N, okey.randbits)
+    x = rand_plain()
+    if np.isscalar(x):
+        x = rng.uniform(-5, 5, N)
+    cur = pk.encrypt(x, r=r0)
+    ocur = orc.api_encrypt(okey, list(x), orc.limbs_to_ints(r0))
+    val = as_np(x)
+    for step in range(6):
+        op = rng.integers(0, 5)
+        y = rand_plain()
+        if op == 0:                                   # ct + plain
+            cur, ocur, val = cur + y, orc.api_add_plain(okey, *ocur, y), val + as_np(y)
+        elif op == 1:                                 # ct - plain
+            cur, ocur, val = cur - y, orc.api_sub_plain(okey, *ocur, y), val - as_np(y)
+        elif op == 2:                                 # ct * plain (negative multipliers take the inversion path)
+            cur, ocur, val = cur * y, orc.api_mul_plain(okey, *ocur, y), val * as_np(y)
+        elif op == 3:                                 # ct + ct with a fresh encryption of different exponents
+            z = rand_plain()
+            if np.isscalar(z):
+                z = [z] * N
+            rz = orc.synth_r_limbs(200 + 10 * seed + step, N, okey.randbits)
+            ez, oz = pk.encrypt(z, r=rz), orc.api_encrypt(okey, list(z), orc.limbs_to_ints(rz))
+            cur, ocur, val = cur + ez, orc.api_add_ct(okey, *ocur, *oz), val + as_np(z)
+        else:                                         # ct - ct
+            z = rng.uniform(-1, 1, N)
+            rz = orc.synth_r_limbs(300 + 10 * seed + step, N, okey.randbits)
+            ez, oz = pk.encrypt(z, r=rz), orc.api_encrypt(okey, list(z), orc.limbs_to_ints(rz))
+            cur, ocur, val = cur - ez, orc.api_sub_ct(okey, *ocur, *oz), val - z
+        assert (ct_ints(cur), list(cur.exponent()) if N > 1 else cur.exponent()) == \
+               (ocur[0], list(ocur[1]) if N > 1 else ocur[1]), (seed, step, int(op))
+    got = np.asarray(sk.decrypt(cur), dtype=np.float64).reshape(-1)
+    assert np.allclose(got, val, rtol=1e-9, atol=1e-9 * max(1.0, float(np.abs(val).max())))
+
+
 def test_broadcast_rules(fixed):
     pk, sk, okey = fixed
     vec = pk.encrypt([1.0, 2.0, 3.0], r=orc.synth_r_limbs(1, 3, okey.randbits))
