@@ -187,6 +187,39 @@ def test_other_key_sizes_roundtrip_and_bits(bits):
     assert limbs_to_ints(out.get()) == m
 
 
+@pytest.mark.parametrize("bits,N", [(1024, 255), (1024, 513), (2048, 1), (2048, 257), (2048, 777), (3072, 256), (3072, 259), (4096, 130)])
+def test_tile_boundaries_every_engine(bits, N):
+    """Batch lengths around the 256-element tile on every key size (each size runs a different set of engines):
+    DJN encrypt bits, decrypt, ct*pt with per-element 53-bit multipliers, inverse — sampled against CPython pow."""
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key = nk.key
+    rng = np.random.default_rng(bits + N)
+    m = plaintexts(key, N, bits + N) if N >= 3 else rand_below(rng, key.n, N)
+    r_l = orc.synth_r_limbs(7000 + N, N, key.randbits)
+    dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r_l)
+    ct = DevArray(shape=(N, nk.cw))
+    _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+    cts = limbs_to_ints(ct.get())
+    rs = limbs_to_ints(r_l)
+    sample = sorted(set([0, N - 1, N // 2] + [int(i) for i in rng.integers(0, N, 6)]))
+    for i in sample:
+        assert cts[i] == orc.encrypt(key, m[i], rs[i]), i
+    out = DevArray(shape=(N, nk.nw))
+    _native.check(nk.lib.pai_decrypt(nk.sk, ct.ptr, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == m
+    es = [int(v) | 1 for v in rng.integers(0, 1 << 53, size=N)]
+    de = DevArray(ints_to_limbs(es, 2))
+    res = DevArray(shape=(N, nk.cw))
+    _native.check(nk.lib.pai_ct_mul(nk.pk, ct.ptr, de.ptr, 2, 53, 0, N, res.ptr, None))
+    got = limbs_to_ints(res.get())
+    for i in sample:
+        assert got[i] == pow(cts[i], es[i], key.nsq), i
+    _native.check(nk.lib.pai_ct_invert(nk.pk, ct.ptr, N, res.ptr, None))
+    got = limbs_to_ints(res.get())
+    for i in sample:
+        assert got[i] * cts[i] % key.nsq == 1, i
+
+
 def test_standard_scheme_2048():
     nk = NativeKey(bench_key(djn=False))
     key, N = nk.key, 70
