@@ -32,6 +32,7 @@ SOURCES = [
     "wide_kernels.hip",
     "padic_dec_kernels.hip",
     "padic_enc_kernels.hip",
+    "padic_enc36_kernels.hip",
     "paillier_capi.hip",
 ]
 

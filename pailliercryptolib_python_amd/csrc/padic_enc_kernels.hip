@@ -1,64 +1,53 @@
 // Instantiations of the base-n digit-pair kernels (kernels_padic_enc.hpp): fixed-base table construction, raw / DJN
-// encryption and ciphertext * plaintext on 72 limbs.  Own translation unit (see padic_dec_kernels.hip).
-#include "geo_ops.hpp"
-#include "kernels_padic_enc.hpp"
+// encryption, apply_obfuscator, ciphertext * plaintext and the standard scheme's r^n.  72 limbs here (n of 1400..2048
+// bits), 36 limbs in padic_enc36_kernels.hip (n of 700..1024 bits).  Own translation units (see padic_dec_kernels.hip).
+#include "padic_enc_launch.hpp"
 
 namespace pai {
 
 #ifndef PAI_ENC_U
 #define PAI_ENC_U 8
 #endif
-constexpr int ENC_U = PAI_ENC_U;     // rows per block of the 72-limb products
+using L72 = EncLaunch<72, PAI_ENC_U>;     // rows per block of the 72-limb products: 8 (12: 68.7 vs 67.4 ms, tools/build_variants.sh)
 
-// ---- digit engine with base n for encryption (kernels_padic_enc.hpp): 1400..2048-bit n, 72 limbs -------
-int padic_enc_nl_for_n_bits(int bits) { return (bits >= 1400 && RB * 72 >= bits + 20) ? 72 : 0; }
+int padic_enc_nl_for_n_bits(int bits) {
+    if (bits >= 700 && RB * 36 >= bits + 20) return 36;
+    if (bits >= 1400 && RB * 72 >= bits + 20) return 72;
+    return 0;
+}
 bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
                            const uint32_t* one_dig, uint32_t* table, int J, int wb) {
-    if (nl != 72) return false;
-    constexpr int bytes = 3 * 72 * 64 * 4 + 2 * 72 * 4;
-    (void)hipFuncSetAttribute((const void*)k_fb_table_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_fb_table_padic<72, 8>), dim3((J + 63) / 64), dim3(64), bytes, s, nctx, nm1, hs_dig, one_dig,
-                       reinterpret_cast<uint4*>(table), J, wb);
+    if (nl == 72) L72::fb_table(s, nctx, nm1, hs_dig, one_dig, table, J, wb);
+    else if (nl == 36) enc36_fb_table(s, nctx, nm1, hs_dig, one_dig, table, J, wb);
+    else return false;
     return true;
 }
 bool launch_fb_expand_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
                             uint32_t* T, int J, int h, uint32_t* mscratch) {
-    if (nl != 72) return false;
-    constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
-    (void)hipFuncSetAttribute((const void*)k_fb_expand_padic<72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_fb_expand_padic<72, 8>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, nctx, nm1,
-                       reinterpret_cast<const uint4*>(S), reinterpret_cast<uint4*>(T), J, h, reinterpret_cast<uint4*>(mscratch));
+    if (nl == 72) L72::fb_expand(s, grid, nctx, nm1, S, T, J, h, mscratch);
+    else if (nl == 36) enc36_fb_expand(s, grid, nctx, nm1, S, T, J, h, mscratch);
+    else return false;
     return true;
 }
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
                           const uint32_t* ct_in, uint32_t* ct_out, int n, int mode) {
-    if (nl != 72) return false;
-    constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
-    if (mode == 2) {
-        (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, ENC_U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        hipLaunchKernelGGL((k_encrypt_padic<72, ENC_U, true>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, ct_in, ct_out, n, mode);
-    } else {
-        (void)hipFuncSetAttribute((const void*)k_encrypt_padic<72, ENC_U, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        hipLaunchKernelGGL((k_encrypt_padic<72, ENC_U, false>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, ct_in, ct_out, n, mode);
-    }
+    if (nl == 72) L72::encrypt(s, grid, P, m, r, ct_in, ct_out, n, mode);
+    else if (nl == 36) enc36_encrypt(s, grid, P, m, r, ct_in, ct_out, n, mode);
+    else return false;
     return true;
 }
-
 size_t ctmul_padic_table_words(int nl, int wbits, size_t blocks) { return ((size_t)1 << wbits) * 2 * nl * blocks * BLOCK_THREADS; }
 bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e,
                         uint32_t* out, int n) {
-    if (nl != 72) return false;
-    constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
-    (void)hipFuncSetAttribute((const void*)k_ctmul_padic<72, ENC_U>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_ctmul_padic<72, ENC_U>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, ct, e, out, n);
+    if (nl == 72) L72::ctmul(s, grid, P, ct, e, out, n);
+    else if (nl == 36) enc36_ctmul(s, grid, P, ct, e, out, n);
+    else return false;
     return true;
 }
-
 bool launch_pow_padic(int nl, hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n) {
-    if (nl != 72) return false;
-    constexpr int bytes = 2 * 72 * BLOCK_THREADS * 4 + 2 * 72 * 4;
-    (void)hipFuncSetAttribute((const void*)k_pow_padic<72, ENC_U>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL((k_pow_padic<72, ENC_U>), dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, base, out, n);
+    if (nl == 72) L72::pow(s, grid, P, base, out, n);
+    else if (nl == 36) enc36_pow(s, grid, P, base, out, n);
+    else return false;
     return true;
 }
 
