@@ -5,17 +5,18 @@
 
 namespace pai {
 
-// ---- p-adic digit engine (kernels_padic.hpp): primes of 700..1024 bits on 36 limbs (12-row blocks, everything
-// in LDS), 1025..1604 bits on 56 limbs and up to 2068 bits on 72 limbs (8-row blocks, quotient digits in scratch)
+// ---- p-adic digit engine (kernels_padic.hpp): primes of 400..676 bits on 24 limbs and up to 1024 bits on 36 limbs
+// (12-row blocks, everything in LDS), 1025..1604 bits on 56 limbs and up to 2068 bits on 72 limbs (8-row blocks, quotient digits in scratch)
 int padic_nl_for_prime_bits(int bits) {
-    if (bits < 700) return 0;
+    if (bits < 400) return 0;
+    if (RB * 24 >= bits + 20) return 24;
     if (RB * 36 >= bits + 20) return 36;
     if (RB * 56 >= bits + 20) return 56;
     if (RB * 72 >= bits + 20) return 72;
     return 0;
 }
 size_t padic_table_words(int nl, size_t blocks) { return (size_t)(PADIC_TBL_ENTRIES + 1) * 2 * nl * blocks * BLOCK_THREADS; }
-size_t padic_scratch_words(int nl, size_t blocks) { return nl == 36 ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS; }
+size_t padic_scratch_words(int nl, size_t blocks) { return nl <= 36 ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS; }
 template <int NL, int U, int MODE>
 static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table) {
     constexpr int bytes = (MODE == PADIC_LDS_M ? 3 : 2) * NL * BLOCK_THREADS * 4 + 2 * NL * 4;
@@ -26,6 +27,7 @@ static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, cons
 bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
                         uint32_t* u_out, int n, uint32_t* table) {
     switch (nl) {
+        case 24: launch_padic<24, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
         case 36: launch_padic<36, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
         case 56: launch_padic<56, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
         case 72: launch_padic<72, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
