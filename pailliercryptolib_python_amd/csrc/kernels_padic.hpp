@@ -92,7 +92,7 @@ template <int NL, int U, int WB, int MODE>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n,
               uint4* __restrict__ table) {
-    using E = Padic<NL, U>;
+    using E = Padic<NL, U, (NL >= 72)>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int which = blockIdx.y;
     const MontCtx* ctx = P.pr[which];
@@ -104,10 +104,14 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     // the modulus limbs are wave-uniform multiplier operands: pin them in SGPRs (every use is statically
     // indexed, so the array never leaves the register file) instead of letting the compiler hoist LDS
     // loads into 36 VGPRs/AGPRs
-    uint32_t sn[NL];
+    constexpr bool SGPR_NM = PADIC_SGPR_MODULUS(NL);
+    uint32_t sn[SGPR_NM ? NL : 1];
+    const uint32_t* nm = ldsn;
+    if constexpr (SGPR_NM) {
 #pragma unroll
-    for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
-    const uint32_t* nm = PADIC_SGPR_MODULUS(NL) ? sn : ldsn;
+        for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
+        nm = sn;
+    }
     const uint32_t* pm1 = ldsn + NL;
     const uint32_t n0inv = ctx->n0inv;
     const uint32_t* __restrict__ kdig = P.kdig[which];
