@@ -83,16 +83,23 @@ PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const u
 // MODE PADIC_WBUF:  LDS holds only the digit pair; quotient digits and the parked first result digit live in
 //                   strided global scratch (wider primes: 2 x 56 / 2 x 72 KB per workgroup).
 // Both run one wave per SIMD (a two-waves-per-SIMD variant was measured and dropped: DESIGN.md section 2).
+#ifndef PADIC_XLDS_FROM
+#define PADIC_XLDS_FROM 56          // LDS-qualified digit accesses from this limb count on (mont_padic.hpp: XLDS)
+#endif
+#ifndef PADIC_SQR_MUL_ABOVE
+#define PADIC_SQR_MUL_ABOVE 40      // squarings as rolled-loop products above this limb count (scratch-resident quotient digits)
+#endif
 #ifndef PADIC_SGPR_MODULUS
-// measured per 65 536 decryptions: 36 limbs 488 vs 508 ms (x16), 56 limbs 174 vs 166 ms (LDS wins), 72 limbs 364 vs 391 ms
-#define PADIC_SGPR_MODULUS(NL) ((NL) <= 36 || (NL) >= 72)
+// measured per 65 536 decryptions with the modulus in SGPRs vs read from LDS: 36 limbs 488 vs 508 ms (x16), 72 limbs 364
+// vs 391 ms; 56 limbs (squaring as product, LDS-qualified accesses) 142 vs 151 ms
+#define PADIC_SGPR_MODULUS(NL) 1
 #endif
 constexpr int PADIC_LDS_M = 0, PADIC_WBUF = 2;
 template <int NL, int U, int WB, int MODE>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n,
               uint4* __restrict__ table) {
-    using E = Padic<NL, U, (NL >= 72)>;
+    using E = Padic<NL, U, (NL >= PADIC_XLDS_FROM)>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int which = blockIdx.y;
     const MontCtx* ctx = P.pr[which];
@@ -126,9 +133,11 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const typename E::MBuf M = MODE != PADIC_LDS_M ? typename E::MBuf{P.wscratch + slot, nslots} : typename E::MBuf{B + E::NC * 64, 64};
     const typename E::MBuf Wb{P.wscratch + (size_t)E::NC * nslots + slot, nslots};      // MODE 2 only
     auto SQR = [&]() {
-        if constexpr (MODE == PADIC_WBUF && NL > 56) {
-            // the limb-class symmetric squaring is fully unrolled (62 KB of code at 72 limbs: it would thrash the
-            // 64 KB instruction cache); squaring as a rolled-loop product costs 14 % more multiplies and fits
+        if constexpr (MODE == PADIC_WBUF && NL > PADIC_SQR_MUL_ABOVE) {
+            // Wide digits square as rolled-loop products.  The limb-class symmetric squaring (sqr_wbuf) is fully
+            // unrolled: 62 KB of code at 72 limbs (beyond the instruction cache), and at 56 limbs it makes the compiler
+            // lose the LDS address space of the whole kernel (flat loads) — 166 ms against 142 ms per 65 536
+            // for 30 % fewer multiplies.
             auto self = [&](const uint4* X) { return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); }; };
             E::mul_wbuf(A, B, M, Wb, self(A), self(B), nm, pm1, n0inv);
         } else if constexpr (MODE == PADIC_WBUF) E::sqr_wbuf(A, B, M, Wb, nm, pm1, n0inv);

@@ -31,7 +31,8 @@ build() {  # tag, dec flags, enc flags, [1 = the flags also reach paillier_capi.
 # quotient-digit buffer with the LDS buffers rotating (no 36 registers held across the second half) 488 vs 481 ms;
 # 56 / 72-limb decrypt (per 65536): modulus in SGPRs 174 vs 166 / 364 vs 391 ms; unpipelined chunk loop at 56 limbs 667 ms;
 # 12-row blocks in the 72-limb decrypt kernel 945 vs 366 ms (spills); -O2, gcn-iterative-ilp within noise, post-RA
-# scheduler off 501 vs 477 ms; 192-thread workgroups with the quotient digits in LDS for 56-limb decrypt 220 vs 166 ms per 65536.
+# scheduler off 501 vs 477 ms; 192-thread workgroups with the quotient digits in LDS for 56-limb decrypt 220 vs 166 ms per 65536;
+# 56 limbs: squaring as product 146, + LDS-qualified accesses 151, + modulus in SGPRs 142 (adopted) vs 166 ms.
 build plain "" "" &
 build trk "-mllvm -amdgpu-use-amdgpu-trackers" "-mllvm -amdgpu-use-amdgpu-trackers" &
 wait
