@@ -235,6 +235,71 @@ def test_random_expression_chains_match_the_oracle_bit_for_bit(fixed, seed):
     assert np.allclose(got, val, rtol=1e-9, atol=1e-9 * max(1.0, float(np.abs(val).max())))
 
 
+def test_reductions_match_the_oracle_bit_for_bit(fixed):
+    """sum / mean / dot / @ / r@ / @= against the oracle's restatement of ipcl_python.py:746-930: the padded
+    rotate-and-add tree (:810-827), the index maps (:777-808) and the per-row maximum-exponent alignment
+    (:868-870) fix the ciphertext bits and the exponents; mixed int / float inputs make the exponents differ."""
+    pk, sk, okey = fixed
+    rng = np.random.default_rng(77)
+    for N in (1, 2, 5, 8, 13):
+        vals = [float(v) for v in rng.uniform(-100, 100, N)]
+        vals[0] = int(rng.integers(-9, 9))                               # exponent 0 next to ~46
+        if N > 2:
+            vals[2] = float(np.ldexp(rng.uniform(1, 2), -30))            # a much larger exponent
+        r = orc.synth_r_limbs(500 + N, N, okey.randbits)
+        en = pk.encrypt(vals, r=r)
+        oc, oe = orc.api_encrypt(okey, vals, orc.limbs_to_ints(r))
+        s = en.sum()
+        want = orc.api_sum(okey, oc, oe)
+        assert (ct_ints(s), s.exponent()) == (want[0], want[1]) and len(s) == 1
+        mean = en.mean()
+        want = orc.api_mean(okey, oc, oe)
+        assert (ct_ints(mean), mean.exponent()) == (want[0], want[1])
+        w = [float(v) for v in rng.uniform(-3, 3, N)]
+        if N > 1:
+            w[1] = 2                                                     # an int multiplier: plaintext exponent 0
+        d = en.dot(w)
+        want = orc.api_dot(okey, oc, oe, w)
+        assert (ct_ints(d), d.exponent()) == (want[0], want[1])
+        assert abs(sk.decrypt(s) - sum(vals)) < 1e-6 and abs(sk.decrypt(d) - float(np.dot(vals, w))) < 1e-6
+    for (m, n, k) in ((1, 1, 1), (2, 3, 2), (3, 4, 1), (1, 5, 3), (4, 2, 5)):
+        x = rng.uniform(-10, 10, (m, n))
+        x[0, 0] = 3.0                                                    # still a float: exponents differ by magnitude
+        y = rng.uniform(-5, 5, (n, k))
+        y[n - 1, 0] = -2.0
+        rx = orc.synth_r_limbs(600 + m * 49 + n * 7 + k, m * n, okey.randbits)
+        en = pk.encrypt(x.flatten(), r=rx)
+        oc, oe = orc.api_encrypt(okey, list(x.flatten()), orc.limbs_to_ints(rx))
+        res = en @ y
+        want = orc.api_matmul(okey, oc, oe, y)
+        assert (ct_ints(res), res.exponent()) == (want[0], want[1]) and len(res) == m * k
+        assert np.allclose(np.array(sk.decrypt(res)).reshape(m, k), x @ y)
+        if k == 1:                                                       # 1-D right operand (ipcl_python.py:788-792)
+            res1 = en @ y[:, 0]
+            want1 = orc.api_matmul(okey, oc, oe, y[:, 0])
+            assert (ct_ints(res1), res1.exponent()) == (want1[0], want1[1])
+        ry = orc.synth_r_limbs(700 + m * 49 + n * 7 + k, n * k, okey.randbits)
+        en_y = pk.encrypt(y.flatten(), r=ry)
+        oyc, oye = orc.api_encrypt(okey, list(y.flatten()), orc.limbs_to_ints(ry))
+        xl = x.tolist()
+        rres = xl @ en_y
+        want = orc.api_matmul(okey, oyc, oye, xl, rhs=True)
+        assert (ct_ints(rres), rres.exponent()) == (want[0], want[1])
+        assert np.allclose(np.array(sk.decrypt(rres)).reshape(m, k), x @ y)
+        if m == 1:                                                       # 1-D left operand
+            rres1 = x[0] @ en_y
+            want1 = orc.api_matmul(okey, oyc, oye, x[0], rhs=True)
+            assert (ct_ints(rres1), rres1.exponent()) == (want1[0], want1[1])
+        en2 = pk.encrypt(x.flatten(), r=rx)
+        en2 @= y
+        assert ct_ints(en2) == orc.api_matmul(okey, oc, oe, y)[0]
+        yi = rng.integers(-5, 6, (n, k))                                # integer matrix: plaintext exponents 0, zeros included
+        resi = en @ yi
+        wanti = orc.api_matmul(okey, oc, oe, yi)
+        assert (ct_ints(resi), resi.exponent()) == (wanti[0], wanti[1])
+        assert np.allclose(np.array(sk.decrypt(resi)).reshape(m, k), x @ yi)
+
+
 def test_broadcast_rules(fixed):
     pk, sk, okey = fixed
     vec = pk.encrypt([1.0, 2.0, 3.0], r=orc.synth_r_limbs(1, 3, okey.randbits))

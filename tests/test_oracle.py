@@ -144,3 +144,38 @@ def test_decode_mantissas_matches_the_scalar_codec():
     want = [orc.fp_decode(int(m) % n, int(e), n, max_int) for m, e in zip(mant, expo)]
     assert got == want
     assert [type(g) for g in got] == [type(w) for w in want]
+
+
+def test_reductions_restatement_is_consistent():
+    """oracle.api_sum / api_mean / api_dot / api_matmul (ipcl_python.py:746-930): the padded rotate-and-add tree
+    equals the plain product of the aligned ciphertexts, and every reduction decrypts to the numpy value."""
+    k = key2048()
+    rng = np.random.default_rng(5)
+    for N in (1, 3, 4, 7):
+        vals = [float(v) for v in rng.uniform(-50, 50, N)]
+        vals[0] = 7
+        rs = [int.from_bytes(rng.bytes(128), "little") for _ in range(N)]
+        xc, xe = orc.api_encrypt(k, vals, rs)
+        sc, se = orc.api_sum(k, xc, xe)
+        prod = 1
+        for c in orc.api_increase_exponent_to(k, xc, xe, max(xe)):
+            prod = prod * c % k.nsq
+        assert sc == [prod] and se == [max(xe)]
+        assert abs(orc.api_decrypt(k, sc, se)[0] - sum(vals)) < 1e-9
+        mc, me = orc.api_mean(k, xc, xe)
+        assert abs(orc.api_decrypt(k, mc, me)[0] - sum(vals) / N) < 1e-9
+        w = [float(v) for v in rng.uniform(-2, 2, N)]
+        dc, de = orc.api_dot(k, xc, xe, w)
+        assert abs(orc.api_decrypt(k, dc, de)[0] - float(np.dot(vals, w))) < 1e-8
+    for (m, n, kk) in ((2, 3, 2), (1, 4, 1), (3, 1, 2)):
+        x, y = rng.uniform(-4, 4, (m, n)), rng.uniform(-4, 4, (n, kk))
+        rs = [int.from_bytes(rng.bytes(128), "little") for _ in range(m * n)]
+        xc, xe = orc.api_encrypt(k, list(x.flatten()), rs)
+        rc, re_ = orc.api_matmul(k, xc, xe, y)
+        assert np.allclose(np.array(orc.api_decrypt(k, rc, re_)).reshape(m, kk), x @ y)
+        rs = [int.from_bytes(rng.bytes(128), "little") for _ in range(n * kk)]
+        yc, ye = orc.api_encrypt(k, list(y.flatten()), rs)
+        rc, re_ = orc.api_matmul(k, yc, ye, x.tolist(), rhs=True)
+        assert np.allclose(np.array(orc.api_decrypt(k, rc, re_)).reshape(m, kk), x @ y)
+    with pytest.raises(ValueError):
+        orc.api_matmul(k, xc, xe, np.ones((5, 2)))
