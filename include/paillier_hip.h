@@ -12,10 +12,14 @@
  *  - pointers named d_* are DEVICE pointers on the key's device; h_* are HOST pointers;
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are asynchronous
  *    with respect to the host unless stated otherwise;
- *  - a key handle owns device scratch (window tables, quotient-digit columns) that its operations reuse: issue
- *    the operations of ONE key handle on one stream, or order them yourself; different handles (also of the same
- *    key material) are independent.  pai_decrypt, pai_ct_invert, pai_modexp_fixed / pai_modexp_var (windowed)
- *    and the standard-scheme pai_encrypt return after their stream work has completed;
+ *  - a key handle owns device scratch (window tables, quotient-digit columns) that its operations reuse.  The
+ *    library orders the users of that scratch itself: operations of one handle issued on the SAME stream are
+ *    ordered by the stream, operations issued on DIFFERENT streams are chained with an event (the later call makes
+ *    its stream wait for the earlier one), so any mix of threads and streams on one handle is safe, and handles
+ *    of the same key material on different devices are independent.  Only pai_ct_invert (it reports
+ *    non-invertible inputs) and pai_modexp_fixed (it stages a host exponent) return after their stream work has
+ *    completed; everything else, pai_decrypt included, is asynchronous;
+ *  - a call never changes the calling thread's current HIP device (it is restored on return);
  *  - there is NO CPU fallback: without a usable gfx950 device key creation fails with
  *    PAI_E_NODEVICE.
  *
@@ -65,7 +69,8 @@ int pai_stream_sync(int device, void* stream);
 /* ipclPublicKey(n, bits, enableDJN) — classes.cpp:24-27 — and the pickle form
  * (scheme, n, bits, hs, randbits) — ipcl_bindings.cpp:66-98.  h_hs == NULL selects the standard
  * scheme (obfuscator r^n); otherwise the DJN scheme (obfuscator hs^r, r of `randbits` bits) and the
- * fixed-base table for hs is built on the device. */
+ * fixed-base table for hs is built on the device by the first call that obfuscates (pai_encrypt with randomness /
+ * pai_obfuscate): a handle that only adds, multiplies or decrypts never allocates it. */
 int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint32_t* h_hs, int hs_words,
                       int randbits, int device, pai_pubkey** out);
 void pai_pubkey_destroy(pai_pubkey* pk);
@@ -107,9 +112,17 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
                int e_bcast, size_t N, uint32_t* d_out, void* stream);
 
 /* Replaces the per-element gmpy2.invert of PaillierEncryptedNumber.__invert_ct (ipcl_python.py:272-276):
- * d_out[i] = d_ct[i]^-1 mod n^2 (batched: simultaneous inversion + one extended GCD per chunk).
- * Synchronous; fails with PAI_E_INVALID if some ciphertext shares a factor with n. d_out must not alias d_ct. */
+ * d_out[i] = d_ct[i]^-1 mod n^2 (batched: simultaneous inversion as a product tree + one extended GCD per top-level
+ * product).  Synchronous; fails with PAI_E_INVALID if some ciphertext shares a factor with n.  d_out may alias d_ct. */
 int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream);
+
+/* The reductions of PaillierEncryptedNumber.sum / __matmul__ (ipcl_python.py:746-762, 810-880): upstream pads to a
+ * power of two with E_raw(0) = 1 and runs log2 steps of CipherText::rotate + operator+ (__padded_ct, :810-827),
+ * i.e. computes the product of a group of ciphertexts modulo n^2.  Here: d_ct holds `count` rows read as
+ * [count/groups][groups] (member-major), and d_out[g] = prod_l d_ct[l*groups + g] mod n^2 for g < groups — a
+ * product tree over halves, one Montgomery product per node.  The product is order-independent, so the bits equal
+ * upstream's rotate-and-add result.  count must be a positive multiple of groups; groups == 1 is sum(). */
+int pai_ct_prod(const pai_pubkey* pk, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out, void* stream);
 
 /* Exponent alignment, ipcl_python.py:570-741 (ct * 2^delta as ciphertext^(2^delta)):
  * for delta_i > 0: d_ct[i] <- d_ct[i]^(2^delta_i) mod n^2; other elements are left untouched. */
@@ -134,6 +147,20 @@ int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64
  * at counter0, carried into nonce word 0), top word of every row masked to randbits. */
 int pai_draw_r(const pai_pubkey* pk, const uint32_t* h_key8, const uint32_t* h_nonce3, uint32_t counter0, size_t N,
                uint32_t* d_r, void* stream);
+
+/* ---- multi-GPU (one node) --------------------------------------------------------------------------------
+ * The hot operations are element-wise (encrypt / decrypt / add / mul forward whole std::vector<BigNumber> batches:
+ * classes.cpp:53-60, 127-133, 318-325), so a batch shards by contiguous blocks with no exchange inside an operation:
+ * shard g of G owns rows [g*ceil(N/G), min(N, (g+1)*ceil(N/G))) (trailing shards may be empty). */
+int pai_shard_plan(size_t N, int nshards, int shard, size_t* begin, size_t* count);
+/* Single-process fan-out over the visible devices (one key handle per device): gathers row shards living on
+ * devices[i] (rows[i] rows of row_words words each, back to back in shard order) into d_out on dst_device, or
+ * scatters d_in on src_device into the shards — peer copies over xGMI, all shards in flight at once; returns when
+ * the copies have completed.  (One-process-per-GPU jobs gather with RCCL instead: sharding.py.) */
+int pai_gather(int nshards, const int* devices, const void* const* d_shards, const size_t* rows, int row_words,
+               int dst_device, void* d_out);
+int pai_scatter(int nshards, const int* devices, void* const* d_shards, const size_t* rows, int row_words,
+                int src_device, const void* d_in);
 
 /* ---- generic modular building blocks (arbitrary odd modulus up to 8192 bits) ------------------- */
 int pai_modulus_create(const uint32_t* h_m, int m_words, int device, pai_modulus** out);

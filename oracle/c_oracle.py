@@ -17,11 +17,12 @@ from . import paillier_oracle as orc
 
 HERE = Path(__file__).resolve().parent
 SRC = HERE / "paillier_ref.c"
+SRC_IFMA = HERE / "paillier_ifma.c"      # included by paillier_ref.c when the host compiler targets AVX512-IFMA
 LIB = HERE / "_build" / "libpaillier_oracle.so"
 
 
 def build(force: bool = False) -> Path:
-    if LIB.exists() and not force and LIB.stat().st_mtime >= SRC.stat().st_mtime:
+    if LIB.exists() and not force and LIB.stat().st_mtime >= max(SRC.stat().st_mtime, SRC_IFMA.stat().st_mtime):
         return LIB
     LIB.parent.mkdir(parents=True, exist_ok=True)
     cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", str(SRC), "-o", str(LIB), "-ldl"]
@@ -54,6 +55,45 @@ def lib():
 def gmp_available() -> bool:
     lib().orc_gmp_available.restype = C.c_int
     return bool(lib().orc_gmp_available())
+
+
+def ifma_available() -> bool:
+    """True when the library was compiled with the AVX512-IFMA mb8 kernels and this CPU has the instructions."""
+    lib().orc_ifma_available.restype = C.c_int
+    return bool(lib().orc_ifma_available())
+
+
+class _IfmaMod(C.Structure):
+    _fields_ = [("bits", C.c_int), ("r2_52", C.c_void_p), ("k0", C.c_uint64)]
+
+
+def _ifma_consts(M: int):
+    """(bits, R^2 mod M as 52-bit limbs, -M^-1 mod 2^52) for R = 2^(52 L), 52 L >= bits + 2."""
+    bits = M.bit_length()
+    L = (bits + 2 + 51) // 52
+    R = 1 << (52 * L)
+    r2 = R * R % M
+    limbs = np.array([(r2 >> (52 * i)) & ((1 << 52) - 1) for i in range(L)], dtype=np.uint64)
+    return bits, limbs, (-pow(M, -1, 1 << 52)) % (1 << 52)
+
+
+def ifma_modexp(M: int, base32: np.ndarray, e, threads: int = 0) -> np.ndarray:
+    """out[i] = base[i]^e mod M through the mb8 kernel; e an int (shared) or a list of ints (per element)."""
+    L = (M.bit_length() + 63) // 64
+    bits, r2, k0 = _ifma_consts(M)
+    b = _as_u64_rows(base32, L)
+    if isinstance(e, int):
+        ebits = max(e.bit_length(), 1)
+        ev, stride = _u64(e, (ebits + 63) // 64), 0
+    else:
+        ebits = max(max(int(v).bit_length() for v in e), 1)
+        stride = (ebits + 63) // 64
+        ev = np.concatenate([_u64(int(v), stride) for v in e])
+    out = np.zeros_like(b)
+    rc = lib().orc_ifma_modexp_batch(b.shape[0], bits, L, _p(_u64(M, L)), _p(r2), C.c_uint64(k0), _p(b), _p(ev), stride, ebits,
+                                     _p(out), threads)
+    assert rc == 0
+    return out.view(np.uint32)[:, : base32.shape[1]]
 
 
 def max_threads() -> int:
@@ -189,4 +229,36 @@ class COracleKey:
         args = [_u64(v, self.Lh) for v in (key.p, key.q, k["hp"], k["hq"], k["pinv_q"])]
         rc = lib().orc_gmp_decrypt_crt_batch(N, self.Ln, self.Lh, *[_p(a) for a in args], _p(ct), _p(m), threads)
         assert rc == 0, "libgmp not available"
+        return m.view(np.uint32)
+
+    # ---- the same two operations on the AVX512-IFMA mb8 kernels (oracle/paillier_ifma.c) ----
+    def _ifma_mod(self, M: int) -> _IfmaMod:
+        bits, r2, k0 = _ifma_consts(M)
+        self._keep.append(r2)
+        return _IfmaMod(bits, _p(r2), k0)
+
+    def ifma_encrypt_djn(self, m32: np.ndarray, r32: np.ndarray, threads: int = 0) -> np.ndarray:
+        key = self.key
+        if not hasattr(self, "_im_nsq"):
+            self._im_nsq = self._ifma_mod(key.nsq)
+        m = _as_u64_rows(m32, self.Ln)
+        Lr = (key.randbits + 63) // 64
+        r = _as_u64_rows(r32, Lr)
+        N = m.shape[0]
+        ct = np.zeros((N, 2 * self.Ln), dtype=np.uint64)
+        rc = lib().orc_ifma_encrypt_djn_batch(N, self.Ln, _p(self.n), _p(self.nsq), self.nsq0, _p(self.nsq_r2), _p(self.hs),
+                                              _p(m), _p(r), Lr, key.randbits, _p(ct), C.byref(self._im_nsq), threads)
+        assert rc == 0
+        return ct.view(np.uint32)
+
+    def ifma_decrypt_crt(self, ct32: np.ndarray, threads: int = 0) -> np.ndarray:
+        key = self.key
+        if not hasattr(self, "_im_p"):
+            self._im_p, self._im_q = self._ifma_mod(key.p * key.p), self._ifma_mod(key.q * key.q)
+        ct = _as_u64_rows(ct32, 2 * self.Ln)
+        N = ct.shape[0]
+        m = np.zeros((N, self.Ln), dtype=np.uint64)
+        rc = lib().orc_ifma_decrypt_crt_batch(N, self.Ln, self.Lh, C.byref(self.pc), C.byref(self.qc), _p(self.pinvqR),
+                                              _p(ct), _p(m), C.byref(self._im_p), C.byref(self._im_q), threads)
+        assert rc == 0
         return m.view(np.uint32)

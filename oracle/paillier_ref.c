@@ -378,3 +378,10 @@ int orc_gmp_decrypt_crt_batch(int N, int Ln, int Lh, const u64* p, const u64* q,
     }
     return 0;
 }
+
+/* AVX512-IFMA multi-buffer (mb8) exponentiation: the CPU algorithm README.md:32 names, restated in our own code */
+#ifdef __AVX512IFMA__
+#include "paillier_ifma.c"
+#else
+int orc_ifma_available(void) { return 0; }
+#endif

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import enum
 import math
+import os
 import secrets
 from typing import List, Optional, Sequence, Union
 
@@ -125,6 +126,21 @@ def _default_device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _env_devices() -> Optional[List[torch.device]]:
+    """PAI_DEVICES=all | "0,1,2": the devices new keys fan their heavy element-wise operations out to (single-process
+    multi-GPU; one-process-per-GPU jobs use sharding.py instead).  Unset: the current device only."""
+    spec = os.environ.get("PAI_DEVICES", "").strip()
+    if not spec:
+        return None
+    if spec == "all":
+        return [torch.device("cuda", i) for i in range(torch.cuda.device_count())]
+    return [torch.device("cuda", int(tok)) for tok in spec.split(",") if tok.strip() != ""]
+
+
+# below this many elements per device a batch stays on the home device (launch + peer-copy latency dominates)
+FANOUT_MIN_PER_DEVICE = int(os.environ.get("PAI_FANOUT_MIN", "2048"))
+
+
 def _random_unit(n: int) -> int:
     while True:
         x = secrets.randbelow(n - 2) + 2
@@ -136,7 +152,7 @@ class ipclPublicKey:
     """Replaces the pybind class at bindings/ipcl_bindings_classes.cpp:12-91."""
 
     def __init__(self, n: Union[ipclBigNumber, int], bits: int = 1024, enableDJN: bool = False, *,
-                 hs: Optional[int] = None, randbits: Optional[int] = None, device=None):
+                 hs: Optional[int] = None, randbits: Optional[int] = None, device=None, devices=None):
         self._n = _as_int(n)
         self._bits = int(bits)
         if self._n.bit_length() > self._bits:
@@ -152,21 +168,53 @@ class ipclPublicKey:
             self._randbits = int(randbits) if randbits is not None else self._bits // 2
         else:
             self._hs, self._randbits = None, 0
-        self._device = torch.device(device) if device is not None else None
-        self._handle: Optional[engine.PublicKeyHandle] = None
+        self._devices: Optional[List[torch.device]] = None
+        if devices is not None:
+            self.set_devices(devices)
+        elif device is not None:
+            self._devices = [torch.device(device)]
+        self._handles: dict = {}
 
-    # -- lazily created device handle --------------------------------------------------------------
+    # -- lazily created device handles (cached per key material and device: engine.public_handle) ----
+    def _device_list(self) -> List[torch.device]:
+        if self._devices is None:
+            self._devices = _env_devices() or [_default_device()]
+        if any(d.index is None for d in self._devices):
+            self._devices = [d if d.index is not None else _default_device() for d in self._devices]
+        return self._devices
+
+    def set_devices(self, devices) -> None:
+        """Extension: the devices of this process the key lives on.  The first one is the home device (containers
+        are resident there); encrypt / decrypt / ct*pt of large batches are sharded over all of them by contiguous
+        blocks and gathered back with peer copies."""
+        devs = [torch.device(d) for d in devices]
+        devs = [torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device()) for d in devs]
+        if not devs:
+            raise ValueError("set_devices: need at least one device")
+        self._devices = devs
+
+    def handle_on(self, device: torch.device) -> engine.PublicKeyHandle:
+        h = self._handles.get(device.index)
+        if h is None:
+            h = engine.public_handle(self._n, self._bits, self._hs, self._randbits, device)
+            self._handles[device.index] = h
+        return h
+
     @property
     def handle(self) -> engine.PublicKeyHandle:
-        if self._handle is None:
-            dev = self._device or _default_device()
-            self._handle = engine.PublicKeyHandle(self._n, self._bits, self._hs, self._randbits, device=dev)
-            self._device = self._handle.device
-        return self._handle
+        """The handle on the home device."""
+        return self.handle_on(self._device_list()[0])
 
     @property
     def device(self) -> torch.device:
         return self.handle.device
+
+    def fanout_devices(self, n_items: int) -> Optional[List[torch.device]]:
+        """The device list to shard a batch of n_items over, or None when it should stay on the home device."""
+        devs = self._device_list()
+        if len(devs) < 2 or n_items < FANOUT_MIN_PER_DEVICE * len(devs):
+            return None
+        return devs
 
     # -- reference surface -------------------------------------------------------------------------
     @property
@@ -209,27 +257,63 @@ class ipclPublicKey:
             self._randbits = int(t[4])
         else:
             self._hs, self._randbits = None, 0
-        self._device = None
-        self._handle = None
+        self._devices = None
+        self._handles = {}
 
-    # randomness for the obfuscator: OS CSPRNG on the host, uploaded as limbs
-    def _draw_r(self, count: int) -> torch.Tensor:
-        h = self.handle
+    # randomness for the obfuscator: OS CSPRNG on the host, expanded / uploaded as limbs
+    def _draw_r(self, count: int, h: Optional[engine.PublicKeyHandle] = None) -> torch.Tensor:
+        h = h or self.handle
         if self._djn:
             # fresh 256-bit key + 96-bit nonce from the OS CSPRNG, expanded on the device (ChaCha20, RFC 8439)
             return h.draw_r(count, secrets.token_bytes(32), secrets.token_bytes(12))
-        vals = [secrets.randbelow(self._n - 1) + 1 for _ in range(count)]
+        # standard scheme: r uniform in [1, n): a draw of bits(n) + 64 bits reduced mod (n - 1) is within 2^-64 of
+        # uniform; one os.urandom call and vectorised limb handling instead of a secrets.randbelow per element
+        nb = (self._n.bit_length() + 64 + 7) // 8
+        raw = os.urandom(nb * count)
+        vals = [int.from_bytes(raw[i * nb:(i + 1) * nb], "little") % (self._n - 1) + 1 for i in range(count)]
         return engine.to_device_words(engine.ints_to_words(vals, h.n_words), h.device)
+
+    def encrypt_words(self, m: torch.Tensor, make_secure: bool = True, r: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Residues [N, n_words] on the home device -> ciphertexts [N, ct_words] on the home device; large batches
+        are sharded over the key's devices (scatter, encrypt per device on its own thread, gather)."""
+        h = self.handle
+        devs = self.fanout_devices(m.shape[0])
+        if devs is None:
+            if not make_secure:
+                return h.raw_encrypt(m)
+            return h.encrypt(m, self._draw_r(m.shape[0]) if r is None else r)
+        m_sh = engine.scatter_shards(m, devs)
+        r_sh = engine.scatter_shards(r, devs) if (make_secure and r is not None) else None
+
+        def work(g, dev, begin, count):
+            hg = self.handle_on(dev)
+            if count == 0:
+                return hg.empty_ct(0)
+            if not make_secure:
+                return hg.raw_encrypt(m_sh[g])
+            return hg.encrypt(m_sh[g], self._draw_r(count, hg) if r_sh is None else r_sh[g])
+
+        return engine.gather_shards(engine.fan_out(devs, work, m.shape[0]), h.device)
+
+    def ct_mul_words(self, ct: torch.Tensor, e: torch.Tensor, ebits_max: int) -> torch.Tensor:
+        """ct_i ^ e_i mod n^2 (classes.cpp:324-325) on the home device's limb matrices, sharded when large."""
+        h = self.handle
+        devs = self.fanout_devices(ct.shape[0])
+        if devs is None:
+            return h.ct_mul(ct, e, ebits_max)
+        ct_sh = engine.scatter_shards(ct, devs)
+        bcast = e.shape[0] == 1 and ct.shape[0] != 1
+        e_sh = [e.to(d) for d in devs] if bcast else engine.scatter_shards(e, devs)
+
+        def work(g, dev, begin, count):
+            hg = self.handle_on(dev)
+            return hg.ct_mul(ct_sh[g], e_sh[g], ebits_max) if count else hg.empty_ct(0)
+
+        return engine.gather_shards(engine.fan_out(devs, work, ct.shape[0]), h.device)
 
     def encrypt(self, pt: "ipclPlainText", make_secure: bool = True, *, r: Optional[torch.Tensor] = None) -> "ipclCipherText":
         """classes.cpp:53-60.  ``r`` (extension) injects the obfuscator randomness for reproducible runs."""
-        h = self.handle
-        m = pt._device_words(h)
-        if not make_secure:
-            return ipclCipherText(self, h.raw_encrypt(m))
-        if r is None:
-            r = self._draw_r(m.shape[0])
-        return ipclCipherText(self, h.encrypt(m, r))
+        return ipclCipherText(self, self.encrypt_words(pt._device_words(self.handle), make_secure, r))
 
     def apply_obfuscator(self, x, *, r: Optional[torch.Tensor] = None):
         """classes.cpp:71-83: BigNumber -> BigNumber, CipherText -> list of BigNumber (as upstream)."""
@@ -259,13 +343,34 @@ class ipclPrivateKey:
         self._p, self._q = (p, q) if p < q else (q, p)
         if self._p * self._q != self._pk._n:
             raise RuntimeError("ipclPrivateKey: p*q does not match the public key")
-        self._handle: Optional[engine.PrivateKeyHandle] = None
+        self._handles: dict = {}
+
+    def handle_on(self, device: torch.device) -> engine.PrivateKeyHandle:
+        h = self._handles.get(device.index)
+        if h is None:
+            h = engine.PrivateKeyHandle(self._pk.handle_on(device), self._p, self._q)
+            self._handles[device.index] = h
+        return h
 
     @property
     def handle(self) -> engine.PrivateKeyHandle:
-        if self._handle is None:
-            self._handle = engine.PrivateKeyHandle(self._pk.handle, self._p, self._q)
-        return self._handle
+        return self.handle_on(self._pk._device_list()[0])
+
+    def decrypt_words(self, ct: torch.Tensor) -> torch.Tensor:
+        """Ciphertexts [N, ct_words] -> residues [N, n_words] on the home device, sharded over the key's devices
+        when the batch is large."""
+        hpub = self.handle.pub
+        words = ct if ct.device == hpub.device else ct.to(hpub.device)
+        devs = self._pk.fanout_devices(words.shape[0])
+        if devs is None:
+            return self.handle.decrypt(words)
+        ct_sh = engine.scatter_shards(words, devs)
+
+        def work(g, dev, begin, count):
+            hg = self.handle_on(dev)
+            return hg.decrypt(ct_sh[g]) if count else hg.pub.empty_pt(0)
+
+        return engine.gather_shards(engine.fan_out(devs, work, words.shape[0]), hpub.device)
 
     @property
     def n(self):
@@ -292,9 +397,7 @@ class ipclPrivateKey:
         """classes.cpp:127-133."""
         if ct.public_key._n != self._pk._n:
             raise RuntimeError("ipclPrivateKey.decrypt: public key mismatch")
-        hpub = self.handle.pub
-        words = ct._t if ct._t.device == hpub.device else ct._t.to(hpub.device)
-        return ipclPlainText(self.handle.decrypt(words))
+        return ipclPlainText(self.decrypt_words(ct._t))
 
     def __getstate__(self):
         return (ipclBigNumber(self._pk._n).to_bytes(), ipclBigNumber(self._p).to_bytes(), ipclBigNumber(self._q).to_bytes())
@@ -303,7 +406,7 @@ class ipclPrivateKey:
         n, p, q = (int.from_bytes(b, "little") for b in t)
         self._pk = ipclPublicKey(n, n.bit_length(), False)
         self._p, self._q = (p, q) if p < q else (q, p)
-        self._handle = None
+        self._handles = {}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -415,21 +518,46 @@ class ipclCipherText(_Container):
     def __init__(self, pubkey: ipclPublicKey, data=None):
         self._pk = pubkey
         self._ints: List[int] = []
-        h = pubkey.handle
+        self._dev: Optional[torch.Tensor] = None      # limb matrix on the key's home device ...
+        self._host: Optional[np.ndarray] = None       # ... or host words that have not been needed on a device yet
+        W = 2 * ((pubkey._bits + 31) // 32)
         if isinstance(data, torch.Tensor):
-            t = data
+            if data.shape[1] != W:
+                raise RuntimeError("ipclCipherText: width does not match the key")
+            self._dev = data
         elif isinstance(data, ipclCipherText):
-            t = data._t
-        elif isinstance(data, (ipclBigNumber, int, np.integer)):
-            t = engine.to_device_words(engine.ints_to_words([_as_int(data)], h.ct_words), h.device)
+            self._dev, self._host = data._dev, data._host
         elif isinstance(data, np.ndarray) and data.dtype == np.uint32 and data.ndim == 2:
-            t = engine.to_device_words(data, h.device)
+            if data.shape[1] != W:
+                raise RuntimeError("ipclCipherText: width does not match the key")
+            self._host = np.ascontiguousarray(data)
         else:
-            vals = [_as_int(v) for v in (data if data is not None else [])]
-            t = engine.to_device_words(engine.ints_to_words(vals, h.ct_words), h.device) if vals else h.empty_ct(0)
-        if t.shape[1] != h.ct_words:
-            raise RuntimeError("ipclCipherText: width does not match the key")
-        self._t = t if t.device == h.device else t.to(h.device)
+            if isinstance(data, (ipclBigNumber, int, np.integer)):
+                vals = [_as_int(data)]
+            else:
+                vals = [_as_int(v) for v in (data if data is not None else [])]
+            for v in vals:
+                if v.bit_length() > 32 * W:
+                    raise RuntimeError("ipclCipherText: width does not match the key")
+            self._host = engine.ints_to_words(vals, W) if vals else np.zeros((0, W), dtype=np.uint32)
+
+    @property
+    def _t(self) -> torch.Tensor:
+        """The limb matrix on the home device; host-built containers (pickles, lists of BigNumbers) are uploaded —
+        and the key's device handle created — only when an operation first needs them."""
+        if self._dev is None:
+            self._dev = engine.to_device_words(self._host, self._pk.handle.device)
+            self._host = None
+        elif self._dev.device != self._pk.handle.device:
+            self._dev = self._dev.to(self._pk.handle.device)
+        return self._dev
+
+    def getSize(self) -> int:
+        return int(self._host.shape[0]) if self._dev is None else int(self._dev.shape[0])
+
+    def getTexts(self) -> List[ipclBigNumber]:
+        words = self._host if self._dev is None else engine.to_host_words(self._dev)
+        return [ipclBigNumber(v) for v in engine.words_to_ints(words)]
 
     @property
     def public_key(self) -> ipclPublicKey:
@@ -474,7 +602,7 @@ class ipclCipherText(_Container):
         bits = max(1, max(v.bit_length() for v in vals))
         ew = (bits + 31) // 32
         e = engine.to_device_words(engine.ints_to_words(vals, ew), h.device)
-        return ipclCipherText(self._pk, h.ct_mul(self._t, e, bits))
+        return ipclCipherText(self._pk, self._pk.ct_mul_words(self._t, e, bits))
 
     def __repr__(self):
         return "<ipclCipherText %s>" % str(id(self))[:10]

@@ -11,9 +11,10 @@ struct GeoInst {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
     static void modmul(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, uint32_t* out,
-                       int n, int w32, int b_bcast) {
-        set_lds((const void*)k_modmul<G>, G::LDS_BYTES);
-        hipLaunchKernelGGL(k_modmul<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, a, b, out, n, w32, b_bcast);
+                       int n, int w32, int b_bcast, int mode) {
+        constexpr int bytes = G::LDS_BYTES + G::STAGE_BYTES;
+        set_lds((const void*)k_modmul<G>, bytes);
+        hipLaunchKernelGGL(k_modmul<G>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
     }
     static void modexp_fixed(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32,
                              const uint32_t* expo, int ewords, int ebits, uint32_t* out, int out_w32, int n,
@@ -53,8 +54,9 @@ struct GeoInst {
     }
     static void pow2(hipStream_t s, int grid, const MontCtx* c, uint32_t* ct, const int32_t* delta, int delta_bcast,
                      int n, int w32) {
-        set_lds((const void*)k_pow2<G>, G::LDS_BYTES);
-        hipLaunchKernelGGL(k_pow2<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, ct, delta, delta_bcast, n, w32);
+        constexpr int bytes = G::LDS_BYTES + G::STAGE_BYTES;
+        set_lds((const void*)k_pow2<G>, bytes);
+        hipLaunchKernelGGL(k_pow2<G>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, ct, delta, delta_bcast, n, w32);
     }
     static size_t table_words(size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * G::NL * blocks * G::EPB; }
 

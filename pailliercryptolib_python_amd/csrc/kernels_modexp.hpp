@@ -9,29 +9,59 @@
 namespace pai {
 
 // ---------------------------------------------------------------------------------------------
+// out_i = a_i * b_i mod M on canonical packed rows.  Tiles move HBM <-> LDS with coalesced full-width copies
+// (load_tile / store_tile); the arithmetic is one or two Montgomery products per element:
+//   mode MODMUL_FULL   out = a*b mod M          (a*b*R^-1, then * R^2 * R^-1; b_bcast: b*R is formed once per block,
+//                                               so a broadcast addend costs ONE product per element)
+//   mode MODMUL_MONT   out = a*b*R^-1 mod M     (canonical residue of the Montgomery product: the body of the
+//                                               product trees of pai_ct_invert / pai_ct_prod, which keep track of
+//                                               the power of R per tree level on the host)
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
-k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
-         uint32_t* __restrict__ out, int n, int w32, int b_bcast) {
+k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, int n, int w32, int b_bcast, int mode) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* stage = lds + G::LDS_WORDS + G::NL;        // behind the operand buffer and the modulus copy
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
     const uint32_t n0inv = ctx->n0inv;
     const int tiles = (n + G::EPB - 1) / G::EPB;
+    uint32_t y[G::NLL];
+    if (b_bcast) {                                       // the shared operand, once per block
+        load_tile<G>(stage, b, 1, w32, true);
+        __syncthreads();
+        unpack_row<G>(y, stage);
+        if (mode == MODMUL_FULL) {
+            uint32_t r2[G::NLL];
+            load_const_slice<G>(r2, ctx->r2);
+            mm_times<G>(y, r2, lds, nm, n0inv);          // b*R (lazy, < 2M)
+        }
+        __syncthreads();
+    }
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int ei = tile * G::EPB + G::elem();
-        const bool live = ei < n;
-        const int es = live ? ei : n - 1;                    // idle groups recompute the last element
-        uint32_t x[G::NLL], y[G::NLL];
-        load_elem<G>(x, a + (size_t)es * w32, w32);
-        load_elem<G>(y, b + (size_t)(b_bcast ? 0 : es) * w32, w32);
-        // x*y*R^-1, then * R^2 * R^-1  => x*y mod M
-        mm_times<G>(x, y, lds, nm, n0inv);
-        uint32_t r2[G::NLL];
-        load_const_slice<G>(r2, ctx->r2);
-        mm_times<G>(x, r2, lds, nm, n0inv);
+        const int row0 = tile * G::EPB;
+        const int rows = min(G::EPB, n - row0);
+        uint32_t x[G::NLL];
+        load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
+        __syncthreads();
+        unpack_row<G>(x, stage);
+        if (!b_bcast) {
+            __syncthreads();
+            load_tile<G>(stage, b + (size_t)row0 * w32, rows, w32);
+            __syncthreads();
+            unpack_row<G>(y, stage);
+        }
+        mm_times<G>(x, y, lds, nm, n0inv);               // a*b*R^-1 (a*b when y = b*R)
+        if (mode == MODMUL_FULL && !b_bcast) {
+            uint32_t r2[G::NLL];
+            load_const_slice<G>(r2, ctx->r2);
+            mm_times<G>(x, r2, lds, nm, n0inv);
+        }
         cond_sub<G::NLL, G::T>(x, nm);
-        if (live) store_elem<G>(x, out + (size_t)ei * w32, w32, lds);
+        __syncthreads();                                 // every lane has unpacked its operands
+        pack_row<G>(x, stage, w32, lds);
+        __syncthreads();
+        store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
+        __syncthreads();
     }
 }
 

@@ -312,49 +312,59 @@ k_dec_b(DecBParams P, const uint32_t* __restrict__ u_in /*[2][n][u_words]*/, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// ct_i <- ct_i^(2^delta_i) mod n^2 for delta_i > 0; other elements are left untouched.
+// ct_i <- ct_i^(2^delta_i) mod n^2 for delta_i > 0; other elements are left untouched.  Tiles move through the
+// staging area (load_tile / store_tile); a tile without any positive delta is skipped by the whole workgroup.
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
-k_pow2(const MontCtx* __restrict__ ctx, uint32_t* __restrict__ ct, const int32_t* __restrict__ delta, int delta_bcast,
+k_pow2(const MontCtx* __restrict__ ctx, uint32_t* ct, const int32_t* __restrict__ delta, int delta_bcast,
        int n, int w32) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* stage = lds + G::LDS_WORDS + G::NL;
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
     const uint32_t n0inv = ctx->n0inv;
     const int tiles = (n + G::EPB - 1) / G::EPB;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int ei = tile * G::EPB + G::elem();
+        const int row0 = tile * G::EPB;
+        const int rows = min(G::EPB, n - row0);
+        const int ei = row0 + G::elem();
         const bool live = ei < n;
-        const int es = live ? ei : n - 1;
-        int dl = live ? delta[delta_bcast ? 0 : es] : 0;
+        int dl = live ? delta[delta_bcast ? 0 : ei] : 0;
         if (dl < 0) dl = 0;
+        if (!__syncthreads_or(dl > 0)) continue;                     // block-uniform; also fences the previous tile's stage use
         int dmax = dl;
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(dmax, off, 64); dmax = o > dmax ? o : dmax; }
-        if (dmax == 0) continue;                                     // wave-uniform
+        load_tile<G>(stage, ct + (size_t)row0 * w32, rows, w32);
+        __syncthreads();
         uint32_t x[G::NLL];
-        {
-            uint32_t r2[G::NLL];
-            load_elem<G>(x, ct + (size_t)es * w32, w32);
-            load_const_slice<G>(r2, ctx->r2);
-            mm_times<G>(x, r2, lds, nm, n0inv);
-        }
+        unpack_row<G>(x, stage);
+        if (dmax > 0) {                                              // wave-uniform
+            {
+                uint32_t r2[G::NLL];
+                load_const_slice<G>(r2, ctx->r2);
+                mm_times<G>(x, r2, lds, nm, n0inv);
+            }
 #pragma unroll 1
-        for (int s = 0; s < dmax; ++s) {
-            uint32_t y[G::NLL];
+            for (int s = 0; s < dmax; ++s) {
+                uint32_t y[G::NLL];
 #pragma unroll
-            for (int j = 0; j < G::NLL; ++j) y[j] = x[j];
-            mm_square<G>(y, lds, nm, n0inv);
-            const bool need = s < dl;
+                for (int j = 0; j < G::NLL; ++j) y[j] = x[j];
+                mm_square<G>(y, lds, nm, n0inv);
+                const bool need = s < dl;
 #pragma unroll
-            for (int j = 0; j < G::NLL; ++j) x[j] = need ? y[j] : x[j];
+                for (int j = 0; j < G::NLL; ++j) x[j] = need ? y[j] : x[j];
+            }
+            {
+                uint32_t one[G::NLL];
+                set_plain_one<G>(one);
+                mm_times<G>(x, one, lds, nm, n0inv);
+                cond_sub<G::NLL, G::T>(x, nm);
+            }
         }
-        {
-            uint32_t one[G::NLL];
-            set_plain_one<G>(one);
-            mm_times<G>(x, one, lds, nm, n0inv);
-            cond_sub<G::NLL, G::T>(x, nm);
-        }
-        if (live && dl > 0) store_elem<G>(x, ct + (size_t)ei * w32, w32, lds);
+        __syncthreads();                                             // every lane has unpacked its row
+        if (dmax > 0) pack_row<G>(x, stage, w32, lds);               // untouched waves leave their staged rows as loaded
+        __syncthreads();
+        store_tile<G>(stage, ct + (size_t)row0 * w32, rows, w32);
     }
 }
 

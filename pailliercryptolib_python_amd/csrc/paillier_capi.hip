@@ -63,18 +63,69 @@ struct DeviceInfo {
     int ncu = 0;
 };
 
-DeviceInfo use_device(int device) {
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
-        throw PaiError(PAI_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
-    if (device < 0 || device >= cnt) throw PaiError(PAI_E_INVALID, "device index out of range");
-    if (hipSetDevice(device) != hipSuccess) throw PaiError(PAI_E_NODEVICE, "hipSetDevice failed");
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) != hipSuccess) throw PaiError(PAI_E_NODEVICE, "hipGetDeviceProperties failed");
-    DeviceInfo d;
-    d.ncu = p.multiProcessorCount;
-    return d;
+// Properties of every visible device, queried once (hipGetDeviceProperties costs ~ms and the hot calls used to
+// pay it every time).
+const std::vector<DeviceInfo>& device_table() {
+    static const std::vector<DeviceInfo> tbl = [] {
+        std::vector<DeviceInfo> t;
+        int cnt = 0;
+        if (hipGetDeviceCount(&cnt) != hipSuccess) cnt = 0;
+        for (int d = 0; d < cnt; ++d) {
+            hipDeviceProp_t p;
+            DeviceInfo di;
+            if (hipGetDeviceProperties(&p, d) == hipSuccess) di.ncu = p.multiProcessorCount;
+            t.push_back(di);
+        }
+        return t;
+    }();
+    return tbl;
 }
+
+// Makes `device` current for the calling thread for the lifetime of the object and restores the previous device
+// afterwards: in a single-process multi-GPU program the caller's current device (which torch reads through
+// hipGetDevice) must not change behind its back.
+struct DeviceScope {
+    int prev = -1;
+    DeviceInfo info;
+    explicit DeviceScope(int device) {
+        const auto& tbl = device_table();
+        if (tbl.empty()) throw PaiError(PAI_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+        if (device < 0 || device >= (int)tbl.size()) throw PaiError(PAI_E_INVALID, "device index out of range");
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device && hipSetDevice(device) != hipSuccess) throw PaiError(PAI_E_NODEVICE, "hipSetDevice failed");
+        info = tbl[device];
+        if (info.ncu <= 0) throw PaiError(PAI_E_NODEVICE, "hipGetDeviceProperties failed");
+    }
+    ~DeviceScope() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+// Orders the operations of one key handle that share its device scratch (window tables, quotient-digit columns)
+// when callers issue them on different streams: the next user on another stream waits for the event the previous
+// user recorded.  Same-stream users are ordered by the stream itself.  Call begin() and end() under the handle's mutex.
+struct ScratchOrder {
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool armed = false;
+    void begin(hipStream_t s) {
+        if (armed && s != last) HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
+    }
+    void end(hipStream_t s) {
+        if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev, s));
+        last = s;
+        armed = true;
+    }
+    void release() {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+        armed = false;
+    }
+};
 
 // grow-only device buffer
 struct DevBuf {
@@ -211,6 +262,7 @@ struct pai_modulus {
     DeviceInfo dev;
     ModSetup ms;
     DevBuf table, expo;
+    ScratchOrder order;
     std::mutex mu;
 };
 
@@ -242,6 +294,15 @@ struct pai_pubkey {
     uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
     mutable DevBuf inv_prod, inv_inv, inv_fail;
+    mutable DevBuf prod_a, prod_b;     // ping-pong levels of pai_ct_prod
+    // Product trees run on single Montgomery products (k_modmul MODMUL_MONT); level k of a tree holds true values
+    // times R^(1 - 2^k).  tree_c[k] = R^(1 - 2^k) mod n^2 brings a node without a partner to its level's form,
+    // tree_fix[L] = R^(2^L) mod n^2 returns the root of an L-level tree to a plain residue (packed rows of ct_words).
+    static constexpr int TREE_LEVELS = 40;
+    uint32_t* d_tree_c = nullptr;
+    uint32_t* d_tree_fix = nullptr;
+    mutable bool fb_ready = false;     // fixed-base tables are built by the first obfuscating call (build_fb_tables)
+    mutable ScratchOrder order;
     mutable std::mutex mu;
     EncParams enc_params() const {
         EncParams P;
@@ -280,12 +341,17 @@ struct pai_privkey {
     int nops[2] = {0, 0};
     int padic_nd = 0;
     DevBuf table, ubuf;
+    ScratchOrder order;
     std::mutex mu;
 };
 
+struct PubkeyDeleter { void operator()(pai_pubkey* p) const; };
+struct PrivkeyDeleter { void operator()(pai_privkey* p) const; };
+struct ModulusDeleter { void operator()(pai_modulus* p) const; };
+
 extern "C" {
 
-int pai_version(void) { return 100; }
+int pai_version(void) { return 200; }
 
 const char* pai_last_error(void) { return g_err.c_str(); }
 
@@ -315,33 +381,33 @@ int pai_profile_last(int index, char* name_out, size_t name_cap, float* ms_out) 
 int pai_malloc(int device, size_t bytes, void** d_ptr) {
     return guarded([&] {
         require(d_ptr != nullptr, "d_ptr is NULL");
-        use_device(device);
+        DeviceScope scope_(device);
         HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 4));
     });
 }
 int pai_free(int device, void* d_ptr) {
     return guarded([&] {
-        use_device(device);
+        DeviceScope scope_(device);
         if (d_ptr) HIP_CHECK(hipFree(d_ptr));
     });
 }
 int pai_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes, void* stream) {
     return guarded([&] {
-        use_device(device);
+        DeviceScope scope_(device);
         HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     });
 }
 int pai_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes, void* stream) {
     return guarded([&] {
-        use_device(device);
+        DeviceScope scope_(device);
         HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     });
 }
 int pai_stream_sync(int device, void* stream) {
     return guarded([&] {
-        use_device(device);
+        DeviceScope scope_(device);
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     });
 }
@@ -350,29 +416,34 @@ int pai_stream_sync(int device, void* stream) {
 int pai_modulus_create(const uint32_t* h_m, int m_words, int device, pai_modulus** out) {
     return guarded([&] {
         require(h_m && out && m_words > 0, "bad arguments");
-        std::unique_ptr<pai_modulus> m(new pai_modulus());
+        std::unique_ptr<pai_modulus, ModulusDeleter> m(new pai_modulus());
         m->device = device;
-        m->dev = use_device(device);
+        DeviceScope scope_(device);
+        m->dev = scope_.info;
         m->ms.init(hbn::from_u32(h_m, (size_t)m_words));
         *out = m.release();
     });
 }
 void pai_modulus_destroy(pai_modulus* m) {
     if (!m) return;
+    int prev_ = -1;
+    (void)hipGetDevice(&prev_);
     (void)hipSetDevice(m->device);
     m->ms.release();
     m->table.release();
     m->expo.release();
+    m->order.release();
     delete m;
+    if (prev_ >= 0) (void)hipSetDevice(prev_);
 }
 int pai_modmul(pai_modulus* m, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N, uint32_t* d_out,
                void* stream) {
     return guarded([&] {
         require(m && d_a && d_b && d_out, "NULL argument");
         if (N == 0) return;
-        use_device(m->device);
+        DeviceScope scope_(m->device);
         const GeoOps* g = m->ms.geo;
-        g->modmul((hipStream_t)stream, grid_for(g, N, m->dev.ncu), m->ms.d_ctx, d_a, d_b, d_out, (int)N, m->ms.w32, b_bcast);
+        g->modmul((hipStream_t)stream, grid_for(g, N, m->dev.ncu), m->ms.d_ctx, d_a, d_b, d_out, (int)N, m->ms.w32, b_bcast, MODMUL_FULL);
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -382,19 +453,21 @@ int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e
         require(m && d_base && h_e && d_out && e_words > 0, "bad arguments");
         if (N == 0) return;
         std::lock_guard<std::mutex> lk(m->mu);
-        use_device(m->device);
+        DeviceScope scope_(m->device);
         const GeoOps* g = m->ms.geo;
         Limbs e = hbn::from_u32(h_e, (size_t)e_words);
         const int ebits = hbn::bitlen(e);
         hipStream_t s = (hipStream_t)stream;
         m->expo.ensure((size_t)e_words * 4);
+        m->order.begin(s);
         HIP_CHECK(hipMemcpyAsync(m->expo.p, h_e, (size_t)e_words * 4, hipMemcpyHostToDevice, s));
         const int grid = grid_for(g, N, m->dev.ncu);
         m->table.ensure(g->table_words((size_t)grid) * 4);
         g->modexp_fixed(s, grid, m->ms.d_ctx, d_base, m->ms.w32, m->expo.as<uint32_t>(), e_words, ebits > 0 ? ebits : 1,
                         d_out, m->ms.w32, (int)N, m->table.as<uint32_t>(), 0);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(s));     // the staged exponent / table are reused by the next call
+        m->order.end(s);
+        HIP_CHECK(hipStreamSynchronize(s));     // h_e is a pageable host buffer owned by the caller
     });
 }
 // window width of the per-element-exponent kernels: table build 2^w - 2 products, then w squarings + 1 product per window
@@ -405,7 +478,7 @@ int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const
     return guarded([&] {
         require(m && d_base && d_e && d_out && e_words > 0 && ebits_max > 0 && ebits_max <= 32 * e_words, "bad arguments");
         if (N == 0) return;
-        use_device(m->device);
+        DeviceScope scope_(m->device);
         const GeoOps* g = m->ms.geo;
         const int grid = grid_for(g, N, m->dev.ncu);
         if (!base_bcast && ebits_max > 8) {
@@ -413,10 +486,11 @@ int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const
             std::lock_guard<std::mutex> lk(m->mu);
             const int wbits = var_window_bits(ebits_max);
             m->table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
+            m->order.begin((hipStream_t)stream);
             g->modexp_var_win((hipStream_t)stream, grid, m->ms.d_ctx, d_base, m->ms.w32, d_e, e_words, ebits_max, e_bcast, d_out,
                               m->ms.w32, (int)N, m->table.as<uint32_t>(), wbits);
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));     // the table is reused by the next call
+            m->order.end((hipStream_t)stream);
             return;
         }
         g->modexp_var((hipStream_t)stream, grid, m->ms.d_ctx, d_base, m->ms.w32, base_bcast ? 31 : 0,
@@ -453,13 +527,143 @@ static std::vector<uint16_t> compile_sliding_schedule(const Limbs& e) {
 }
 
 // ---- public key -----------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+std::vector<uint32_t> pubkey_digits_of(const pai_pubkey* pk, const Limbs& v) {
+    const int pnl = pk->penc_nl;
+    Limbs rem;
+    Limbs quo = hbn::divq(v, pk->n, &rem);
+    std::vector<uint32_t> h(2 * (size_t)pnl, 0);
+    auto ra = hbn::to_r29(rem, pnl), rb = hbn::to_r29(quo, pnl);
+    std::memcpy(h.data(), ra.data(), (size_t)pnl * 4);
+    std::memcpy(h.data() + pnl, rb.data(), (size_t)pnl * 4);
+    return h;
+}
+uint32_t* upload_vec(const std::vector<uint32_t>& h) {
+    uint32_t* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, h.size() * 4));
+    HIP_CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+// Fixed-base tables of the DJN obfuscator hs^r, built by the FIRST call that obfuscates (pai_encrypt with
+// randomness / pai_obfuscate), under pk->mu: a handle that only adds, multiplies or decrypts — every unpickled
+// ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
+void build_fb_tables(const pai_pubkey* cpk) {
+    pai_pubkey* pk = const_cast<pai_pubkey*>(cpk);
+    if (pk->fb_ready || !pk->djn) return;
+    const int nl = pk->msq.nl;
+    const int randbits = pk->randbits;
+    // Fixed-base window width of the lane-group table (built only when the digit engine does not serve this key
+    // size): up to 14 bits within 1/64 of device memory (4096-bit keys: 2.8 GB; k_encrypt 84 -> 61 ms per 65536).
+    size_t mem_free0 = 0, mem_total0 = 0;
+    HIP_CHECK(hipMemGetInfo(&mem_free0, &mem_total0));
+    const double lg_budget = pk->penc_nl ? 256.0 * 1048576.0
+                                         : std::max(256.0 * 1048576.0, std::min((double)mem_total0 / 64.0, (double)mem_free0 / 8.0));
+    int wb = pk->penc_nl ? 12 : 14;
+    while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > lg_budget) --wb;
+    if (const char* env = std::getenv("PAI_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 14) wb = v; }
+    pk->fb_wbits = wb;
+    const int J = (randbits + wb - 1) / wb;
+    const size_t ENT = (size_t)1 << wb;
+    pk->fb_windows = J;
+    if (!pk->penc_nl) {
+        // window bases B_j = hs^(2^(wb j)) on the host, then T[j][d] = B_j^d on the device (lane-group kernels)
+        hbn::Mont32 mt(pk->nsq);
+        std::vector<uint32_t> bases((size_t)J * pk->ct_words, 0);
+        Limbs b = mt.to_mont(pk->hs);
+        for (int j = 0; j < J; ++j) {
+            Limbs plain = mt.from_mont(b);
+            std::memcpy(&bases[(size_t)j * pk->ct_words], plain.data(), plain.size() * 4);
+            for (int s = 0; s < wb; ++s) b = mt.mmul(b, b);
+        }
+        const size_t NE = (size_t)J * ENT;
+        std::vector<uint32_t> expo(NE);
+        for (size_t i = 0; i < NE; ++i) expo[i] = (uint32_t)(i & (ENT - 1));
+        DevBuf d_bases, d_expo;
+        d_bases.ensure(bases.size() * 4);
+        d_expo.ensure(NE * 4);
+        HIP_CHECK(hipMemcpy(d_bases.p, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_expo.p, expo.data(), NE * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc((void**)&pk->d_fb, NE * (size_t)nl * 4));
+        const GeoOps* g = pk->msq.geo;
+        g->modexp_var(nullptr, grid_for(g, NE, pk->dev.ncu), pk->msq.d_ctx, d_bases.as<uint32_t>(), pk->ct_words, wb /* base = i >> wb */,
+                      d_expo.as<uint32_t>(), 1, wb, 0, pk->d_fb, 0, (int)NE, 1 /*keep_mont*/, 1 /*out_raw*/);
+        hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+        d_bases.release();
+        d_expo.release();
+        HIP_CHECK(e1);
+        HIP_CHECK(e2);
+    } else {
+        // digit-form fixed-base table for the base-n digit engine
+        const int pnl = pk->penc_nl;
+        const Limbs Rm = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * pnl), pk->nsq);
+        uint32_t* d_one = pk->d_one_dig;
+        DevBuf d_hs, d_half;
+        {
+            const std::vector<uint32_t> h = pubkey_digits_of(pk, hbn::mulmod(pk->hs, Rm, pk->nsq));
+            d_hs.ensure(h.size() * 4);
+            HIP_CHECK(hipMemcpy(d_hs.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        }
+        // Window width of the digit-form table.  Every window costs one multiplication mod n^2 per
+        // ciphertext, and HBM is plentiful: take the widest even width (<= 20 bits) whose table fits the
+        // budget — 1/32 of the device memory unless PAI_FB_TABLE_MB says otherwise (MI355X, 288 GB:
+        // 9 GB => 2048-bit keys get 18 bits, 57 windows x 262144 entries x 576 B = 8.6 GB; measured
+        // k_encrypt per 2^20: 109 / 95 / 84 / 75 / 70 ms at 12 / 14 / 16 / 18 / 20 bits).
+        // PAI_FB_DIGIT_WBITS pins the width (<= 12, or an even value up to 20).
+        const size_t ent_bytes = 2 * (size_t)pnl * 4;
+        auto table_bytes = [&](int w) { return (double)((randbits + w - 1) / w) * (double)((size_t)1 << w) * (double)ent_bytes; };
+        size_t mem_free = 0, mem_total = 0;
+        HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
+        double budget = std::min((double)mem_total / 32.0, (double)mem_free / 4.0);   // never more than a quarter of what is free
+        if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) budget = v * 1048576.0; }
+        int dwb = wb;
+        for (int cand = 20; cand > 12; cand -= 2)
+            if (table_bytes(cand) <= budget) { dwb = cand; break; }
+        if (const char* env = std::getenv("PAI_FB_DIGIT_WBITS")) {
+            int v = std::atoi(env);
+            if ((v >= 4 && v <= 12) || (v > 12 && v <= 20 && v % 2 == 0)) dwb = v;
+        }
+        const int DJ = (randbits + dwb - 1) / dwb;
+        pk->fbd_wbits = dwb;
+        pk->fbd_windows = DJ;
+        HIP_CHECK(hipMalloc((void**)&pk->d_fb_dig, ((size_t)DJ << dwb) * ent_bytes));
+        bool ok = true;
+        if (dwb <= 12) {
+            ok = launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs.as<uint32_t>(), d_one, pk->d_fb_dig, DJ, dwb);
+        } else {
+            // two levels: half-width windows at twice the density (sequential chains of 2^h entries), then
+            // one parallel pass of DJ * 2^dwb independent products
+            const int h = dwb / 2;
+            d_half.ensure(((size_t)(2 * DJ) << h) * ent_bytes);
+            ok = launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs.as<uint32_t>(), d_one, d_half.as<uint32_t>(), 2 * DJ, h) &&
+                 launch_fb_expand_padic(pnl, nullptr, pk->dev.ncu, pk->nmod.d_ctx, pk->d_nm1, d_half.as<uint32_t>(), pk->d_fb_dig, DJ, h,
+                                        pk->d_mscratch);
+        }
+        hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+        d_hs.release();
+        d_half.release();
+        if (!ok) throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
+        HIP_CHECK(e1);
+        HIP_CHECK(e2);
+    }
+    pk->fb_ready = true;
+}
+
+}  // namespace
+
+extern "C" {
+
 int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint32_t* h_hs, int hs_words,
                       int randbits, int device, pai_pubkey** out) {
     return guarded([&] {
         require(h_n && out && n_words > 0 && key_bits > 0, "bad arguments");
-        std::unique_ptr<pai_pubkey> pk(new pai_pubkey());
+        DeviceScope scope_(device);
+        std::unique_ptr<pai_pubkey, PubkeyDeleter> pk(new pai_pubkey());     // frees device memory if set-up throws midway
         pk->device = device;
-        pk->dev = use_device(device);
+        pk->dev = scope_.info;
         pk->n = hbn::from_u32(h_n, (size_t)n_words);
         require(hbn::is_odd(pk->n) && hbn::bitlen(pk->n) > 16, "n must be an odd integer of more than 16 bits");
         require(hbn::bitlen(pk->n) <= key_bits, "n is wider than key_bits");
@@ -472,42 +676,44 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         pk->d_nR = upload_r29(hbn::mulmod(pk->n, pk->msq.R, pk->nsq), nl);
         pk->d_nexp = upload_words(pk->n, pk->n_words);
         pk->d_nsq_words = upload_words(pk->nsq, pk->ct_words);
+        {   // per-level constants of the single-product trees (see pai_pubkey::d_tree_c)
+            const int K = pai_pubkey::TREE_LEVELS;
+            const size_t W = (size_t)pk->ct_words;
+            std::vector<uint32_t> hc((size_t)K * W, 0), hf((size_t)K * W, 0);
+            const Limbs one{1u};
+            Limbs inv2 = hbn::shr(hbn::add(pk->nsq, one), 1);                 // 2^-1 mod n^2
+            hbn::Mont32 mt(pk->nsq);
+            Limbs rinv = mt.powmod(inv2, hbn::from_u64((uint64_t)hbn::RB * (uint64_t)nl));
+            require(hbn::cmp(hbn::mulmod(rinv, pk->msq.R, pk->nsq), one) == 0, "R^-1 check failed");
+            Limbs c = one, f = pk->msq.R;                                     // R^(1 - 2^0) = 1, R^(2^0) = R
+            for (int k = 0; k < K; ++k) {
+                std::memcpy(&hc[(size_t)k * W], c.data(), c.size() * 4);
+                std::memcpy(&hf[(size_t)k * W], f.data(), f.size() * 4);
+                c = hbn::mulmod(hbn::mulmod(c, c, pk->nsq), rinv, pk->nsq);   // 1 - 2^(k+1) = 2 (1 - 2^k) - 1
+                f = hbn::mulmod(f, f, pk->nsq);
+            }
+            pk->d_tree_c = upload_vec(hc);
+            pk->d_tree_fix = upload_vec(hf);
+        }
         // ---- base-n digit engine (kernels_padic_enc.hpp): raw / DJN encryption and ct * pt run on it when n fits 72
         // limbs (PAI_DISABLE_PADIC=1 falls back to the lane-group kernels, which serve every other key size)
         pk->penc_nl = padic_enc_nl_for_n_bits(hbn::bitlen(pk->n));
         if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') pk->penc_nl = 0; }
-        Limbs Rm;
-        auto digits_of = [&](const Limbs& v) {
-            const int pnl = pk->penc_nl;
-            Limbs rem;
-            Limbs quo = hbn::divq(v, pk->n, &rem);
-            std::vector<uint32_t> h(2 * (size_t)pnl, 0);
-            auto ra = hbn::to_r29(rem, pnl), rb = hbn::to_r29(quo, pnl);
-            std::memcpy(h.data(), ra.data(), (size_t)pnl * 4);
-            std::memcpy(h.data() + pnl, rb.data(), (size_t)pnl * 4);
-            return h;
-        };
-        auto upload_vec = [&](const std::vector<uint32_t>& h) {
-            uint32_t* d = nullptr;
-            HIP_CHECK(hipMalloc((void**)&d, h.size() * 4));
-            HIP_CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-            return d;
-        };
         if (pk->penc_nl) {
             const int pnl = pk->penc_nl;
             pk->nmod.init(pk->n, pnl);
             const Limbs one{1u};
             pk->d_nm1 = upload_r29(hbn::sub(pk->n, one), pnl);
             pk->d_nsq29 = upload_r29(pk->nsq, 2 * pnl);
-            Rm = hbn::mod(hbn::shl(one, hbn::RB * pnl), pk->nsq);
-            pk->d_one_dig = upload_vec(digits_of(Rm));
+            const Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * pnl), pk->nsq);
+            pk->d_one_dig = upload_vec(pubkey_digits_of(pk.get(), Rm));
             HIP_CHECK(hipMalloc((void**)&pk->d_mscratch, 2 * (size_t)pk->dev.ncu * BLOCK_THREADS * (size_t)pnl * 4));
             // digit pairs of R^(i+2) mod n^2: a ciphertext enters digit form through its base-R digits (as in stage A)
             pk->ct_nd = (32 * pk->ct_words + hbn::RB * pnl - 1) / (hbn::RB * pnl);
             std::vector<uint32_t> kd;
             Limbs K = hbn::mulmod(Rm, Rm, pk->nsq);
             for (int i = 0; i < pk->ct_nd; ++i) {
-                auto h = digits_of(K);
+                auto h = pubkey_digits_of(pk.get(), K);
                 kd.insert(kd.end(), h.begin(), h.end());
                 K = hbn::mulmod(K, Rm, pk->nsq);
             }
@@ -515,102 +721,12 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         }
         if (h_hs) {
             require(hs_words > 0 && randbits > 0, "DJN key needs hs and randbits");
-            // Fixed-base window width of the lane-group table (built only when the digit engine does not serve this key
-            // size, i.e. 1024/3072/4096-bit keys): up to 14 bits within 1/64 of device memory (4096-bit keys: 2.8 GB;
-            // k_encrypt 84 -> 61 ms per 65536).
-            size_t mem_free0 = 0, mem_total0 = 0;
-            HIP_CHECK(hipMemGetInfo(&mem_free0, &mem_total0));
-            const double lg_budget = pk->penc_nl ? 256.0 * 1048576.0
-                                                 : std::max(256.0 * 1048576.0, std::min((double)mem_total0 / 64.0, (double)mem_free0 / 8.0));
-            int wb = pk->penc_nl ? 12 : 14;
-            while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > lg_budget) --wb;
-            if (const char* env = std::getenv("PAI_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 14) wb = v; }
-            pk->fb_wbits = wb;
             pk->djn = true;
             pk->hs = hbn::from_u32(h_hs, (size_t)hs_words);
             require(hbn::cmp(pk->hs, pk->nsq) < 0 && !hbn::is_zero(pk->hs), "hs must lie in (0, n^2)");
             pk->randbits = randbits;
             pk->r_words = words_for_bits(randbits);
-            const int J = (randbits + wb - 1) / wb;
-            const size_t ENT = (size_t)1 << wb;
-            pk->fb_windows = J;
-            // window bases B_j = hs^(2^(8 j)) on the host, then T[j][d] = B_j^d on the device — only when the lane-group
-            // kernel is the one that encrypts (the digit engine has its own table below)
-            if (!pk->penc_nl) {
-            hbn::Mont32 mt(pk->nsq);
-            std::vector<uint32_t> bases((size_t)J * pk->ct_words, 0);
-            Limbs b = mt.to_mont(pk->hs);
-            for (int j = 0; j < J; ++j) {
-                Limbs plain = mt.from_mont(b);
-                std::memcpy(&bases[(size_t)j * pk->ct_words], plain.data(), plain.size() * 4);
-                for (int s = 0; s < wb; ++s) b = mt.mmul(b, b);
-            }
-            const size_t NE = (size_t)J * ENT;
-            std::vector<uint32_t> expo(NE);
-            for (size_t i = 0; i < NE; ++i) expo[i] = (uint32_t)(i & (ENT - 1));
-            uint32_t *d_bases = nullptr, *d_expo = nullptr;
-            HIP_CHECK(hipMalloc((void**)&d_bases, bases.size() * 4));
-            HIP_CHECK(hipMalloc((void**)&d_expo, NE * 4));
-            HIP_CHECK(hipMemcpy(d_bases, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy(d_expo, expo.data(), NE * 4, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMalloc((void**)&pk->d_fb, NE * (size_t)nl * 4));
-            const GeoOps* g = pk->msq.geo;
-            g->modexp_var(nullptr, grid_for(g, NE, pk->dev.ncu), pk->msq.d_ctx, d_bases, pk->ct_words, wb /* base = i >> wb */,
-                          d_expo, 1, wb, 0, pk->d_fb, 0, (int)NE, 1 /*keep_mont*/, 1 /*out_raw*/);
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipDeviceSynchronize());
-            HIP_CHECK(hipFree(d_bases));
-            HIP_CHECK(hipFree(d_expo));
-            }
-            // digit-form fixed-base table for the base-n digit engine
-            if (pk->penc_nl) {
-                const int pnl = pk->penc_nl;
-                uint32_t* d_one = pk->d_one_dig;
-                uint32_t* d_hs = upload_vec(digits_of(hbn::mulmod(pk->hs, Rm, pk->nsq)));
-                // Window width of the digit-form table.  Every window costs one multiplication mod n^2 per
-                // ciphertext, and HBM is plentiful: take the widest even width (<= 20 bits) whose table fits the
-                // budget — 1/32 of the device memory unless PAI_FB_TABLE_MB says otherwise (MI355X, 288 GB:
-                // 9 GB => 2048-bit keys get 18 bits, 57 windows x 262144 entries x 576 B = 8.6 GB; measured
-                // k_encrypt per 2^20: 109 / 95 / 84 / 75 / 70 ms at 12 / 14 / 16 / 18 / 20 bits).
-                // PAI_FB_DIGIT_WBITS pins the width (<= 12, or an even value up to 20).
-                const size_t ent_bytes = 2 * (size_t)pnl * 4;
-                auto table_bytes = [&](int w) { return (double)((randbits + w - 1) / w) * (double)((size_t)1 << w) * (double)ent_bytes; };
-                size_t mem_free = 0, mem_total = 0;
-                HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
-                double budget = std::min((double)mem_total / 32.0, (double)mem_free / 4.0);   // never more than a quarter of what is free
-                if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) budget = v * 1048576.0; }
-                int dwb = wb;
-                for (int cand = 20; cand > 12; cand -= 2)
-                    if (table_bytes(cand) <= budget) { dwb = cand; break; }
-                if (const char* env = std::getenv("PAI_FB_DIGIT_WBITS")) {
-                    int v = std::atoi(env);
-                    if ((v >= 4 && v <= 12) || (v > 12 && v <= 20 && v % 2 == 0)) dwb = v;
-                }
-                const int DJ = (randbits + dwb - 1) / dwb;
-                pk->fbd_wbits = dwb;
-                pk->fbd_windows = DJ;
-                HIP_CHECK(hipMalloc((void**)&pk->d_fb_dig, ((size_t)DJ << dwb) * ent_bytes));
-                if (dwb <= 12) {
-                    if (!launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs, d_one, pk->d_fb_dig, DJ, dwb))
-                        throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
-                } else {
-                    // two levels: half-width windows at twice the density (sequential chains of 2^h entries), then
-                    // one parallel pass of DJ * 2^dwb independent products
-                    const int h = dwb / 2;
-                    uint32_t* d_half = nullptr;
-                    HIP_CHECK(hipMalloc((void**)&d_half, ((size_t)(2 * DJ) << h) * ent_bytes));
-                    if (!launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs, d_one, d_half, 2 * DJ, h) ||
-                        !launch_fb_expand_padic(pnl, nullptr, pk->dev.ncu, pk->nmod.d_ctx, pk->d_nm1, d_half, pk->d_fb_dig, DJ, h,
-                                                pk->d_mscratch))
-                        throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
-                    HIP_CHECK(hipGetLastError());
-                    HIP_CHECK(hipDeviceSynchronize());
-                    HIP_CHECK(hipFree(d_half));
-                }
-                HIP_CHECK(hipGetLastError());
-                HIP_CHECK(hipDeviceSynchronize());
-                HIP_CHECK(hipFree(d_hs));
-            }
+            // the fixed-base tables for hs are built by the first obfuscating call (build_fb_tables)
         } else {
             pk->djn = false;
             pk->randbits = 0;
@@ -628,6 +744,8 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
 
 void pai_pubkey_destroy(pai_pubkey* pk) {
     if (!pk) return;
+    int prev_ = -1;
+    (void)hipGetDevice(&prev_);
     (void)hipSetDevice(pk->device);
     pk->msq.release();
     if (pk->d_nR) (void)hipFree(pk->d_nR);
@@ -643,12 +761,18 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_pow_ops) (void)hipFree(pk->d_pow_ops);
     pk->ctmul_table.release();
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
+    if (pk->d_tree_c) (void)hipFree(pk->d_tree_c);
+    if (pk->d_tree_fix) (void)hipFree(pk->d_tree_fix);
+    pk->prod_a.release();
+    pk->prod_b.release();
+    pk->order.release();
     pk->inv_prod.release();
     pk->inv_inv.release();
     pk->inv_fail.release();
     pk->table.release();
     pk->tmp.release();
     delete pk;
+    if (prev_ >= 0) (void)hipSetDevice(prev_);
 }
 
 int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_words, int* r_words, int* randbits,
@@ -667,12 +791,17 @@ int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_w
 
 static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint32_t* d_r, const uint32_t* d_ct_in,
                            uint32_t* d_ct_out, size_t N, void* stream, bool from_plain) {
-    use_device(pk->device);
+    DeviceScope scope_(pk->device);
     const GeoOps* g = pk->msq.geo;
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for(g, N, pk->dev.ncu);
-    EncParams P = pk->enc_params();
     g_last_times.clear();
+    // every path below shares per-key device scratch (quotient-digit columns, window tables): one at a time per
+    // handle, ordered across streams by pk->order
+    std::lock_guard<std::mutex> lk(pk->mu);
+    if (d_r && pk->djn) build_fb_tables(pk);
+    EncParams P = pk->enc_params();
+    pk->order.begin(s);
     if (pk->penc_nl && ((from_plain && (d_r == nullptr || pk->djn)) || (!from_plain && d_r && pk->djn))) {
         // raw / DJN encryption on the base-n digit engine: one workgroup per CU
         EncPadicParams Q;
@@ -705,7 +834,6 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         t.stop();
     } else {
         // standard scheme: obf_i = r_i^n mod n^2 (uniform exponent), then one fused multiply
-        std::lock_guard<std::mutex> lk(pk->mu);
         pk->tmp.ensure(N * (size_t)pk->ct_words * 4);
         if (pk->penc_nl && pk->d_pow_ops) {
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
@@ -733,10 +861,9 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
                             pk->tmp.as<uint32_t>(), pk->ct_words, (int)N, pk->table.as<uint32_t>(), 0);
         }
         g->encrypt(s, grid, P, d_m, pk->tmp.as<uint32_t>(), d_ct_in, d_ct_out, (int)N, from_plain ? 3 : 4);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(s));     // scratch is shared between calls
     }
     HIP_CHECK(hipGetLastError());
+    pk->order.end(s);
 }
 
 // ---- data formats either side of the path (kernels_codec.hpp) ---------------------------------------------
@@ -745,7 +872,7 @@ int pai_fp_encode_f64(const pai_pubkey* pk, const double* d_x, size_t N, uint32_
         require(pk && d_x && d_m && d_expo, "NULL argument");
         require(hbn::bitlen(pk->n) > 66, "device encode needs a modulus of more than 66 bits");
         if (N == 0) return;
-        use_device(pk->device);
+        DeviceScope scope_(pk->device);
         hipLaunchKernelGGL(k_fp_encode_f64, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, pk->d_nexp,
                            pk->n_words, d_m, d_expo, N);
         HIP_CHECK(hipGetLastError());
@@ -757,7 +884,7 @@ int pai_fp_encode_i64(const pai_pubkey* pk, const int64_t* d_x, size_t N, uint32
         require(pk && d_x && d_m && d_expo, "NULL argument");
         require(hbn::bitlen(pk->n) > 66, "device encode needs a modulus of more than 66 bits");
         if (N == 0) return;
-        use_device(pk->device);
+        DeviceScope scope_(pk->device);
         hipLaunchKernelGGL(k_fp_encode_i64, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, pk->d_nexp,
                            pk->n_words, d_m, d_expo, N);
         HIP_CHECK(hipGetLastError());
@@ -769,7 +896,7 @@ int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64
         require(pk && d_m && d_mant && d_flag, "NULL argument");
         require(hbn::bitlen(pk->n) > 66, "device decode needs a modulus of more than 66 bits");
         if (N == 0) return;
-        use_device(pk->device);
+        DeviceScope scope_(pk->device);
         hipLaunchKernelGGL(k_fp_decode_i64, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_m, pk->d_nexp,
                            pk->n_words, d_mant, d_flag, N);
         HIP_CHECK(hipGetLastError());
@@ -782,7 +909,7 @@ int pai_draw_r(const pai_pubkey* pk, const uint32_t* h_key8, const uint32_t* h_n
         require(pk && h_key8 && h_nonce3 && d_r, "NULL argument");
         require(pk->djn, "pai_draw_r serves DJN keys (r < 2^randbits); the standard scheme draws r in [1, n) on the host");
         if (N == 0) return;
-        use_device(pk->device);
+        DeviceScope scope_(pk->device);
         ChaChaKey K;
         std::memcpy(K.k, h_key8, 32);
         std::memcpy(K.nonce, h_nonce3, 12);
@@ -825,9 +952,13 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
     return guarded([&] {
         require(pk && d_a && d_b && d_out, "NULL argument");
         if (N == 0) return;
-        use_device(pk->device);
+        DeviceScope scope_(pk->device);
         const GeoOps* g = pk->msq.geo;
-        g->modmul((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast);
+        g_last_times.clear();
+        ScopedKernelTimer t("k_modmul", (hipStream_t)stream);
+        g->modmul((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
+                  MODMUL_FULL);
+        t.stop();
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -838,7 +969,8 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         require(pk && d_ct && d_e && d_out, "NULL argument");
         require(e_words > 0 && ebits_max > 0 && ebits_max <= 32 * e_words, "bad exponent shape");
         if (N == 0) return;
-        use_device(pk->device);
+        DeviceScope scope_(pk->device);
+        hipStream_t s = (hipStream_t)stream;
         g_last_times.clear();
         if (pk->penc_nl) {
             // base-n digit engine: fixed windows sized to the exponent width (table build 2^w - 2 products, then
@@ -862,11 +994,13 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
             Q.e_words = e_words;
             Q.ebits_max = ebits_max;
             Q.e_bcast = e_bcast;
-            ScopedKernelTimer t("k_ctmul", (hipStream_t)stream);
-            if (!launch_ctmul_padic(pk->penc_nl, (hipStream_t)stream, grid, Q, d_ct, d_e, d_out, (int)N))
+            pk->order.begin(s);
+            ScopedKernelTimer t("k_ctmul", s);
+            if (!launch_ctmul_padic(pk->penc_nl, s, grid, Q, d_ct, d_e, d_out, (int)N))
                 throw PaiError(PAI_E_INTERNAL, "no digit-engine ct*pt kernel for this limb count");
             t.stop();
             HIP_CHECK(hipGetLastError());
+            pk->order.end(s);
             return;
         }
         const GeoOps* g = pk->msq.geo;
@@ -875,14 +1009,16 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
             std::lock_guard<std::mutex> lk(pk->mu);
             const int wbits = var_window_bits(ebits_max);
             pk->ctmul_table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
-            ScopedKernelTimer t("k_ctmul", (hipStream_t)stream);
-            g->modexp_var_win((hipStream_t)stream, grid, pk->msq.d_ctx, d_ct, pk->ct_words, d_e, e_words, ebits_max, e_bcast, d_out,
+            pk->order.begin(s);
+            ScopedKernelTimer t("k_ctmul", s);
+            g->modexp_var_win(s, grid, pk->msq.d_ctx, d_ct, pk->ct_words, d_e, e_words, ebits_max, e_bcast, d_out,
                               pk->ct_words, (int)N, pk->ctmul_table.as<uint32_t>(), wbits);
             t.stop();
             HIP_CHECK(hipGetLastError());
+            pk->order.end(s);
             return;
         }
-        g->modexp_var((hipStream_t)stream, grid, pk->msq.d_ctx, d_ct, pk->ct_words, 0, d_e, e_words,
+        g->modexp_var(s, grid, pk->msq.d_ctx, d_ct, pk->ct_words, 0, d_e, e_words,
                       ebits_max, e_bcast, d_out, pk->ct_words, (int)N, 0, 0);
         HIP_CHECK(hipGetLastError());
     });
@@ -893,10 +1029,62 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
     return guarded([&] {
         require(pk && d_ct && d_delta, "NULL argument");
         if (N == 0) return;
-        use_device(pk->device);
+        DeviceScope scope_(pk->device);
         const GeoOps* g = pk->msq.geo;
+        g_last_times.clear();
+        ScopedKernelTimer t("k_pow2", (hipStream_t)stream);
         g->pow2((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words);
+        t.stop();
         HIP_CHECK(hipGetLastError());
+    });
+}
+
+// one level of a product tree on single Montgomery products: out[i] = a[i] * b[i] * R^-1 mod n^2
+static void tree_mul(const pai_pubkey* pk, hipStream_t s, const uint32_t* a, const uint32_t* b, int b_bcast, uint32_t* out, size_t n) {
+    if (n == 0) return;
+    const GeoOps* g = pk->msq.geo;
+    g->modmul(s, grid_for(g, n, pk->dev.ncu), pk->msq.d_ctx, a, b, out, (int)n, pk->ct_words, b_bcast, MODMUL_MONT);
+    HIP_CHECK(hipGetLastError());
+}
+
+int pai_ct_prod(const pai_pubkey* pk, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && d_ct && d_out, "NULL argument");
+        require(groups > 0 && count >= groups && count % groups == 0, "count must be a positive multiple of groups");
+        std::lock_guard<std::mutex> lk(pk->mu);
+        DeviceScope scope_(pk->device);
+        hipStream_t s = (hipStream_t)stream;
+        const size_t W = (size_t)pk->ct_words, ROW = W * 4;
+        size_t members = count / groups;
+        if (members == 1) {
+            if (d_out != d_ct) HIP_CHECK(hipMemcpyAsync(d_out, d_ct, count * ROW, hipMemcpyDeviceToDevice, s));
+            return;
+        }
+        // Product over halves, member-major rows [member][group]: level k + 1 has h = ceil(members / 2) members,
+        // P[i] = X[i] * X[i + h] for i < members - h (one k_modmul launch over (members - h) * groups contiguous rows);
+        // a member without a partner is multiplied by tree_c[k] so that the whole level shares the form R^(1 - 2^(k+1)).
+        const size_t h0 = (members + 1) / 2;
+        pk->prod_a.ensure(h0 * groups * ROW);
+        pk->prod_b.ensure(((h0 + 1) / 2) * groups * ROW);
+        pk->order.begin(s);
+        g_last_times.clear();
+        ScopedKernelTimer t("k_modmul(tree)", s);
+        const uint32_t* src = d_ct;
+        uint32_t* bufs[2] = {pk->prod_a.as<uint32_t>(), pk->prod_b.as<uint32_t>()};
+        int level = 0;
+        while (members > 1) {
+            require(level < pai_pubkey::TREE_LEVELS, "ct_prod: too many levels");
+            const size_t h = (members + 1) / 2, lo = members - h;
+            uint32_t* dst = bufs[level & 1];
+            tree_mul(pk, s, src, src + h * groups * W, 0, dst, lo * groups);
+            if (lo < h) tree_mul(pk, s, src + lo * groups * W, pk->d_tree_c + (size_t)level * W, 1, dst + lo * groups * W, groups);
+            src = dst;
+            members = h;
+            ++level;
+        }
+        tree_mul(pk, s, src, pk->d_tree_fix + (size_t)level * W, 1, d_out, groups);     // R^(1 - 2^L) * R^(2^L) * R^-1 = 1
+        t.stop();
+        pk->order.end(s);
     });
 }
 
@@ -905,12 +1093,15 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
         require(pk && d_ct && d_out, "NULL argument");
         if (N == 0) return;
         std::lock_guard<std::mutex> lk(pk->mu);
-        use_device(pk->device);
-        const GeoOps* g = pk->msq.geo;
+        DeviceScope scope_(pk->device);
         hipStream_t s = (hipStream_t)stream;
         const size_t W = (size_t)pk->ct_words, ROW = W * 4;
         // product tree over halves (kernels_invert.hpp): level k + 1 has ceil(count_k / 2) products; the tree stops
-        // at <= `top` values, each inverted by one wave's extended GCD
+        // at <= `top` values, each inverted by one wave's extended GCD.  Every tree product is ONE Montgomery
+        // product: level k holds (true value) * R^(1 - 2^k) on the way up (a value without a partner is brought to
+        // its level's form by the constant tree_c[k]); the extended GCD inverts the stored top values, and on the
+        // way down level k holds (true inverse) * R^(2^k - 1) — the powers of R telescope, so the leaves come out as
+        // plain canonical inverses.
         size_t top = 64;
         if (const char* env = std::getenv("PAI_INVERT_CHUNK")) {     // test hook: where the tree stops
             int k = std::atoi(env);
@@ -919,6 +1110,7 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
         std::vector<size_t> cnt{N};
         while (cnt.back() > top) cnt.push_back((cnt.back() + 1) / 2);
         const int L = (int)cnt.size() - 1;
+        require(L < pai_pubkey::TREE_LEVELS, "ct_invert: too many levels");
         size_t upper = 0;                                              // rows of all levels above the leaves
         std::vector<size_t> off(L + 1, 0);
         for (int k = 1; k <= L; ++k) { off[k] = upper; upper += cnt[k]; }
@@ -926,6 +1118,7 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
         pk->inv_prod.ensure(std::max<size_t>(1, upper + (alias ? N : 0)) * ROW);
         pk->inv_inv.ensure(std::max<size_t>(1, upper + (L == 0 ? N : 0)) * ROW);
         pk->inv_fail.ensure(4);
+        pk->order.begin(s);
         HIP_CHECK(hipMemsetAsync(pk->inv_fail.p, 0, 4, s));
         uint32_t* prod = pk->inv_prod.as<uint32_t>();
         uint32_t* inv = pk->inv_inv.as<uint32_t>();
@@ -936,17 +1129,15 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
             leaves = copy;
         }
         auto level = [&](int k) -> const uint32_t* { return k == 0 ? leaves : prod + off[k] * W; };
-        auto mul = [&](const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
-            if (n == 0) return;
-            g->modmul(s, grid_for(g, n, pk->dev.ncu), pk->msq.d_ctx, a, b, out, (int)n, (int)W, 0);
-            HIP_CHECK(hipGetLastError());
-        };
+        auto tree_c = [&](int k) -> const uint32_t* { return pk->d_tree_c + (size_t)k * W; };
+        g_last_times.clear();
+        ScopedKernelTimer t("k_invert", s);
         for (int k = 0; k < L; ++k) {                                   // up
             const size_t h = cnt[k + 1], lo = cnt[k] - h;
             const uint32_t* src = level(k);
             uint32_t* dst = prod + off[k + 1] * W;
-            mul(src, src + h * W, dst, lo);
-            if (lo < h) HIP_CHECK(hipMemcpyAsync(dst + lo * W, src + lo * W, ROW, hipMemcpyDeviceToDevice, s));
+            tree_mul(pk, s, src, src + h * W, 0, dst, lo);
+            if (lo < h) tree_mul(pk, s, src + lo * W, tree_c(k), 1, dst + lo * W, 1);
         }
         uint32_t* top_out = (L == 0) ? d_out : inv + off[L] * W;
         if (L == 0 && alias) top_out = inv;                             // in-place single level: stage, then copy back
@@ -959,12 +1150,14 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
             const uint32_t* src = level(k);
             const uint32_t* pinv = inv + off[k + 1] * W;
             uint32_t* dst = (k == 0) ? d_out : inv + off[k] * W;
-            mul(pinv, src + h * W, dst, lo);                            // a[i]^-1     = P[i]^-1 a[i + h]
-            mul(pinv, src, dst + h * W, lo);                            // a[i + h]^-1 = P[i]^-1 a[i]
-            if (lo < h) HIP_CHECK(hipMemcpyAsync(dst + lo * W, pinv + lo * W, ROW, hipMemcpyDeviceToDevice, s));
+            tree_mul(pk, s, pinv, src + h * W, 0, dst, lo);             // a[i]^-1     = P[i]^-1 a[i + h]
+            tree_mul(pk, s, pinv, src, 0, dst + h * W, lo);             // a[i + h]^-1 = P[i]^-1 a[i]
+            if (lo < h) tree_mul(pk, s, pinv + lo * W, tree_c(k), 1, dst + lo * W, 1);
         }
+        t.stop();
         int fail = 0;
         HIP_CHECK(hipMemcpyAsync(&fail, pk->inv_fail.p, 4, hipMemcpyDeviceToHost, s));
+        pk->order.end(s);
         HIP_CHECK(hipStreamSynchronize(s));
         if (fail) throw PaiError(PAI_E_INVALID, "ct_invert: a ciphertext is not invertible modulo n^2");
     });
@@ -975,8 +1168,8 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
                        pai_privkey** out) {
     return guarded([&] {
         require(pk && h_p && h_q && out && p_words > 0 && q_words > 0, "bad arguments");
-        std::unique_ptr<pai_privkey> sk(new pai_privkey());
-        use_device(pk->device);
+        std::unique_ptr<pai_privkey, PrivkeyDeleter> sk(new pai_privkey());
+        DeviceScope scope_(pk->device);
         sk->pk = pk;
         Limbs p = hbn::from_u32(h_p, (size_t)p_words), q = hbn::from_u32(h_q, (size_t)q_words);
         if (hbn::cmp(p, q) > 0) std::swap(p, q);            // upstream keeps p < q
@@ -1066,6 +1259,8 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
 
 void pai_privkey_destroy(pai_privkey* sk) {
     if (!sk) return;
+    int prev_ = -1;
+    (void)hipGetDevice(&prev_);
     (void)hipSetDevice(sk->pk ? sk->pk->device : 0);
     for (int w = 0; w < 2; ++w) {
         sk->sq[w].release();
@@ -1084,7 +1279,9 @@ void pai_privkey_destroy(pai_privkey* sk) {
     sk->table.release();
     sk->wscratch.release();
     sk->ubuf.release();
+    sk->order.release();
     delete sk;
+    if (prev_ >= 0) (void)hipSetDevice(prev_);
 }
 
 int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream) {
@@ -1093,7 +1290,8 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         if (N == 0) return;
         std::lock_guard<std::mutex> lk(sk->mu);
         const pai_pubkey* pk = sk->pk;
-        DeviceInfo dev = use_device(pk->device);
+        DeviceScope scope_(pk->device);
+        DeviceInfo dev = scope_.info;
         hipStream_t s = (hipStream_t)stream;
         const GeoOps* ga = sk->sq[0].geo;
         const GeoOps* gb = sk->pr[0].geo;
@@ -1112,6 +1310,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
             sk->table.ensure(ga->table_words((size_t)gridx * 2) * 4);
         }
         sk->ubuf.ensure(2 * N * (size_t)sk->u_words * 4);
+        sk->order.begin(s);
         DecAParams A;
         for (int w = 0; w < 2; ++w) {
             A.sq[w] = sk->sq[w].d_ctx;
@@ -1167,8 +1366,60 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
             t.stop();
         }
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(s));     // table / u scratch are reused by the next call
+        sk->order.end(s);                       // table / u scratch are reused by the next call: ordered by stream or event
     });
 }
 
+// ---- multi-GPU helpers (one node) -------------------------------------------------------------------
+int pai_shard_plan(size_t N, int nshards, int shard, size_t* begin, size_t* count) {
+    return guarded([&] {
+        require(nshards > 0 && shard >= 0 && shard < nshards && begin && count, "bad arguments");
+        const size_t per = (N + (size_t)nshards - 1) / (size_t)nshards;
+        const size_t b = std::min(N, (size_t)shard * per), e = std::min(N, ((size_t)shard + 1) * per);
+        *begin = b;
+        *count = e - b;
+    });
+}
+
+static void peer_copy_all(int nshards, const int* devices, void* const* d_shards, const size_t* rows, int row_words, int hub_device,
+                          void* d_hub, bool to_hub) {
+    require(nshards > 0 && devices && d_shards && rows && d_hub && row_words > 0, "bad arguments");
+    const size_t ROW = (size_t)row_words * 4;
+    size_t off = 0;
+    for (int i = 0; i < nshards; ++i) {           // one copy per shard on the null stream of the shard's device: they overlap
+        const size_t bytes = rows[i] * ROW;
+        if (bytes) {
+            require(d_shards[i] != nullptr, "NULL shard");
+            DeviceScope scope_(devices[i]);
+            char* hub = static_cast<char*>(d_hub) + off;
+            if (devices[i] == hub_device) {
+                HIP_CHECK(hipMemcpyAsync(to_hub ? (void*)hub : d_shards[i], to_hub ? d_shards[i] : (void*)hub, bytes, hipMemcpyDeviceToDevice, nullptr));
+            } else if (to_hub) {
+                HIP_CHECK(hipMemcpyPeerAsync(hub, hub_device, d_shards[i], devices[i], bytes, nullptr));
+            } else {
+                HIP_CHECK(hipMemcpyPeerAsync(d_shards[i], devices[i], hub, hub_device, bytes, nullptr));
+            }
+        }
+        off += bytes;
+    }
+    for (int i = 0; i < nshards; ++i) {
+        DeviceScope scope_(devices[i]);
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
+}
+
+int pai_gather(int nshards, const int* devices, const void* const* d_shards, const size_t* rows, int row_words,
+               int dst_device, void* d_out) {
+    return guarded([&] { peer_copy_all(nshards, devices, const_cast<void* const*>(d_shards), rows, row_words, dst_device, d_out, true); });
+}
+
+int pai_scatter(int nshards, const int* devices, void* const* d_shards, const size_t* rows, int row_words,
+                int src_device, const void* d_in) {
+    return guarded([&] { peer_copy_all(nshards, devices, d_shards, rows, row_words, src_device, const_cast<void*>(d_in), false); });
+}
+
 }  // extern "C"
+
+void PubkeyDeleter::operator()(pai_pubkey* p) const { pai_pubkey_destroy(p); }
+void PrivkeyDeleter::operator()(pai_privkey* p) const { pai_privkey_destroy(p); }
+void ModulusDeleter::operator()(pai_modulus* p) const { pai_modulus_destroy(p); }

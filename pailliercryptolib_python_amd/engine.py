@@ -10,6 +10,8 @@ streams and (in ``sharding.py``) ``torch.distributed``; all arithmetic is in ``l
 from __future__ import annotations
 
 import ctypes as C
+import threading
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -156,6 +158,16 @@ class PublicKeyHandle:
                                           _ptr(out), _stream(self.device)))
         return out
 
+    def ct_prod(self, ct: torch.Tensor, groups: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[members * groups, W] read member-major -> [groups, W]: out[g] = prod_l ct[l * groups + g] mod n^2
+        (the product tree that replaces upstream's pad-rotate-add reduction, ipcl_python.py:810-827)."""
+        self._chk(ct, self.ct_words, "ct")
+        if groups <= 0 or ct.shape[0] == 0 or ct.shape[0] % groups:
+            raise ValueError("ct_prod: the number of rows must be a positive multiple of groups")
+        out = self.empty_ct(groups) if out is None else out
+        _native.check(self.lib.pai_ct_prod(self.h, _ptr(ct), ct.shape[0], int(groups), _ptr(out), _stream(self.device)))
+        return out
+
     def ct_invert(self, ct: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(ct, self.ct_words, "ct")
         out = self.empty_ct(ct.shape[0]) if out is None else out
@@ -252,6 +264,98 @@ class PrivateKeyHandle:
         out = self.pub.empty_pt(ct.shape[0]) if out is None else out
         _native.check(self.lib.pai_decrypt(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.pub.device)))
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# handle cache and single-process multi-GPU fan-out
+# ------------------------------------------------------------------------------------------------
+_pub_cache: "weakref.WeakValueDictionary" = weakref.WeakValueDictionary()
+_cache_lock = threading.Lock()
+
+
+def public_handle(n: int, key_bits: int, hs: Optional[int], randbits: int, device) -> PublicKeyHandle:
+    """One PublicKeyHandle per (key material, device) for as long as somebody holds it: every unpickled public key
+    or ciphertext of the same key shares the device constants (and, once built, the fixed-base tables)."""
+    dev = _require_cuda(torch.device(device))
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (int(n), int(key_bits), None if hs is None else int(hs), int(randbits), dev.index)
+    with _cache_lock:
+        h = _pub_cache.get(key)
+        if h is None:
+            h = PublicKeyHandle(n, key_bits, hs, randbits, device=dev)
+            _pub_cache[key] = h
+        return h
+
+
+def shard_plan(n: int, nshards: int):
+    """[(begin, count)] of the contiguous block partition (pai_shard_plan)."""
+    lib = _native.load()
+    out = []
+    b, c = C.c_size_t(0), C.c_size_t(0)
+    for g in range(nshards):
+        _native.check(lib.pai_shard_plan(n, nshards, g, C.byref(b), C.byref(c)))
+        out.append((int(b.value), int(c.value)))
+    return out
+
+
+def _peer_copy(fn_name: str, shards, hub: torch.Tensor) -> None:
+    lib = _native.load()
+    k = len(shards)
+    devs = (C.c_int32 * k)(*[t.device.index for t in shards])
+    ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in shards])
+    rows = (C.c_size_t * k)(*[t.shape[0] for t in shards])
+    words = hub.shape[1] * hub.element_size() // 4
+    for t in shards:
+        torch.cuda.synchronize(t.device)          # the copies run on the devices' null streams
+    torch.cuda.synchronize(hub.device)
+    _native.check(getattr(lib, fn_name)(k, devs, ptrs, rows, words, hub.device.index, C.c_void_p(hub.data_ptr())))
+
+
+def gather_shards(shards, device) -> torch.Tensor:
+    """Row shards on several devices of this process -> one [sum rows, W] tensor on `device` (pai_gather)."""
+    total = sum(t.shape[0] for t in shards)
+    out = torch.empty((total,) + tuple(shards[0].shape[1:]), dtype=shards[0].dtype, device=device)
+    if total:
+        _peer_copy("pai_gather", [t.contiguous() for t in shards], out)
+    return out
+
+
+def scatter_shards(src: torch.Tensor, devices) -> list:
+    """[N, W] on one device -> contiguous block shards on `devices` (pai_scatter)."""
+    plan = shard_plan(src.shape[0], len(devices))
+    shards = [torch.empty((c,) + tuple(src.shape[1:]), dtype=src.dtype, device=d) for (_, c), d in zip(plan, devices)]
+    if src.shape[0]:
+        _peer_copy("pai_scatter", shards, src.contiguous())
+    return shards
+
+
+def fan_out(devices, fn, n_items: int):
+    """Runs fn(g, device, begin, count) for every shard of the block partition on its own host thread (ctypes and
+    torch release the GIL while the GPU works) and returns the results in shard order; exceptions propagate."""
+    plan = shard_plan(n_items, len(devices))
+    results = [None] * len(devices)
+    errors = []
+
+    def work(g):
+        try:
+            torch.cuda.set_device(devices[g])
+            results[g] = fn(g, devices[g], plan[g][0], plan[g][1])
+            torch.cuda.synchronize(devices[g])
+        except BaseException as e:      # noqa: BLE001 - re-raised on the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(g,)) for g in range(1, len(devices))]
+    for t in threads:
+        t.start()
+    prev = torch.cuda.current_device()
+    work(0)
+    torch.cuda.set_device(prev)
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
 
 
 def profile_enable(on: bool) -> None:

@@ -106,28 +106,50 @@ class PaillierPublicKey:
             ok = all(isinstance(v, (int, float, np.integer, np.floating)) for v in values)
         if not ok:
             raise ValueError("PaillierPublicKey.encrypt: input value(s) should be integer or float")
-        h = self.pubkey.handle
-        if _fp.is_float_batch(values) and self.n.bit_length() > 66:
+        pub = self.pubkey
+        h = pub.handle
+        if isinstance(r, np.ndarray):
+            r = engine.to_device_words(r, h.device)
+        is_f64 = _fp.is_float_batch(values) and self.n.bit_length() > 66
+        is_i64 = (isinstance(values, np.ndarray) and values.dtype in (np.int16, np.int32, np.int64) and values.ndim == 1
+                  and values.shape[0] > 0 and self.n.bit_length() > 66)
+        devs = pub.fanout_devices(len(values)) if (is_f64 or is_i64) else None
+        if devs is not None:
+            # Multi-GPU: contiguous block shards, each H2D'd straight from the host array to its own
+            # device (8 B per element), encoded, obfuscated and encrypted there; ciphertext shards are gathered onto
+            # the home device with peer copies.
+            x = _fp.checked_float64(values) if is_f64 else np.ascontiguousarray(values, dtype=np.int64)
+            r_sh = engine.scatter_shards(r, devs) if (apply_obfuscator and r is not None) else None
+
+            def work(g, dev, begin, count):
+                hg = pub.handle_on(dev)
+                if count == 0:
+                    return hg.empty_ct(0), np.zeros(0, dtype=np.int32)
+                xs = torch.from_numpy(x[begin:begin + count]).to(dev)
+                m, expo_d = hg.fp_encode_f64(xs) if is_f64 else hg.fp_encode_i64(xs)
+                if not apply_obfuscator:
+                    ct_g = hg.raw_encrypt(m)
+                else:
+                    ct_g = hg.encrypt(m, pub._draw_r(count, hg) if r_sh is None else r_sh[g])
+                return ct_g, (expo_d.cpu().numpy() if is_f64 else np.zeros(count, dtype=np.int32))
+
+            parts = engine.fan_out(devs, work, len(values))
+            ct = engine.gather_shards([p[0] for p in parts], h.device)
+            expos = np.concatenate([p[1] for p in parts])
+            return PaillierEncryptedNumber(self, ipclCipherText(pub, ct), exponents=expos, length=len(values))
+        if is_f64:
             # float arrays: 8 B per element cross PCIe and the codec runs on the device (pai_fp_encode_f64)
             x = _fp.checked_float64(values)
             m, expo_d = h.fp_encode_f64(torch.from_numpy(x).to(h.device))
             expos = expo_d.cpu().numpy()
-        elif (isinstance(values, np.ndarray) and values.dtype in (np.int16, np.int32, np.int64) and values.ndim == 1
-              and values.shape[0] > 0 and self.n.bit_length() > 66):
+        elif is_i64:
             # the integer dtypes the reference's codec accepts (fixedpoint.py:72): exponent 0, residue = x mod n
             m, expo_d = h.fp_encode_i64(torch.from_numpy(np.ascontiguousarray(values, dtype=np.int64)).to(h.device))
             expos = np.zeros(values.shape[0], dtype=np.int32)
         else:
             residues, expos = _fp.encode_array(values, self.n, self.max_int, h.n_words)
             m = engine.to_device_words(residues, h.device)
-        if not apply_obfuscator:
-            ct = h.raw_encrypt(m)
-        else:
-            if r is None:
-                r = self.pubkey._draw_r(m.shape[0])
-            elif isinstance(r, np.ndarray):
-                r = engine.to_device_words(r, h.device)
-            ct = h.encrypt(m, r)
+        ct = pub.encrypt_words(m, apply_obfuscator, r)
         return PaillierEncryptedNumber(self, ipclCipherText(self.pubkey, ct), exponents=expos, length=len(values))
 
 
@@ -166,14 +188,33 @@ class PaillierPrivateKey:
         return repr(self.prikey)
 
     def _decrypt_words(self, enc: "PaillierEncryptedNumber") -> np.ndarray:
-        return engine.to_host_words(self.prikey.decrypt(enc.ciphertext())._t)
+        return engine.to_host_words(self.prikey.decrypt_words(enc.words))
 
     def _decrypt_mantissas(self, enc: "PaillierEncryptedNumber"):
         """(int64 mantissas, None) through the device decoder, or (None, residue words) when some element
-        needs the exact big-integer path (|mantissa| >= 2^63, overflow zone, corrupt residue)."""
-        t = self.prikey.decrypt(enc.ciphertext())._t
+        needs the exact big-integer path (|mantissa| >= 2^63, overflow zone, corrupt residue).  Large batches are
+        sharded over the key's devices: ciphertext shards go out by peer copy, every device decrypts and decodes
+        its block, and only 8-byte mantissas come back."""
+        pub = enc.public_key.pubkey
+        devs = pub.fanout_devices(len(enc)) if self.__n.bit_length() > 66 else None
+        if devs is not None:
+            ct_sh = engine.scatter_shards(enc.words, devs)
+
+            def work(g, dev, begin, count):
+                if count == 0:
+                    return np.zeros(0, dtype=np.int64), False, None
+                t = self.prikey.handle_on(dev).decrypt(ct_sh[g])
+                mant, flag = pub.handle_on(dev).fp_decode_i64(t)
+                bad = bool(flag.any())
+                return mant.cpu().numpy(), bad, (engine.to_host_words(t) if bad else None)
+
+            parts = engine.fan_out(devs, work, len(enc))
+            if not any(p[1] for p in parts):
+                return np.concatenate([p[0] for p in parts]), None
+            return None, self._decrypt_words(enc)
+        t = self.prikey.decrypt_words(enc.words)
         if self.__n.bit_length() > 66:
-            mant, flag = enc.public_key.pubkey.handle.fp_decode_i64(t)
+            mant, flag = pub.handle.fp_decode_i64(t)
             if not bool(flag.any()):
                 return mant.cpu().numpy(), None
         return None, engine.to_host_words(t)
@@ -339,7 +380,7 @@ class PaillierEncryptedNumber:
         bits = max(1, max(v.bit_length() for v in mags))
         ew = (bits + 31) // 32
         e = engine.to_device_words(engine.ints_to_words(mags, ew), h.device)
-        return h.ct_mul(base, e, bits)
+        return self.public_key.pubkey.ct_mul_words(base, e, bits)
 
     def _pow_small(self, ct: torch.Tensor, mant: np.ndarray) -> torch.Tensor:
         """The same for a batch of signed 64-bit multipliers (float mantissas): no per-element Python objects."""
@@ -360,7 +401,7 @@ class PaillierEncryptedNumber:
         e[:, 0] = (mag & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         e[:, 1] = (mag >> np.uint64(32)).astype(np.uint32)
         ew = (bits + 31) // 32
-        return h.ct_mul(base, engine.to_device_words(np.ascontiguousarray(e[:, :ew]), h.device), bits)
+        return self.public_key.pubkey.ct_mul_words(base, engine.to_device_words(np.ascontiguousarray(e[:, :ew]), h.device), bits)
 
     def __mul__(self, other):
         """ipcl_python.py:412-488."""
@@ -441,27 +482,17 @@ class PaillierEncryptedNumber:
         return self.__length
 
     # -- reductions (SURVEY §8f-1) -----------------------------------------------------------------
-    def _tree_product(self, ct: torch.Tensor, group: int) -> torch.Tensor:
-        """[G*group, W] -> [G, W]: product of each run of `group` consecutive ciphertexts modulo n^2.
-        The result does not depend on the association order, so it equals the reference's
-        pad-with-E(0)=1-and-rotate scheme (ipcl_python.py:810-827) bit for bit."""
-        h = self._h()
-        W = ct.shape[1]
-        x = ct.reshape(-1, group, W)
-        while x.shape[1] > 1:
-            g = x.shape[1]
-            half = g // 2
-            a = x[:, :half].reshape(-1, W).contiguous()
-            b = x[:, half:2 * half].reshape(-1, W).contiguous()
-            prod = h.ct_add(a, b).reshape(-1, half, W)
-            x = torch.cat([prod, x[:, 2 * half:]], dim=1) if g % 2 else prod
-        return x.reshape(-1, W).contiguous()
+    def _tree_product(self, ct: torch.Tensor, groups: int) -> torch.Tensor:
+        """[members * groups, W] read member-major -> [groups, W]: out[g] = product over l of ct[l * groups + g]
+        modulo n^2 (pai_ct_prod: a product tree over halves).  The result does not depend on the association order,
+        so it equals the reference's pad-with-E(0)=1-and-rotate scheme (ipcl_python.py:810-827) bit for bit."""
+        return self._h().ct_prod(ct.contiguous(), groups)
 
     def sum(self) -> "PaillierEncryptedNumber":
         """ipcl_python.py:746-762 (intended behaviour)."""
         max_exponent = int(self._expo.max())
         aligned = self.increase_exponent_to(self.words, self._expo, max_exponent)
-        return self._wrap(self._tree_product(aligned, len(self)), [max_exponent], 1)
+        return self._wrap(self._tree_product(aligned, 1), [max_exponent], 1)
 
     def mean(self) -> "PaillierEncryptedNumber":
         return self.sum() / len(self)
@@ -476,7 +507,9 @@ class PaillierEncryptedNumber:
         other n x k), or (n x k) when rhs is True (result = other @ self, other m x n).  Output element
         (i, j) = sum_l ct[.] * pt[.], one aligned tree product per output element."""
         h = self._h()
-        i_idx, j_idx, l_idx = np.meshgrid(np.arange(m), np.arange(k), np.arange(n), indexing="ij")
+        # member-major order (l, i, j): the n addends of output element (i, j) are n rows that lie m*k apart, which is
+        # the layout pai_ct_prod reduces with contiguous halves
+        l_idx, i_idx, j_idx = np.meshgrid(np.arange(n), np.arange(m), np.arange(k), indexing="ij")
         if rhs:
             idx_self = (l_idx * k + j_idx).reshape(-1)
             pts = (other[i_idx, l_idx] if other.ndim == 2 else other[l_idx]).reshape(-1)
@@ -487,14 +520,15 @@ class PaillierEncryptedNumber:
         big = PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, self.words[gather].contiguous()),
                                       self._expo[idx_self], idx_self.shape[0])
         prod = big * np.asarray(pts)
-        pe = prod._expo.reshape(m * k, n)
-        gmax = pe.max(axis=1)
-        target = np.repeat(gmax, n)
-        words = prod.words.clone()
+        pe = prod._expo.reshape(n, m * k)
+        gmax = pe.max(axis=0)                                      # per output element (ipcl_python.py:868-870)
+        target = np.tile(gmax, n)
+        words = prod.words
         delta = (target - prod._expo).astype(np.int32)
         if (delta > 0).any():
+            words = words.clone()
             h.ct_pow2_(words, torch.from_numpy(np.ascontiguousarray(delta)).to(h.device))
-        out = self._tree_product(words, n)
+        out = self._tree_product(words, m * k)
         return self._wrap(out, gmax.astype(np.int32), m * k)
 
     def __matmul__(self, other: Union[np.ndarray, list]) -> "PaillierEncryptedNumber":

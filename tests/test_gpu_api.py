@@ -377,3 +377,49 @@ def test_key_sizes_1024_default_and_non_djn():
     assert np.array_equal(np.array(sk.decrypt(pk.encrypt(x))), x)
     pk2, sk2 = PaillierKeypair.generate_keypair(1024, False)
     assert sk2.decrypt(pk2.encrypt([1.25, -7]) * 2) == [2.5, -14]
+
+
+# ---- round 2: single-process multi-device fan-out, handle cache --------------------------------------------------
+def test_fanout_over_a_device_list_gives_the_same_bits(fixed, monkeypatch):
+    """The key replicated on a device list (here cuda:0 twice — the sharding, the per-device threads, the peer
+    scatter / gather and the host-side concatenation are the code that runs over 8 GPUs): encrypt, ct*pt and decrypt
+    of a batch large enough to shard equal the single-device results bit for bit."""
+    import torch
+    from pailliercryptolib_python_amd import bindings
+
+    pk, sk, okey = fixed
+    monkeypatch.setattr(bindings, "FANOUT_MIN_PER_DEVICE", 64)
+    N = 64 * 3 + 17
+    rng = np.random.default_rng(123)
+    x = rng.uniform(-1000, 1000, N)
+    r = orc.synth_r_limbs(77, N, okey.randbits)
+    single = pk.encrypt(x, r=r)
+    raw2 = ipclPublicKey(okey.n, 2048, True, hs=okey.hs, randbits=okey.randbits, devices=["cuda:0", "cuda:0", "cuda:0"])
+    pk2 = PaillierPublicKey(raw2)
+    sk2 = PaillierPrivateKey(pk2, orc.BENCH_P, orc.BENCH_Q)
+    assert raw2.fanout_devices(N) is not None and raw2.fanout_devices(100) is None
+    multi = pk2.encrypt(x, r=r)
+    assert torch.equal(multi.words, single.words) and multi.exponent() == single.exponent()
+    assert torch.equal(pk2.raw_encrypt(x).words, pk.raw_encrypt(x).words)
+    xi = rng.integers(-10**9, 10**9, N)
+    assert torch.equal(pk2.encrypt(xi, r=r).words, pk.encrypt(xi, r=r).words)
+    w = rng.uniform(-3, 3, N)
+    assert torch.equal((multi * w).words, (single * w).words)
+    assert np.array_equal(sk2.decrypt_to_numpy(multi), x) and sk2.decrypt(multi) == sk.decrypt(single)
+    assert sk2.raw_decrypt(multi) == sk.raw_decrypt(single)
+    fresh = pk2.encrypt(x)                                     # device-drawn randomness per shard
+    assert np.array_equal(sk2.decrypt_to_numpy(fresh), x)
+    assert raw2.handle is pk.pubkey.handle                     # same key material + device => one cached handle
+
+
+def test_unpickled_ciphertexts_share_one_handle_and_stay_on_the_host_until_used(fixed):
+    pk, sk, okey = fixed
+    en = pk.encrypt([1.5, -2.0, 3.25], r=orc.synth_r_limbs(9, 3, okey.randbits))
+    blobs = [pickle.dumps(en) for _ in range(4)]
+    back = [pickle.loads(b) for b in blobs]
+    for b in back:
+        assert b.ciphertext()._dev is None                     # nothing uploaded, no handle touched
+        assert ct_ints(b) == ct_ints(en)
+    s = back[0] + back[1]
+    assert sk.decrypt(s) == [3.0, -4.0, 6.5]
+    assert back[2].public_key.pubkey.handle is pk.pubkey.handle

@@ -298,3 +298,159 @@ def test_ct_invert_other_key_sizes():
         out = DevArray(shape=(N, nk.cw))
         _native.check(nk.lib.pai_ct_invert(nk.pk, da.ptr, N, out.ptr, None))
         assert limbs_to_ints(out.get()) == [pow(x, -1, key.nsq) for x in a]
+
+
+# ---- round 2: tile I/O kernels, single-product trees, reductions in the library -------------------------------
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
+def test_ct_add_tile_edges_and_broadcast(bits):
+    """k_modmul with coalesced tile I/O: ragged last tile, one-element batches, broadcast addend (one Montgomery
+    product per element), in-place output — against a*b mod n^2."""
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key = nk.key
+    rng = np.random.default_rng(bits + 1)
+    for N in (1, 63, 64, 65, 200, 1031):
+        a, b = rand_below(rng, key.nsq, N), rand_below(rng, key.nsq, N)
+        a[0], b[0] = key.nsq - 1, key.nsq - 1
+        if N > 2:
+            a[1], b[1] = 0, 5
+            a[2], b[2] = 1, key.nsq - 2
+        da, db = DevArray(ints_to_limbs(a, nk.cw)), DevArray(ints_to_limbs(b, nk.cw))
+        out = DevArray(shape=(N, nk.cw))
+        _native.check(nk.lib.pai_ct_add(nk.pk, da.ptr, db.ptr, 0, N, out.ptr, None))
+        assert limbs_to_ints(out.get()) == [x * y % key.nsq for x, y in zip(a, b)]
+        _native.check(nk.lib.pai_ct_add(nk.pk, da.ptr, db.ptr, 1, N, out.ptr, None))          # b[0] for everyone
+        assert limbs_to_ints(out.get()) == [x * b[0] % key.nsq for x in a]
+        _native.check(nk.lib.pai_ct_add(nk.pk, da.ptr, db.ptr, 0, N, da.ptr, None))           # d_out aliases d_a
+        assert limbs_to_ints(da.get()) == [x * y % key.nsq for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("bits,members,groups", [(2048, 1, 5), (2048, 2, 1), (2048, 3, 70), (2048, 7, 9), (2048, 64, 3),
+                                                  (2048, 1000, 1), (2048, 129, 65), (1024, 37, 4), (3072, 11, 6), (4096, 5, 33)])
+def test_ct_prod_matches_plain_products(bits, members, groups):
+    """pai_ct_prod: out[g] = prod_l ct[l*groups + g] mod n^2 (member-major) on single Montgomery products with the
+    per-level R-power bookkeeping; odd member counts exercise the partner-less nodes."""
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key = nk.key
+    rng = np.random.default_rng(members * 1000 + groups)
+    count = members * groups
+    a = rand_below(rng, key.nsq, count)
+    a[0] = key.nsq - 1
+    da = DevArray(ints_to_limbs(a, nk.cw))
+    out = DevArray(shape=(groups, nk.cw))
+    _native.check(nk.lib.pai_ct_prod(nk.pk, da.ptr, count, groups, out.ptr, None))
+    want = []
+    for g in range(groups):
+        p = 1
+        for l in range(members):
+            p = p * a[l * groups + g] % key.nsq
+        want.append(p)
+    assert limbs_to_ints(out.get()) == want
+    assert nk.lib.pai_ct_prod(nk.pk, da.ptr, count, groups + count + 1, out.ptr, None) == _native.PAI_E_INVALID
+
+
+def test_pow2_tile_skips_and_mixed_deltas(k2048):
+    """k_pow2 on tile I/O: tiles whose deltas are all <= 0 are skipped by the workgroup, untouched rows inside a live
+    tile are written back unchanged."""
+    key, N = k2048.key, 64 * 5 + 9
+    rng = np.random.default_rng(4242)
+    a = rand_below(rng, key.nsq, N)
+    delta = np.zeros(N, dtype=np.int32)
+    delta[70] = 3                      # one live element in tile 1
+    delta[128:192] = rng.integers(-2, 12, 64)
+    delta[N - 1] = 1
+    da = DevArray(ints_to_limbs(a, k2048.cw))
+    dd = DevArray(delta)
+    _native.check(k2048.lib.pai_ct_pow2(k2048.pk, da.ptr, dd.ptr, 0, N, None))
+    want = [pow(x, 1 << int(d), key.nsq) if d > 0 else x for x, d in zip(a, delta)]
+    assert limbs_to_ints(da.get()) == want
+    one = DevArray(np.array([2], dtype=np.int32))
+    _native.check(k2048.lib.pai_ct_pow2(k2048.pk, da.ptr, one.ptr, 1, N, None))
+    assert limbs_to_ints(da.get()) == [pow(x, 4, key.nsq) for x in want]
+
+
+def test_fixed_base_table_is_built_lazily_and_calls_keep_the_device():
+    """creating a DJN handle must not allocate the multi-GB fixed-base table; the first obfuscating call
+    does.  No call changes the thread's current device."""
+    hip = C.CDLL("libamdhip64.so")
+    free0, total = C.c_size_t(), C.c_size_t()
+    nk = None
+    hip.hipMemGetInfo(C.byref(free0), C.byref(total))
+    nk = NativeKey(bench_key())
+    free1 = C.c_size_t()
+    hip.hipMemGetInfo(C.byref(free1), C.byref(total))
+    assert free0.value - free1.value < (512 << 20), "key creation allocated the fixed-base table"
+    key, N = nk.key, 5
+    m = plaintexts(key, N, 3)
+    ct = DevArray(shape=(N, nk.cw))
+    dm = DevArray(ints_to_limbs(m, nk.nw))
+    _native.check(nk.lib.pai_raw_encrypt(nk.pk, dm.ptr, N, ct.ptr, None))
+    out = DevArray(shape=(N, nk.nw))
+    _native.check(nk.lib.pai_decrypt(nk.sk, ct.ptr, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == m
+    free2 = C.c_size_t()
+    hip.hipMemGetInfo(C.byref(free2), C.byref(total))
+    assert free0.value - free2.value < (1024 << 20), "raw encrypt / decrypt built the fixed-base table"
+    r = orc.synth_r_limbs(5, N, key.randbits)
+    dr = DevArray(r)
+    _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+    assert limbs_to_ints(ct.get()) == [orc.encrypt(key, x, rr) for x, rr in zip(m, orc.limbs_to_ints(r))]
+    dev = C.c_int(-1)
+    hip.hipGetDevice(C.byref(dev))
+    assert dev.value == 0
+
+
+def test_two_streams_share_one_key_handle(k2048):
+    """Scratch users of one handle on different streams are chained with events: interleaved decrypt / ct*pt calls on
+    two streams give the same bits as serial calls."""
+    hip = C.CDLL("libamdhip64.so")
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(s1)) == 0 and hip.hipStreamCreate(C.byref(s2)) == 0
+    key, N = k2048.key, 600
+    rng = np.random.default_rng(31337)
+    m1, m2 = plaintexts(key, N, 1), plaintexts(key, N, 2)
+    c1 = [orc.raw_encrypt(x, key.n) * pow(key.hs, 3 + i, key.nsq) % key.nsq for i, x in enumerate(m1)]
+    c2 = [orc.raw_encrypt(x, key.n) * pow(key.hs, 5 + i, key.nsq) % key.nsq for i, x in enumerate(m2)]
+    d1, d2 = DevArray(ints_to_limbs(c1, k2048.cw)), DevArray(ints_to_limbs(c2, k2048.cw))
+    o1, o2 = DevArray(shape=(N, k2048.nw)), DevArray(shape=(N, k2048.nw))
+    e = [int(v) for v in rng.integers(1, 1 << 40, N)]
+    de = DevArray(ints_to_limbs(e, 2))
+    p1, p2 = DevArray(shape=(N, k2048.cw)), DevArray(shape=(N, k2048.cw))
+    for _ in range(3):
+        _native.check(k2048.lib.pai_decrypt(k2048.sk, d1.ptr, N, o1.ptr, s1))
+        _native.check(k2048.lib.pai_decrypt(k2048.sk, d2.ptr, N, o2.ptr, s2))
+        _native.check(k2048.lib.pai_ct_mul(k2048.pk, d1.ptr, de.ptr, 2, 40, 0, N, p1.ptr, s1))
+        _native.check(k2048.lib.pai_ct_mul(k2048.pk, d2.ptr, de.ptr, 2, 40, 0, N, p2.ptr, s2))
+    _native.check(k2048.lib.pai_stream_sync(0, s1))
+    _native.check(k2048.lib.pai_stream_sync(0, s2))
+    assert limbs_to_ints(o1.get()) == m1 and limbs_to_ints(o2.get()) == m2
+    assert limbs_to_ints(p1.get())[:50] == [pow(c, x, key.nsq) for c, x in zip(c1[:50], e[:50])]
+    assert limbs_to_ints(p2.get())[-50:] == [pow(c, x, key.nsq) for c, x in zip(c2[-50:], e[-50:])]
+    hip.hipStreamDestroy(s1)
+    hip.hipStreamDestroy(s2)
+
+
+def test_shard_plan_gather_scatter_roundtrip(k2048):
+    """pai_shard_plan / pai_scatter / pai_gather through raw ctypes, with the shards living on device 0 (the only
+    device a test box has): the copies and the offsets are the same code that runs across xGMI peers."""
+    lib = k2048.lib
+    N, W, G = 1003, 8, 3
+    host = np.random.default_rng(8).integers(0, 1 << 32, size=(N, W), dtype=np.uint32)
+    src = DevArray(host)
+    b, c = C.c_size_t(), C.c_size_t()
+    plan = []
+    for g in range(G):
+        _native.check(lib.pai_shard_plan(N, G, g, C.byref(b), C.byref(c)))
+        plan.append((b.value, c.value))
+    assert plan == [(0, 335), (335, 335), (670, 333)]
+    shards = [DevArray(shape=(cnt, W)) for _, cnt in plan]
+    devs = (C.c_int32 * G)(0, 0, 0)
+    ptrs = (C.c_void_p * G)(*[s.ptr.value for s in shards])
+    rows = (C.c_size_t * G)(*[cnt for _, cnt in plan])
+    _native.check(lib.pai_scatter(G, devs, ptrs, rows, W, 0, src.ptr))
+    for (beg, cnt), s in zip(plan, shards):
+        assert np.array_equal(s.get(), host[beg:beg + cnt])
+    out = DevArray(shape=(N, W))
+    _native.check(lib.pai_gather(G, devs, ptrs, rows, W, 0, out.ptr))
+    assert np.array_equal(out.get(), host)
+    assert lib.pai_shard_plan(10, 4, 3, C.byref(b), C.byref(c)) == 0 and (b.value, c.value) == (9, 1)
+    assert lib.pai_shard_plan(2, 4, 3, C.byref(b), C.byref(c)) == 0 and (b.value, c.value) == (2, 0)

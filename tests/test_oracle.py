@@ -179,3 +179,33 @@ def test_reductions_restatement_is_consistent():
         assert np.allclose(np.array(orc.api_decrypt(k, rc, re_)).reshape(m, kk), x @ y)
     with pytest.raises(ValueError):
         orc.api_matmul(k, xc, xe, np.ones((5, 2)))
+
+
+@pytest.mark.skipif(not co.ifma_available(), reason="host CPU / compiler without AVX512-IFMA")
+def test_ifma_mb8_kernels_match_cpython_pow():
+    """oracle/paillier_ifma.c (8-lane, 52-bit-limb, 5-bit-window almost-Montgomery exponentiation: the algorithm of the
+    mbx_exp_mb8 kernels README.md:32 names) against CPython pow, on the moduli the Paillier path uses; then the two
+    Paillier operations built on it against the Python-int oracle and the scalar C port."""
+    rng = np.random.default_rng(52)
+    k = key2048()
+    for M in (k.p * k.p, k.nsq, k.q, (1 << 1023) + 1155):
+        N, W = 19, (M.bit_length() + 31) // 32
+        base = [int.from_bytes(rng.bytes(600), "little") % M for _ in range(N)]
+        base[0], base[1], base[2] = 0, 1, M - 1
+        b32 = orc.ints_to_limbs(base, W)
+        e = int.from_bytes(rng.bytes(128), "little")
+        assert orc.limbs_to_ints(co.ifma_modexp(M, b32, e)) == [pow(b, e, M) for b in base]
+        es = [int.from_bytes(rng.bytes(int(rng.integers(1, 130))), "little") for _ in range(N)]
+        es[3], es[4] = 0, 1
+        assert orc.limbs_to_ints(co.ifma_modexp(M, b32, es)) == [pow(b, x, M) for b, x in zip(base, es)]
+    for bits in (1024, 2048, 3072):
+        key = key2048() if bits == 2048 else fixture_key(bits)
+        ck = co.COracleKey(key)
+        N, nw = 21, bits // 32
+        m = [int.from_bytes(rng.bytes(bits // 8 + 8), "little") % key.n for _ in range(N)]
+        m[0], m[1] = 0, key.n - 1
+        m32, r32 = orc.ints_to_limbs(m, nw), orc.synth_r_limbs(bits, N, key.randbits)
+        ct = ck.ifma_encrypt_djn(m32, r32)
+        assert orc.limbs_to_ints(ct) == [orc.encrypt(key, a, b) for a, b in zip(m, orc.limbs_to_ints(r32))]
+        assert np.array_equal(ct, ck.encrypt_djn(m32, r32))
+        assert np.array_equal(ck.ifma_decrypt_crt(ct), m32)
