@@ -1,31 +1,43 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Paillier encrypt+decrypt ops/sec, 2048-bit key, batch = 1 M per GPU.
+"""Headline benchmark: Paillier encrypt+decrypt ops/sec, 2048-bit key, batch = 1 M.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scaling weak|strong] [--no-cpu-baseline] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
-DJN-obfuscated encryption of B plaintext residues (pai_encrypt) followed by CRT decryption of the B
+DJN-obfuscated encryption of the plaintext residues (pai_encrypt) followed by CRT decryption of the
 ciphertexts (pai_decrypt).  One op = one element encrypted AND decrypted (BASELINE.json metric,
-SURVEY.md §8d).  With N > 1 every rank runs the same per-GPU batch on its own device (the path shards
-by independent elements, no data-path collective: "weak" scaling); the timed region is bracketed by a
-barrier + torch.cuda.synchronize() and the maximum over ranks is taken.
+SURVEY.md §8d).  The path shards by independent elements (no data-path collective):
+  --scaling weak   (default) every rank runs B elements on its own device;
+  --scaling strong the B elements are split over the ranks by the contiguous block partition of
+                   pai_shard_plan (BASELINE's "batch = 1 M on 1/2/4/8 GPUs"); the final RCCL gather of the
+                   ciphertext shards is timed separately and reported as gather_ms (it is not part of an op).
+The timed region is bracketed by a barrier + torch.cuda.synchronize() and the maximum over ranks is taken.
 
 Inputs: key = the reference's bench constants P, Q (bench/bench_ipcl_python.py:83-97, stored in
-tests/golden/fixture_keys.json) with a fixed DJN base — built here from plain integers, the oracle only checks; plaintexts = fixed-point encodings of default_rng(1002).uniform(-1000, 1000, B); randomness
-r = seeded device generator (1024 random bits per element), all uploaded before the timed region.
+tests/golden/fixture_keys.json) with a fixed DJN base — built here from plain integers, the oracle only checks;
+plaintexts = fixed-point encodings of default_rng(1002).uniform(-1000, 1000, B); randomness r = seeded device
+generator (1024 random bits per element), all uploaded before the timed region.
 
 The JSON line also carries
-  roofline     — the dominant kernel (k_dec_a: the two CRT half-size modexps) priced in canonical
-                 32x32->64 MACs against the measured v_mad_u64_u32 peak of the
-                 chip (profiles/r01/ubench_valu_mi355x.jsonl); the path is integer-VALU bound, so the
-                 "bound" is "valu_int" — the HBM view is reported beside it in "hbm".
-  cpu_baseline — the same two operations on the host cores (oracle/paillier_ref.c, through libgmp's
-                 mpz_powm when present, else the plain-C port), on a bounded sample.
+  roofline     — the dominant kernel (k_dec_a: the two CRT half-size modexps) against the measured v_mad_u64_u32
+                 peak of the chip (profiles/r01/ubench_valu_mi355x.jsonl); the path is integer-VALU bound, so the
+                 "bound" is "valu_int".  frac = EXECUTED multiply-accumulates / peak (kernel quality, <= 1);
+                 canonical_frac prices the kernel at the canonical algorithm's work and can
+                 exceed 1 because the kernel runs a cheaper algorithm.  traffic = HBM bytes per launch from the PMC
+                 passes committed under profiles/ (file and sha256 named; null when no such file is present).
+  cpu_baseline — the same two operations on the host cores on a bounded sample: the AVX512-IFMA mb8 port
+                 (oracle/paillier_ifma.c — the algorithm of README.md:32's mbx_exp_mb8) when the host has IFMA,
+                 else libgmp, else the plain-C port.
+  api_level    — host float64 array -> PaillierPublicKey.encrypt -> PaillierPrivateKey.decrypt_to_numpy -> host
+                 float64 array (codec, CSPRNG-keyed randomness and PCIe included): SURVEY.md §8d(i).
+  other_ops    — BASELINE configs[2]: ct+ct add, ct x pt mul (and ct^-1, sum) on the same resident batch, each
+                 checked against the oracle; small_batch — latency at the reference's own batch sizes 16 / 64.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -44,8 +56,9 @@ DJN_X = 0x1234567
 PEAK_MAC32_PER_S = 35.9e12        # measured v_mad_u64_u32 rate, 8 waves/SIMD (profiles/r01/ubench_valu_mi355x.jsonl)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md
 # canonical MAC32 per op at 2048-bit keys (CIOS 2L^2+L, 5-bit window)
-CANON_MAC_ENC, CANON_MAC_DEC = 41.52e6, 20.86e6
-BYTES_ENC, BYTES_DEC = 648, 520   # algorithmic bytes per op
+CANON_MAC_ENC, CANON_MAC_DEC, CANON_MAC_ADD, CANON_MAC_MUL53 = 41.52e6, 20.86e6, 65.8e3, 3.16e6
+BYTES_ENC, BYTES_DEC, BYTES_ADD = 648, 520, 1536   # algorithmic bytes per op
+PMC_FILES = ["profiles/r02/pmc_bench_r02.json", "profiles/r01/pmc_bench_r01d.json"]   # newest first
 
 
 def _sliding_counts(e: int, w: int = 6):
@@ -97,14 +110,35 @@ def executed_macs_decrypt(p: int, q: int, nl: int = 36, w: int = 6, ct_bits: int
     return total
 
 
+def pmc_traffic(kernel_prefix: str, batch: int):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, KiB units; gfx950 FETCH_SIZE counts half of a wide streaming read => doubled, as
+    MI355X_MICROARCH.md prescribes).  The profiles were taken at batch 2^20; scaled linearly to `batch`."""
+    for rel in PMC_FILES:
+        f = ROOT / rel
+        if not f.exists():
+            continue
+        raw = f.read_bytes()
+        data = json.loads(raw)
+        for name, c in data.items():
+            if name.startswith(kernel_prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                scale = batch / float(1 << 20)
+                return {"bytes": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * scale, "fetch_KiB": c["FETCH_SIZE"],
+                        "write_KiB": c["WRITE_SIZE"], "source": rel, "sha256": hashlib.sha256(raw).hexdigest()[:16],
+                        "kernel": name}
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="elements per GPU per step")
+    ap.add_argument("--batch", type=int, default=1 << 20, help="elements per GPU (weak) or in total (strong) per step")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
+    ap.add_argument("--no-extras", action="store_true", help="skip api_level / other_ops / small_batch (profiling runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     args = ap.parse_args()
 
     import torch
@@ -120,7 +154,7 @@ def main() -> None:
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
-    from pailliercryptolib_python_amd import engine, fixedpoint
+    from pailliercryptolib_python_amd import engine, fixedpoint, sharding
 
     key = synthetic_key(KEY_BITS, DJN_X)
     pub = engine.PublicKeyHandle(key.n, KEY_BITS, key.hs, key.randbits, device=device)
@@ -130,20 +164,28 @@ def main() -> None:
     okey = orc.make_key(key.p, key.q, djn_x=DJN_X, bits=KEY_BITS)
     assert okey.n == key.n and okey.hs == key.hs and okey.randbits == key.randbits
 
-    B = args.batch
-    x = np.random.default_rng(1002 + rank).uniform(-1000.0, 1000.0, B)
+    if args.scaling == "strong":
+        begin, B = engine.shard_plan(args.batch, world)[rank]        # this rank's contiguous block of the global batch
+        x_all = np.random.default_rng(1002).uniform(-1000.0, 1000.0, args.batch)
+        x = x_all[begin:begin + B]
+        total_per_step = float(args.batch)
+    else:
+        B = args.batch
+        x = np.random.default_rng(1002 + rank).uniform(-1000.0, 1000.0, B)
+        total_per_step = float(B) * world
     res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
     m = engine.to_device_words(res, device)
     gen = torch.Generator(device=device)
     gen.manual_seed(4002 + rank)
-    r = pub.random_r(B, generator=gen)
+    r = pub.random_r(max(B, 1), generator=gen)[:B].contiguous()
     ct = pub.empty_ct(B)
     out = pub.empty_pt(B)
     torch.cuda.synchronize()
 
     def step():
-        pub.encrypt(m, r, out=ct)
-        priv.decrypt(ct, out=out)
+        if B:
+            pub.encrypt(m, r, out=ct)
+            priv.decrypt(ct, out=out)
 
     def barrier():
         if world > 1:
@@ -166,13 +208,15 @@ def main() -> None:
 
     # ---- correctness of what was just timed (outside the timed region) ---------------------------
     ok = bool(torch.equal(out, m))
-    got_x = fixedpoint.decode_float64_array(engine.to_host_words(out[:4096]), expo[:4096], key.n, key.max_int)
-    ok = ok and bool(np.array_equal(got_x, x[:4096]))
-    idx = [0, 1, B // 2, B - 1]
-    ct_h = engine.to_host_words(ct[idx])
-    r_h = engine.words_to_ints(engine.to_host_words(r[idx]))
-    m_h = engine.words_to_ints(res[idx])
-    ok = ok and engine.words_to_ints(ct_h) == [orc.encrypt(okey, mm, rr) for mm, rr in zip(m_h, r_h)]
+    nchk = min(B, 4096)
+    got_x = fixedpoint.decode_float64_array(engine.to_host_words(out[:nchk]), expo[:nchk], key.n, key.max_int)
+    ok = ok and bool(np.array_equal(got_x, x[:nchk]))
+    if B:
+        idx = sorted({0, min(1, B - 1), B // 2, B - 1})
+        ct_h = engine.to_host_words(ct[idx])
+        r_h = engine.words_to_ints(engine.to_host_words(r[idx]))
+        m_h = engine.words_to_ints(res[idx])
+        ok = ok and engine.words_to_ints(ct_h) == [orc.encrypt(okey, mm, rr) for mm, rr in zip(m_h, r_h)]
     if world > 1:
         flag = torch.tensor([1 if ok else 0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -180,56 +224,113 @@ def main() -> None:
     if not ok:
         raise SystemExit("bench.py: parity check failed (decrypt(encrypt(m)) != m or ciphertext bits differ from the oracle)")
 
-    # ---- per-kernel durations with HIP events on the launch stream (rank 0) ----------------------
-    kern = {}
-    if rank == 0:
-        engine.profile_enable(True)
-        acc = {}
-        reps = max(1, min(args.steps, 3))
-        for _ in range(reps):
-            pub.encrypt(m, r, out=ct)
-            for k_, v in engine.profile_last().items():
-                acc[k_] = acc.get(k_, 0.0) + v
-            priv.decrypt(ct, out=out)
-            for k_, v in engine.profile_last().items():
-                acc[k_] = acc.get(k_, 0.0) + v
-        engine.profile_enable(False)
-        kern = {k_: v / reps for k_, v in acc.items()}
+    # ---- the final gather of the sharded result (strong scaling; RCCL all-gather over xGMI) ------
+    gather_ms = None
+    if args.scaling == "strong" and world > 1:
+        full = sharding.gather_rows(ct, args.batch)              # warm-up (communicator set-up)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        full = sharding.gather_rows(ct, args.batch)
+        torch.cuda.synchronize()
+        gather_ms = 1e3 * (time.perf_counter() - t1)
+        if not torch.equal(full[begin:begin + B], ct):
+            raise SystemExit("bench.py: gathered ciphertexts differ from the local shard")
+        del full
+
+    # ---- per-kernel durations with HIP events on the launch stream (every rank; rank 0 reports) ----
+    engine.profile_enable(True)
+    acc = {}
+    reps = max(1, min(args.steps, 3))
+    for _ in range(reps):
+        if not B:
+            break
+        pub.encrypt(m, r, out=ct)
+        for k_, v in engine.profile_last().items():
+            acc[k_] = acc.get(k_, 0.0) + v
+        priv.decrypt(ct, out=out)
+        for k_, v in engine.profile_last().items():
+            acc[k_] = acc.get(k_, 0.0) + v
+    engine.profile_enable(False)
+    kern = {k_: v / reps for k_, v in acc.items()}
+    per_rank_kern = [kern]
+    if world > 1:
+        per_rank_kern = [None] * world
+        dist.all_gather_object(per_rank_kern, kern)
+
+    single = rank == 0 and world == 1
+    extras = single and not args.no_extras
 
     # ---- CPU baseline on the host cores (rank 0, N = 1 only) -------------------------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:
+        import ctypes.util
+
         from oracle import c_oracle as co
 
         ck = co.COracleKey(okey)
-        use_gmp = co.gmp_available()
-        enc = ck.gmp_encrypt_djn if use_gmp else ck.encrypt_djn
-        dec = ck.gmp_decrypt_crt if use_gmp else ck.decrypt_crt
+        # the reference's own kernel library, if the box happens to have it
+        mb_lib = ctypes.util.find_library("crypto_mb") or ctypes.util.find_library("ippcp")
+        if co.ifma_available():
+            enc, dec, how, kind = ck.ifma_encrypt_djn, ck.ifma_decrypt_crt, "AVX512-IFMA mb8 port oracle/paillier_ifma.c (8 lanes x 52-bit limbs, 5-bit windows)", "port (IFMA mb8)"
+        elif co.gmp_available():
+            enc, dec, how, kind = ck.gmp_encrypt_djn, ck.gmp_decrypt_crt, "libgmp mpz_powm via oracle/paillier_ref.c", "port (GMP)"
+        else:
+            enc, dec, how, kind = ck.encrypt_djn, ck.decrypt_crt, "plain-C CIOS port oracle/paillier_ref.c", "port"
         threads = co.max_threads()
-        cap = min(B, 4096 * threads)
+        cap = min(B, 8192 * max(1, threads // 2))
         r_host = engine.to_host_words(r[:cap])
-        probe = 4 * threads
+        probe = 8 * threads
+        dec(enc(res[:probe], r_host[:probe]))                        # cold call: thread pool, page faults
         t1 = time.perf_counter()
-        dec(enc(res[:probe], r_host[:probe]))
+        dec(enc(res[:probe], r_host[:probe]))                        # warm probe sizes the sample
         t_probe = time.perf_counter() - t1
-        sample = int(min(cap, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-3))))
+        sample = int(min(cap, max(8192, probe * args.cpu_seconds / max(t_probe, 1e-4))))
+        sample -= sample % 8
         t1 = time.perf_counter()
         c_ct = enc(res[:sample], r_host[:sample])
+        t_enc_cpu = time.perf_counter() - t1
         c_m = dec(c_ct)
         t_cpu = time.perf_counter() - t1
         assert np.array_equal(c_m, res[:sample]), "CPU baseline failed its own round trip"
         assert np.array_equal(c_ct[:256], engine.to_host_words(ct[:256])), "CPU baseline and GPU ciphertexts differ"
         cpu = {
-            "value": sample / t_cpu, "unit": "encrypt+decrypt ops/s", "cores": threads, "kind": "port",
-            "sample": f"{sample} elements of the same batch, same key and randomness; "
-                      + ("libgmp mpz_powm via oracle/paillier_ref.c" if use_gmp else "plain-C CIOS port oracle/paillier_ref.c")
-                      + f", OpenMP over {threads} host threads, {t_cpu:.1f} s",
+            "value": sample / t_cpu, "unit": "encrypt+decrypt ops/s", "cores": threads, "kind": kind,
+            "sample": f"{sample} elements of the same batch, same key and randomness; {how}, OpenMP over {threads} host "
+                      f"threads, {t_cpu:.1f} s (encrypt {t_enc_cpu:.1f} s)",
+            "reference_kernel_library": mb_lib or "libcrypto_mb / libippcp not present on this box (IPP-Crypto is un-vendored upstream)",
         }
 
-    # ---- the other operations of BASELINE configs[2] (ct+ct add, ct x pt mul), kernel-resident, rank 0, N = 1 ----
+    # ---- API level: host float64 -> encrypt -> decrypt -> host float64 (rank 0, N = 1) ----------
+    api = None
+    if extras:
+        from pailliercryptolib_python_amd import PaillierPrivateKey, PaillierPublicKey
+        from pailliercryptolib_python_amd.bindings import ipclPublicKey
+
+        apk = PaillierPublicKey(ipclPublicKey(key.n, KEY_BITS, True, hs=key.hs, randbits=key.randbits, device=device))
+        ask = PaillierPrivateKey(apk, key.p, key.q)
+        warm = apk.encrypt(x[:4096])
+        ask.decrypt_to_numpy(warm)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        en = apk.encrypt(x)
+        torch.cuda.synchronize()
+        t_api_enc = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        back = ask.decrypt_to_numpy(en)
+        t_api_dec = time.perf_counter() - t1
+        if not np.array_equal(back, x):
+            raise SystemExit("bench.py: API-level round trip failed")
+        api = {"encrypt_s": t_api_enc, "decrypt_s": t_api_dec, "ops_per_s": B / (t_api_enc + t_api_dec), "batch": B,
+               "note": "PaillierPublicKey.encrypt(float64 ndarray) + PaillierPrivateKey.decrypt_to_numpy: device codec, "
+                       "ChaCha20 randomness under an OS-CSPRNG key, H2D/D2H over PCIe included"}
+        del en, warm
+
+    # ---- the other operations of BASELINE configs[2], kernel-resident, each checked against the oracle ----
     other = None
-    if rank == 0 and world == 1:
-        def wall(f, reps=2):
+    small = None
+    if extras:
+        def wall(f, reps=3):
             f()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -238,28 +339,74 @@ def main() -> None:
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / reps
 
+        chk = [0, B // 3, B - 1]
+
+        def rows(t_):
+            return engine.words_to_ints(engine.to_host_words(t_[chk]))
+
+        ct_b = torch.roll(ct, 1, dims=0).contiguous()
         ct2 = pub.empty_ct(B)
         e53 = torch.randint(0, 1 << 30, (B, 2), dtype=torch.int32, device=device)     # 53-bit multipliers (float mantissas)
         e53[:, 1] &= (1 << 21) - 1
         e53[:, 1] |= 1 << 20
-        t_add = wall(lambda: pub.ct_add(ct, ct, out=ct2))
-        t_mul = wall(lambda: pub.ct_mul(ct, e53, 53, out=ct2))
-        t_inv = wall(lambda: pub.ct_invert(ct, out=ct2))
-        chk = [0, B - 1]
-        c_h = engine.words_to_ints(engine.to_host_words(ct[chk]))
-        i_h = engine.words_to_ints(engine.to_host_words(ct2[chk]))
-        if any((a * b) % key.nsq != 1 for a, b in zip(c_h, i_h)):
+        ca, cb = rows(ct), rows(ct_b)
+        t_add = wall(lambda: pub.ct_add(ct, ct_b, out=ct2))
+        if rows(ct2) != [orc.ct_add(a, b, key.nsq) for a, b in zip(ca, cb)]:
+            raise SystemExit("bench.py: ct_add parity check failed")
+        t_add_b = wall(lambda: pub.ct_add(ct, ct_b[:1], out=ct2))
+        if rows(ct2) != [orc.ct_add(a, engine.words_to_ints(engine.to_host_words(ct_b[:1]))[0], key.nsq) for a in ca]:
+            raise SystemExit("bench.py: broadcast ct_add parity check failed")
+        t_mul = wall(lambda: pub.ct_mul(ct, e53, 53, out=ct2), reps=2)
+        e_h = [int(v[0]) & 0xFFFFFFFF | (int(v[1]) & 0xFFFFFFFF) << 32 for v in e53[chk].cpu().numpy()]
+        if rows(ct2) != [orc.ct_mul(a, e, key.nsq) for a, e in zip(ca, e_h)]:
+            raise SystemExit("bench.py: ct_mul parity check failed")
+        t_inv = wall(lambda: pub.ct_invert(ct, out=ct2), reps=2)
+        if rows(ct2) != [orc.ct_inv(a, key.nsq) for a in ca]:
             raise SystemExit("bench.py: ct_invert parity check failed")
-        other = {"ct_add_ops_per_s": B / t_add, "ct_mul_53bit_ops_per_s": B / t_mul, "ct_invert_ops_per_s": B / t_inv,
-                 "batch": B, "note": "BASELINE configs[2] operations on the same resident batch (wall clock around the C-ABI call)"}
+        nsum = min(B, 1 << 16)
+        t_sum = wall(lambda: pub.ct_prod(ct[:nsum], 1), reps=2)
+        prod_h = engine.words_to_ints(engine.to_host_words(pub.ct_prod(ct[:4096].contiguous(), 1)))[0]
+        want = 1
+        for v in engine.words_to_ints(engine.to_host_words(ct[:4096])):
+            want = want * v % key.nsq
+        if prod_h != want:
+            raise SystemExit("bench.py: ct_prod parity check failed")
+        engine.profile_enable(True)
+        pub.ct_add(ct, ct_b, out=ct2)
+        k_add = engine.profile_last().get("k_modmul")
+        engine.profile_enable(False)
+        other = {
+            "ct_add_ops_per_s": B / t_add, "ct_add_bcast_ops_per_s": B / t_add_b, "ct_mul_53bit_ops_per_s": B / t_mul,
+            "ct_invert_ops_per_s": B / t_inv, "ct_sum_elements_per_s": nsum / t_sum, "batch": B,
+            "k_modmul_ms": k_add,
+            "ct_add_roofline": {"bound": "valu_int", "canonical_frac": CANON_MAC_ADD * B / t_add / PEAK_MAC32_PER_S,
+                                "executed_frac": 2 * 2 * 144 * 144 * B / t_add / PEAK_MAC32_PER_S,
+                                "hbm_GBs": BYTES_ADD * B / t_add / 1e9, "hbm_frac": BYTES_ADD * B / t_add / 1e9 / HBM_PEAK_GBS},
+            "note": "BASELINE configs[2] operations on the same resident batch (wall clock around the C-ABI call); results "
+                    "checked against the oracle on 3 elements each",
+        }
+        del ct_b, ct2, e53
+        # latency at the reference's own batch sizes (bench/bench_ipcl_python.py:24-25,34-35,45-46)
+        small = {}
+        for nb in (16, 64):
+            ms_, rs_ = m[:nb].contiguous(), r[:nb].contiguous()
+            cts_ = pub.encrypt(ms_, rs_)
+            es_ = torch.full((nb, 2), 3, dtype=torch.int32, device=device)
+            small[str(nb)] = {
+                "encrypt_ms": 1e3 * wall(lambda: pub.encrypt(ms_, rs_), reps=5),
+                "decrypt_ms": 1e3 * wall(lambda: priv.decrypt(cts_), reps=5),
+                "ct_add_ms": 1e3 * wall(lambda: pub.ct_add(cts_, cts_), reps=5),
+                "ct_mul_53bit_ms": 1e3 * wall(lambda: pub.ct_mul(cts_, es_, 53), reps=5),
+            }
 
     if rank == 0:
-        total_ops = float(B) * world * args.steps
+        total_ops = total_per_step * args.steps
         value = total_ops / elapsed
         t_deca = kern.get("k_dec_a", 0.0) * 1e-3
         t_enc = kern.get("k_encrypt(djn)", 0.0) * 1e-3
-        achieved = (CANON_MAC_DEC * B / t_deca) if t_deca > 0 else None
+        canonical = (CANON_MAC_DEC * B / t_deca) if t_deca > 0 else None
         executed = (executed_macs_decrypt(key.p, key.q) * B / t_deca) if t_deca > 0 else None
+        traffic = pmc_traffic("k_dec_a_padic", B)
         line = {
             "metric": "Paillier encrypt+decrypt ops/sec, 2048-bit key",
             "value": value,
@@ -269,34 +416,34 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32 limbs (radix-2^29 in 32-bit registers, 64-bit accumulators)",
             "data": "synthetic",
             "config": {
-                "workload": f"2048-bit key (reference bench P,Q), DJN encrypt + CRT decrypt, batch={B} per GPU, "
-                            f"inputs resident in HBM",
-                "key_bits": KEY_BITS, "batch_per_gpu": B, "scheme": "DJN", "parallelism": f"shard{world}",
+                "workload": f"2048-bit key (reference bench P,Q), DJN encrypt + CRT decrypt, "
+                            + (f"batch={args.batch} in total, block-sharded over {world} GPU(s)" if args.scaling == "strong"
+                               else f"batch={B} per GPU")
+                            + ", inputs resident in HBM",
+                "key_bits": KEY_BITS, "batch_per_gpu": B if args.scaling == "weak" else None,
+                "batch_total": int(total_per_step), "scheme": "DJN", "parallelism": f"shard{world}",
             },
             "roofline": {
                 "bound": "valu_int",
                 "kernel": "k_dec_a_padic (CRT-decrypt stage A: (ct mod s^2)^(s-1) for both primes)",
-                "achieved": (achieved / 1e12) if achieved else None,
+                "achieved": (executed / 1e12) if executed else None,
                 "peak": PEAK_MAC32_PER_S / 1e12,
-                "unit": "T MAC32/s (canonical 32x32->64 multiply-accumulates, SURVEY §8d)",
-                "frac": (achieved / PEAK_MAC32_PER_S) if achieved else None,
-                "note": "achieved/frac price the kernel at the CANONICAL algorithm's work (SURVEY §8d); the kernel runs an "
-                        "asymptotically cheaper algorithm (arithmetic mod s on base-s digit pairs instead of mod s^2), "
-                        "so the canonical fraction can exceed 1 — executed_* is the issue-rate view of kernel quality",
-                "executed_T_MAC_s": (executed / 1e12) if executed else None,
-                "executed_frac": (executed / PEAK_MAC32_PER_S) if executed else None,
+                "unit": "T MAC/s (29x29-bit multiply-accumulates actually executed, v_mad_u64_u32)",
+                "frac": (executed / PEAK_MAC32_PER_S) if executed else None,
+                "canonical_T_MAC32_s": (canonical / 1e12) if canonical else None,
+                "canonical_frac": (canonical / PEAK_MAC32_PER_S) if canonical else None,
+                "note": "frac = executed MACs / measured v_mad_u64_u32 peak (kernel quality).  canonical_* price the kernel at "
+                        "the CANONICAL algorithm's work (SURVEY §8d: CIOS mod s^2, 5-bit windows); the kernel runs a cheaper "
+                        "algorithm (arithmetic mod s on base-s digit pairs), so the canonical fraction can exceed 1",
                 "kernel_ms": kern,
-                # HBM bytes per launch of the dominant kernel at batch = 2^20 from the PMC passes committed in
-                # profiles/r01/pmc_bench_r01d.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE halving applied).
-                # It is ~200x the algorithmic bytes because every resident element keeps its 33-entry window table in
-                # HBM scratch (19 GB written, 88 GB read per launch = 0.2 TB/s, 3 % of the HBM roof): compute bound.
-                "traffic": (2 * 43612792.0625 + 19988491.90625) * 1024 * (B / float(1 << 20)),
-                "traffic_unit": "bytes per k_dec_a_padic launch (PMC, scaled linearly from batch 2^20)",
+                "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": traffic,
+                "traffic_unit": "HBM bytes per k_dec_a_padic launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, scaled from batch 2^20)",
                 "hbm": {
                     "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                     "achieved_decrypt": (BYTES_DEC * B / t_deca / 1e9) if t_deca > 0 else None,
@@ -304,8 +451,12 @@ def main() -> None:
                 },
                 "encrypt_canonical_T_MAC32_s": (CANON_MAC_ENC * B / t_enc / 1e12) if t_enc > 0 else None,
             },
+            "per_rank_kernel_ms": per_rank_kern if world > 1 else None,
+            "gather_ms": gather_ms,
             "cpu_baseline": cpu,
+            "api_level": api,
             "other_ops": other,
+            "small_batch": small,
             "parity_checked": True,
         }
         print(json.dumps(line), flush=True)

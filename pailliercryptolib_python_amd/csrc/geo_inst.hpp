@@ -3,18 +3,27 @@
 #include "geo_ops.hpp"
 #include "kernels_modexp.hpp"
 
+#ifndef PAI_TILE_NMLDS
+#define PAI_TILE_NMLDS false
+#endif
+
 namespace pai {
 
 template <class G>
 struct GeoInst {
+    // The tile-I/O kernels (k_modmul, k_pow2) re-read the modulus slice from LDS during the q*n step: the 36 VGPRs this
+    // frees keep the tile staging registers, both operands and the accumulator window out of scratch memory (whose
+    // reloads cost hundreds of cycles each in kernels this short), and the products run at the same rate
+    // (profiles/r01/mm_bench_dpp.jsonl: 24.5 vs 24.8 T MAC/s).
+    using GM = Geo<G::NLL, G::T, G::U, PAI_TILE_NMLDS>;
     static void set_lds(const void* fn, int bytes) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
     static void modmul(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, uint32_t* out,
                        int n, int w32, int b_bcast, int mode) {
-        constexpr int bytes = G::LDS_BYTES + G::STAGE_BYTES;
-        set_lds((const void*)k_modmul<G>, bytes);
-        hipLaunchKernelGGL(k_modmul<G>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
+        constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
+        set_lds((const void*)k_modmul<GM>, bytes);
+        hipLaunchKernelGGL(k_modmul<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
     }
     static void modexp_fixed(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32,
                              const uint32_t* expo, int ewords, int ebits, uint32_t* out, int out_w32, int n,
@@ -54,9 +63,9 @@ struct GeoInst {
     }
     static void pow2(hipStream_t s, int grid, const MontCtx* c, uint32_t* ct, const int32_t* delta, int delta_bcast,
                      int n, int w32) {
-        constexpr int bytes = G::LDS_BYTES + G::STAGE_BYTES;
-        set_lds((const void*)k_pow2<G>, bytes);
-        hipLaunchKernelGGL(k_pow2<G>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, ct, delta, delta_bcast, n, w32);
+        constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
+        set_lds((const void*)k_pow2<GM>, bytes);
+        hipLaunchKernelGGL(k_pow2<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, ct, delta, delta_bcast, n, w32);
     }
     static size_t table_words(size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * G::NL * blocks * G::EPB; }
 

@@ -80,34 +80,68 @@ PAI_DEV void load_elem(uint32_t (&x)[G::NLL], const uint32_t* __restrict__ row, 
 // ---- coalesced tile I/O ------------------------------------------------------------------------------------
 // load_elem above issues 2*NLL dependent-address dword loads per lane (the compiler hoists the 2*NLL per-limb
 // offsets out of the tile loop, spills them, and serialises load -> wait -> extract: ~100 us per tile on MI355X,
-// which is what bounded k_modmul in round 1).  Kernels whose arithmetic per tile is short use this pair instead:
-// the workgroup copies the tile's rows HBM -> LDS with full-width coalesced loads, then every lane funnel-shifts
-// its own bit window out of LDS (one runtime shift per lane, compile-time limb positions after it).
+// which is what bounded k_modmul in round 1).  Kernels whose arithmetic per tile is short use the helpers below
+// instead.  The unit is a WAVE tile: the 64 / T elements of one wavefront, whose packed rows are consecutive in
+// memory.  The wave copies them HBM -> LDS with full-width coalesced loads into its own slice of the staging area
+// (rows elem() of stride G::SW), then every lane funnel-shifts its bit window out of LDS (one runtime shift per
+// lane, compile-time limb positions after it).  Nothing here needs a workgroup barrier — lane groups never span
+// waves — so the waves of a workgroup run their load / multiply / store phases independently and the two waves
+// that share a SIMD overlap one's memory phase with the other's multiply phase.
+template <class G>
+struct WaveTile {
+    static constexpr int EPW = 64 / G::T;                    // elements (rows) per wave
+    static constexpr int SV = G::SW / 4;
+    static constexpr int IT4 = (EPW * SV + 63) / 64;         // 16-byte copy iterations per lane
+    PAI_DEV static int lane() { return (int)threadIdx.x & 63; }
+    PAI_DEV static int wave() { return (int)threadIdx.x >> 6; }
+    PAI_DEV static uint32_t* slice(uint32_t* stage) { return stage + wave() * EPW * G::SW; }
+};
 
-// Cooperative copy of `rows` consecutive packed rows (W32 words each, starting at `src`) into the staging area,
-// row stride G::SW, zero beyond W32 / beyond `rows`.  All threads of the block must call it; the caller
-// synchronises before unpacking.  bcast: every staged row is a copy of row 0 of src.
+// Zeroes this wave's staging slice once per kernel: the pad words behind every row (the funnel shift of unpack_row
+// peeks at them) and the rows of a ragged last tile then read as zero / stale-but-unused without per-tile filling.
+template <class G>
+PAI_DEV void clear_stage(uint32_t* stage) {
+    using WT = WaveTile<G>;
+    uint4* d4 = reinterpret_cast<uint4*>(WT::slice(stage));
+    for (int i = WT::lane(); i < WT::EPW * WT::SV; i += 64) d4[i] = make_uint4(0u, 0u, 0u, 0u);
+    wave_lds_fence();
+}
+
+// Copies `rows` (<= EPW) consecutive packed rows of W32 words starting at `src` into this wave's staging slice (pad
+// words untouched: clear_stage).  The rows are contiguous in memory, so lane l of iteration `it` simply loads 16-byte
+// chunk l + 64 it of the tile — straight-line code: every load is issued (index clamped, never branched around)
+// before the first LDS write, one HBM round trip per tile.  bcast: every staged row is a copy of row 0 of src.
 template <class G>
 PAI_DEV void load_tile(uint32_t* stage, const uint32_t* __restrict__ src, int rows, int W32, bool bcast = false) {
-    if ((W32 & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-        constexpr int SV = G::SW / 4;
-        const int wv = W32 >> 2;
+    using WT = WaveTile<G>;
+    uint32_t* dst = WT::slice(stage);
+    const int lane = WT::lane();
+    wave_lds_fence();
+    if (!bcast && (W32 & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const int wv = W32 >> 2;                             // 16-byte chunks per row (wave-uniform)
+        const int total = rows * wv;
+        const uint32_t inv = (65536u + (uint32_t)wv - 1u) / (uint32_t)wv;     // c / wv == (c * inv) >> 16 for c < 1024
         const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
-        uint4* d4 = reinterpret_cast<uint4*>(stage);
-        for (int i = threadIdx.x; i < G::EPB * SV; i += BLOCK_THREADS) {
-            const int e = i / SV, k = i - e * SV;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (k < wv && (bcast || e < rows)) v = s4[(size_t)(bcast ? 0 : e) * wv + k];
-            d4[i] = v;
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        uint4 v[WT::IT4];
+#pragma unroll
+        for (int it = 0; it < WT::IT4; ++it) {
+            const int c = lane + it * 64;
+            v[it] = s4[c < total ? c : total - 1];
         }
-    } else {
-        for (int i = threadIdx.x; i < G::EPB * G::SW; i += BLOCK_THREADS) {
+#pragma unroll
+        for (int it = 0; it < WT::IT4; ++it) {
+            const int c = lane + it * 64;
+            const int e = (int)(((uint32_t)c * inv) >> 16), k = c - e * wv;
+            if (c < total) d4[e * WT::SV + k] = v[it];
+        }
+    } else {                                                 // broadcast row / odd word counts / unaligned rows
+        for (int i = lane; i < WT::EPW * G::SW; i += 64) {
             const int e = i / G::SW, k = i - e * G::SW;
-            uint32_t v = 0u;
-            if (k < W32 && (bcast || e < rows)) v = src[(size_t)(bcast ? 0 : e) * W32 + k];
-            stage[i] = v;
+            if (k < W32 && (bcast || e < rows)) dst[i] = src[(size_t)(bcast ? 0 : e) * W32 + k];
         }
     }
+    wave_lds_fence();
 }
 
 // this lane's limb slice of its element's staged row
@@ -149,44 +183,83 @@ PAI_DEV void store_elem(const uint32_t (&x)[G::NLL], uint32_t* __restrict__ row,
     wave_lds_fence();
 }
 
-// limb slices -> packed words of the element's staged row (through the [limb][element] buffer `lds`, as store_elem);
-// the caller synchronises, then store_tile writes the rows out with coalesced full-width stores
+// limb slices (canonical 29-bit limbs) -> packed words of the element's staged row: the inverse of unpack_row.  Every
+// lane assembles the words its bit window overlaps in registers (compile-time limb positions, then one runtime
+// funnel shift by the window's bit offset); the word that straddles two lanes of a group is completed with the piece
+// handed over by the previous lane (DPP / bpermute), and the lane writes the words that start inside its window.
+// Bits above 32*W32 must be zero.  The caller synchronises, then store_tile writes the rows out coalesced.
 template <class G>
-PAI_DEV void pack_row(const uint32_t (&x)[G::NLL], uint32_t* stage, int W32, uint32_t* lds) {
-    const int t = G::gl(), e = G::elem();
-    wave_lds_fence();
+PAI_DEV void pack_row(const uint32_t (&x)[G::NLL], uint32_t* stage) {
+    constexpr int NW = G::NWIN;                              // words a window can overlap, both partial ends included
+    constexpr int WBITS = RB * G::NLL;
+    static_assert(WBITS % 32 >= 2 && NW - 2 == WBITS / 32, "window geometry");
+    const int t = G::gl();
+    const int start = WBITS * t;
+    const int k0 = start >> 5;
+    const uint32_t s = (uint32_t)start & 31u;
+    uint32_t w[NW];
 #pragma unroll
-    for (int j = 0; j < G::NLL; ++j) lds[(G::NLL * t + j) * G::EPB + e] = x[j];
-    wave_lds_fence();
-    uint32_t* row = stage + e * G::SW;
-    for (int k = t; k < W32; k += G::T) {
-        const int j0 = (32 * k) / RB;
-        const int s0 = 32 * k - RB * j0;
-        uint64_t v = (uint64_t)lds[j0 * G::EPB + e] >> s0;
-        if (j0 + 1 < G::NL) v |= (uint64_t)lds[(j0 + 1) * G::EPB + e] << (RB - s0);
-        if (j0 + 2 < G::NL) v |= (uint64_t)lds[(j0 + 2) * G::EPB + e] << (2 * RB - s0);
-        row[k] = (uint32_t)v;
+    for (int i = 0; i < NW; ++i) w[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < G::NLL; ++j) {                       // the window with its first bit at w[0] bit 0
+        const int bit = RB * j, k = bit >> 5, sh = bit & 31;
+        w[k] |= x[j] << sh;
+        if (sh + RB > 32) w[k + 1] |= x[j] >> (32 - sh);
     }
+    // shift left by s bits across the words (64-bit shifts take the count 32 when s == 0)
+#pragma unroll
+    for (int i = NW - 1; i >= 1; --i) w[i] = (uint32_t)((((uint64_t)w[i] << 32) | w[i - 1]) >> (32u - s));
+    w[0] <<= s;
+    uint32_t* row = stage + G::elem() * G::SW + k0;
     wave_lds_fence();
+    if constexpr (G::T > 1) {
+        // This lane owns the words that START inside its window: own = k0(t + 1) - k0(t) of them (NW - 2 or NW - 1).
+        // The word after them straddles into the next lane's window: hand this lane's piece of it over.
+        const int own = ((WBITS * (t + 1)) >> 5) - k0;
+        const uint32_t top = own == NW - 1 ? w[NW - 1] : w[NW - 2];
+        w[0] |= from_prev<G::T>(top);
+#pragma unroll
+        for (int i = 0; i < NW - 2; ++i) row[i] = w[i];
+        if (own == NW - 1) row[NW - 2] = w[NW - 2];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW - 1; ++i) row[i] = w[i];      // T == 1: k0 == 0, everything is this lane's
+    }
 }
 
+// this wave's staged rows -> `rows` consecutive packed rows at dst, coalesced full-width stores
 template <class G>
 PAI_DEV void store_tile(const uint32_t* stage, uint32_t* __restrict__ dst, int rows, int W32) {
+    using WT = WaveTile<G>;
+    const uint32_t* src = WT::slice(const_cast<uint32_t*>(stage));
+    const int lane = WT::lane();
+    wave_lds_fence();
     if ((W32 & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-        constexpr int SV = G::SW / 4;
         const int wv = W32 >> 2;
-        const uint4* s4 = reinterpret_cast<const uint4*>(stage);
+        const int total = rows * wv;
+        const uint32_t inv = (65536u + (uint32_t)wv - 1u) / (uint32_t)wv;
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
         uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
-        for (int i = threadIdx.x; i < rows * wv; i += BLOCK_THREADS) {
-            const int e = i / wv, k = i - e * wv;
-            d4[i] = s4[e * SV + k];
+        uint4 v[WT::IT4];
+#pragma unroll
+        for (int it = 0; it < WT::IT4; ++it) {               // every LDS read first, then the stores
+            const int c = lane + it * 64;
+            const int cc = c < total ? c : total - 1;
+            const int e = (int)(((uint32_t)cc * inv) >> 16), k = cc - e * wv;
+            v[it] = s4[e * WT::SV + k];
+        }
+#pragma unroll
+        for (int it = 0; it < WT::IT4; ++it) {
+            const int c = lane + it * 64;
+            if (c < total) d4[c] = v[it];
         }
     } else {
-        for (int i = threadIdx.x; i < rows * W32; i += BLOCK_THREADS) {
+        for (int i = lane; i < rows * W32; i += 64) {
             const int e = i / W32, k = i - e * W32;
-            dst[i] = stage[e * G::SW + k];
+            dst[i] = src[e * G::SW + k];
         }
     }
+    wave_lds_fence();
 }
 
 // publish this lane's slice as the element's multiplier operand b in LDS

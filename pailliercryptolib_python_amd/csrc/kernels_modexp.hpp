@@ -9,60 +9,122 @@
 namespace pai {
 
 // ---------------------------------------------------------------------------------------------
-// out_i = a_i * b_i mod M on canonical packed rows.  Tiles move HBM <-> LDS with coalesced full-width copies
-// (load_tile / store_tile); the arithmetic is one or two Montgomery products per element:
-//   mode MODMUL_FULL   out = a*b mod M          (a*b*R^-1, then * R^2 * R^-1; b_bcast: b*R is formed once per block,
+// out_i = a_i * b_i mod M on canonical packed rows.  Every wave works on its own tiles of 64 / T consecutive
+// elements: coalesced full-width copies HBM <-> LDS (load_tile / store_tile), one or two Montgomery products, no
+// workgroup barrier anywhere in the loop, so the waves drift apart and the two waves of a SIMD overlap one's
+// memory phase with the other's multiply phase.
+//   mode MODMUL_FULL   out = a*b mod M          (a*b*R^-1, then * R^2 * R^-1; b_bcast: b*R is formed once per wave,
 //                                               so a broadcast addend costs ONE product per element)
 //   mode MODMUL_MONT   out = a*b*R^-1 mod M     (canonical residue of the Montgomery product: the body of the
 //                                               product trees of pai_ct_invert / pai_ct_prod, which keep track of
 //                                               the power of R per tree level on the host)
+// Dev builds only (-DPAI_PHASE_TIMING, tools/phase_probe.sh): thread 0 of block 0 accumulates cycle-counter deltas per
+// phase of the tile loop and prints them when the kernel ends; compiled out of the product library.
+#ifdef PAI_PHASE_TIMING
+#define PHASE_INIT() unsigned long long ph_t0 = __builtin_readcyclecounter()
+#define PHASE_DECL() unsigned long long ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_MARK(i)                                                       \
+    do {                                                                    \
+        unsigned long long ph_t1 = __builtin_readcyclecounter();            \
+        ph_acc[i] += ph_t1 - ph_t0;                                         \
+        ph_t0 = __builtin_readcyclecounter();                               \
+    } while (0)
+#define PHASE_REPORT(name)                                                                                          \
+    do {                                                                                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                                                    \
+            printf("PHASES %s mode=%d bcast=%d: %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", name, mode, b_bcast, ph_acc[0], \
+                   ph_acc[1], ph_acc[2], ph_acc[3], ph_acc[4], ph_acc[5], ph_acc[6], ph_acc[7], ph_acc[8]);          \
+    } while (0)
+#else
+#define PHASE_INIT() do { } while (0)
+#define PHASE_DECL() do { } while (0)
+#define PHASE_MARK(i) do { } while (0)
+#define PHASE_REPORT(name) do { } while (0)
+#endif
+
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
-k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, int n, int w32, int b_bcast, int mode) {
+k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
+         int n, int w32, int b_bcast, int mode) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using WT = WaveTile<G>;
     uint32_t* stage = lds + G::LDS_WORDS + G::NL;        // behind the operand buffer and the modulus copy
+    uint32_t* r2_lds = stage + G::STAGE_WORDS;           // R^2 mod M, one copy per workgroup
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
+    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) r2_lds[i] = ctx->r2[i];
+    __syncthreads();
     const uint32_t n0inv = ctx->n0inv;
-    const int tiles = (n + G::EPB - 1) / G::EPB;
-    uint32_t y[G::NLL];
-    if (b_bcast) {                                       // the shared operand, once per block
+    constexpr int WPB = BLOCK_THREADS / 64;
+    const int wtiles = (n + WT::EPW - 1) / WT::EPW;
+    clear_stage<G>(stage);
+    PHASE_DECL();
+    // Register plan: the left operand x lives in registers (the row engine's `a`), the right operand streams from
+    // LDS — the per-element operand buffer for b, the workgroup's R^2 copy for the domain fix-up — so nothing but x,
+    // the modulus slice and the accumulator window is live inside the row loops (no scratch traffic there).
+    const uint32_t* b_lds = lds + G::elem();             // column of this element in the [limb][element] buffer
+    if (b_bcast) {                                       // the shared operand, staged once per wave for all its elements
+        uint32_t bb[G::NLL];
         load_tile<G>(stage, b, 1, w32, true);
-        __syncthreads();
-        unpack_row<G>(y, stage);
-        if (mode == MODMUL_FULL) {
-            uint32_t r2[G::NLL];
-            load_const_slice<G>(r2, ctx->r2);
-            mm_times<G>(y, r2, lds, nm, n0inv);          // b*R (lazy, < 2M)
+        unpack_row<G>(bb, stage);
+        if (mode == MODMUL_FULL) {                       // b*R (lazy, < 2M): a broadcast addend then costs ONE product per element
+            uint32_t t[G::NLL];
+            mont_mul<G::NLL, G::U, G::T>(t, bb, r2_lds, 1, nm, n0inv);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) bb[j] = t[j];
         }
-        __syncthreads();
+        stage_b<G>(bb, lds);
     }
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int row0 = tile * G::EPB;
-        const int rows = min(G::EPB, n - row0);
+    // the products of one tile run through ONE rolled loop body (pass 0: the operand pair; pass 1 of MODMUL_FULL
+    // without broadcast: the domain fix-up by R^2): a second inlined copy of the row engine was measured at 3-4x
+    // the cycles of the first (register allocation across two copies spills inside the row loops)
+    const int npass = (mode == MODMUL_FULL && !b_bcast) ? 2 : 1;
+    // every wave streams through ONE contiguous run of tiles
+    const int per_wave = (wtiles + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
+    const int wt_begin = ((int)blockIdx.x * WPB + WT::wave()) * per_wave;
+    const int wt_end = min(wtiles, wt_begin + per_wave);
+    for (int wt = wt_begin; wt < wt_end; ++wt) {
+        const int row0 = wt * WT::EPW;
+        const int rows = min(WT::EPW, n - row0);
         uint32_t x[G::NLL];
-        load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
-        __syncthreads();
-        unpack_row<G>(x, stage);
+        PHASE_INIT();
+        // The tile I/O phases are short on VALU work and long on memory latency: they run at raised priority so that
+        // the multiply stream of the other wave on this SIMD does not starve their address arithmetic (VALU
+        // arbitration is priority, then age); the products run at base priority.
+        __builtin_amdgcn_s_setprio(2);
         if (!b_bcast) {
-            __syncthreads();
             load_tile<G>(stage, b + (size_t)row0 * w32, rows, w32);
-            __syncthreads();
-            unpack_row<G>(y, stage);
+            PHASE_MARK(2);
+            unpack_row<G>(x, stage);
+            stage_b<G>(x, lds);
+            PHASE_MARK(3);
         }
-        mm_times<G>(x, y, lds, nm, n0inv);               // a*b*R^-1 (a*b when y = b*R)
-        if (mode == MODMUL_FULL && !b_bcast) {
-            uint32_t r2[G::NLL];
-            load_const_slice<G>(r2, ctx->r2);
-            mm_times<G>(x, r2, lds, nm, n0inv);
+        load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
+        PHASE_MARK(0);
+        unpack_row<G>(x, stage);
+        PHASE_MARK(1);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll 1
+        for (int pass = 0; pass < npass; ++pass) {
+            uint32_t r[G::NLL];
+            // pass 0: a*b*R^-1 (a*b when the staged operand is b*R); pass 1: * R^2 * R^-1
+            mont_mul<G::NLL, G::U, G::T>(r, x, pass == 0 ? b_lds : r2_lds, pass == 0 ? G::EPB : 1, nm, n0inv);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
+            PHASE_MARK(4 + pass);
         }
         cond_sub<G::NLL, G::T>(x, nm);
-        __syncthreads();                                 // every lane has unpacked its operands
-        pack_row<G>(x, stage, w32, lds);
-        __syncthreads();
+        __builtin_amdgcn_s_setprio(2);
+        PHASE_MARK(6);
+        pack_row<G>(x, stage);
+        PHASE_MARK(7);
+#ifndef PAI_PROBE_NOSTORE
         store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
-        __syncthreads();
+#endif
+        PHASE_MARK(8);
     }
+    __builtin_amdgcn_s_setprio(0);
+    PHASE_REPORT("k_modmul");
 }
 
 // ---------------------------------------------------------------------------------------------

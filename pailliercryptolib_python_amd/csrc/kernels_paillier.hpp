@@ -312,59 +312,64 @@ k_dec_b(DecBParams P, const uint32_t* __restrict__ u_in /*[2][n][u_words]*/, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// ct_i <- ct_i^(2^delta_i) mod n^2 for delta_i > 0; other elements are left untouched.  Tiles move through the
-// staging area (load_tile / store_tile); a tile without any positive delta is skipped by the whole workgroup.
+// ct_i <- ct_i^(2^delta_i) mod n^2 for delta_i > 0; other elements are left untouched.  Wave tiles as in k_modmul
+// (load_tile / store_tile, no workgroup barrier); a wave tile without any positive delta is skipped.
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_pow2(const MontCtx* __restrict__ ctx, uint32_t* ct, const int32_t* __restrict__ delta, int delta_bcast,
        int n, int w32) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using WT = WaveTile<G>;
     uint32_t* stage = lds + G::LDS_WORDS + G::NL;
+    uint32_t* r2_lds = stage + G::STAGE_WORDS;           // R^2 mod M, one copy per workgroup
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
+    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) r2_lds[i] = ctx->r2[i];
+    __syncthreads();
     const uint32_t n0inv = ctx->n0inv;
-    const int tiles = (n + G::EPB - 1) / G::EPB;
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int row0 = tile * G::EPB;
-        const int rows = min(G::EPB, n - row0);
-        const int ei = row0 + G::elem();
+    constexpr int WPB = BLOCK_THREADS / 64;
+    const int wtiles = (n + WT::EPW - 1) / WT::EPW;
+    clear_stage<G>(stage);
+    const int per_wave = (wtiles + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
+    const int wt_begin = ((int)blockIdx.x * WPB + WT::wave()) * per_wave;
+    const int wt_end = min(wtiles, wt_begin + per_wave);
+    for (int wt = wt_begin; wt < wt_end; ++wt) {
+        const int row0 = wt * WT::EPW;
+        const int rows = min(WT::EPW, n - row0);
+        const int ei = row0 + (WT::lane() / G::T);
         const bool live = ei < n;
         int dl = live ? delta[delta_bcast ? 0 : ei] : 0;
         if (dl < 0) dl = 0;
-        if (!__syncthreads_or(dl > 0)) continue;                     // block-uniform; also fences the previous tile's stage use
         int dmax = dl;
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(dmax, off, 64); dmax = o > dmax ? o : dmax; }
+        if (dmax == 0) continue;                                     // wave-uniform
+        __builtin_amdgcn_s_setprio(2);
         load_tile<G>(stage, ct + (size_t)row0 * w32, rows, w32);
-        __syncthreads();
         uint32_t x[G::NLL];
         unpack_row<G>(x, stage);
-        if (dmax > 0) {                                              // wave-uniform
-            {
-                uint32_t r2[G::NLL];
-                load_const_slice<G>(r2, ctx->r2);
-                mm_times<G>(x, r2, lds, nm, n0inv);
-            }
+        __builtin_amdgcn_s_setprio(0);
+        // one rolled loop body for every product of the tile: step -1 enters the Montgomery domain (* R^2), steps
+        // 0 .. dmax-1 square (kept only by the elements that still need it), step dmax leaves the domain (* 1)
 #pragma unroll 1
-            for (int s = 0; s < dmax; ++s) {
-                uint32_t y[G::NLL];
+        for (int s = -1; s <= dmax; ++s) {
+            uint32_t y[G::NLL], z[G::NLL];
+            const int gl = G::gl();
 #pragma unroll
-                for (int j = 0; j < G::NLL; ++j) y[j] = x[j];
-                mm_square<G>(y, lds, nm, n0inv);
-                const bool need = s < dl;
+            for (int j = 0; j < G::NLL; ++j) {
+                const uint32_t c = s < 0 ? r2_lds[G::NLL * gl + j] : ((gl == 0 && j == 0) ? 1u : 0u);
+                y[j] = (s >= 0 && s < dmax) ? x[j] : c;
+                z[j] = x[j];
+            }
+            mm_times<G>(z, y, lds, nm, n0inv);
+            const bool keep = s < 0 || s >= dmax || s < dl;
 #pragma unroll
-                for (int j = 0; j < G::NLL; ++j) x[j] = need ? y[j] : x[j];
-            }
-            {
-                uint32_t one[G::NLL];
-                set_plain_one<G>(one);
-                mm_times<G>(x, one, lds, nm, n0inv);
-                cond_sub<G::NLL, G::T>(x, nm);
-            }
+            for (int j = 0; j < G::NLL; ++j) x[j] = keep ? z[j] : x[j];
         }
-        __syncthreads();                                             // every lane has unpacked its row
-        if (dmax > 0) pack_row<G>(x, stage, w32, lds);               // untouched waves leave their staged rows as loaded
-        __syncthreads();
+        cond_sub<G::NLL, G::T>(x, nm);
+        __builtin_amdgcn_s_setprio(2);
+        pack_row<G>(x, stage);                                       // rows with delta <= 0 come back unchanged
         store_tile<G>(stage, ct + (size_t)row0 * w32, rows, w32);
+        __builtin_amdgcn_s_setprio(0);
     }
 }
 

@@ -99,6 +99,13 @@ template <int T> PAI_DEV bool group_any(bool p) {
 }
 // orders this wave's LDS writes before its later LDS reads (lane groups never span waves)
 PAI_DEV void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's global
+// stores / loads in flight (vmcnt), so a tile's stores drain behind the next tile's loads
+PAI_DEV void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // ---- the row engine ---------------------------------------------------------------------------
 // Each lane owns NLL limbs; acc is its window of NLL+U lazy 64-bit columns.  Row i adds

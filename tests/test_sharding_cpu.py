@@ -20,6 +20,15 @@ def test_shard_bounds_cover_the_batch_exactly():
             assert max(sizes) - min(s for s in sizes if s or n == 0 or True) <= -(-n // world)
 
 
+def test_library_shard_plan_agrees_with_the_python_partition():
+    """pai_shard_plan (C ABI, no device needed) == sharding.shard_bounds for every rank."""
+    from pailliercryptolib_python_amd import engine
+
+    for n in (0, 1, 7, 8, 9, 1000, (1 << 20) + 3):
+        for world in (1, 2, 3, 8):
+            assert [(b, b + c) for b, c in engine.shard_plan(n, world)] == sharding.shard_bounds(n, world)
+
+
 def _worker(rank, world, port, n_total, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -1,5 +1,5 @@
 import sys, time, json
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 from bench import synthetic_key
 from pailliercryptolib_python_amd import engine, fixedpoint
