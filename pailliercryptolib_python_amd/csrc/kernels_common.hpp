@@ -221,6 +221,7 @@ PAI_DEV void pack_row(const uint32_t (&x)[G::NLL], uint32_t* stage) {
 #pragma unroll
         for (int i = 0; i < NW - 2; ++i) row[i] = w[i];
         if (own == NW - 1) row[NW - 2] = w[NW - 2];
+        if (t == G::T - 1) row[own] = top;                  // nobody follows the group's last lane: it keeps its top piece
     } else {
 #pragma unroll
         for (int i = 0; i < NW - 1; ++i) row[i] = w[i];      // T == 1: k0 == 0, everything is this lane's
