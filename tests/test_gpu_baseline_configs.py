@@ -34,6 +34,18 @@ def test_config0_1024bit_100_floats_roundtrip_bit_exact():
     pk, sk = PaillierKeypair.generate_keypair(1024)
     x = np.random.default_rng(1000).uniform(-1000, 1000, 100)
     assert np.array_equal(np.array(sk.decrypt(pk.encrypt(x))), x)
+    # the same configuration on a fixed 1024-bit key with injected randomness: every ciphertext against the oracle
+    from pailliercryptolib_python_amd import PaillierPrivateKey, PaillierPublicKey
+    from pailliercryptolib_python_amd.bindings import ipclPublicKey
+
+    key = fixture_key(1024)
+    fpk = PaillierPublicKey(ipclPublicKey(key.n, 1024, True, hs=key.hs, randbits=key.randbits))
+    fsk = PaillierPrivateKey(fpk, key.p, key.q)
+    r_l = orc.synth_r_limbs(4000, 100, key.randbits)
+    en = fpk.encrypt(x, r=r_l)
+    want_ct, want_e = orc.api_encrypt(key, list(x), orc.limbs_to_ints(r_l))
+    assert [int(c) for c in en.ciphertextBN()] == want_ct and en.exponent() == want_e
+    assert fsk.decrypt(en) == orc.api_decrypt(key, want_ct, want_e) == [float(v) for v in x]
 
 
 def test_config1_2048bit_batch_65536_encrypt_decrypt():
@@ -100,11 +112,28 @@ def test_config3_4_one_rank_shard_roundtrip(bits, total_n):
     x = np.random.default_rng(1000 + bits).uniform(-1000, 1000, total_n)[s0:e0]
     res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
     m = engine.to_device_words(res, pub.device)
-    ct = pub.encrypt(m, pub.random_r(N))
+    r_l = orc.synth_r_limbs(4000 + bits, N, key.randbits)                  # explicit randomness: the bits are defined
+    ct = pub.encrypt(m, engine.to_device_words(r_l, pub.device))
     back = priv.decrypt(ct)
     torch.cuda.synchronize()
     assert torch.equal(back, m)
-    # and a handful of ciphertexts decrypt correctly under the oracle's CRT definition
-    for i in (0, N // 2, N - 1):
-        c = engine.words_to_ints(engine.to_host_words(ct[i:i + 1]))[0]
+    assert np.array_equal(fixedpoint.decode_float64_array(engine.to_host_words(back), expo, key.n, key.max_int), x)
+    # ciphertext bits against the C oracle (IFMA mb8 kernels when the host has them) on a sample spread over the
+    # shard, three of them also against the Python-int oracle; the oracle's CRT decryption returns the residues
+    idx = np.linspace(0, N - 1, 96).astype(np.int64)
+    ck = co.COracleKey(key)
+    want = (ck.ifma_encrypt_djn if co.ifma_available() else ck.encrypt_djn)(res[idx], r_l[idx])
+    got = engine.to_host_words(ct[torch.from_numpy(idx).to(pub.device)])
+    assert np.array_equal(got, want)
+    for j in (0, 47, 95):
+        i = int(idx[j])
+        c = engine.words_to_ints(got[j:j + 1])[0]
+        assert c == orc.encrypt(key, engine.words_to_ints(res[i:i + 1])[0], orc.limbs_to_ints(r_l[i:i + 1])[0])
         assert orc.decrypt_crt(key, c) == engine.words_to_ints(res[i:i + 1])[0]
+    # homomorphic identities on the shard: D(E(a) E(a)) = 2a and D(E(a)^3) = 3a (mod n)
+    s2 = engine.to_host_words(priv.decrypt(pub.ct_add(ct, ct))[:64])
+    e3 = torch.full((1, 1), 3, dtype=torch.int32, device=pub.device)
+    p3 = engine.to_host_words(priv.decrypt(pub.ct_mul(ct, e3, 2))[:64])
+    ai = engine.words_to_ints(res[:64])
+    assert engine.words_to_ints(s2) == [2 * a % key.n for a in ai]
+    assert engine.words_to_ints(p3) == [3 * a % key.n for a in ai]
