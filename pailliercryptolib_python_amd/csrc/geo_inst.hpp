@@ -44,6 +44,10 @@ struct GeoInst {
         set_lds((const void*)k_encrypt<G>, G::LDS_BYTES);
         hipLaunchKernelGGL(k_encrypt<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, m, r, ct_in, ct_out, n, mode);
     }
+    static void fb_expand(hipStream_t s, int grid, const MontCtx* c, const uint32_t* S, uint32_t* T, int J, int h) {
+        set_lds((const void*)k_fb_expand<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_fb_expand<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, S, T, J, h);
+    }
     static void dec_a(hipStream_t s, int gridx, DecAParams P, const uint32_t* ct, uint32_t* u_out, int n,
                       uint32_t* table) {
         set_lds((const void*)k_dec_a<G, MODEXP_WINDOW>, G::LDS_BYTES);
@@ -71,7 +75,7 @@ struct GeoInst {
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &dec_a, &dec_b, &pow2, &table_words};
+                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &table_words};
         return &o;
     }
 };

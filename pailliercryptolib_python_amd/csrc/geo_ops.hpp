@@ -28,6 +28,8 @@ struct GeoOps {
                            int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits);
     void (*encrypt)(hipStream_t, int grid, EncParams, const uint32_t* m, const uint32_t* r, const uint32_t* ct_in,
                     uint32_t* ct_out, int n, int mode);
+    // T[j][hi * 2^h + lo] = S[2 j + 1][hi] * S[2 j][lo]: second level of the fixed-base table build (raw Montgomery rows)
+    void (*fb_expand)(hipStream_t, int grid, const MontCtx*, const uint32_t* S, uint32_t* T, int J, int h);
     void (*dec_a)(hipStream_t, int gridx, DecAParams, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table);
     void (*dec_b)(hipStream_t, int grid, DecBParams, const uint32_t* u_in, uint32_t* m_out, int n);
     void (*pow2)(hipStream_t, int grid, const MontCtx*, uint32_t* ct, const int32_t* delta, int delta_bcast, int n,

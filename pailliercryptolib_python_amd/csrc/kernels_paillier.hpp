@@ -129,6 +129,50 @@ k_encrypt(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Second level of the fixed-base table build for the lane-group k_encrypt: with half = 2^h entries per half-width
+// window, T[j][hi * half + lo] = S[2 j + 1][hi] * S[2 j][lo] (Montgomery form in and out, raw radix-29 rows of NL
+// limbs) — one independent product per entry instead of a binary exponentiation per entry (4096-bit keys: 1.35 s of
+// k_modexp_var -> one pass of 2.4 M products).  Wave tiles of 64 / T consecutive entries; the right operand streams
+// from the LDS operand buffer as in k_modmul.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_fb_expand(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ S, uint32_t* __restrict__ T, int J, int h) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t n0inv = ctx->n0inv;
+    const int t = G::gl();
+    const size_t half = (size_t)1 << h, per_window = half * half, total = (size_t)J * per_window;
+    const size_t tiles = (total + G::EPB - 1) / G::EPB;
+    const uint32_t* b_lds = lds + G::elem();
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t ei = tile * G::EPB + G::elem();
+        const bool live = ei < total;
+        const size_t es = live ? ei : total - 1;
+        const size_t j = es / per_window, d = es - j * per_window, hi = d >> h, lo = d & (half - 1);
+        const uint4* a4 = reinterpret_cast<const uint4*>(S + (((2 * j + 1) << h) + hi) * G::NL + G::NLL * t);
+        const uint4* b4 = reinterpret_cast<const uint4*>(S + (((2 * j) << h) + lo) * G::NL + G::NLL * t);
+        uint32_t x[G::NLL], y[G::NLL];
+        static_assert(G::NLL % 4 == 0, "limb slices are moved as 16-byte vectors");
+#pragma unroll
+        for (int c = 0; c < G::NLL / 4; ++c) {
+            const uint4 va = a4[c], vb = b4[c];
+            x[4 * c] = va.x; x[4 * c + 1] = va.y; x[4 * c + 2] = va.z; x[4 * c + 3] = va.w;
+            y[4 * c] = vb.x; y[4 * c + 1] = vb.y; y[4 * c + 2] = vb.z; y[4 * c + 3] = vb.w;
+        }
+        stage_b<G>(y, lds);
+        uint32_t r[G::NLL];
+        mont_mul<G::NLL, G::U, G::T>(r, x, b_lds, G::EPB, nm, n0inv);
+        cond_sub<G::NLL, G::T>(r, nm);                   // canonical Montgomery representative, as k_modexp_var stores it
+        if (live) {
+            uint4* o4 = reinterpret_cast<uint4*>(T + ei * G::NL + G::NLL * t);
+#pragma unroll
+            for (int c = 0; c < G::NLL / 4; ++c) o4[c] = make_uint4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Decrypt stage A.  blockIdx.y selects the prime (0: p, 1: q).  The ciphertext (2 NL limbs of the
 // s^2 geometry) is folded into Montgomery form as lo*R + hi*R^2 = MM(lo, R^2) + MM(hi, R^3).
 struct DecAParams {

@@ -570,30 +570,48 @@ void build_fb_tables(const pai_pubkey* cpk) {
     const size_t ENT = (size_t)1 << wb;
     pk->fb_windows = J;
     if (!pk->penc_nl) {
-        // window bases B_j = hs^(2^(wb j)) on the host, then T[j][d] = B_j^d on the device (lane-group kernels)
+        // Lane-group table T[j][d] = hs^(d 2^(wb j)), Montgomery form, raw radix-29 rows.  Two levels when the window
+        // width is even: half-width windows S[i][e] = hs^(e 2^(h i)) (2 J windows of 2^h entries, binary method,
+        // a few thousand entries), then ONE product per entry, T[j][hi 2^h + lo] = S[2 j + 1][hi] * S[2 j][lo]
+        // (k_fb_expand).  Odd widths (only reachable through PAI_FB_WBITS) keep the one-level build.
         hbn::Mont32 mt(pk->nsq);
-        std::vector<uint32_t> bases((size_t)J * pk->ct_words, 0);
+        const bool two_level = (wb % 2 == 0) && wb >= 8;
+        const int h = two_level ? wb / 2 : wb;                     // bits per first-level window
+        const int J1 = two_level ? 2 * J : J;
+        std::vector<uint32_t> bases((size_t)J1 * pk->ct_words, 0);
         Limbs b = mt.to_mont(pk->hs);
-        for (int j = 0; j < J; ++j) {
+        for (int j = 0; j < J1; ++j) {
             Limbs plain = mt.from_mont(b);
             std::memcpy(&bases[(size_t)j * pk->ct_words], plain.data(), plain.size() * 4);
-            for (int s = 0; s < wb; ++s) b = mt.mmul(b, b);
+            for (int s = 0; s < h; ++s) b = mt.mmul(b, b);
         }
-        const size_t NE = (size_t)J * ENT;
-        std::vector<uint32_t> expo(NE);
-        for (size_t i = 0; i < NE; ++i) expo[i] = (uint32_t)(i & (ENT - 1));
-        DevBuf d_bases, d_expo;
+        const size_t E1 = (size_t)1 << h, NE1 = (size_t)J1 * E1;
+        std::vector<uint32_t> expo(NE1);
+        for (size_t i = 0; i < NE1; ++i) expo[i] = (uint32_t)(i & (E1 - 1));
+        DevBuf d_bases, d_expo, d_half;
         d_bases.ensure(bases.size() * 4);
-        d_expo.ensure(NE * 4);
+        d_expo.ensure(NE1 * 4);
         HIP_CHECK(hipMemcpy(d_bases.p, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(d_expo.p, expo.data(), NE * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_expo.p, expo.data(), NE1 * 4, hipMemcpyHostToDevice));
+        const size_t NE = (size_t)J * ENT;
         HIP_CHECK(hipMalloc((void**)&pk->d_fb, NE * (size_t)nl * 4));
         const GeoOps* g = pk->msq.geo;
-        g->modexp_var(nullptr, grid_for(g, NE, pk->dev.ncu), pk->msq.d_ctx, d_bases.as<uint32_t>(), pk->ct_words, wb /* base = i >> wb */,
-                      d_expo.as<uint32_t>(), 1, wb, 0, pk->d_fb, 0, (int)NE, 1 /*keep_mont*/, 1 /*out_raw*/);
-        hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+        uint32_t* level1 = pk->d_fb;
+        if (two_level) {
+            d_half.ensure(NE1 * (size_t)nl * 4);
+            level1 = d_half.as<uint32_t>();
+        }
+        g->modexp_var(nullptr, grid_for(g, NE1, pk->dev.ncu), pk->msq.d_ctx, d_bases.as<uint32_t>(), pk->ct_words, h /* base = i >> h */,
+                      d_expo.as<uint32_t>(), 1, h, 0, level1, 0, (int)NE1, 1 /*keep_mont*/, 1 /*out_raw*/);
+        hipError_t e1 = hipGetLastError();
+        if (two_level && e1 == hipSuccess) {
+            g->fb_expand(nullptr, grid_for(g, NE, pk->dev.ncu), pk->msq.d_ctx, level1, pk->d_fb, J, h);
+            e1 = hipGetLastError();
+        }
+        hipError_t e2 = hipDeviceSynchronize();
         d_bases.release();
         d_expo.release();
+        d_half.release();
         HIP_CHECK(e1);
         HIP_CHECK(e2);
     } else {
