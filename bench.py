@@ -309,22 +309,26 @@ def main() -> None:
 
         apk = PaillierPublicKey(ipclPublicKey(key.n, KEY_BITS, True, hs=key.hs, randbits=key.randbits, device=device))
         ask = PaillierPrivateKey(apk, key.p, key.q)
-        warm = apk.encrypt(x[:4096])
-        ask.decrypt_to_numpy(warm)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        en = apk.encrypt(x)
-        torch.cuda.synchronize()
-        t_api_enc = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        back = ask.decrypt_to_numpy(en)
-        t_api_dec = time.perf_counter() - t1
-        if not np.array_equal(back, x):
-            raise SystemExit("bench.py: API-level round trip failed")
+        def api_pass():
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            en_ = apk.encrypt(x)
+            torch.cuda.synchronize()
+            te = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            back_ = ask.decrypt_to_numpy(en_)
+            td = time.perf_counter() - t1
+            if not np.array_equal(back_, x):
+                raise SystemExit("bench.py: API-level round trip failed")
+            return te, td
+
+        first = api_pass()                   # first call of this size: fixed-base table build, scratch growth
+        t_api_enc, t_api_dec = api_pass()    # steady state
         api = {"encrypt_s": t_api_enc, "decrypt_s": t_api_dec, "ops_per_s": B / (t_api_enc + t_api_dec), "batch": B,
-               "note": "PaillierPublicKey.encrypt(float64 ndarray) + PaillierPrivateKey.decrypt_to_numpy: device codec, "
-                       "ChaCha20 randomness under an OS-CSPRNG key, H2D/D2H over PCIe included"}
-        del en, warm
+               "first_call": {"encrypt_s": first[0], "decrypt_s": first[1]},
+               "note": "PaillierPublicKey.encrypt(float64 ndarray) + PaillierPrivateKey.decrypt_to_numpy, steady state (second "
+                       "full-size call; first_call includes the one-off fixed-base table build and scratch allocation): "
+                       "device codec, ChaCha20 randomness under an OS-CSPRNG key, H2D/D2H over PCIe included"}
 
     # ---- the other operations of BASELINE configs[2], kernel-resident, each checked against the oracle ----
     other = None

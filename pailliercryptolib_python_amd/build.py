@@ -28,6 +28,10 @@ SOURCES = [
     "geo_36x4.hip",
     "geo_28x8.hip",
     "geo_36x8.hip",
+    "geo_3x16.hip",
+    "geo_3x32.hip",
+    "geo_3x64.hip",
+    "geo_9x32.hip",
     "inv_eea.hip",
     "wide_kernels.hip",
     "padic_dec_kernels.hip",

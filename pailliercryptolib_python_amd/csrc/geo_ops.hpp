@@ -44,9 +44,16 @@ const GeoOps* geo_ops_28x4();
 const GeoOps* geo_ops_36x4();
 const GeoOps* geo_ops_28x8();
 const GeoOps* geo_ops_36x8();
+// latency geometries (an integer spread over 16 / 32 / 64 lanes): small batches
+const GeoOps* geo_ops_3x16();
+const GeoOps* geo_ops_3x32();
+const GeoOps* geo_ops_3x64();
+const GeoOps* geo_ops_9x32();
 
 // smallest geometry whose capacity covers a modulus of `bits` bits (R = 2^(29 NL) > 4 M), or nullptr
 const GeoOps* geo_for_bits(int bits);
+// the same for the latency geometries
+const GeoOps* geo_latency_for_bits(int bits);
 
 // Wide engine (one integer per lane, mont_wide.hpp): limb count serving a modulus of `bits` bits (0 = none),
 // table scratch words, and the stage-A decrypt launcher (grid = gridx x 2 primes, 256 elements per block).

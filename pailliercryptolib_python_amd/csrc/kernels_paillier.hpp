@@ -150,24 +150,36 @@ k_fb_expand(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ S, uin
         const bool live = ei < total;
         const size_t es = live ? ei : total - 1;
         const size_t j = es / per_window, d = es - j * per_window, hi = d >> h, lo = d & (half - 1);
-        const uint4* a4 = reinterpret_cast<const uint4*>(S + (((2 * j + 1) << h) + hi) * G::NL + G::NLL * t);
-        const uint4* b4 = reinterpret_cast<const uint4*>(S + (((2 * j) << h) + lo) * G::NL + G::NLL * t);
+        const uint32_t* ap = S + (((2 * j + 1) << h) + hi) * G::NL + G::NLL * t;
+        const uint32_t* bp = S + (((2 * j) << h) + lo) * G::NL + G::NLL * t;
         uint32_t x[G::NLL], y[G::NLL];
-        static_assert(G::NLL % 4 == 0, "limb slices are moved as 16-byte vectors");
+        if constexpr (G::NLL % 4 == 0) {                 // limb slices move as 16-byte vectors
+            const uint4* a4 = reinterpret_cast<const uint4*>(ap);
+            const uint4* b4 = reinterpret_cast<const uint4*>(bp);
 #pragma unroll
-        for (int c = 0; c < G::NLL / 4; ++c) {
-            const uint4 va = a4[c], vb = b4[c];
-            x[4 * c] = va.x; x[4 * c + 1] = va.y; x[4 * c + 2] = va.z; x[4 * c + 3] = va.w;
-            y[4 * c] = vb.x; y[4 * c + 1] = vb.y; y[4 * c + 2] = vb.z; y[4 * c + 3] = vb.w;
+            for (int c = 0; c < G::NLL / 4; ++c) {
+                const uint4 va = a4[c], vb = b4[c];
+                x[4 * c] = va.x; x[4 * c + 1] = va.y; x[4 * c + 2] = va.z; x[4 * c + 3] = va.w;
+                y[4 * c] = vb.x; y[4 * c + 1] = vb.y; y[4 * c + 2] = vb.z; y[4 * c + 3] = vb.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < G::NLL; ++k) { x[k] = ap[k]; y[k] = bp[k]; }
         }
         stage_b<G>(y, lds);
         uint32_t r[G::NLL];
         mont_mul<G::NLL, G::U, G::T>(r, x, b_lds, G::EPB, nm, n0inv);
         cond_sub<G::NLL, G::T>(r, nm);                   // canonical Montgomery representative, as k_modexp_var stores it
         if (live) {
-            uint4* o4 = reinterpret_cast<uint4*>(T + ei * G::NL + G::NLL * t);
+            uint32_t* op = T + ei * G::NL + G::NLL * t;
+            if constexpr (G::NLL % 4 == 0) {
+                uint4* o4 = reinterpret_cast<uint4*>(op);
 #pragma unroll
-            for (int c = 0; c < G::NLL / 4; ++c) o4[c] = make_uint4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]);
+                for (int c = 0; c < G::NLL / 4; ++c) o4[c] = make_uint4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < G::NLL; ++k) op[k] = r[k];
+            }
         }
     }
 }

@@ -65,7 +65,16 @@ template <int T> PAI_DEV uint32_t bcast0(uint32_t v) {
     if constexpr (T == 1) return v;
     else if constexpr (T == 2) return dpp_mov<0xA0>(v);          // quad_perm [0,0,2,2]
     else if constexpr (T == 4) return dpp_mov<0x00>(v);          // quad_perm [0,0,0,0]
-    else return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63) & ~(T - 1)), 64);
+    else if constexpr (T == 64) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);      // through an SGPR: no LDS-pipe latency
+    else if constexpr (T == 32) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+        return (threadIdx.x & 32) ? hi : lo;
+    } else if constexpr (T == 16) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+        const uint32_t lo = (threadIdx.x & 16) ? b : a, hi = (threadIdx.x & 16) ? d : c;
+        return (threadIdx.x & 32) ? hi : lo;
+    } else return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63) & ~(T - 1)), 64);
 }
 // value held by the next lane of the group (lane T-1 receives 0)
 template <int T> PAI_DEV uint32_t from_next(uint32_t v) {
@@ -74,6 +83,7 @@ template <int T> PAI_DEV uint32_t from_next(uint32_t v) {
         uint32_t r;
         if constexpr (T == 2) r = dpp_mov<0xF5>(v);              // quad_perm [1,1,3,3]
         else if constexpr (T == 4) r = dpp_mov<0x101>(v);        // row_shl:1  (lane i <- lane i+1)
+        else if constexpr (T >= 16) r = dpp_mov<0x130>(v);       // wave_shl:1 (lane i <- lane i+1 across the whole wave)
         else r = (uint32_t)__shfl_down((int)v, 1, 64);
         return (group_lane<T>() == T - 1) ? 0u : r;
     }
@@ -85,6 +95,7 @@ template <int T> PAI_DEV uint32_t from_prev(uint32_t v) {
         uint32_t r;
         if constexpr (T == 2) r = dpp_mov<0xA0>(v);              // quad_perm [0,0,2,2]
         else if constexpr (T == 4) r = dpp_mov<0x111>(v);        // row_shr:1  (lane i <- lane i-1)
+        else if constexpr (T >= 16) r = dpp_mov<0x138>(v);       // wave_shr:1 (lane i <- lane i-1 across the whole wave)
         else r = (uint32_t)__shfl_up((int)v, 1, 64);
         return (group_lane<T>() == 0) ? 0u : r;
     }
@@ -93,8 +104,11 @@ template <int T> PAI_DEV bool group_any(bool p) {
     if constexpr (T == 1) return p;
     else {
         unsigned long long m = __ballot(p);
-        const int base = (threadIdx.x & 63) & ~(T - 1);
-        return ((m >> base) & ((1ull << T) - 1ull)) != 0ull;
+        if constexpr (T == 64) return m != 0ull;
+        else {
+            const int base = (threadIdx.x & 63) & ~(T - 1);
+            return ((m >> base) & ((1ull << T) - 1ull)) != 0ull;
+        }
     }
 }
 // orders this wave's LDS writes before its later LDS reads (lane groups never span waves)

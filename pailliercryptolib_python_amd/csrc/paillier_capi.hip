@@ -174,14 +174,15 @@ struct ModSetup {
     int bits = 0, w32 = 0;
     int nl = 0;       // radix-29 limbs of the Montgomery representation (R = 2^(29 nl))
     // nl_override != 0: constants for the wide engine's limb count instead of the lane-group geometry's
-    void init(const Limbs& mod_, int nl_override = 0) {
+    void init(const Limbs& mod_, int nl_override = 0, const GeoOps* force_geo = nullptr) {
         M = mod_;
         require(hbn::is_odd(M), "modulus must be odd");
         bits = hbn::bitlen(M);
         w32 = words_for_bits(bits);
-        geo = geo_for_bits(bits);
+        geo = force_geo ? force_geo : geo_for_bits(bits);
         if (!geo) throw PaiError(PAI_E_UNSUPPORTED, "modulus wider than 8192 bits is not supported");
         nl = nl_override ? nl_override : geo->nl;
+        require(nl <= NLMAX, "geometry wider than the constant tables");
         R = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * nl), M);
         R2 = hbn::mulmod(R, R, M);
         R3 = hbn::mulmod(R2, R, M);
@@ -239,6 +240,14 @@ struct ScopedKernelTimer {
     }
 };
 
+// Batches up to this many elements take the latency path: every integer spread over 16-64 lanes, (element, prime)
+// pairs filling the device instead of lanes (PAI_LATENCY_MAX overrides; 0 disables it).  Measured on MI355X at
+// 2048-bit keys: decrypt 7.3 ms up to 1024 elements, 10.2 ms at 2048, against 14.6 ms on the throughput kernels.
+size_t latency_max_elements() {
+    if (const char* env = std::getenv("PAI_LATENCY_MAX")) return (size_t)std::strtoull(env, nullptr, 10);
+    return (size_t)2048;
+}
+
 int grid_for(const GeoOps* g, size_t N, int ncu, int blocks_per_cu = 2) {
     size_t tiles = (N + g->epb - 1) / g->epb;
     size_t cap = (size_t)ncu * blocks_per_cu;
@@ -250,6 +259,12 @@ int grid_for(const GeoOps* g, size_t N, int ncu, int blocks_per_cu = 2) {
 namespace pai {
 const GeoOps* geo_for_bits(int bits) {
     const GeoOps* all[] = {geo_ops_36x1(), geo_ops_36x2(), geo_ops_28x4(), geo_ops_36x4(), geo_ops_28x8(), geo_ops_36x8()};
+    for (const GeoOps* g : all)
+        if (hbn::RB * g->nl >= bits + 2) return g;
+    return nullptr;
+}
+const GeoOps* geo_latency_for_bits(int bits) {
+    const GeoOps* all[] = {geo_ops_3x16(), geo_ops_3x32(), geo_ops_3x64(), geo_ops_9x32()};
     for (const GeoOps* g : all)
         if (hbn::RB * g->nl >= bits + 2) return g;
     return nullptr;
@@ -302,6 +317,10 @@ struct pai_pubkey {
     uint32_t* d_tree_c = nullptr;
     uint32_t* d_tree_fix = nullptr;
     mutable bool fb_ready = false;     // fixed-base tables are built by the first obfuscating call (build_fb_tables)
+    // latency path of ct * pt (small batches): n^2 on a wide-group geometry, built by the first small call
+    mutable bool lat_ready = false, lat_usable = false;
+    mutable ModSetup lat_msq;
+    mutable DevBuf lat_table;
     mutable ScratchOrder order;
     mutable std::mutex mu;
     EncParams enc_params() const {
@@ -341,6 +360,19 @@ struct pai_privkey {
     int nops[2] = {0, 0};
     int padic_nd = 0;
     DevBuf table, ubuf;
+    // Latency path (small batches): stage A and B on the wide-group geometries (an integer spread over 16 / 32 / 64
+    // lanes), with their own Montgomery constants; built by the first small call (build_latency_consts).
+    Limbs h_host[2], pinvq_host;
+    struct Lat {
+        bool ready = false, usable = false;
+        ModSetup sq[2], pr[2];
+        uint32_t* d_r3[2] = {nullptr, nullptr};
+        uint32_t* d_sinv2[2] = {nullptr, nullptr};
+        uint32_t* d_nsinv2[2] = {nullptr, nullptr};
+        uint32_t* d_hR[2] = {nullptr, nullptr};
+        uint32_t* d_pinvqR = nullptr;
+        DevBuf table;
+    } lat;
     ScratchOrder order;
     std::mutex mu;
 };
@@ -783,6 +815,8 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_tree_fix) (void)hipFree(pk->d_tree_fix);
     pk->prod_a.release();
     pk->prod_b.release();
+    pk->lat_msq.release();
+    pk->lat_table.release();
     pk->order.release();
     pk->inv_prod.release();
     pk->inv_inv.release();
@@ -990,6 +1024,31 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         DeviceScope scope_(pk->device);
         hipStream_t s = (hipStream_t)stream;
         g_last_times.clear();
+        if (N <= 4 * latency_max_elements() && ebits_max > 8) {          // 0.9 ms against 4.8 ms up to ~8192 elements
+            // small batch: windowed exponentiation with n^2 spread over a whole wavefront per ciphertext
+            std::lock_guard<std::mutex> lk(pk->mu);
+            if (!pk->lat_ready) {
+                pk->lat_ready = true;
+                if (const GeoOps* gl = geo_latency_for_bits(hbn::bitlen(pk->nsq))) {
+                    pk->lat_msq.init(pk->nsq, 0, gl);
+                    pk->lat_usable = true;
+                }
+            }
+            if (pk->lat_usable) {
+                const GeoOps* g = pk->lat_msq.geo;
+                const int grid = (int)((N + g->epb - 1) / g->epb);
+                const int wbits = var_window_bits(ebits_max);
+                pk->lat_table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
+                pk->order.begin(s);
+                ScopedKernelTimer t("k_ctmul", s);
+                g->modexp_var_win(s, grid, pk->lat_msq.d_ctx, d_ct, pk->ct_words, d_e, e_words, ebits_max, e_bcast, d_out,
+                                  pk->ct_words, (int)N, pk->lat_table.as<uint32_t>(), wbits);
+                t.stop();
+                HIP_CHECK(hipGetLastError());
+                pk->order.end(s);
+                return;
+            }
+        }
         if (pk->penc_nl) {
             // base-n digit engine: fixed windows sized to the exponent width (table build 2^w - 2 products, then
             // w squarings + 1 product per window)
@@ -1228,6 +1287,7 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
             require(hbn::is_zero(rem), "L function not exact: p/q are not the factors of n");
             Limbs h = hbn::inv_mod_prime(hbn::mod(L, s), s);
             require(hbn::cmp(hbn::mulmod(h, L, s), one) == 0, "p or q is not prime (inverse check failed)");
+            sk->h_host[w] = h;
             const int nl = sk->pr[w].geo->nl;
             sk->d_hR[w] = upload_r29(hbn::mulmod(h, sk->pr[w].R, s), nl);
             const int k = hbn::RB * nl;
@@ -1270,6 +1330,7 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
         }
         Limbs pinvq = hbn::inv_mod_prime(hbn::mod(p, q), q);
         require(hbn::cmp(hbn::mulmod(pinvq, p, q), one) == 0, "q is not prime (inverse check failed)");
+        sk->pinvq_host = pinvq;
         sk->d_pinvqR = upload_r29(hbn::mulmod(pinvq, sk->pr[1].R, q), sk->pr[1].geo->nl);
         *out = sk.release();
     });
@@ -1294,12 +1355,47 @@ void pai_privkey_destroy(pai_privkey* sk) {
         if (sk->d_ops[w]) (void)hipFree(sk->d_ops[w]);
     }
     if (sk->d_pinvqR) (void)hipFree(sk->d_pinvqR);
+    for (int w = 0; w < 2; ++w) {
+        sk->lat.sq[w].release();
+        sk->lat.pr[w].release();
+        if (sk->lat.d_r3[w]) (void)hipFree(sk->lat.d_r3[w]);
+        if (sk->lat.d_sinv2[w]) (void)hipFree(sk->lat.d_sinv2[w]);
+        if (sk->lat.d_nsinv2[w]) (void)hipFree(sk->lat.d_nsinv2[w]);
+        if (sk->lat.d_hR[w]) (void)hipFree(sk->lat.d_hR[w]);
+    }
+    if (sk->lat.d_pinvqR) (void)hipFree(sk->lat.d_pinvqR);
+    sk->lat.table.release();
     sk->table.release();
     sk->wscratch.release();
     sk->ubuf.release();
     sk->order.release();
     delete sk;
     if (prev_ >= 0) (void)hipSetDevice(prev_);
+}
+
+
+static void build_latency_consts(pai_privkey* sk) {
+    pai_privkey::Lat& L = sk->lat;
+    if (L.ready) return;
+    L.ready = true;
+    const Limbs prime[2] = {sk->p, sk->q};
+    const GeoOps* ga = geo_latency_for_bits(hbn::bitlen(hbn::mul(sk->q, sk->q)));
+    const GeoOps* gb = geo_latency_for_bits(hbn::bitlen(sk->q));
+    if (!ga || !gb) return;                                  // key too wide for the latency geometries: throughput path only
+    const Limbs one{1u};
+    for (int w = 0; w < 2; ++w) {
+        const Limbs& s = prime[w];
+        L.sq[w].init(hbn::mul(s, s), 0, ga);
+        L.pr[w].init(s, 0, gb);
+        L.d_r3[w] = upload_r29(L.sq[w].R3, L.sq[w].nl);
+        const int nl = gb->nl, k = hbn::RB * nl;
+        L.d_hR[w] = upload_r29(hbn::mulmod(sk->h_host[w], L.pr[w].R, s), nl);
+        Limbs sinv2 = hbn::inv_mod_pow2(s, k);
+        L.d_sinv2[w] = upload_r29(sinv2, nl);
+        L.d_nsinv2[w] = upload_r29(hbn::sub(hbn::shl(one, k), sinv2), nl);
+    }
+    L.d_pinvqR = upload_r29(hbn::mulmod(sk->pinvq_host, L.pr[1].R, sk->q), gb->nl);
+    L.usable = true;
 }
 
 int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream) {
@@ -1311,6 +1407,55 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         DeviceScope scope_(pk->device);
         DeviceInfo dev = scope_.info;
         hipStream_t s = (hipStream_t)stream;
+        if (N <= latency_max_elements()) {
+            build_latency_consts(sk);
+            if (sk->lat.usable) {
+                // small batch: every integer is spread over 16-64 lanes, one product takes microseconds instead of
+                // tens of microseconds; (element, prime) pairs fill the device instead of lanes
+                pai_privkey::Lat& L = sk->lat;
+                const GeoOps* ga = L.sq[0].geo;
+                const GeoOps* gb = L.pr[0].geo;
+                const int u_words = std::max(L.sq[0].w32, L.sq[1].w32);
+                const int gridx = (int)((N + ga->epb - 1) / ga->epb);
+                L.table.ensure(ga->table_words((size_t)gridx * 2) * 4);
+                sk->ubuf.ensure(2 * N * (size_t)u_words * 4);
+                sk->order.begin(s);
+                DecAParams A;
+                DecBParams B;
+                for (int w = 0; w < 2; ++w) {
+                    A.sq[w] = L.sq[w].d_ctx;
+                    A.r3[w] = L.d_r3[w];
+                    A.expo[w] = sk->d_expo[w];
+                    A.ewords[w] = sk->ewords[w];
+                    A.ebits[w] = sk->ebits[w];
+                    B.pr[w] = L.pr[w].d_ctx;
+                    B.sinv2[w] = L.d_sinv2[w];
+                    B.nsinv2[w] = L.d_nsinv2[w];
+                    B.hR[w] = L.d_hR[w];
+                }
+                A.ct_words = pk->ct_words;
+                A.u_words = u_words;
+                B.pinvqR = L.d_pinvqR;
+                B.u_words = u_words;
+                B.pt_words = pk->n_words;
+                B.u_is_L = 0;
+                g_last_times.clear();
+                {
+                    ScopedKernelTimer t("k_dec_a", s);
+                    ga->dec_a(s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, L.table.as<uint32_t>());
+                    t.stop();
+                }
+                HIP_CHECK(hipGetLastError());
+                {
+                    ScopedKernelTimer t("k_dec_b", s);
+                    gb->dec_b(s, (int)((N + gb->epb - 1) / gb->epb), B, sk->ubuf.as<uint32_t>(), d_m, (int)N);
+                    t.stop();
+                }
+                HIP_CHECK(hipGetLastError());
+                sk->order.end(s);
+                return;
+            }
+        }
         const GeoOps* ga = sk->sq[0].geo;
         const GeoOps* gb = sk->pr[0].geo;
         int gridx = grid_for(ga, N, dev.ncu, 1);          // x2 primes => 2 workgroups per CU

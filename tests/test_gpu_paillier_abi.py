@@ -454,3 +454,39 @@ def test_shard_plan_gather_scatter_roundtrip(k2048):
     assert np.array_equal(out.get(), host)
     assert lib.pai_shard_plan(10, 4, 3, C.byref(b), C.byref(c)) == 0 and (b.value, c.value) == (9, 1)
     assert lib.pai_shard_plan(2, 4, 3, C.byref(b), C.byref(c)) == 0 and (b.value, c.value) == (2, 0)
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
+def test_decrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
+    """Small batches decrypt on the wide-group geometries (an integer spread over 16-64 lanes: latency path), large
+    ones on the digit-pair engine (throughput path); PAI_LATENCY_MAX moves the switch.  Both against the oracle."""
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key = nk.key
+    for N in (3, 7, 33, 150):
+        m = plaintexts(key, N, bits + N)
+        rng = np.random.default_rng(N)
+        ct = [orc.encrypt(key, x, int.from_bytes(rng.bytes(key.randbits // 8), "little")) for x in m]
+        dct = DevArray(ints_to_limbs(ct, nk.cw))
+        for switch in ("0", "100000"):
+            monkeypatch.setenv("PAI_LATENCY_MAX", switch)
+            out = DevArray(shape=(N, nk.nw))
+            _native.check(nk.lib.pai_decrypt(nk.sk, dct.ptr, N, out.ptr, None))
+            assert limbs_to_ints(out.get()) == m, (bits, N, switch)
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 4096])
+def test_ct_mul_latency_and_throughput_paths_agree(bits, monkeypatch):
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key = nk.key
+    rng = np.random.default_rng(bits)
+    for N, ebits in ((5, 53), (40, 12), (64, 300)):
+        c = rand_below(rng, key.nsq, N)
+        e = [int.from_bytes(rng.bytes(ebits // 8 + 1), "little") % (1 << ebits) for _ in range(N)]
+        e[0] = 0
+        ew = (ebits + 31) // 32
+        dc, de = DevArray(ints_to_limbs(c, nk.cw)), DevArray(ints_to_limbs(e, ew))
+        for switch in ("0", "100000"):
+            monkeypatch.setenv("PAI_LATENCY_MAX", switch)
+            out = DevArray(shape=(N, nk.cw))
+            _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
+            assert limbs_to_ints(out.get()) == [pow(a, b, key.nsq) for a, b in zip(c, e)], (bits, N, ebits, switch)

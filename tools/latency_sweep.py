@@ -1,0 +1,32 @@
+"""Dev probe: decrypt / encrypt latency over the batch size on both paths (PAI_LATENCY_MAX = 0: throughput kernels only)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np, torch
+from bench import synthetic_key
+from pailliercryptolib_python_amd import engine
+dev = torch.device('cuda', 0)
+bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+key = synthetic_key(bits, 0x1234567)
+pub = engine.PublicKeyHandle(key.n, bits, key.hs, key.randbits, device=dev)
+priv = engine.PrivateKeyHandle(pub, key.p, key.q)
+def tm(f, reps=3):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+g = torch.Generator(device=dev); g.manual_seed(1)
+for N in (1, 16, 64, 256, 512, 1024, 2048, 4096, 16384):
+    m = torch.randint(0, 2**31 - 1, (N, pub.n_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    m[:, -1] &= 0x0FFFFFFF
+    r = pub.random_r(N, generator=g)
+    ct = pub.encrypt(m, r)
+    row = {"bits": bits, "N": N}
+    for name, sw in (("lat", "1000000"), ("thr", "0")):
+        os.environ["PAI_LATENCY_MAX"] = sw
+        out = priv.decrypt(ct)
+        assert torch.equal(out, m), (N, name)
+        row[f"dec_{name}_ms"] = round(tm(lambda: priv.decrypt(ct)), 3)
+        e = torch.randint(1, 1 << 30, (N, 2), dtype=torch.int32, device=dev); e[:, 1] &= (1 << 21) - 1
+        row[f"mul_{name}_ms"] = round(tm(lambda: pub.ct_mul(ct, e, 53)), 3)
+    print(json.dumps(row), flush=True)
