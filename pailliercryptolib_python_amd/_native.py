@@ -80,20 +80,27 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
-        # not built yet (fresh checkout): compile it in-tree with hipcc; this is a build step, not a fallback
-        try:
-            from . import build as _build
+    build_error = None
+    try:
+        from . import build as _build
 
-            if _build.LIB == LIB_PATH:
+        if _build.LIB == LIB_PATH:
+            if not LIB_PATH.exists():
+                # not built yet (fresh checkout): compile it in-tree with hipcc; a build step, not a fallback
                 _build.build_native()
-        except Exception:      # noqa: BLE001 - reported below
-            pass
+            elif LIB_PATH.stat().st_mtime < _build._deps_mtime():
+                # never rebuilt implicitly (several ranks may be importing at once): say so instead
+                import warnings
+
+                warnings.warn("libpaillier_hip.so is older than csrc/: run `python -m pailliercryptolib_python_amd.build`")
+    except Exception as e:      # noqa: BLE001 - reported below if the library is unusable
+        build_error = e
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m pailliercryptolib_python_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
-        )
+            + (f"  The in-tree build failed: {build_error}" if build_error else "")
+        ) from build_error
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = ABI/header mismatch

@@ -1,0 +1,53 @@
+"""GPU: key sizes at the engine-selection boundaries: the library picks a different kernel family per size —
+digit-pair decrypt from 400-bit primes (24 / 36 / 56 / 72 limbs), wide engine or lane groups below, base-n digit
+encryption for n of 700-1024 and 1400-2068 bits, lane groups elsewhere, host codec for n <= 66 bits — and
+`generate_keypair` accepts any multiple of 4 from 64 bits.  Every size: ciphertext bits with explicit randomness,
+decryption on both sides of the latency switch, add / mul / inverse, against the Python-int oracle."""
+import numpy as np
+import pytest
+
+from oracle import paillier_oracle as orc
+from pailliercryptolib_python_amd import PaillierPrivateKey, PaillierPublicKey
+from pailliercryptolib_python_amd.bindings import ipclPublicKey
+
+pytestmark = pytest.mark.gpu
+
+
+def make(bits):
+    p = orc.seeded_prime(bits // 2, 7000 + bits)
+    q = orc.seeded_prime(bits // 2, 9000 + bits)
+    while q == p or (p * q).bit_length() != bits:
+        q = orc.seeded_prime(bits // 2, q % 100003)
+    key = orc.make_key(p, q, djn_x=0xABCDEF1234567, bits=bits)
+    pk = PaillierPublicKey(ipclPublicKey(key.n, bits, True, hs=key.hs, randbits=key.randbits))
+    return key, pk, PaillierPrivateKey(pk, p, q)
+
+
+@pytest.mark.parametrize("bits", [64, 128, 256, 512, 768, 800, 1280, 1536, 2560])
+def test_key_size_boundaries(bits, monkeypatch):
+    key, pk, sk = make(bits)
+    rng = np.random.default_rng(bits)
+    N = 37
+    small = bits <= 128                                   # max_int = n/3: keep |mantissa * 2^exponent| inside it
+    vals = [int(v) for v in rng.integers(-1000, 1000, N)] if small else [float(v) for v in rng.uniform(-1000, 1000, N)]
+    r = orc.synth_r_limbs(bits, N, key.randbits)
+    en = pk.encrypt(vals, r=r)
+    want_ct, want_e = orc.api_encrypt(key, vals, orc.limbs_to_ints(r))
+    assert [int(c) for c in en.ciphertextBN()] == want_ct and en.exponent() == want_e
+    for switch in ("0", "100000"):
+        monkeypatch.setenv("PAI_LATENCY_MAX", switch)
+        assert sk.decrypt(en) == orc.api_decrypt(key, want_ct, want_e) == vals
+        assert sk.raw_decrypt(en) == [orc.decrypt_crt(key, c) for c in want_ct]
+    monkeypatch.delenv("PAI_LATENCY_MAX")
+    s = en + en
+    want = orc.api_add_ct(key, want_ct, want_e, want_ct, want_e)
+    assert ([int(c) for c in s.ciphertextBN()], s.exponent()) == (want[0], want[1])
+    w = [int(v) for v in rng.integers(-9, 9, N)]         # negative multipliers: batch inversion
+    pr = en * w
+    want = orc.api_mul_plain(key, want_ct, want_e, w)
+    assert ([int(c) for c in pr.ciphertextBN()], pr.exponent()) == (want[0], want[1])
+    tot = en.sum()
+    want = orc.api_sum(key, want_ct, want_e)
+    assert ([int(c) for c in tot.ciphertextBN()], tot.exponent()) == (want[0], want[1])
+    if not small:
+        assert abs(sk.decrypt(tot) - sum(vals)) < 1e-6
