@@ -138,8 +138,9 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
             // unrolled: 62 KB of code at 72 limbs (beyond the instruction cache), and at 56 limbs it makes the compiler
             // lose the LDS address space of the whole kernel (flat loads) — 166 ms against 142 ms per 65 536
             // for 30 % fewer multiplies.
-            auto self = [&](const uint4* X) { return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); }; };
-            E::mul_wbuf(A, B, M, Wb, self(A), self(B), nm, pm1, n0inv);
+            // sqr_rolled_wbuf keeps both halves in rolled loops and does the second half in one pass (4 NL^2 limb
+            // products instead of the 5 NL^2 of the product rule applied to (x, x)).
+            E::sqr_rolled_wbuf(A, B, M, Wb, nm, pm1, n0inv);
         } else if constexpr (MODE == PADIC_WBUF) E::sqr_wbuf(A, B, M, Wb, nm, pm1, n0inv);
         else E::sqr(A, B, M, nm, pm1, n0inv);
     };

@@ -407,7 +407,7 @@ k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_
 #pragma unroll 1
         for (int wi = nwin - 2; wi >= 0; --wi) {
 #pragma unroll 1
-            for (int sq = 0; sq < W; ++sq) E::mul_wbuf(A, B, M, Wb, self(A), self(B), nm, nm1, n0inv);
+            for (int sq = 0; sq < W; ++sq) E::sqr_rolled_wbuf(A, B, M, Wb, nm, nm1, n0inv);      // 4 NL^2 instead of the product rule's 5
             const int d = (int)window(wi);
             if (__any(d != 0)) E::mul_wbuf(A, B, M, Wb, from_table(d, 0), from_table(d, 1), nm, nm1, n0inv);
         }
@@ -497,7 +497,7 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
         };
     };
     auto self = [&](const uint4* X) { return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); }; };
-    auto SQR = [&]() { E::mul_wbuf(A, B, M, Wb, self(A), self(B), nm, nm1, n0inv); };
+    auto SQR = [&]() { E::sqr_rolled_wbuf(A, B, M, Wb, nm, nm1, n0inv); };      // 4 NL^2 instead of the product rule's 5
     const int NT = P.tbl_entries;
     const int nd = (32 * P.in_words + RB * NL - 1) / (RB * NL);
     const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;

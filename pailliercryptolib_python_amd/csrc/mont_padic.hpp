@@ -449,6 +449,53 @@ struct Padic {
         }
     }
 
+    // Squaring for wide digits with BOTH halves in rolled loops (nothing to overflow the instruction cache): the first
+    // half is the product loop with the element's own first digit as multiplier (a * a, every limb pair twice — the
+    // limb-class symmetric first half is fully unrolled code), the second half is the squaring's own
+    // v = (2 a b - m + R p + m' p) / R with doubled multiplier digits: ONE pass over a instead of the two (a d + b c)
+    // of the product rule.  4 NL^2 limb products per squaring instead of the 5 NL^2 of mul_wbuf(x, x).
+    PAI_DEV static void sqr_rolled_wbuf(uint4* A, uint4* B, MBuf M, MBuf Wb, const uint32_t* __restrict__ nm,
+                                        const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        {
+            uint64_t acc[NW];
+            zero(acc);
+            uint32_t dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+            uint32_t xn[U];
+            digits(A, 0, xn);
+#pragma unroll 1
+            for (int blk = 0; blk < NB; ++blk) {
+                uint32_t xv[U], q[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = xn[u];
+                digits(A, blk + 1 < NB ? blk + 1 : blk, xn);
+                block<true, 0, NL, false, false>(acc, A, xv, A, dummy, nm, n0inv, nm, blk, q);
+                store_q(M, blk, q);
+                if (blk != NB - 1 && ((blk + 1) * U) % P1 == 0) normalize(acc);
+            }
+            finish_to_buf(acc, Wb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            uint64_t acc[NW];
+            mm2_init(acc, M);
+            uint32_t dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+            for (int blk = 0; blk < NB; ++blk) {
+                uint32_t xv[U], q[U];
+                digits(B, blk, xv);
+                block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);   // HI = 0: every limb doubled
+                if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
+            }
+            wave_lds_fence();
+            finish_into(acc, B, A, Wb);
+            wave_lds_fence();
+        }
+    }
+
     // ---- register-lean variant (two waves per SIMD; EXPERIMENTAL — exercised by tools/padic_bench.hip only: it gains
     // 10 % in isolation and nothing inside the decrypt kernel): quotient digits m stay in VGPRs (the first half is fully
     // unrolled so that they can be indexed statically), the first result digit is parked in a global scratch
