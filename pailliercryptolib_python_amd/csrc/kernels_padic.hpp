@@ -89,6 +89,9 @@ PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const u
 #ifndef PADIC_SQR_MUL_ABOVE
 #define PADIC_SQR_MUL_ABOVE 40      // squarings as rolled-loop products above this limb count (scratch-resident quotient digits)
 #endif
+#ifndef PADIC_SQR_SYM_MAX_NL
+#define PADIC_SQR_SYM_MAX_NL 56      // limb-class symmetric first half of the wide-digit squaring up to this limb count
+#endif
 #ifndef PADIC_SGPR_MODULUS
 // measured per 65 536 decryptions with the modulus in SGPRs vs read from LDS: 36 limbs 488 vs 508 ms (x16), 72 limbs 364
 // vs 391 ms; 56 limbs (squaring as product, LDS-qualified accesses) 142 vs 151 ms
@@ -134,13 +137,17 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const typename E::MBuf Wb{P.wscratch + (size_t)E::NC * nslots + slot, nslots};      // MODE 2 only
     auto SQR = [&]() {
         if constexpr (MODE == PADIC_WBUF && NL > PADIC_SQR_MUL_ABOVE) {
-            // Wide digits square as rolled-loop products.  The limb-class symmetric squaring (sqr_wbuf) is fully
-            // unrolled: 62 KB of code at 72 limbs (beyond the instruction cache), and at 56 limbs it makes the compiler
-            // lose the LDS address space of the whole kernel (flat loads) — 166 ms against 142 ms per 65 536
-            // for 30 % fewer multiplies.
+            // Wide digits: the fully unrolled limb-class symmetric squaring (sqr_wbuf) is 62 KB of code at 72 limbs
+            // (beyond the instruction cache), and at 56 limbs it made the compiler lose the LDS address space of the
+            // whole kernel (flat loads); round 1 therefore squared as a product (mul_wbuf(x, x), 5 NL^2).
             // sqr_rolled_wbuf keeps both halves in rolled loops and does the second half in one pass (4 NL^2 limb
             // products instead of the 5 NL^2 of the product rule applied to (x, x)).
-            E::sqr_rolled_wbuf(A, B, M, Wb, nm, pm1, n0inv);
+            // Up to 56 limbs the first half is additionally limb-class symmetric (sqr_sym_wbuf: specialised a-parts
+            // behind a wave-uniform switch, shared reduction body; 3.5 NL^2): 121.0 -> 112.7 ms per 65 536 at 3072-bit
+            // keys.  At 72 limbs the same code LOSES (282.6 -> 383.4 ms: the nine specialised a-parts next to the
+            // 160-register window no longer fit), so 4096-bit keys keep the plain rolled first half.
+            if constexpr (NL <= PADIC_SQR_SYM_MAX_NL) E::sqr_sym_wbuf(A, B, M, Wb, nm, pm1, n0inv);
+            else E::sqr_rolled_wbuf(A, B, M, Wb, nm, pm1, n0inv);
         } else if constexpr (MODE == PADIC_WBUF) E::sqr_wbuf(A, B, M, Wb, nm, pm1, n0inv);
         else E::sqr(A, B, M, nm, pm1, n0inv);
     };

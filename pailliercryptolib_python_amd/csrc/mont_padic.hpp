@@ -496,6 +496,77 @@ struct Padic {
         }
     }
 
+    // The same with a limb-class symmetric first half that still fits the instruction cache: per row block, the
+    // a-part (the element's own limbs >= U b against its digits of class b: diagonal class once per pair, classes above
+    // doubled) is one of NB specialised straight-line routines selected by a wave-uniform switch — NL (NL + U) / 2 limb
+    // products of code in total — and the reduction part (quotient chain and p * q, identical for every block) is the
+    // shared rolled body.  3.5 NL^2 limb products per squaring.
+    template <int B>
+    PAI_DEV static void sqr_apart(uint64_t (&acc)[NW], const uint4* X, const uint32_t (&xv)[U]) {
+        constexpr int LO = U * B, HI = U * (B + 1);
+        uint32_t xv2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv2[u] = xv[u] << 1;
+#pragma unroll
+        for (int c = LO / 4; c < NC; ++c) {
+            const uint4 t = ld(X, c);
+            const uint32_t xa[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = 4 * c + k;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int mult = j >= HI ? 2 : (j - LO < u ? 0 : (j - LO == u ? 1 : 2));
+                    if (mult) acc[j + u] += (uint64_t)xa[k] * (mult == 2 ? xv2[u] : xv[u]);
+                }
+            }
+        }
+    }
+    template <int B>
+    PAI_DEV static void sqr_apart_dispatch(uint64_t (&acc)[NW], const uint4* X, const uint32_t (&xv)[U], int blk) {
+        if (blk == B) sqr_apart<B>(acc, X, xv);
+        else if constexpr (B + 1 < NB) sqr_apart_dispatch<B + 1>(acc, X, xv, blk);
+    }
+    PAI_DEV static void sqr_sym_wbuf(uint4* A, uint4* B, MBuf M, MBuf Wb, const uint32_t* __restrict__ nm,
+                                     const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        {
+            uint64_t acc[NW];
+            zero(acc);
+            uint32_t dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+            for (int blk = 0; blk < NB; ++blk) {
+                uint32_t xv[U], q[U];
+                digits(A, blk, xv);
+                sqr_apart_dispatch<0>(acc, A, xv, blk);
+                __builtin_amdgcn_sched_barrier(0);
+                block<false, 0, NL, false, false>(acc, A, dummy, A, dummy, nm, n0inv, nm, blk, q);
+                store_q(M, blk, q);
+                if (sqr1_normalize_after(blk)) normalize(acc);
+            }
+            finish_to_buf(acc, Wb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            uint64_t acc[NW];
+            mm2_init(acc, M);
+            uint32_t dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+            for (int blk = 0; blk < NB; ++blk) {
+                uint32_t xv[U], q[U];
+                digits(B, blk, xv);
+                block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);   // HI = 0: every limb doubled
+                if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
+            }
+            wave_lds_fence();
+            finish_into(acc, B, A, Wb);
+            wave_lds_fence();
+        }
+    }
+
     // ---- register-lean variant (two waves per SIMD; EXPERIMENTAL — exercised by tools/padic_bench.hip only: it gains
     // 10 % in isolation and nothing inside the decrypt kernel): quotient digits m stay in VGPRs (the first half is fully
     // unrolled so that they can be indexed statically), the first result digit is parked in a global scratch
