@@ -259,6 +259,7 @@ class ipclPublicKey:
             self._hs, self._randbits = None, 0
         self._devices = None
         self._handles = {}
+        self._obf_pool = None
 
     # randomness for the obfuscator: OS CSPRNG on the host, expanded / uploaded as limbs
     def _draw_r(self, count: int, h: Optional[engine.PublicKeyHandle] = None) -> torch.Tensor:
@@ -273,10 +274,38 @@ class ipclPublicKey:
         vals = [int.from_bytes(raw[i * nb:(i + 1) * nb], "little") % (self._n - 1) + 1 for i in range(count)]
         return engine.to_device_words(engine.ints_to_words(vals, h.n_words), h.device)
 
+    # -- obfuscator pool: obfuscators hs^r (or r^n) computed ahead of time, each used once ---------
+    def fill_obfuscator_pool(self, count: int) -> None:
+        """Extension: precomputes `count` fresh obfuscators on the home device (randomness from the same CSPRNG-keyed
+        source as encrypt).  Later encryptions take theirs from the pool — an encryption is then the raw form times
+        one pooled obfuscator, i.e. ONE modular multiplication instead of the fixed-base exponentiation (the
+        reference's `apply_obfuscator=False` fast path followed by re-obfuscation, ipcl_python.py:103-106,342-346, done
+        ahead of time).  Every pooled value is consumed exactly once; a batch larger than the pool encrypts directly."""
+        h = self.handle
+        one = torch.zeros((count, h.n_words), dtype=torch.int32, device=h.device)      # E(0; r) = 1 * obf(r)
+        fresh = h.encrypt(one, self._draw_r(count))
+        pool = getattr(self, "_obf_pool", None)
+        self._obf_pool = fresh if pool is None or pool.shape[0] == 0 else torch.cat([pool, fresh], dim=0)
+
+    def obfuscator_pool_size(self) -> int:
+        pool = getattr(self, "_obf_pool", None)
+        return 0 if pool is None else int(pool.shape[0])
+
+    def _take_obfuscators(self, count: int) -> Optional[torch.Tensor]:
+        pool = getattr(self, "_obf_pool", None)
+        if pool is None or pool.shape[0] < count or count == 0:
+            return None
+        taken, self._obf_pool = pool[:count].contiguous(), pool[count:]
+        return taken
+
     def encrypt_words(self, m: torch.Tensor, make_secure: bool = True, r: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Residues [N, n_words] on the home device -> ciphertexts [N, ct_words] on the home device; large batches
         are sharded over the key's devices (scatter, encrypt per device on its own thread, gather)."""
         h = self.handle
+        if make_secure and r is None:
+            obf = self._take_obfuscators(m.shape[0])
+            if obf is not None:
+                return h.ct_add(h.raw_encrypt(m), obf)             # (1 + m n) * obf mod n^2: the same bits as a direct encryption
         devs = self.fanout_devices(m.shape[0])
         if devs is None:
             if not make_secure:

@@ -89,6 +89,11 @@ class PaillierPublicKey:
             return self.pubkey.apply_obfuscator(BNUtils.int2BN(x))
         return self.pubkey.apply_obfuscator(x)
 
+    def precompute_obfuscators(self, count: int) -> None:
+        """Extension: fill the key's obfuscator pool; the next `count` encrypted elements cost one
+        modular multiplication each (bindings.ipclPublicKey.fill_obfuscator_pool)."""
+        self.pubkey.fill_obfuscator_pool(int(count))
+
     def raw_encrypt(self, plaintext: Union[np.ndarray, list, int, float]) -> "PaillierEncryptedNumber":
         return self.encrypt(plaintext, apply_obfuscator=False)
 
@@ -114,6 +119,8 @@ class PaillierPublicKey:
         is_i64 = (isinstance(values, np.ndarray) and values.dtype in (np.int16, np.int32, np.int64) and values.ndim == 1
                   and values.shape[0] > 0 and self.n.bit_length() > 66)
         devs = pub.fanout_devices(len(values)) if (is_f64 or is_i64) else None
+        if apply_obfuscator and r is None and pub.obfuscator_pool_size() >= len(values):
+            devs = None                                            # pooled obfuscators live on the home device
         if devs is not None:
             # Multi-GPU: contiguous block shards, each H2D'd straight from the host array to its own
             # device (8 B per element), encoded, obfuscated and encrypted there; ciphertext shards are gathered onto

@@ -423,3 +423,28 @@ def test_unpickled_ciphertexts_share_one_handle_and_stay_on_the_host_until_used(
     s = back[0] + back[1]
     assert sk.decrypt(s) == [3.0, -4.0, 6.5]
     assert back[2].public_key.pubkey.handle is pk.pubkey.handle
+
+
+def test_obfuscator_pool_encryptions_are_valid_and_consume_the_pool(fixed):
+    """pooled obfuscators.  A pooled encryption is raw_encrypt(m) * obf with obf = E(0; r): it decrypts
+    to m, differs from the raw ciphertext, equals the oracle's product of the two, and every pooled value is used once."""
+    import torch
+
+    pk, sk, okey = fixed
+    pub = pk.pubkey
+    pub._obf_pool = None
+    pk.precompute_obfuscators(40)
+    assert pub.obfuscator_pool_size() == 40
+    pool = [int(v) for v in engine.words_to_ints(engine.to_host_words(pub._obf_pool))]
+    assert len(set(pool)) == 40 and all(orc.decrypt_crt(okey, c) == 0 for c in pool[:5])       # encryptions of zero
+    x = [1.5, -2.25, 1000.0, 7]
+    en = pk.encrypt(x)
+    assert pub.obfuscator_pool_size() == 36
+    raw_ct, raw_e = orc.api_encrypt(okey, x, None)
+    assert ct_ints(en) == [orc.ct_add(a, b, okey.nsq) for a, b in zip(raw_ct, pool[:4])] and en.exponent() == raw_e
+    assert sk.decrypt(en) == [1.5, -2.25, 1000.0, 7]
+    en2 = pk.encrypt(list(range(36)))
+    assert pub.obfuscator_pool_size() == 0 and sk.decrypt(en2) == list(range(36))
+    en3 = pk.encrypt([3.0, 4.0])                               # pool empty: direct encryption
+    assert sk.decrypt(en3) == [3.0, 4.0]
+    assert torch.equal(pk.raw_encrypt([5]).words, pk.raw_encrypt([5]).words)
