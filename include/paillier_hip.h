@@ -141,10 +141,11 @@ int pai_fp_encode_f64(const pai_pubkey* pk, const double* d_x, size_t N, uint32_
 int pai_fp_encode_i64(const pai_pubkey* pk, const int64_t* d_x, size_t N, uint32_t* d_m, int32_t* d_expo, void* stream);
 int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64_t* d_mant, int32_t* d_flag, void* stream);
 
-/* Obfuscator randomness for DJN keys, replacing upstream ipcl's per-element getRandomBN inside
+/* Obfuscator randomness, replacing upstream ipcl's per-element getRandomBN inside
  * PublicKey::encrypt (called at classes.cpp:57): d_r[N][r_words] <- ChaCha20 key stream (RFC 8439 block
  * function; h_key8 = 256-bit key from the OS CSPRNG, h_nonce3 = 96-bit nonce, 32-bit block counter starting
- * at counter0, carried into nonce word 0), top word of every row masked to randbits. */
+ * at counter0, carried into nonce word 0), top word of every row masked to randbits.  Standard-scheme keys get rows of
+ * bits(n) random bits: candidates for r, of which the caller keeps those in [1, n) (rejection sampling). */
 int pai_draw_r(const pai_pubkey* pk, const uint32_t* h_key8, const uint32_t* h_nonce3, uint32_t counter0, size_t N,
                uint32_t* d_r, void* stream);
 

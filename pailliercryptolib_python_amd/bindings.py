@@ -148,6 +148,17 @@ def _random_unit(n: int) -> int:
             return x
 
 
+def _rows_not_in_1_n(r: torch.Tensor, n_words: torch.Tensor) -> torch.Tensor:
+    """[N] bool: row i of the limb matrix r (int32 bit patterns of uint32 limbs, little-endian) is 0 or >= n."""
+    u = r.to(torch.int64) & 0xFFFFFFFF
+    lt = torch.zeros(r.shape[0], dtype=torch.bool, device=r.device)
+    eq = torch.ones(r.shape[0], dtype=torch.bool, device=r.device)
+    for w in range(r.shape[1] - 1, -1, -1):
+        lt |= eq & (u[:, w] < n_words[w])
+        eq &= u[:, w] == n_words[w]
+    return ~lt | (u.sum(dim=1) == 0)
+
+
 class ipclPublicKey:
     """Replaces the pybind class at bindings/ipcl_bindings_classes.cpp:12-91."""
 
@@ -267,12 +278,19 @@ class ipclPublicKey:
         if self._djn:
             # fresh 256-bit key + 96-bit nonce from the OS CSPRNG, expanded on the device (ChaCha20, RFC 8439)
             return h.draw_r(count, secrets.token_bytes(32), secrets.token_bytes(12))
-        # standard scheme: r uniform in [1, n): a draw of bits(n) + 64 bits reduced mod (n - 1) is within 2^-64 of
-        # uniform; one os.urandom call and vectorised limb handling instead of a secrets.randbelow per element
-        nb = (self._n.bit_length() + 64 + 7) // 8
-        raw = os.urandom(nb * count)
-        vals = [int.from_bytes(raw[i * nb:(i + 1) * nb], "little") % (self._n - 1) + 1 for i in range(count)]
-        return engine.to_device_words(engine.ints_to_words(vals, h.n_words), h.device)
+        # standard scheme: r uniform in [1, n) by rejection sampling on the device — candidates of bits(n) random bits
+        # from the ChaCha20 stream (a fresh OS-CSPRNG key per round), a limb-wise comparison with n, redraw of the
+        # rejected rows (each round keeps more than half of them)
+        n_w = torch.from_numpy(engine.int_to_words(self._n, h.n_words).astype(np.int64)).to(h.device)
+        r = h.draw_r(count, secrets.token_bytes(32), secrets.token_bytes(12))
+        for _ in range(128):
+            bad = _rows_not_in_1_n(r, n_w)
+            nbad = int(bad.sum())
+            if nbad == 0:
+                return r
+            idx = torch.nonzero(bad, as_tuple=False).reshape(-1)
+            r[idx] = h.draw_r(nbad, secrets.token_bytes(32), secrets.token_bytes(12))
+        raise RuntimeError("standard-scheme randomness: rejection sampling did not terminate")
 
     # -- obfuscator pool: obfuscators hs^r (or r^n) computed ahead of time, each used once ---------
     def fill_obfuscator_pool(self, count: int) -> None:

@@ -959,7 +959,6 @@ int pai_draw_r(const pai_pubkey* pk, const uint32_t* h_key8, const uint32_t* h_n
                uint32_t* d_r, void* stream) {
     return guarded([&] {
         require(pk && h_key8 && h_nonce3 && d_r, "NULL argument");
-        require(pk->djn, "pai_draw_r serves DJN keys (r < 2^randbits); the standard scheme draws r in [1, n) on the host");
         if (N == 0) return;
         DeviceScope scope_(pk->device);
         ChaChaKey K;
@@ -968,7 +967,10 @@ int pai_draw_r(const pai_pubkey* pk, const uint32_t* h_key8, const uint32_t* h_n
         K.counter0 = counter0;
         const size_t total = N * (size_t)pk->r_words;
         const size_t blocks = (total + 15) / 16;
-        const int top = pk->randbits - 32 * (pk->r_words - 1);
+        // DJN keys: r < 2^randbits.  Standard keys: candidates of bits(n) bits — the caller keeps those in [1, n)
+        // (rejection sampling, bindings.py) so that r is uniform there.
+        const int rbits = pk->djn ? pk->randbits : hbn::bitlen(pk->n);
+        const int top = rbits - 32 * (pk->r_words - 1);
         const uint32_t mask = top >= 32 ? 0xFFFFFFFFu : ((1u << top) - 1u);
         hipLaunchKernelGGL(k_draw_r, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, d_r, total,
                            pk->r_words, mask);

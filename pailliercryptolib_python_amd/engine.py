@@ -211,10 +211,9 @@ class PublicKeyHandle:
         return mant, flag
 
     def draw_r(self, n: int, key: bytes, nonce: bytes, counter0: int = 0) -> torch.Tensor:
-        """DJN obfuscator randomness r < 2^randbits: ChaCha20 key stream under ``key`` (32 bytes, from the OS
-        CSPRNG) and ``nonce`` (12 bytes), generated on the device."""
-        if self.hs is None:
-            raise NotImplementedError("draw_r serves DJN keys")
+        """Obfuscator randomness on the device: ChaCha20 key stream under ``key`` (32 bytes, from the OS CSPRNG) and
+        ``nonce`` (12 bytes).  DJN keys: r < 2^randbits.  Standard keys: rows of bits(n) random bits (candidates; the
+        caller rejects those outside [1, n))."""
         if len(key) != 32 or len(nonce) != 12:
             raise ValueError("ChaCha20 needs a 32-byte key and a 12-byte nonce")
         k = np.frombuffer(key, dtype="<u4").copy()

@@ -92,11 +92,19 @@ def test_draw_r_is_the_rfc8439_key_stream(N, counter0):
     assert all(r < (1 << nk_.key.randbits) for r in limbs_to_ints(dr.get()))
 
 
-def test_draw_r_rejects_standard_scheme_keys():
+def test_draw_r_serves_standard_scheme_keys_with_candidates_of_bits_n():
+    """Standard-scheme keys get rows of bits(n) random bits from the same ChaCha20 stream (the caller keeps those in
+    [1, n): bindings.ipclPublicKey._draw_r); the stream itself is pinned by the RFC 8439 oracle as for DJN keys."""
     nk_ = NativeKey(bench_key(djn=False))
-    k = np.zeros(8, dtype=np.uint32)
-    dr = DevArray(shape=(4, nk_.rw))
-    assert nk_.lib.pai_draw_r(nk_.pk, host_ptr(k), host_ptr(k), 0, 4, dr.ptr, None) == _native.PAI_E_INVALID
+    key = bytes(range(1, 33))
+    nonce = bytes(range(40, 52))
+    k = np.frombuffer(key, dtype="<u4").copy()
+    nn = np.frombuffer(nonce, dtype="<u4").copy()
+    N = 5
+    dr = DevArray(shape=(N, nk_.rw))
+    _native.check(nk_.lib.pai_draw_r(nk_.pk, host_ptr(k), host_ptr(nn), 3, N, dr.ptr, None))
+    want = cc.draw_r_words(key, nonce, 3, N, nk_.rw, nk_.key.n.bit_length())
+    assert np.array_equal(dr.get(), want)
 
 
 def test_api_float_arrays_use_the_device_codec_and_keep_reference_semantics():
