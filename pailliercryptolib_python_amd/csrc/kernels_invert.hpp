@@ -88,7 +88,9 @@ __device__ __forceinline__ bool wave_add(WaveInt<WPL>& d, const WaveInt<WPL>& x,
 template <int WPL>
 __device__ __forceinline__ void wave_shr1(WaveInt<WPL>& x, bool top) {
     const int lane = threadIdx.x & 63;
-    uint32_t next = __shfl_down(x.w[0], 1);
+    // lane l <- word 0 of lane l + 1: wave_shl DPP (a VALU move; __shfl_down goes through the LDS pipe, ~100 cycles
+    // of latency on the critical path of every halving)
+    uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.w[0], 0x130, 0xF, 0xF, true);
     if (lane == 63) next = top ? 1u : 0u;
 #pragma unroll
     for (int k = 0; k < WPL; ++k) {
@@ -128,8 +130,10 @@ k_inv_eea_wave(const uint32_t* __restrict__ mod, const uint32_t* __restrict__ a_
     }
     if (lane == 0) x1.w[0] = 1;
     for (int step = 0; step < max_steps; ++step) {
-        if (wave_is_zero<WPL>(u)) break;
-        const bool u_odd = __shfl(u.w[0], 0) & 1u;
+        // once u is 0 nothing below touches v or x2 (u stays even: only u and x1 are halved), so the exit test can be
+        // sparse; lane 0's low words travel through SGPRs (readfirstlane), not the LDS pipe
+        if ((step & 15) == 0 && wave_is_zero<WPL>(u)) break;
+        const bool u_odd = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.w[0]) & 1u;
         if (u_odd) {
             WaveInt<WPL> d;
             const bool lt = wave_sub<WPL>(d, u, v);
@@ -148,7 +152,7 @@ k_inv_eea_wave(const uint32_t* __restrict__ mod, const uint32_t* __restrict__ a_
         // u is even: halve it, and x1 modulo M
         wave_shr1<WPL>(u, false);
         bool top = false;
-        if (__shfl(x1.w[0], 0) & 1u) top = wave_add<WPL>(x1, x1, m);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)x1.w[0]) & 1u) top = wave_add<WPL>(x1, x1, m);
         wave_shr1<WPL>(x1, top);
     }
     // v = gcd(a, M)
