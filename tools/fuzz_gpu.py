@@ -1,0 +1,77 @@
+"""Randomised differential run of the C ABI against CPython integers (dev tool; the committed tests are the fixed cases).
+Random batch sizes, operand patterns with long carry chains (all-ones runs, values next to 0 / M), every key size.
+    python tools/fuzz_gpu.py [seconds]"""
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np
+from oracle import paillier_oracle as orc
+from pailliercryptolib_python_amd import _native
+from tests._util import DevArray, host_ptr, ints_to_limbs, limbs_to_ints
+from tests.test_gpu_paillier_abi import NativeKey, bench_key, seeded_key
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(time.time()))
+keys = {b: NativeKey(bench_key() if b == 2048 else seeded_key(b)) for b in (1024, 2048, 3072, 4096)}
+
+def pattern(M, n):
+    out = []
+    bits = M.bit_length()
+    for _ in range(n):
+        k = rng.integers(0, 8)
+        if k == 0: v = int(rng.integers(0, 3))
+        elif k == 1: v = M - 1 - int(rng.integers(0, 3))
+        elif k == 2: v = (1 << int(rng.integers(1, bits))) - 1                      # run of ones
+        elif k == 3: v = ((1 << bits) - 1) ^ ((1 << int(rng.integers(1, bits))) - 1)  # ones on top
+        elif k == 4: v = 1 << int(rng.integers(0, bits))
+        else: v = int.from_bytes(rng.bytes(bits // 8 + 8), "little")
+        out.append(v % M)
+    return out
+
+t0 = time.time(); rounds = 0; checks = 0
+while time.time() - t0 < budget:
+    bits = int(rng.choice([1024, 2048, 3072, 4096]))
+    nk = keys[bits]; key = nk.key; M = key.nsq; lib = nk.lib
+    N = int(rng.integers(1, 700))
+    a, b = pattern(M, N), pattern(M, N)
+    da, db = DevArray(ints_to_limbs(a, nk.cw)), DevArray(ints_to_limbs(b, nk.cw))
+    out = DevArray(shape=(N, nk.cw))
+    bc = int(rng.integers(0, 2))
+    _native.check(lib.pai_ct_add(nk.pk, da.ptr, db.ptr, bc, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == [x * (b[0] if bc else y) % M for x, y in zip(a, b)], ("ct_add", bits, N, bc)
+    groups = int(rng.choice([g for g in (1, 2, 3, 5, 7, 16) if N % g == 0] or [1])) if N > 1 else 1
+    if N % groups == 0:
+        og = DevArray(shape=(groups, nk.cw))
+        _native.check(lib.pai_ct_prod(nk.pk, da.ptr, N, groups, og.ptr, None))
+        want = []
+        for g in range(groups):
+            p = 1
+            for l in range(N // groups): p = p * a[l * groups + g] % M
+            want.append(p)
+        assert limbs_to_ints(og.get()) == want, ("ct_prod", bits, N, groups)
+    delta = rng.integers(-3, 9, N).astype(np.int32)
+    dd = DevArray(delta); dc = DevArray(ints_to_limbs(a, nk.cw))
+    _native.check(lib.pai_ct_pow2(nk.pk, dc.ptr, dd.ptr, 0, N, None))
+    assert limbs_to_ints(dc.get()) == [pow(x, 1 << int(d), M) if d > 0 else x for x, d in zip(a, delta)], ("pow2", bits, N)
+    units = [x if (x % key.p and x % key.q) else 1 for x in a]
+    du = DevArray(ints_to_limbs(units, nk.cw))
+    _native.check(lib.pai_ct_invert(nk.pk, du.ptr, N, out.ptr, None))
+    got = limbs_to_ints(out.get())
+    for i in range(0, N, max(1, N // 40)): assert got[i] == pow(units[i], -1, M), ("invert", bits, N, i)
+    # decrypt on both paths + ct*pt on both paths, small N
+    n2 = int(rng.integers(1, 40))
+    m = pattern(key.n, n2)
+    cts = [orc.encrypt(key, x, int(rng.integers(1, 1 << 62))) for x in m]
+    dct = DevArray(ints_to_limbs(cts, nk.cw)); om = DevArray(shape=(n2, nk.nw))
+    ebits = int(rng.choice([9, 31, 53, 64, 200]))
+    e = [int.from_bytes(rng.bytes(ebits // 8 + 1), "little") % (1 << ebits) for _ in range(n2)]
+    ew = (ebits + 31) // 32
+    de = DevArray(ints_to_limbs(e, ew)); oc = DevArray(shape=(n2, nk.cw))
+    for sw in ("0", "100000"):
+        os.environ["PAI_LATENCY_MAX"] = sw
+        _native.check(lib.pai_decrypt(nk.sk, dct.ptr, n2, om.ptr, None))
+        assert limbs_to_ints(om.get()) == m, ("decrypt", bits, n2, sw)
+        _native.check(lib.pai_ct_mul(nk.pk, dct.ptr, de.ptr, ew, ebits, 0, n2, oc.ptr, None))
+        assert limbs_to_ints(oc.get()) == [pow(c, x, M) for c, x in zip(cts, e)], ("ct_mul", bits, n2, ebits, sw)
+    os.environ.pop("PAI_LATENCY_MAX", None)
+    rounds += 1; checks += 6
+print(json.dumps({"rounds": rounds, "checks": checks, "seconds": round(time.time() - t0, 1), "failures": 0}))
