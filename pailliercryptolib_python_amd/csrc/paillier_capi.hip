@@ -321,6 +321,11 @@ struct pai_pubkey {
     mutable bool lat_ready = false, lat_usable = false;
     mutable ModSetup lat_msq;
     mutable DevBuf lat_table;
+    // latency path of DJN encryption: n R and a 10-bit fixed-base table in the wide-group geometry (81 MB at 2048-bit keys)
+    mutable bool lat_fb_ready = false;
+    mutable uint32_t* d_lat_nR = nullptr;
+    mutable uint32_t* d_lat_fb = nullptr;
+    mutable int lat_fb_windows = 0, lat_fb_wbits = 10;
     mutable ScratchOrder order;
     mutable std::mutex mu;
     EncParams enc_params() const {
@@ -580,6 +585,61 @@ uint32_t* upload_vec(const std::vector<uint32_t>& h) {
     return d;
 }
 
+// Lane-group fixed-base table T[j][d] = hs^(d 2^(wb j)) for the modulus context `ms` (Montgomery form for ITS R, raw
+// radix-29 rows of ms.nl limbs).  Two levels when the window width is even: half-width windows
+// S[i][e] = hs^(e 2^(h i)) (2 J windows of 2^h entries, binary method, a few thousand entries), then ONE product per
+// entry, T[j][hi 2^h + lo] = S[2 j + 1][hi] * S[2 j][lo] (k_fb_expand).  Odd widths (only reachable through
+// PAI_FB_WBITS) keep the one-level build.
+uint32_t* build_lane_group_fb(const pai_pubkey* pk, const ModSetup& ms, int wb, int J) {
+    const int nl = ms.nl;
+    const size_t ENT = (size_t)1 << wb;
+    hbn::Mont32 mt(pk->nsq);
+    const bool two_level = (wb % 2 == 0) && wb >= 8;
+    const int h = two_level ? wb / 2 : wb;                     // bits per first-level window
+    const int J1 = two_level ? 2 * J : J;
+    std::vector<uint32_t> bases((size_t)J1 * pk->ct_words, 0);
+    Limbs b = mt.to_mont(pk->hs);
+    for (int j = 0; j < J1; ++j) {
+        Limbs plain = mt.from_mont(b);
+        std::memcpy(&bases[(size_t)j * pk->ct_words], plain.data(), plain.size() * 4);
+        for (int s = 0; s < h; ++s) b = mt.mmul(b, b);
+    }
+    const size_t E1 = (size_t)1 << h, NE1 = (size_t)J1 * E1;
+    std::vector<uint32_t> expo(NE1);
+    for (size_t i = 0; i < NE1; ++i) expo[i] = (uint32_t)(i & (E1 - 1));
+    DevBuf d_bases, d_expo, d_half;
+    d_bases.ensure(bases.size() * 4);
+    d_expo.ensure(NE1 * 4);
+    HIP_CHECK(hipMemcpy(d_bases.p, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_expo.p, expo.data(), NE1 * 4, hipMemcpyHostToDevice));
+    const size_t NE = (size_t)J * ENT;
+    uint32_t* d_fb = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d_fb, NE * (size_t)nl * 4));
+    const GeoOps* g = ms.geo;
+    uint32_t* level1 = d_fb;
+    if (two_level) {
+        d_half.ensure(NE1 * (size_t)nl * 4);
+        level1 = d_half.as<uint32_t>();
+    }
+    const int g1 = (int)std::max<size_t>(1, std::min<size_t>((NE1 + g->epb - 1) / g->epb, (size_t)pk->dev.ncu * 8));
+    g->modexp_var(nullptr, g1, ms.d_ctx, d_bases.as<uint32_t>(), pk->ct_words, h /* base = i >> h */,
+                  d_expo.as<uint32_t>(), 1, h, 0, level1, 0, (int)NE1, 1 /*keep_mont*/, 1 /*out_raw*/);
+    hipError_t e1 = hipGetLastError();
+    if (two_level && e1 == hipSuccess) {
+        const int g2 = (int)std::max<size_t>(1, std::min<size_t>((NE + g->epb - 1) / g->epb, (size_t)pk->dev.ncu * 8));
+        g->fb_expand(nullptr, g2, ms.d_ctx, level1, d_fb, J, h);
+        e1 = hipGetLastError();
+    }
+    hipError_t e2 = hipDeviceSynchronize();
+    d_bases.release();
+    d_expo.release();
+    d_half.release();
+    if (e1 != hipSuccess || e2 != hipSuccess) (void)hipFree(d_fb);
+    HIP_CHECK(e1);
+    HIP_CHECK(e2);
+    return d_fb;
+}
+
 // Fixed-base tables of the DJN obfuscator hs^r, built by the FIRST call that obfuscates (pai_encrypt with
 // randomness / pai_obfuscate), under pk->mu: a handle that only adds, multiplies or decrypts — every unpickled
 // ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
@@ -602,50 +662,7 @@ void build_fb_tables(const pai_pubkey* cpk) {
     const size_t ENT = (size_t)1 << wb;
     pk->fb_windows = J;
     if (!pk->penc_nl) {
-        // Lane-group table T[j][d] = hs^(d 2^(wb j)), Montgomery form, raw radix-29 rows.  Two levels when the window
-        // width is even: half-width windows S[i][e] = hs^(e 2^(h i)) (2 J windows of 2^h entries, binary method,
-        // a few thousand entries), then ONE product per entry, T[j][hi 2^h + lo] = S[2 j + 1][hi] * S[2 j][lo]
-        // (k_fb_expand).  Odd widths (only reachable through PAI_FB_WBITS) keep the one-level build.
-        hbn::Mont32 mt(pk->nsq);
-        const bool two_level = (wb % 2 == 0) && wb >= 8;
-        const int h = two_level ? wb / 2 : wb;                     // bits per first-level window
-        const int J1 = two_level ? 2 * J : J;
-        std::vector<uint32_t> bases((size_t)J1 * pk->ct_words, 0);
-        Limbs b = mt.to_mont(pk->hs);
-        for (int j = 0; j < J1; ++j) {
-            Limbs plain = mt.from_mont(b);
-            std::memcpy(&bases[(size_t)j * pk->ct_words], plain.data(), plain.size() * 4);
-            for (int s = 0; s < h; ++s) b = mt.mmul(b, b);
-        }
-        const size_t E1 = (size_t)1 << h, NE1 = (size_t)J1 * E1;
-        std::vector<uint32_t> expo(NE1);
-        for (size_t i = 0; i < NE1; ++i) expo[i] = (uint32_t)(i & (E1 - 1));
-        DevBuf d_bases, d_expo, d_half;
-        d_bases.ensure(bases.size() * 4);
-        d_expo.ensure(NE1 * 4);
-        HIP_CHECK(hipMemcpy(d_bases.p, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(d_expo.p, expo.data(), NE1 * 4, hipMemcpyHostToDevice));
-        const size_t NE = (size_t)J * ENT;
-        HIP_CHECK(hipMalloc((void**)&pk->d_fb, NE * (size_t)nl * 4));
-        const GeoOps* g = pk->msq.geo;
-        uint32_t* level1 = pk->d_fb;
-        if (two_level) {
-            d_half.ensure(NE1 * (size_t)nl * 4);
-            level1 = d_half.as<uint32_t>();
-        }
-        g->modexp_var(nullptr, grid_for(g, NE1, pk->dev.ncu), pk->msq.d_ctx, d_bases.as<uint32_t>(), pk->ct_words, h /* base = i >> h */,
-                      d_expo.as<uint32_t>(), 1, h, 0, level1, 0, (int)NE1, 1 /*keep_mont*/, 1 /*out_raw*/);
-        hipError_t e1 = hipGetLastError();
-        if (two_level && e1 == hipSuccess) {
-            g->fb_expand(nullptr, grid_for(g, NE, pk->dev.ncu), pk->msq.d_ctx, level1, pk->d_fb, J, h);
-            e1 = hipGetLastError();
-        }
-        hipError_t e2 = hipDeviceSynchronize();
-        d_bases.release();
-        d_expo.release();
-        d_half.release();
-        HIP_CHECK(e1);
-        HIP_CHECK(e2);
+        pk->d_fb = build_lane_group_fb(pk, pk->msq, wb, J);
     } else {
         // digit-form fixed-base table for the base-n digit engine
         const int pnl = pk->penc_nl;
@@ -817,6 +834,8 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->prod_b.release();
     pk->lat_msq.release();
     pk->lat_table.release();
+    if (pk->d_lat_nR) (void)hipFree(pk->d_lat_nR);
+    if (pk->d_lat_fb) (void)hipFree(pk->d_lat_fb);
     pk->order.release();
     pk->inv_prod.release();
     pk->inv_inv.release();
@@ -851,6 +870,41 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
     // every path below shares per-key device scratch (quotient-digit columns, window tables): one at a time per
     // handle, ordered across streams by pk->order
     std::lock_guard<std::mutex> lk(pk->mu);
+    if (d_r && pk->djn && N <= 2 * latency_max_elements()) {      // 1.2 ms against 3.5 ms up to 1024 elements, 2.4 against 3.6 at 4096
+        // small DJN batch: n^2 spread over a wavefront per ciphertext, 10-bit fixed-base windows in that geometry
+        if (!pk->lat_ready) {
+            pk->lat_ready = true;
+            if (const GeoOps* gl = geo_latency_for_bits(hbn::bitlen(pk->nsq))) {
+                pk->lat_msq.init(pk->nsq, 0, gl);
+                pk->lat_usable = true;
+            }
+        }
+        if (pk->lat_usable && !pk->lat_fb_ready) {
+            pk->lat_fb_windows = (pk->randbits + pk->lat_fb_wbits - 1) / pk->lat_fb_wbits;
+            pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
+            pk->d_lat_fb = build_lane_group_fb(pk, pk->lat_msq, pk->lat_fb_wbits, pk->lat_fb_windows);
+            pk->lat_fb_ready = true;
+        }
+        if (pk->lat_usable) {
+            const GeoOps* gl = pk->lat_msq.geo;
+            EncParams PL;
+            PL.nsq = pk->lat_msq.d_ctx;
+            PL.nR = pk->d_lat_nR;
+            PL.fb_table = pk->d_lat_fb;
+            PL.fb_windows = pk->lat_fb_windows;
+            PL.fb_wbits = pk->lat_fb_wbits;
+            PL.pt_words = pk->n_words;
+            PL.ct_words = pk->ct_words;
+            PL.r_words = pk->r_words;
+            pk->order.begin(s);
+            ScopedKernelTimer t(from_plain ? "k_encrypt(djn)" : "k_encrypt(obfuscate)", s);
+            gl->encrypt(s, (int)((N + gl->epb - 1) / gl->epb), PL, d_m, d_r, d_ct_in, d_ct_out, (int)N, from_plain ? 1 : 2);
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            pk->order.end(s);
+            return;
+        }
+    }
     if (d_r && pk->djn) build_fb_tables(pk);
     EncParams P = pk->enc_params();
     pk->order.begin(s);

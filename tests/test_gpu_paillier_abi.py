@@ -490,3 +490,25 @@ def test_ct_mul_latency_and_throughput_paths_agree(bits, monkeypatch):
             out = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
             assert limbs_to_ints(out.get()) == [pow(a, b, key.nsq) for a, b in zip(c, e)], (bits, N, ebits, switch)
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
+def test_djn_encrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
+    """Small DJN batches encrypt (and re-obfuscate) on the wide-group geometry with its own 10-bit fixed-base table."""
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key = nk.key
+    for N in (3, 20, 65):
+        m = plaintexts(key, N, bits + 3 * N)
+        r = orc.synth_r_limbs(bits + N, N, key.randbits)
+        r[0] = 0                                                   # r = 0: obfuscator 1
+        r[1] = 0xFFFFFFFF
+        r[1, -1] &= np.uint32((1 << (key.randbits - 32 * (r.shape[1] - 1))) - 1) if key.randbits % 32 else np.uint32(0xFFFFFFFF)
+        want = [orc.encrypt(key, x, rr) for x, rr in zip(m, orc.limbs_to_ints(r))]
+        dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
+        for switch in ("0", "100000"):
+            monkeypatch.setenv("PAI_LATENCY_MAX", switch)
+            ct = DevArray(shape=(N, nk.cw))
+            _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+            assert limbs_to_ints(ct.get()) == want, (bits, N, switch)
+            _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
+            assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, orc.limbs_to_ints(r))]

@@ -27,6 +27,8 @@ for N in (1, 16, 64, 256, 512, 1024, 2048, 4096, 16384):
         out = priv.decrypt(ct)
         assert torch.equal(out, m), (N, name)
         row[f"dec_{name}_ms"] = round(tm(lambda: priv.decrypt(ct)), 3)
+        assert torch.equal(pub.encrypt(m, r), ct), (N, name, "encrypt")
+        row[f"enc_{name}_ms"] = round(tm(lambda: pub.encrypt(m, r)), 3)
         e = torch.randint(1, 1 << 30, (N, 2), dtype=torch.int32, device=dev); e[:, 1] &= (1 << 21) - 1
         row[f"mul_{name}_ms"] = round(tm(lambda: pub.ct_mul(ct, e, 53)), 3)
     print(json.dumps(row), flush=True)
