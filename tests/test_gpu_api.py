@@ -470,4 +470,4 @@ def test_standard_scheme_randomness_is_drawn_on_the_device_inside_1_n():
     n_w = torch.from_numpy(engine.int_to_words(n_small, 32).astype(np.int64)).to(r.device)
     bad = _rows_not_in_1_n(r, n_w)
     want = [not (0 < v < n_small) for v in vals]
-    assert bad.cpu().tolist() == want and 0.2 < sum(want) / len(want) < 0.8
+    assert bad.cpu().tolist() == want and 0.05 < sum(want) / len(want) < 0.8       # n >= 0.5625 * 2^1024: at least 11 % lie above n_small
