@@ -33,6 +33,10 @@ build() {  # tag, dec flags, enc flags, [1 = the flags also reach paillier_capi.
 # 12-row blocks in the 72-limb decrypt kernel 945 vs 366 ms (spills); -O2, gcn-iterative-ilp within noise, post-RA
 # scheduler off 501 vs 477 ms; 192-thread workgroups with the quotient digits in LDS for 56-limb decrypt 220 vs 166 ms per 65536;
 # 56 limbs: squaring as product 146, + LDS-qualified accesses 151, + modulus in SGPRs 142 (adopted) vs 166 ms.
+# Round 2 (tools/variant_dec.sh builds one variant of padic_dec_kernels.hip in 45 s): table digits fetched two row blocks
+# ahead in the 36-limb multiplications 481.9 vs 474.9 ms (the extra 24 registers cost more than the latency they hide);
+# 56 limbs: rolled two-half squaring 143.9 -> 122.2, + switch-dispatched symmetric first half 112.7 (adopted); 72 limbs:
+# rolled 320.9 -> 284.4 (adopted), symmetric first half 383.4 (rejected: scratch 1356 -> 2752 B/lane).
 build plain "" "" &
 build trk "-mllvm -amdgpu-use-amdgpu-trackers" "-mllvm -amdgpu-use-amdgpu-trackers" &
 wait
