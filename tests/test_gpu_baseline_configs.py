@@ -103,37 +103,59 @@ def test_config2_2048bit_batch_1M_add_and_mul():
 
 
 @pytest.mark.parametrize("bits,total_n", [(3072, 1 << 20), (4096, 1 << 18)])
-def test_config3_4_one_rank_shard_roundtrip(bits, total_n):
-    """Configs 4/5 shard the batch over 8 GPUs; one GPU runs rank 0's shard."""
+def test_config3_4_every_rank_shard_at_full_size(bits, total_n):
+    """Configs 4/5 shard the batch over 8 GPUs (block partition, no exchange inside an operation).  The one GPU of the
+    test box runs the shards of ALL eight ranks one after the other — the whole configuration at its full size — with,
+    per shard: the round trip of every element, ciphertext bits of a sample against the C oracle (explicit
+    randomness), and over the whole batch: the product of all ciphertexts (pai_ct_prod per shard, combined on the host —
+    what the 8-way final product of SURVEY §8e's reduction does) decrypts to the sum of all residues."""
     key = fixture_key(bits)
     pub, priv = handles(key)
-    s0, e0 = sharding.my_shard(total_n, 0, 8)
-    N = e0 - s0
-    x = np.random.default_rng(1000 + bits).uniform(-1000, 1000, total_n)[s0:e0]
-    res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
-    m = engine.to_device_words(res, pub.device)
-    r_l = orc.synth_r_limbs(4000 + bits, N, key.randbits)                  # explicit randomness: the bits are defined
-    ct = pub.encrypt(m, engine.to_device_words(r_l, pub.device))
-    back = priv.decrypt(ct)
-    torch.cuda.synchronize()
-    assert torch.equal(back, m)
-    assert np.array_equal(fixedpoint.decode_float64_array(engine.to_host_words(back), expo, key.n, key.max_int), x)
-    # ciphertext bits against the C oracle (IFMA mb8 kernels when the host has them) on a sample spread over the
-    # shard, three of them also against the Python-int oracle; the oracle's CRT decryption returns the residues
-    idx = np.linspace(0, N - 1, 96).astype(np.int64)
+    world = 8
+    x_all = np.random.default_rng(1000 + bits).uniform(-1000, 1000, total_n)
     ck = co.COracleKey(key)
-    want = (ck.ifma_encrypt_djn if co.ifma_available() else ck.encrypt_djn)(res[idx], r_l[idx])
-    got = engine.to_host_words(ct[torch.from_numpy(idx).to(pub.device)])
-    assert np.array_equal(got, want)
-    for j in (0, 47, 95):
-        i = int(idx[j])
-        c = engine.words_to_ints(got[j:j + 1])[0]
-        assert c == orc.encrypt(key, engine.words_to_ints(res[i:i + 1])[0], orc.limbs_to_ints(r_l[i:i + 1])[0])
-        assert orc.decrypt_crt(key, c) == engine.words_to_ints(res[i:i + 1])[0]
-    # homomorphic identities on the shard: D(E(a) E(a)) = 2a and D(E(a)^3) = 3a (mod n)
-    s2 = engine.to_host_words(priv.decrypt(pub.ct_add(ct, ct))[:64])
-    e3 = torch.full((1, 1), 3, dtype=torch.int32, device=pub.device)
-    p3 = engine.to_host_words(priv.decrypt(pub.ct_mul(ct, e3, 2))[:64])
-    ai = engine.words_to_ints(res[:64])
-    assert engine.words_to_ints(s2) == [2 * a % key.n for a in ai]
-    assert engine.words_to_ints(p3) == [3 * a % key.n for a in ai]
+    c_enc = ck.ifma_encrypt_djn if co.ifma_available() else ck.encrypt_djn
+    total_residues, shard_products = 0, []
+
+    def colsum(words):
+        acc = 0
+        for col in range(words.shape[1] - 1, -1, -1):
+            acc = (acc << 32) + int(words[:, col].astype(np.uint64).sum())
+        return acc
+
+    for rank in range(world):
+        s0, e0 = sharding.my_shard(total_n, rank, world)
+        N = e0 - s0
+        x = x_all[s0:e0]
+        # raw residues of the SAME exponent class would be needed for a float sum; the check below is on residues mod n
+        res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
+        m = engine.to_device_words(res, pub.device)
+        r_l = orc.synth_r_limbs(4000 + bits + rank, N, key.randbits)           # explicit randomness: the bits are defined
+        ct = pub.encrypt(m, engine.to_device_words(r_l, pub.device))
+        back = priv.decrypt(ct)
+        torch.cuda.synchronize()
+        assert torch.equal(back, m), rank
+        assert np.array_equal(fixedpoint.decode_float64_array(engine.to_host_words(back), expo, key.n, key.max_int), x)
+        idx = np.linspace(0, N - 1, 24).astype(np.int64)
+        got = engine.to_host_words(ct[torch.from_numpy(idx).to(pub.device)])
+        assert np.array_equal(got, c_enc(res[idx], r_l[idx])), rank
+        if rank in (0, world - 1):
+            i = int(idx[-1])
+            c = engine.words_to_ints(got[-1:])[0]
+            assert c == orc.encrypt(key, engine.words_to_ints(res[i:i + 1])[0], orc.limbs_to_ints(r_l[i:i + 1])[0])
+            assert orc.decrypt_crt(key, c) == engine.words_to_ints(res[i:i + 1])[0]
+        total_residues += colsum(res)
+        shard_products.append(engine.words_to_ints(engine.to_host_words(pub.ct_prod(ct, 1)))[0])
+        if rank == 0:
+            # homomorphic identities on a shard: D(E(a) E(a)) = 2a and D(E(a)^3) = 3a (mod n)
+            s2 = engine.to_host_words(priv.decrypt(pub.ct_add(ct, ct))[:64])
+            e3 = torch.full((1, 1), 3, dtype=torch.int32, device=pub.device)
+            p3 = engine.to_host_words(priv.decrypt(pub.ct_mul(ct, e3, 2))[:64])
+            ai = engine.words_to_ints(res[:64])
+            assert engine.words_to_ints(s2) == [2 * a % key.n for a in ai]
+            assert engine.words_to_ints(p3) == [3 * a % key.n for a in ai]
+        del ct, back, m
+    prod = 1
+    for c in shard_products:
+        prod = prod * c % key.nsq
+    assert orc.decrypt_crt(key, prod) == total_residues % key.n
