@@ -33,7 +33,14 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     padded = torch.zeros((per,) + tuple(W), dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     out = torch.empty((world * per,) + tuple(W), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded, group=group) if local.is_cuda else _gather_cpu(out, padded, group)
+    if local.is_cuda and dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, padded, group=group)          # RCCL all-gather over xGMI
+    elif local.is_cuda:                                                # gloo with device tensors (plumbing tests): through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        _gather_cpu(host, padded.cpu(), group)
+        out.copy_(host)
+    else:
+        _gather_cpu(out, padded, group)
     return out[:n_total]
 
 
