@@ -649,14 +649,19 @@ void build_fb_tables(const pai_pubkey* cpk) {
     const int nl = pk->msq.nl;
     const int randbits = pk->randbits;
     // Fixed-base window width of the lane-group table (built only when the digit engine does not serve this key
-    // size): up to 14 bits within 1/64 of device memory (4096-bit keys: 2.8 GB; k_encrypt 84 -> 61 ms per 65536).
+    // size): the widest even width up to 16 bits whose table fits 1/32 of device memory (PAI_FB_TABLE_MB overrides) —
+    // every window is one multiplication mod n^2 per ciphertext and the two-level build costs one product per entry
+    // (4096-bit keys: 16 bits = 128 windows x 65536 entries x 1152 B = 9.7 GB; 14 bits: 147 windows, 2.8 GB).
     size_t mem_free0 = 0, mem_total0 = 0;
     HIP_CHECK(hipMemGetInfo(&mem_free0, &mem_total0));
-    const double lg_budget = pk->penc_nl ? 256.0 * 1048576.0
-                                         : std::max(256.0 * 1048576.0, std::min((double)mem_total0 / 64.0, (double)mem_free0 / 8.0));
-    int wb = pk->penc_nl ? 12 : 14;
-    while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > lg_budget) --wb;
-    if (const char* env = std::getenv("PAI_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 14) wb = v; }
+    double lg_budget = pk->penc_nl ? 256.0 * 1048576.0
+                                   : std::max(256.0 * 1048576.0, std::min((double)mem_total0 / 32.0, (double)mem_free0 / 4.0));
+    if (!pk->penc_nl) {
+        if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) lg_budget = v * 1048576.0; }
+    }
+    int wb = pk->penc_nl ? 12 : 16;
+    while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > lg_budget) wb -= (wb > 8 ? 2 : 1);
+    if (const char* env = std::getenv("PAI_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 16) wb = v; }
     pk->fb_wbits = wb;
     const int J = (randbits + wb - 1) / wb;
     const size_t ENT = (size_t)1 << wb;
