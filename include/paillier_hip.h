@@ -116,6 +116,14 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
  * product).  Synchronous; fails with PAI_E_INVALID if some ciphertext shares a factor with n.  d_out may alias d_ct. */
 int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream);
 
+/* __raw_add with its exponent alignment fused (ipcl_python.py:490-526 + :570-741): delta_i = exponent(a_i) - exponent(b_i)
+ * (base-2 fixed-point exponents, int32 on the device); the operand with the LOWER exponent is raised first:
+ * d_out[i] = delta_i > 0 ? d_a[i] * d_b[i]^(2^delta_i) : d_a[i]^(2^-delta_i) * d_b[i]   (mod n^2).
+ * The result's exponent is max(exponent(a_i), exponent(b_i)) (the caller's bookkeeping).  One pass over the data instead
+ * of two pai_ct_pow2 passes and a pai_ct_add.  b_bcast != 0: one ciphertext b for every i.  d_out may alias d_a or d_b. */
+int pai_ct_add_aligned(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
+                       size_t N, uint32_t* d_out, void* stream);
+
 /* The reductions of PaillierEncryptedNumber.sum / __matmul__ (ipcl_python.py:746-762, 810-880): upstream pads to a
  * power of two with E_raw(0) = 1 and runs log2 steps of CipherText::rotate + operator+ (__padded_ct, :810-827),
  * i.e. computes the product of a group of ciphertexts modulo n^2.  Here: d_ct holds `count` rows read as

@@ -71,11 +71,17 @@ struct GeoInst {
         set_lds((const void*)k_pow2<GM>, bytes);
         hipLaunchKernelGGL(k_pow2<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, ct, delta, delta_bcast, n, w32);
     }
+    static void add_aligned(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, int b_bcast,
+                            const int32_t* delta, uint32_t* out, int n, int w32) {
+        constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;
+        set_lds((const void*)k_add_aligned<GM>, bytes);
+        hipLaunchKernelGGL(k_add_aligned<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, b_bcast, delta, out, n, w32);
+    }
     static size_t table_words(size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * G::NL * blocks * G::EPB; }
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &table_words};
+                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &add_aligned, &table_words};
         return &o;
     }
 };

@@ -34,6 +34,9 @@ struct GeoOps {
     void (*dec_b)(hipStream_t, int grid, DecBParams, const uint32_t* u_in, uint32_t* m_out, int n);
     void (*pow2)(hipStream_t, int grid, const MontCtx*, uint32_t* ct, const int32_t* delta, int delta_bcast, int n,
                  int w32);
+    // out_i = a_i * b_i with the lower-exponent side raised by ^(2^|delta_i|) first (delta = exponent(a) - exponent(b))
+    void (*add_aligned)(hipStream_t, int grid, const MontCtx*, const uint32_t* a, const uint32_t* b, int b_bcast,
+                        const int32_t* delta, uint32_t* out, int n, int w32);
     // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups
     size_t (*table_words)(size_t blocks);
 };

@@ -429,4 +429,76 @@ k_pow2(const MontCtx* __restrict__ ctx, uint32_t* ct, const int32_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exponent alignment fused with the addition: PaillierEncryptedNumber.__raw_add (ipcl_python.py:490-526) raises the
+// operand with the LOWER fixed-point exponent by ct^(2^delta) (:570-741) and then multiplies the two ciphertexts.
+//   delta_i = exponent(a_i) - exponent(b_i);   out_i = delta_i > 0 ? a_i * b_i^(2^delta_i) : a_i^(2^-delta_i) * b_i   (mod n^2)
+// One pass over the data and dmax + 2 Montgomery products per wave tile (domain entry of the operand to be raised,
+// dmax squarings kept only by the elements that still need them, the product with the other operand, which stays
+// plain and thereby leaves the domain) instead of two k_pow2 passes and a k_modmul: 2 dmax + 6.  The bits are the
+// same: the same integers are multiplied.  b_bcast: one ciphertext b for every i.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_add_aligned(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, int b_bcast,
+              const int32_t* __restrict__ delta, uint32_t* out, int n, int w32) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using WT = WaveTile<G>;
+    uint32_t* stage = lds + G::LDS_WORDS + G::NL;
+    uint32_t* r2_lds = stage + G::STAGE_WORDS;           // R^2 mod M, one copy per workgroup
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) r2_lds[i] = ctx->r2[i];
+    __syncthreads();
+    const uint32_t n0inv = ctx->n0inv;
+    constexpr int WPB = BLOCK_THREADS / 64;
+    const int wtiles = (n + WT::EPW - 1) / WT::EPW;
+    clear_stage<G>(stage);
+    const uint32_t* o_lds = lds + G::elem();             // column of this element in the [limb][element] operand buffer (staged x)
+    const int per_wave = (wtiles + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
+    const int wt_begin = ((int)blockIdx.x * WPB + WT::wave()) * per_wave;
+    const int wt_end = min(wtiles, wt_begin + per_wave);
+    for (int wt = wt_begin; wt < wt_end; ++wt) {
+        const int row0 = wt * WT::EPW;
+        const int rows = min(WT::EPW, n - row0);
+        const int ei = row0 + (WT::lane() / G::T);
+        const int dl = ei < n ? delta[ei] : 0;
+        const bool raise_b = dl > 0;                     // a has the larger exponent: b is the one to be raised
+        const int cnt = dl > 0 ? dl : -dl;
+        int dmax = cnt;
+        for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(dmax, off, 64); dmax = o > dmax ? o : dmax; }
+        __builtin_amdgcn_s_setprio(2);
+        uint32_t x[G::NLL], o[G::NLL];
+        {
+            uint32_t xa[G::NLL], xb[G::NLL];
+            load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
+            unpack_row<G>(xa, stage);
+            load_tile<G>(stage, b + (size_t)(b_bcast ? 0 : row0) * w32, b_bcast ? 1 : rows, w32, b_bcast != 0);
+            unpack_row<G>(xb, stage);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) { x[j] = raise_b ? xb[j] : xa[j]; o[j] = raise_b ? xa[j] : xb[j]; }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // one rolled loop body for every product of the tile: step -1 enters the Montgomery domain (x * R^2), steps
+        // 0 .. dmax-1 square x (kept only by the elements that still need it), step dmax multiplies the plain other
+        // operand o by x (Montgomery form), which leaves the domain: o * x R * R^-1 = o * x
+#pragma unroll 1
+        for (int s = -1; s <= dmax; ++s) {
+            uint32_t lhs[G::NLL], r[G::NLL];
+            const bool last = s == dmax;
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) lhs[j] = last ? o[j] : x[j];
+            if (s >= 0) stage_b<G>(x, lds);              // the right operand of squarings and of the last product: x itself
+            mont_mul<G::NLL, G::U, G::T>(r, lhs, s < 0 ? r2_lds : o_lds, s < 0 ? 1 : G::EPB, nm, n0inv);
+            const bool keep = s < 0 || last || s < cnt;
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) x[j] = keep ? r[j] : x[j];
+        }
+        cond_sub<G::NLL, G::T>(x, nm);
+        __builtin_amdgcn_s_setprio(2);
+        pack_row<G>(x, stage);
+        store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
 }  // namespace pai

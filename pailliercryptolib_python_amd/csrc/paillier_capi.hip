@@ -1177,6 +1177,22 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
     });
 }
 
+int pai_ct_add_aligned(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
+                       size_t N, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && d_a && d_b && d_delta && d_out, "NULL argument");
+        if (N == 0) return;
+        DeviceScope scope_(pk->device);
+        const GeoOps* g = pk->msq.geo;
+        g_last_times.clear();
+        ScopedKernelTimer t("k_add_aligned", (hipStream_t)stream);
+        g->add_aligned((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, b_bcast, d_delta, d_out, (int)N,
+                       pk->ct_words);
+        t.stop();
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 // one level of a product tree on single Montgomery products: out[i] = a[i] * b[i] * R^-1 mod n^2
 static void tree_mul(const pai_pubkey* pk, hipStream_t s, const uint32_t* a, const uint32_t* b, int b_bcast, uint32_t* out, size_t n) {
     if (n == 0) return;

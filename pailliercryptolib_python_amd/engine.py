@@ -146,6 +146,21 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_ct_add(self.h, _ptr(a), _ptr(b), bcast, a.shape[0], _ptr(out), _stream(self.device)))
         return out
 
+    def ct_add_aligned(self, a: torch.Tensor, b: torch.Tensor, delta: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """a_i * b_i mod n^2 after raising the lower-exponent side by ^(2^|delta_i|), delta = exponent(a) - exponent(b)
+        (int32 [N] on the device): __raw_add with its alignment in one pass (ipcl_python.py:490-526, 570-741)."""
+        self._chk(a, self.ct_words, "a")
+        self._chk(b, self.ct_words, "b")
+        bcast = 1 if (b.shape[0] == 1 and a.shape[0] != 1) else 0
+        if not bcast and a.shape[0] != b.shape[0]:
+            raise RuntimeError("Size mismatch")
+        if delta.dtype != torch.int32 or delta.dim() != 1 or delta.shape[0] != a.shape[0] or not delta.is_contiguous():
+            raise ValueError("delta: expected contiguous int32 [N]")
+        out = self.empty_ct(a.shape[0]) if out is None else out
+        _native.check(self.lib.pai_ct_add_aligned(self.h, _ptr(a), _ptr(b), bcast, _ptr(delta), a.shape[0], _ptr(out),
+                                                  _stream(self.device)))
+        return out
+
     def ct_mul(self, ct: torch.Tensor, e: torch.Tensor, ebits_max: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(ct, self.ct_words, "ct")
         if e.dtype != torch.int32 or e.dim() != 2 or not e.is_contiguous():

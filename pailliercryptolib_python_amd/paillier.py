@@ -449,9 +449,18 @@ class PaillierEncryptedNumber:
                 raise ValueError("PaillierEncryptedNumber.__raw_add: CipherText size mismatch with PaillierEncryptedNumber")
         else:
             raise TypeError(f"PaillierEncryptedNumber.__raw_add: unsupported operand {type(other)}")
-        x_ct, y_ct, res_expo = self.__align_exponent(self.words, self._expo, other.words, other._expo)
-        res = self._h().ct_add(x_ct, y_ct)
-        return self._wrap(res, res_expo, self.__length)
+        # alignment (ipcl_python.py:570-741: the lower-exponent side is raised by ct^(2^delta)) fused with the addition
+        h = self._h()
+        xe = np.asarray(self._expo, dtype=np.int64)
+        ye = np.asarray(other._expo, dtype=np.int64)
+        if other.words.shape[0] == 1 and self.words.shape[0] > 1:
+            ye = np.broadcast_to(ye, xe.shape)
+        delta = (xe - ye).astype(np.int32)
+        if not delta.any():
+            res = h.ct_add(self.words, other.words)
+        else:
+            res = h.ct_add_aligned(self.words, other.words, torch.from_numpy(np.ascontiguousarray(delta)).to(h.device))
+        return self._wrap(res, np.maximum(xe, ye).astype(np.int32), self.__length)
 
     def increase_exponent_to(self, x_ct, x_expo, exponent: int):
         """ipcl_python.py:528-568: raise every element of x to `exponent` (ct^(2^delta) where delta > 0)."""

@@ -512,3 +512,29 @@ def test_djn_encrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
             assert limbs_to_ints(ct.get()) == want, (bits, N, switch)
             _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
             assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, orc.limbs_to_ints(r))]
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
+def test_ct_add_aligned_matches_the_two_step_definition(bits):
+    """pai_ct_add_aligned: the lower-exponent side is raised by ^(2^|delta|), then the ciphertexts are multiplied
+    (ipcl_python.py:570-741 + :490-526) — one kernel, against CPython pow, with zero / positive / negative deltas
+    mixed inside wave tiles, a broadcast right operand and in-place output."""
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key, M = nk.key, nk.key.nsq
+    rng = np.random.default_rng(bits + 7)
+    for N in (1, 17, 130):
+        a, b = rand_below(rng, M, N), rand_below(rng, M, N)
+        delta = rng.integers(-6, 7, N).astype(np.int32)
+        delta[0] = 0
+        if N > 3:
+            delta[1], delta[2], delta[3] = 9, -11, 0
+        da, db, dd = DevArray(ints_to_limbs(a, nk.cw)), DevArray(ints_to_limbs(b, nk.cw)), DevArray(delta)
+        out = DevArray(shape=(N, nk.cw))
+        _native.check(nk.lib.pai_ct_add_aligned(nk.pk, da.ptr, db.ptr, 0, dd.ptr, N, out.ptr, None))
+        want = [x * pow(y, 1 << int(d), M) % M if d > 0 else pow(x, 1 << int(-d), M) * y % M for x, y, d in zip(a, b, delta)]
+        assert limbs_to_ints(out.get()) == want, (bits, N)
+        _native.check(nk.lib.pai_ct_add_aligned(nk.pk, da.ptr, db.ptr, 1, dd.ptr, N, out.ptr, None))
+        want_b = [x * pow(b[0], 1 << int(d), M) % M if d > 0 else pow(x, 1 << int(-d), M) * b[0] % M for x, d in zip(a, delta)]
+        assert limbs_to_ints(out.get()) == want_b, (bits, N, "bcast")
+        _native.check(nk.lib.pai_ct_add_aligned(nk.pk, da.ptr, db.ptr, 0, dd.ptr, N, da.ptr, None))
+        assert limbs_to_ints(da.get()) == want, (bits, N, "in place")
