@@ -346,15 +346,48 @@ class PaillierEncryptedNumber:
         return self + other
 
     def __sub__(self, other):
-        """ipcl_python.py:383-389."""
+        """ipcl_python.py:383-389: self + other * -1.0."""
         if isinstance(other, list):
             other = np.array(other)
+        if (isinstance(other, PaillierEncryptedNumber) and self.public_key == other.public_key
+                and (len(other) == self.__length or len(other) == 1) and self.public_key.n.bit_length() > 66):
+            return self.__sub_ct(other)
         return self.__raw_add(other * -1.0)
 
+    def __sub_ct(self, other: "PaillierEncryptedNumber") -> "PaillierEncryptedNumber":
+        """ct - ct with the reference's bits at half the squarings.  The reference forms nb = (b^-1)^(2^52) (the
+        multiplier -1.0 encodes as n - 2^52 with exponent 52: ipcl_python.py:426-437), then aligns: with E =
+        max(e_a, e_b + 52) it returns a^(2^(E - e_a)) * nb^(2^(E - e_b - 52)).  Powers of two distribute over the
+        product, so the same residue is t^(2^(E - m)) with t = a^(2^(m - e_a)) * (b^-1)^(2^(m - e_b)), m = max(e_a, e_b):
+        |e_a - e_b| + (E - m) squarings instead of (E - e_a) + 52 + (E - e_b - 52)."""
+        h = self._h()
+        xe = np.asarray(self._expo, dtype=np.int64)
+        ye = np.asarray(other._expo, dtype=np.int64)
+        if other.words.shape[0] == 1 and self.words.shape[0] > 1:
+            ye = np.broadcast_to(ye, xe.shape)
+        m = np.maximum(xe, ye)
+        E = np.maximum(xe, ye + FixedPointNumber.FLOAT_MANTISSA_BITS - 1)
+        b_inv = h.ct_invert(other.words)
+        delta = torch.from_numpy(np.ascontiguousarray((xe - ye).astype(np.int32))).to(h.device)
+        t = h.ct_add_aligned(self.words, b_inv, delta)
+        k = (E - m).astype(np.int32)
+        if (k > 0).any():
+            h.ct_pow2_(t, torch.from_numpy(np.ascontiguousarray(k)).to(h.device))
+        return self._wrap(t, E.astype(np.int32), self.__length)
+
     def __rsub__(self, other):
-        """ipcl_python.py:391-397."""
+        """ipcl_python.py:391-397: (self * -1.0) + other; for a plaintext `other` the sum raw-encrypts it first (:495-504),
+        and the product of the two ciphertexts is commutative, so this is (raw-encrypted other) - self."""
         if isinstance(other, PaillierEncryptedNumber):
             return other - self
+        if isinstance(other, list):
+            other = np.array(other)
+        plain_ok = (isinstance(other, np.ndarray) and other.ndim == 1 and len(other) == self.__length) or \
+                   (np.isscalar(other) and isinstance(other, (int, float, np.integer, np.floating)))
+        if plain_ok and self.public_key.n.bit_length() > 66:
+            pos = self.public_key.encrypt(other, apply_obfuscator=False)
+            if len(pos) == self.__length:
+                return pos.__sub_ct(self)
         return (self * (-1.0)).__raw_add(other)
 
     def __rmul__(self, other):
