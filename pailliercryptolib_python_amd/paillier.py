@@ -537,11 +537,40 @@ class PaillierEncryptedNumber:
         so it equals the reference's pad-with-E(0)=1-and-rotate scheme (ipcl_python.py:810-827) bit for bit."""
         return self._h().ct_prod(ct.contiguous(), groups)
 
+    def _aligned_tree(self, ct: torch.Tensor, expo: np.ndarray, groups: int):
+        """[members * groups, W] read member-major with per-element exponents -> ([groups, W], exponents [groups]):
+        out[g] = prod_l ct[l * groups + g]^(2^(max_g - e[l * groups + g])) mod n^2 — what the reference computes by
+        raising every element to its group's maximum exponent (ipcl_python.py:746-750, 868-870) and reducing
+        (:810-827).  Here the alignment rides along the product tree: a node is pai_ct_add_aligned of its two children
+        (the lower-exponent child is raised by the DIFFERENCE of the children's exponents, a few squarings) and carries
+        the larger exponent upwards, so every leaf is raised by max_g - e in total along its path — the same residue —
+        without a pass that squares every element up to the global maximum first."""
+        h = self._h()
+        W = ct.shape[1]
+        e = np.asarray(expo, dtype=np.int64).reshape(-1, groups)
+        if (e == e[0:1]).all():
+            return h.ct_prod(ct.contiguous(), groups), e.max(axis=0)          # nothing to align: one product per node
+        x = ct.reshape(-1, groups, W)
+        while x.shape[0] > 1:
+            n = x.shape[0]
+            hh = (n + 1) // 2
+            lo = n - hh
+            ea, eb = e[:lo], e[hh:hh + lo]
+            delta = torch.from_numpy(np.ascontiguousarray((ea - eb).reshape(-1).astype(np.int32))).to(h.device)
+            prod = h.ct_add_aligned(x[:lo].reshape(-1, W).contiguous(), x[hh:hh + lo].reshape(-1, W).contiguous(), delta)
+            prod = prod.reshape(lo, groups, W)
+            em = np.maximum(ea, eb)
+            if lo < hh:
+                x = torch.cat([prod, x[lo:hh]], dim=0)
+                e = np.concatenate([em, e[lo:hh]], axis=0)
+            else:
+                x, e = prod, em
+        return x.reshape(groups, W).contiguous(), e.reshape(groups)
+
     def sum(self) -> "PaillierEncryptedNumber":
         """ipcl_python.py:746-762 (intended behaviour)."""
-        max_exponent = int(self._expo.max())
-        aligned = self.increase_exponent_to(self.words, self._expo, max_exponent)
-        return self._wrap(self._tree_product(aligned, 1), [max_exponent], 1)
+        out, e = self._aligned_tree(self.words, self._expo, 1)
+        return self._wrap(out, [int(e[0])], 1)
 
     def mean(self) -> "PaillierEncryptedNumber":
         return self.sum() / len(self)
@@ -569,15 +598,7 @@ class PaillierEncryptedNumber:
         big = PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, self.words[gather].contiguous()),
                                       self._expo[idx_self], idx_self.shape[0])
         prod = big * np.asarray(pts)
-        pe = prod._expo.reshape(n, m * k)
-        gmax = pe.max(axis=0)                                      # per output element (ipcl_python.py:868-870)
-        target = np.tile(gmax, n)
-        words = prod.words
-        delta = (target - prod._expo).astype(np.int32)
-        if (delta > 0).any():
-            words = words.clone()
-            h.ct_pow2_(words, torch.from_numpy(np.ascontiguousarray(delta)).to(h.device))
-        out = self._tree_product(words, m * k)
+        out, gmax = self._aligned_tree(prod.words, prod._expo, m * k)     # per output element (ipcl_python.py:868-870)
         return self._wrap(out, gmax.astype(np.int32), m * k)
 
     def __matmul__(self, other: Union[np.ndarray, list]) -> "PaillierEncryptedNumber":
