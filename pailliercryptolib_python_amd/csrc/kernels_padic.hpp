@@ -92,6 +92,14 @@ PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const u
 #ifndef PADIC_SQR_SYM_MAX_NL
 #define PADIC_SQR_SYM_MAX_NL 56      // limb-class symmetric first half of the wide-digit squaring up to this limb count
 #endif
+// Fused product rule for the wide-digit (scratch-parked) kernels: PADIC_FUSED_56 / PADIC_FUSED_72 (mont_padic.hpp: mul_fused)
+#ifndef PADIC_FUSED_56
+#define PADIC_FUSED_56 true
+#endif
+#ifndef PADIC_FUSED_72
+#define PADIC_FUSED_72 true
+#endif
+#define PADIC_FUSED(NL) ((NL) == 56 ? PADIC_FUSED_56 : ((NL) == 72 ? PADIC_FUSED_72 : false))
 #ifndef PADIC_SGPR_MODULUS
 // measured per 65 536 decryptions with the modulus in SGPRs vs read from LDS: 36 limbs 488 vs 508 ms (x16), 72 limbs 364
 // vs 391 ms; 56 limbs (squaring as product, LDS-qualified accesses) 142 vs 151 ms
@@ -146,13 +154,13 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
             // behind a wave-uniform switch, shared reduction body; 3.5 NL^2): 121.0 -> 112.7 ms per 65 536 at 3072-bit
             // keys.  At 72 limbs the same code LOSES (282.6 -> 383.4 ms: the nine specialised a-parts next to the
             // 160-register window no longer fit), so 4096-bit keys keep the plain rolled first half.
-            if constexpr (NL <= PADIC_SQR_SYM_MAX_NL) E::sqr_sym_wbuf(A, B, M, Wb, nm, pm1, n0inv);
-            else E::sqr_rolled_wbuf(A, B, M, Wb, nm, pm1, n0inv);
+            if constexpr (NL <= PADIC_SQR_SYM_MAX_NL) E::template sqr_sym_w<PADIC_FUSED(NL)>(A, B, M, Wb, nm, pm1, n0inv);
+            else E::template sqr_rolled_w<PADIC_FUSED(NL)>(A, B, M, Wb, nm, pm1, n0inv);
         } else if constexpr (MODE == PADIC_WBUF) E::sqr_wbuf(A, B, M, Wb, nm, pm1, n0inv);
         else E::sqr(A, B, M, nm, pm1, n0inv);
     };
     auto MUL = [&](auto&& csrc, auto&& dsrc) {
-        if constexpr (MODE == PADIC_WBUF) E::mul_wbuf(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);
+        if constexpr (MODE == PADIC_WBUF) E::template mul_w<PADIC_FUSED(NL)>(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);
         else E::mul(A, B, M, csrc, dsrc, nm, pm1, n0inv);
     };
     // table entry e: digit d (0 = first, 1 = second), chunk c

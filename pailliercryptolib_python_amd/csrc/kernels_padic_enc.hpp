@@ -20,8 +20,27 @@ namespace pai {
 #ifndef PAI_XLDS_CTMUL
 #define PAI_XLDS_CTMUL false
 #endif
+#ifndef PAI_XLDS_ENCRYPT
+#define PAI_XLDS_ENCRYPT false
+#endif
 #ifndef PAI_XLDS_POW
 #define PAI_XLDS_POW true
+#endif
+// Fused product rule (Padic::mul_fused: both halves in one pass, no quotient digits / parked digit in HBM scratch) per kernel
+#ifndef PAI_FUSED_ENCRYPT
+#define PAI_FUSED_ENCRYPT true
+#endif
+#ifndef PAI_FUSED_OBFUSCATE
+#define PAI_FUSED_OBFUSCATE true
+#endif
+#ifndef PAI_FUSED_EXPAND
+#define PAI_FUSED_EXPAND true
+#endif
+#ifndef PAI_FUSED_CTMUL
+#define PAI_FUSED_CTMUL true
+#endif
+#ifndef PAI_FUSED_POW
+#define PAI_FUSED_POW(NL) ((NL) > 36)      // 36 limbs (1024-bit keys): r^n 25.1 ms unfused vs 29.0 fused per 65536
 #endif
 
 struct EncPadicParams {
@@ -154,7 +173,7 @@ k_fb_expand_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1g, const 
                 }
             };
         };
-        E::mul_wbuf(A, B, M, Wb, from_hi(0), from_hi(1), nm, nm1, n0inv);
+        E::template mul_w<PAI_FUSED_EXPAND>(A, B, M, Wb, from_hi(0), from_hi(1), nm, nm1, n0inv);
         if (live) {
             uint4* out = T + is * 2 * E::NC;
 #pragma unroll 1
@@ -209,7 +228,7 @@ template <int NL, int U, bool OBF>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
                 const uint32_t* __restrict__ ct_in, uint32_t* __restrict__ ct_out, int n, int mode) {
-    using E = Padic<NL, U>;
+    using E = Padic<NL, U, PAI_XLDS_ENCRYPT>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // the modulus and n - 1 are read from LDS (broadcast reads): through the kernel-argument struct the
     // compiler cannot prove them unclobbered and would fetch them with vector global loads inside the loops
@@ -275,7 +294,7 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
                             }
                         };
                     };
-                    E::mul_wbuf(A, B, M, Wb, from_ent(0), from_ent(1), nm, nm1, n0inv);
+                    E::template mul_w<(OBF ? PAI_FUSED_OBFUSCATE : PAI_FUSED_ENCRYPT)>(A, B, M, Wb, from_ent(0), from_ent(1), nm, nm1, n0inv);
                 }
             }
             // times the plain digit pair (1, m) of 1 + m n  => plain digit pair of the ciphertext
@@ -392,7 +411,7 @@ k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_
         }
 #pragma unroll 1
         for (int k = 2; k < NT; ++k) {
-            E::mul_wbuf(A, B, M, Wb, from_table(1, 0), from_table(1, 1), nm, nm1, n0inv);
+            E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_table(1, 0), from_table(1, 1), nm, nm1, n0inv);
 #pragma unroll 1
             for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
         }
@@ -407,9 +426,9 @@ k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_
 #pragma unroll 1
         for (int wi = nwin - 2; wi >= 0; --wi) {
 #pragma unroll 1
-            for (int sq = 0; sq < W; ++sq) E::sqr_rolled_wbuf(A, B, M, Wb, nm, nm1, n0inv);      // 4 NL^2 instead of the product rule's 5
+            for (int sq = 0; sq < W; ++sq) E::template sqr_rolled_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);      // 4 NL^2 instead of the product rule's 5
             const int d = (int)window(wi);
-            if (__any(d != 0)) E::mul_wbuf(A, B, M, Wb, from_table(d, 0), from_table(d, 1), nm, nm1, n0inv);
+            if (__any(d != 0)) E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_table(d, 0), from_table(d, 1), nm, nm1, n0inv);
         }
         // leave Montgomery form (times the plain pair (1, 0)), then ct = w + v n as one integer, canonical
         uint32_t w[NL], v[NL];
@@ -497,7 +516,7 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
         };
     };
     auto self = [&](const uint4* X) { return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); }; };
-    auto SQR = [&]() { E::sqr_rolled_wbuf(A, B, M, Wb, nm, nm1, n0inv); };      // 4 NL^2 instead of the product rule's 5
+    auto SQR = [&]() { E::template sqr_rolled_w<PAI_FUSED_POW(NL)>(A, B, M, Wb, nm, nm1, n0inv); };      // 4 NL^2 instead of the product rule's 5
     const int NT = P.tbl_entries;
     const int nd = (32 * P.in_words + RB * NL - 1) / (RB * NL);
     const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
@@ -518,7 +537,7 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
         wave_lds_fence();
 #pragma unroll 1
         for (int k = 1; k < NT; ++k) {
-            E::mul_wbuf(A, B, M, Wb, from_table(NT, 0), from_table(NT, 1), nm, nm1, n0inv);
+            E::template mul_w<PAI_FUSED_POW(NL)>(A, B, M, Wb, from_table(NT, 0), from_table(NT, 1), nm, nm1, n0inv);
 #pragma unroll 1
             for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
         }
@@ -535,7 +554,7 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
             const int nsq = op & 0xFF, idx = op >> 8;
 #pragma unroll 1
             for (int s_ = 0; s_ < nsq; ++s_) SQR();
-            if (idx != 0xFF) E::mul_wbuf(A, B, M, Wb, from_table(idx, 0), from_table(idx, 1), nm, nm1, n0inv);
+            if (idx != 0xFF) E::template mul_w<PAI_FUSED_POW(NL)>(A, B, M, Wb, from_table(idx, 0), from_table(idx, 1), nm, nm1, n0inv);
         }
         // leave Montgomery form, w + v n as one canonical integer, packed words (as in k_encrypt_padic)
         uint32_t w[NL], v[NL];

@@ -670,6 +670,138 @@ struct Padic {
         wave_lds_fence();
     }
 
+    // ---- both halves of the product rule in ONE pass over the row blocks -------------------------------------------
+    // Row block k of the first half produces the quotient digits m[U k .. U k + U) — exactly the columns the second
+    // half's window starts at in ITS row block k — so the two accumulator windows advance together: the quotient digits
+    // go from registers straight into the second window as (2^29 - 1 - m_j) and never exist as a stored number, and the
+    // first result digit w stays in its window until v is finished as well, so nothing is parked either.  Wide digits
+    // (NL = 56 / 72) otherwise bounce both through strided HBM scratch (MBuf): 2 NL limbs written and read per product.
+    // Price: two windows of NL + U lazy columns live at once (4 (NL + U) VGPRs; one wave per SIMD has 512).
+    PAI_DEV static void finish_pair(const uint64_t (&acc1)[NW], const uint64_t (&acc2)[NW], uint4* Adst, uint4* Bdst) {
+        uint64_t c1 = 0, c2 = 0;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            uint32_t w[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t t1 = acc1[4 * ch + k] + c1;
+                w[k] = (uint32_t)t1 & RMASK;
+                c1 = t1 >> RB;
+                const uint64_t t2 = acc2[4 * ch + k] + c2;
+                v[k] = (uint32_t)t2 & RMASK;
+                c2 = t2 >> RB;
+            }
+            st(Adst, ch, make_uint4(w[0], w[1], w[2], w[3]));
+            st(Bdst, ch, make_uint4(v[0], v[1], v[2], v[3]));
+        }
+    }
+    template <class CSrc, class DSrc>
+    PAI_DEV static void mul_fused(uint4* A, uint4* B, CSrc&& csrc, DSrc&& dsrc, const uint32_t* __restrict__ nm,
+                                  const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        uint64_t acc1[NW], acc2[NW];
+        zero(acc1);
+        zero(acc2);
+        acc2[0] = 1;                          // (R - 1 - m) + 1
+        uint32_t dummy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dummy[u] = 0;
+        uint32_t cn[U], dn[U];
+        csrc(0, cn);
+        dsrc(0, dn);
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t cv[U], dv[U], q1[U], q2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cv[u] = cn[u]; dv[u] = dn[u]; }
+            csrc(blk + 1 < NB ? blk + 1 : blk, cn);
+            dsrc(blk + 1 < NB ? blk + 1 : blk, dn);
+            block<true, 0, NL, false, false>(acc1, A, cv, A, dummy, nm, n0inv, nm, blk, q1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc2[u] += (uint64_t)(RMASK - q1[u]);
+            block<true, 0, NL, true, true>(acc2, A, dv, B, cv, nm, n0inv, pm1, blk, q2);
+            if (blk != NB - 1 && ((blk + 1) * U) % P1 == 0) normalize(acc1);
+            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc2);
+        }
+        wave_lds_fence();
+        finish_pair(acc1, acc2, A, B);
+        wave_lds_fence();
+    }
+    // squaring: first half a * a (every limb pair twice), second half 2 a b with doubled multiplier digits — 4 NL^2
+    PAI_DEV static void sqr_fused(uint4* A, uint4* B, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
+                                  uint32_t n0inv) {
+        uint64_t acc1[NW], acc2[NW];
+        zero(acc1);
+        zero(acc2);
+        acc2[0] = 1;
+        uint32_t dummy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t av[U], bv[U], q1[U], q2[U];
+            digits(A, blk, av);
+            digits(B, blk, bv);
+            block<true, 0, NL, false, false>(acc1, A, av, A, dummy, nm, n0inv, nm, blk, q1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc2[u] += (uint64_t)(RMASK - q1[u]);
+            block<true, 0, 0, false, true>(acc2, A, bv, A, dummy, nm, n0inv, pm1, blk, q2);   // HI = 0: every limb doubled
+            if (blk != NB - 1 && ((blk + 1) * U) % P1 == 0) normalize(acc1);
+            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc2);
+        }
+        wave_lds_fence();
+        finish_pair(acc1, acc2, A, B);
+        wave_lds_fence();
+    }
+
+    // fused counterpart of sqr_sym_wbuf: limb-class symmetric first half (3.5 NL^2)
+    PAI_DEV static void sqr_sym_fused(uint4* A, uint4* B, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
+                                      uint32_t n0inv) {
+        uint64_t acc1[NW], acc2[NW];
+        zero(acc1);
+        zero(acc2);
+        acc2[0] = 1;
+        uint32_t dummy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t av[U], bv[U], q1[U], q2[U];
+            digits(A, blk, av);
+            digits(B, blk, bv);
+            sqr_apart_dispatch<0>(acc1, A, av, blk);
+            __builtin_amdgcn_sched_barrier(0);
+            block<false, 0, NL, false, false>(acc1, A, dummy, A, dummy, nm, n0inv, nm, blk, q1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc2[u] += (uint64_t)(RMASK - q1[u]);
+            block<true, 0, 0, false, true>(acc2, A, bv, A, dummy, nm, n0inv, pm1, blk, q2);
+            if (sqr1_normalize_after(blk)) normalize(acc1);
+            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc2);
+        }
+        wave_lds_fence();
+        finish_pair(acc1, acc2, A, B);
+        wave_lds_fence();
+    }
+    // compile-time choice between the scratch-parked and the fused forms (per kernel: the fused form trades the scratch
+    // round trips for register pressure)
+    template <bool FUSED, class CSrc, class DSrc>
+    PAI_DEV static void mul_w(uint4* A, uint4* B, MBuf M, MBuf Wb, CSrc&& csrc, DSrc&& dsrc, const uint32_t* __restrict__ nm,
+                              const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        if constexpr (FUSED) mul_fused(A, B, csrc, dsrc, nm, pm1, n0inv);
+        else mul_wbuf(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);
+    }
+    template <bool FUSED>
+    PAI_DEV static void sqr_rolled_w(uint4* A, uint4* B, MBuf M, MBuf Wb, const uint32_t* __restrict__ nm,
+                                     const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        if constexpr (FUSED) sqr_fused(A, B, nm, pm1, n0inv);
+        else sqr_rolled_wbuf(A, B, M, Wb, nm, pm1, n0inv);
+    }
+    template <bool FUSED>
+    PAI_DEV static void sqr_sym_w(uint4* A, uint4* B, MBuf M, MBuf Wb, const uint32_t* __restrict__ nm,
+                                  const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        if constexpr (FUSED) sqr_sym_fused(A, B, nm, pm1, n0inv);
+        else sqr_sym_wbuf(A, B, M, Wb, nm, pm1, n0inv);
+    }
+
     // (A, B) <- (A, B)^2
     PAI_DEV static void sqr(uint4* A, uint4* B, MBuf M, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
                             uint32_t n0inv) {

@@ -17,6 +17,9 @@ int padic_nl_for_prime_bits(int bits) {
 }
 size_t padic_table_words(int nl, size_t blocks) { return (size_t)(PADIC_TBL_ENTRIES + 1) * 2 * nl * blocks * BLOCK_THREADS; }
 size_t padic_scratch_words(int nl, size_t blocks) { return nl <= 36 ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS; }
+#ifndef PADIC_U72
+#define PADIC_U72 8
+#endif
 template <int NL, int U, int MODE>
 static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table) {
     constexpr int bytes = (MODE == PADIC_LDS_M ? 3 : 2) * NL * BLOCK_THREADS * 4 + 2 * NL * 4;
@@ -30,7 +33,7 @@ bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& 
         case 24: launch_padic<24, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
         case 36: launch_padic<36, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
         case 56: launch_padic<56, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
-        case 72: launch_padic<72, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
+        case 72: launch_padic<72, PADIC_U72, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
         default: return false;
     }
 }

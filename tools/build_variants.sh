@@ -41,3 +41,8 @@ build plain "" "" &
 build trk "-mllvm -amdgpu-use-amdgpu-trackers" "-mllvm -amdgpu-use-amdgpu-trackers" &
 wait
 ls -la $OUT
+# Fused product rule (tools/variant_enc.sh builds enc + dec variants; -DPAI_FUSED_*=false / -DPADIC_FUSED_56/72=false give
+# the scratch-parked forms back): per 65536 — 4096-bit decrypt 282.9 -> 257.5, 3072-bit decrypt 117.4 -> 113.0, 2048-bit
+# ct*pt 5.36 -> 4.82; DJN encrypt per 2^20: 8-row fused 69.8 (no gain), 12-row fused 64-67 (adopted, -DPAI_ENCRYPT_U);
+# rejected: -DPADIC_U72=12 (1127 ms, spills), -DPADIC_SQR_SYM_MAX_NL=72 fused (887 ms), -DPAI_XLDS_ENCRYPT=true (70.2),
+# fused r^n at 36 limbs (29.0 vs 25.1 ms), 12-row r^n (within noise).

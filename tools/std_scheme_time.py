@@ -1,23 +1,31 @@
-import sys, time, json
-sys.path.insert(0, '.')
-import numpy as np, torch
-from bench import synthetic_key
-from pailliercryptolib_python_amd import engine, fixedpoint
-dev = torch.device('cuda', 0)
-key = synthetic_key(2048, None)
-pub = engine.PublicKeyHandle(key.n, 2048, None, 0, device=dev)
-priv = engine.PrivateKeyHandle(pub, key.p, key.q)
-B = 65536
-x = np.random.default_rng(7).uniform(-1000.0, 1000.0, B)
-res, _ = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
-m = engine.to_device_words(res, dev)
-r = torch.randint(-(2**31), 2**31, (B, pub.n_words), dtype=torch.int64, device=dev).to(torch.int32)
-r[:, -1] &= 0x3FFFFFFF
-r[:, 0] |= 1
-ct = pub.encrypt(m, r); torch.cuda.synchronize()
-t0 = time.perf_counter(); ct = pub.encrypt(m, r); torch.cuda.synchronize(); t = time.perf_counter() - t0
-out = priv.decrypt(ct)
-idx = [0, 5, B - 1]
-r_h = engine.words_to_ints(engine.to_host_words(r[idx])); m_h = engine.words_to_ints(res[idx])
-ok = engine.words_to_ints(engine.to_host_words(ct[idx])) == [(1 + mm * key.n) * pow(rr, key.n, key.nsq) % key.nsq for mm, rr in zip(m_h, r_h)]
-print(json.dumps({"standard_scheme_encrypt_ms_per_65536": round(t * 1e3, 1), "roundtrip": bool(torch.equal(out, m)), "bits_ok": ok}))
+"""Times the standard-scheme (non-DJN) encryption r^n path (k_pow_padic at <= 2048-bit keys) and apply_obfuscator
+through the public API: python tools/std_scheme_time.py [bits] [batch]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pailliercryptolib_python_amd import PaillierKeypair  # noqa: E402
+
+bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+x = np.random.default_rng(1).uniform(-100, 100, N)
+out = {"key_bits": bits, "batch": N}
+for djn in (False, True):
+    pk, sk = PaillierKeypair.generate_keypair(bits, djn)
+    ct = pk.encrypt(x)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ct = pk.encrypt(x)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    out["encrypt_ms_djn" if djn else "encrypt_ms_standard"] = round(best * 1e3, 2)
+    back = sk.decrypt_to_numpy(ct)
+    out["ok_djn" if djn else "ok_standard"] = bool(np.array_equal(back, x))
+print(json.dumps(out))
