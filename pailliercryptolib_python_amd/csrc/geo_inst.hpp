@@ -44,6 +44,11 @@ struct GeoInst {
         set_lds((const void*)k_encrypt<G>, G::LDS_BYTES);
         hipLaunchKernelGGL(k_encrypt<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, m, r, ct_in, ct_out, n, mode);
     }
+    static void pair_finish(hipStream_t s, int grid, EncParams P, const uint32_t* wv, int wv_words, const uint32_t* ct_in,
+                            uint32_t* ct_out, int n, int mul_ct) {
+        set_lds((const void*)k_pair_finish<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_pair_finish<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, wv, wv_words, ct_in, ct_out, n, mul_ct);
+    }
     static void fb_expand(hipStream_t s, int grid, const MontCtx* c, const uint32_t* S, uint32_t* T, int J, int h) {
         set_lds((const void*)k_fb_expand<G>, G::LDS_BYTES);
         hipLaunchKernelGGL(k_fb_expand<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, S, T, J, h);
@@ -81,7 +86,7 @@ struct GeoInst {
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &add_aligned, &table_words};
+                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &add_aligned, &table_words, &pair_finish};
         return &o;
     }
 };

@@ -39,6 +39,9 @@ struct GeoOps {
                         const int32_t* delta, uint32_t* out, int n, int w32);
     // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups
     size_t (*table_words)(size_t blocks);
+    // ct = w + v n [or ct_in (w + v n)] from the plain digit pairs of the lane-group pair kernels (rows [2][wv_words])
+    void (*pair_finish)(hipStream_t, int grid, EncParams, const uint32_t* wv, int wv_words, const uint32_t* ct_in,
+                        uint32_t* ct_out, int n, int mul_ct);
 };
 
 const GeoOps* geo_ops_36x1();
@@ -93,6 +96,17 @@ bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams&
                         uint32_t* out, int n);
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
                           const uint32_t* ct_in, uint32_t* ct_out, int n, int mode);
+
+// digit pairs with base n on the lane-group engine (kernels_pair.hpp): DJN obfuscator / encryption for n of 2049 .. 4156 bits
+struct PairParams;
+int pair_nl_for_n_bits(int bits);                 // 112 / 144 limbs, 0 = not served
+int pair_epb(int nl);                             // elements per workgroup
+bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
+                          const uint32_t* one_pair, uint32_t* S, int nwin, int h);
+bool launch_pair_fb_expand(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
+                           uint32_t* T, int J, int h);
+bool launch_pair_fixed_base(int nl, hipStream_t s, int grid, const PairParams& P, const uint32_t* m, const uint32_t* r,
+                            uint32_t* wv_out, int n, int with_m);
 
 // x = a^-1 mod M for `count` values of `words` 32-bit words each (words in {64,128,192,256}); *fail counts
 // non-invertible inputs.  Returns false if `words` has no instantiation.

@@ -129,6 +129,44 @@ k_encrypt(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Last step of the digit-pair obfuscator (kernels_pair.hpp): the plain pair (w, v) of x = hs^r (1 + m n) [or hs^r]
+// arrives as two packed rows of `wv_words` words per element; ct = w + v n (mul_ct = 0) or ct_in (w + v n) mod n^2.
+// A kernel of its own: as extra modes of k_encrypt it cost that kernel's fixed-base loop 50 % (36x8: 61 -> 94 ms per 65536).
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_pair_finish(EncParams P, const uint32_t* __restrict__ wv, int wv_words, const uint32_t* __restrict__ ct_in,
+              uint32_t* __restrict__ ct_out, int n, int mul_ct) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typename G::NM nm;
+    load_modulus<G>(nm, P.nsq, lds);
+    const uint32_t n0inv = P.nsq->n0inv;
+    const int tiles = (n + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * G::EPB + G::elem();
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        const uint32_t* row = wv + (size_t)es * 2 * wv_words;
+        // v n as a Montgomery product with n R: v < 2n + eps, so the result is v n mod n^2 up to one n^2
+        uint32_t x[G::NLL], t[G::NLL];
+        load_elem<G>(x, row + wv_words, wv_words);
+        load_const_slice<G>(t, P.nR);
+        mm_times<G>(x, t, lds, nm, n0inv);
+        load_elem<G>(t, row, wv_words);
+        add_limbs<G>(x, t);
+        cond_sub<G::NLL, G::T>(x, nm);
+        if (mul_ct) {
+            // ct_in * x = MM(MM(ct_in, x), R^2)
+            load_elem<G>(t, ct_in + (size_t)es * P.ct_words, P.ct_words);
+            mm_times<G>(x, t, lds, nm, n0inv);
+            load_const_slice<G>(t, P.nsq->r2);
+            mm_times<G>(x, t, lds, nm, n0inv);
+        }
+        cond_sub<G::NLL, G::T>(x, nm);
+        if (live) store_elem<G>(x, ct_out + (size_t)ei * P.ct_words, P.ct_words, lds);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Second level of the fixed-base table build for the lane-group k_encrypt: with half = 2^h entries per half-width
 // window, T[j][hi * half + lo] = S[2 j + 1][hi] * S[2 j][lo] (Montgomery form in and out, raw radix-29 rows of NL
 // limbs) — one independent product per entry instead of a binary exponentiation per entry (4096-bit keys: 1.35 s of

@@ -1,0 +1,240 @@
+// DJN obfuscator / encryption on base-n digit pairs for public moduli beyond the one-element-per-lane digit engine
+// (n of 2049 .. 4156 bits: 3072- and 4096-bit keys), on the lane-group engine (mont_dev.hpp: pair_mul).
+//
+// An element of Z/n^2 is the pair (a, b), a + b n == x R (mod n^2), R = 2^(29 NL), NL = limbs of n spread over the T
+// lanes of a group; a multiplication is 5 NL^2 limb products with reductions modulo n instead of the 8 NL^2 of the
+// Montgomery product modulo n^2 that k_encrypt (kernels_paillier.hpp) runs on 2 NL limbs.
+//   k_pair_fb_chain    first table level  S[i][e] = pair(hs^(e 2^(h i))),   one sequential chain per half-width window
+//   k_pair_fb_expand   second level       T[j][hi 2^h + lo] = S[2 j + 1][hi] (x) S[2 j][lo],  one product per entry
+//   k_pair_fixed_base  (w, v) = plain pair of  hs^r  or  hs^r (1 + m n)  =  prod_j T[j][r_j] (x) (1, m)
+// The plain pair leaves as two packed rows per element; w + v n mod n^2 (one more product, on the 2 NL-limb geometry
+// where the packed-word I/O lives) is k_pair_finish (kernels_paillier.hpp).  Same contract as k_encrypt mode 1 / 2:
+// ipcl::PublicKey::encrypt / apply_obfuscator reached from bindings/ipcl_bindings_classes.cpp:53-60,71-83.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace pai {
+
+// waves per SIMD the pair kernels are compiled for, by group size (tools/variant_tu.sh for A/B timing)
+#ifndef PAIR_WAVES_T8
+#define PAIR_WAVES_T8 2
+#endif
+#define PAIR_WAVES_PER_SIMD(T) ((T) >= 8 ? PAIR_WAVES_T8 : 1)
+#ifndef PAIR_PREFETCH
+#define PAIR_PREFETCH 1             // the next window's table entry is loaded while the current product runs
+#endif
+
+struct PairParams {
+    const MontCtx* nctx;         // modulus n on the pair geometry (NL limbs, R = 2^(29 NL))
+    const uint32_t* nm1;         // n - 1, NL limbs radix 29
+    const uint32_t* fb_table;    // [J][2^fb_wbits][2][NL] lazy digit pairs, Montgomery digit form
+    int fb_windows, fb_wbits;
+    int pt_words, r_words;
+    int out_words;               // packed words per output digit row (>= ceil(29 NL / 32))
+};
+
+// LDS: [c rows][d rows] ([limb][element] operand buffers, G::LDS_WORDS each), then the NL limbs of n - 1
+template <class G>
+struct PairLds {
+    static constexpr int BYTES = (2 * G::LDS_WORDS + G::NL) * 4;
+    PAI_DEV static uint32_t* c(uint32_t* lds) { return lds; }
+    PAI_DEV static uint32_t* d(uint32_t* lds) { return lds + G::LDS_WORDS; }
+    PAI_DEV static uint32_t* nm1(uint32_t* lds) { return lds + 2 * G::LDS_WORDS; }
+};
+
+template <class G>
+PAI_DEV void pair_setup(uint32_t* lds, const uint32_t* __restrict__ nm1) {
+    static_assert(!G::NMLDS, "the pair kernels keep the modulus slice in registers");
+    uint32_t* dst = PairLds<G>::nm1(lds);
+    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) dst[i] = nm1[i];
+    __syncthreads();
+}
+
+// this lane's slices of a raw digit pair [2][NL] (16-byte vectors when the slice length allows, else 8-byte)
+template <class G>
+PAI_DEV void pair_load(uint32_t (&a)[G::NLL], uint32_t (&b)[G::NLL], const uint32_t* __restrict__ ent) {
+    static_assert(G::NLL % 2 == 0, "limb slices move as vectors");
+    const uint32_t* pa = ent + G::NLL * G::gl();
+    const uint32_t* pb = ent + G::NL + G::NLL * G::gl();
+    if constexpr (G::NLL % 4 == 0) {
+        const uint4* a4 = reinterpret_cast<const uint4*>(pa);
+        const uint4* b4 = reinterpret_cast<const uint4*>(pb);
+#pragma unroll
+        for (int c = 0; c < G::NLL / 4; ++c) {
+            const uint4 va = a4[c], vb = b4[c];
+            a[4 * c] = va.x; a[4 * c + 1] = va.y; a[4 * c + 2] = va.z; a[4 * c + 3] = va.w;
+            b[4 * c] = vb.x; b[4 * c + 1] = vb.y; b[4 * c + 2] = vb.z; b[4 * c + 3] = vb.w;
+        }
+    } else {
+        const uint2* a2 = reinterpret_cast<const uint2*>(pa);
+        const uint2* b2 = reinterpret_cast<const uint2*>(pb);
+#pragma unroll
+        for (int c = 0; c < G::NLL / 2; ++c) {
+            const uint2 va = a2[c], vb = b2[c];
+            a[2 * c] = va.x; a[2 * c + 1] = va.y;
+            b[2 * c] = vb.x; b[2 * c + 1] = vb.y;
+        }
+    }
+}
+template <class G>
+PAI_DEV void pair_store(const uint32_t (&a)[G::NLL], const uint32_t (&b)[G::NLL], uint32_t* __restrict__ ent) {
+    uint32_t* pa = ent + G::NLL * G::gl();
+    uint32_t* pb = ent + G::NL + G::NLL * G::gl();
+    if constexpr (G::NLL % 4 == 0) {
+        uint4* a4 = reinterpret_cast<uint4*>(pa);
+        uint4* b4 = reinterpret_cast<uint4*>(pb);
+#pragma unroll
+        for (int c = 0; c < G::NLL / 4; ++c) {
+            a4[c] = make_uint4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+            b4[c] = make_uint4(b[4 * c], b[4 * c + 1], b[4 * c + 2], b[4 * c + 3]);
+        }
+    } else {
+        uint2* a2 = reinterpret_cast<uint2*>(pa);
+        uint2* b2 = reinterpret_cast<uint2*>(pb);
+#pragma unroll
+        for (int c = 0; c < G::NLL / 2; ++c) {
+            a2[c] = make_uint2(a[2 * c], a[2 * c + 1]);
+            b2[c] = make_uint2(b[2 * c], b[2 * c + 1]);
+        }
+    }
+}
+// (a, b) <- (a, b) (x) (c, d) with (c, d) in registers: staged as LDS rows, then the fused product
+template <class G>
+PAI_DEV void pair_times(uint32_t (&a)[G::NLL], uint32_t (&b)[G::NLL], const uint32_t (&c)[G::NLL],
+                        const uint32_t (&d)[G::NLL], uint32_t* lds, const typename G::NM& nm, uint32_t n0inv) {
+    stage_b<G>(c, PairLds<G>::c(lds));
+    stage_b<G>(d, PairLds<G>::d(lds));
+    pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
+                                 PairLds<G>::nm1(lds), nm, n0inv);
+}
+
+// ---- first table level: element i walks S[i][e] = S[i][e - 1] (x) B_i, S[i][0] = pair(1) -------------------------------
+// B_i = B_0^(2^(h i)) is reached by h i squarings of B_0 = pair(hs R) on the device (the host would need a long division
+// per window base: 2.5 s of set-up at 4096-bit keys against ~0.1 s here); the elements of a workgroup run the longest
+// chain among them and keep their own prefix.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
+k_pair_fb_chain(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ nm1, const uint32_t* __restrict__ base0,
+                const uint32_t* __restrict__ one_pair, uint32_t* __restrict__ S, int nwin, int h) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    pair_setup<G>(lds, nm1);
+    typename G::NM nm;
+    load_modulus<G>(nm, nctx, lds);
+    const uint32_t n0inv = nctx->n0inv;
+    const int E1 = 1 << h;
+    const int tiles = (nwin + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int i = tile * G::EPB + G::elem();
+        const bool live = i < nwin;
+        const int is = live ? i : nwin - 1;
+        uint32_t a[G::NLL], b[G::NLL], c[G::NLL], d[G::NLL];
+        pair_load<G>(c, d, base0);
+        const int smax = h * min(nwin - 1, tile * G::EPB + G::EPB - 1);
+#pragma unroll 1
+        for (int sq = 0; sq < smax; ++sq) {
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) { a[j] = c[j]; b[j] = d[j]; }
+            pair_times<G>(a, b, c, d, lds, nm, n0inv);
+            const bool keep = sq < h * is;
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) { c[j] = keep ? a[j] : c[j]; d[j] = keep ? b[j] : d[j]; }
+        }
+        stage_b<G>(c, PairLds<G>::c(lds));
+        stage_b<G>(d, PairLds<G>::d(lds));
+        pair_load<G>(a, b, one_pair);
+        uint32_t* out = S + ((size_t)is << h) * 2 * G::NL;
+        if (live) pair_store<G>(a, b, out);
+#pragma unroll 1
+        for (int e = 1; e < E1; ++e) {
+            pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
+                                         PairLds<G>::nm1(lds), nm, n0inv);
+            if (live) pair_store<G>(a, b, out + (size_t)e * 2 * G::NL);
+        }
+    }
+}
+
+// ---- second level: one independent product per entry ------------------------------------------------------------
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
+k_pair_fb_expand(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ nm1, const uint32_t* __restrict__ S,
+                 uint32_t* __restrict__ T, int J, int h) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    pair_setup<G>(lds, nm1);
+    typename G::NM nm;
+    load_modulus<G>(nm, nctx, lds);
+    const uint32_t n0inv = nctx->n0inv;
+    const size_t half = (size_t)1 << h, per_window = half * half, total = (size_t)J * per_window;
+    const size_t tiles = (total + G::EPB - 1) / G::EPB;
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t ei = tile * G::EPB + G::elem();
+        const bool live = ei < total;
+        const size_t es = live ? ei : total - 1;
+        const size_t j = es / per_window, dd = es - j * per_window, hi = dd >> h, lo = dd & (half - 1);
+        uint32_t a[G::NLL], b[G::NLL], c[G::NLL], d[G::NLL];
+        pair_load<G>(a, b, S + (((2 * j + 1) << h) + hi) * 2 * G::NL);
+        pair_load<G>(c, d, S + (((2 * j) << h) + lo) * 2 * G::NL);
+        pair_times<G>(a, b, c, d, lds, nm, n0inv);
+        if (live) pair_store<G>(a, b, T + ei * 2 * G::NL);
+    }
+}
+
+// ---- hs^r (and the plaintext factor) ------------------------------------------------------------------------------
+// with_m != 0: (w, v) = plain pair of hs^r (1 + m n): the last factor is the PLAIN pair (1, m), which also takes the
+// product out of Montgomery form; with_m == 0: plain pair of hs^r (last factor (1, 0)).
+// wv_out: [n][2][out_words] packed rows, w first.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
+k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
+                  uint32_t* __restrict__ wv_out, int n, int with_m) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    pair_setup<G>(lds, P.nm1);
+    typename G::NM nm;
+    load_modulus<G>(nm, P.nctx, lds);
+    const uint32_t n0inv = P.nctx->n0inv;
+    const int tiles = (n + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * G::EPB + G::elem();
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        const uint32_t* rrow = r + (size_t)es * P.r_words;
+        auto entry = [&](int jw) -> const uint32_t* {
+            const int bit = jw * P.fb_wbits, k = bit >> 5;
+            uint64_t bits2 = rrow[k];
+            if (k + 1 < P.r_words) bits2 |= (uint64_t)rrow[k + 1] << 32;
+            const uint32_t d = (uint32_t)(bits2 >> (bit & 31)) & ((1u << P.fb_wbits) - 1u);
+            return P.fb_table + (((size_t)jw << P.fb_wbits) + d) * 2 * G::NL;
+        };
+        uint32_t a[G::NLL], b[G::NLL], c[G::NLL], d[G::NLL];
+        pair_load<G>(a, b, entry(0));
+        if (P.fb_windows > 1) pair_load<G>(c, d, entry(1));
+#pragma unroll 1
+        for (int jw = 1; jw < P.fb_windows; ++jw) {
+#if PAIR_PREFETCH
+            stage_b<G>(c, PairLds<G>::c(lds));
+            stage_b<G>(d, PairLds<G>::d(lds));
+            // the next window's entry travels from HBM while this product runs
+            if (jw + 1 < P.fb_windows) pair_load<G>(c, d, entry(jw + 1));
+#else
+            if (jw > 1) pair_load<G>(c, d, entry(jw));
+            stage_b<G>(c, PairLds<G>::c(lds));
+            stage_b<G>(d, PairLds<G>::d(lds));
+#endif
+            pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
+                                         PairLds<G>::nm1(lds), nm, n0inv);
+        }
+        set_plain_one<G>(c);
+        if (with_m) load_elem<G>(d, m + (size_t)es * P.pt_words, P.pt_words);
+        else {
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) d[j] = 0;
+        }
+        pair_times<G>(a, b, c, d, lds, nm, n0inv);
+        if (live) {
+            uint32_t* row = wv_out + (size_t)ei * 2 * P.out_words;
+            store_elem<G>(a, row, P.out_words, PairLds<G>::c(lds));
+            store_elem<G>(b, row + P.out_words, P.out_words, PairLds<G>::c(lds));
+        }
+    }
+}
+
+}  // namespace pai

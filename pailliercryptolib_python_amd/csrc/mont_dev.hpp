@@ -54,8 +54,7 @@ struct MontCtx {
 // ---- lane-group helpers -------------------------------------------------------------------------
 template <int T> PAI_DEV int group_lane() { return (int)(threadIdx.x & (T - 1)); }
 
-// Cross-lane moves inside a lane group.  T = 2 and 4 use DPP (a VALU move, no LDS pipe, short
-// latency); T = 8 falls back to ds_bpermute through __shfl.
+// Cross-lane moves inside a lane group: DPP (a VALU move, no LDS pipe, short latency) for every group size.
 //   quad_perm control = p0 | p1<<2 | p2<<4 | p3<<6 ; row_shl:1 = 0x101 ; row_shr:1 = 0x111
 template <int CTRL> PAI_DEV uint32_t dpp_mov(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);   // bound_ctrl: missing source -> 0
@@ -65,7 +64,13 @@ template <int T> PAI_DEV uint32_t bcast0(uint32_t v) {
     if constexpr (T == 1) return v;
     else if constexpr (T == 2) return dpp_mov<0xA0>(v);          // quad_perm [0,0,2,2]
     else if constexpr (T == 4) return dpp_mov<0x00>(v);          // quad_perm [0,0,0,0]
-    else if constexpr (T == 64) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);      // through an SGPR: no LDS-pipe latency
+    else if constexpr (T == 8) {
+        // two DPP moves instead of ds_bpermute: lane 0 / 4 of each quad pair, then the upper quad fetches from 4 lanes below
+        // (groups of 8 are aligned halves of a 16-lane DPP row)
+        const uint32_t q = dpp_mov<0x00>(v);
+        const uint32_t w = dpp_mov<0x114>(q);                    // row_shr:4
+        return (threadIdx.x & 4) ? w : q;
+    } else if constexpr (T == 64) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);      // through an SGPR: no LDS-pipe latency
     else if constexpr (T == 32) {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
         return (threadIdx.x & 32) ? hi : lo;
@@ -82,7 +87,7 @@ template <int T> PAI_DEV uint32_t from_next(uint32_t v) {
     else {
         uint32_t r;
         if constexpr (T == 2) r = dpp_mov<0xF5>(v);              // quad_perm [1,1,3,3]
-        else if constexpr (T == 4) r = dpp_mov<0x101>(v);        // row_shl:1  (lane i <- lane i+1)
+        else if constexpr (T == 4 || T == 8) r = dpp_mov<0x101>(v);   // row_shl:1  (lane i <- lane i+1 inside a 16-lane row)
         else if constexpr (T >= 16) r = dpp_mov<0x130>(v);       // wave_shl:1 (lane i <- lane i+1 across the whole wave)
         else r = (uint32_t)__shfl_down((int)v, 1, 64);
         return (group_lane<T>() == T - 1) ? 0u : r;
@@ -94,7 +99,7 @@ template <int T> PAI_DEV uint32_t from_prev(uint32_t v) {
     else {
         uint32_t r;
         if constexpr (T == 2) r = dpp_mov<0xA0>(v);              // quad_perm [0,0,2,2]
-        else if constexpr (T == 4) r = dpp_mov<0x111>(v);        // row_shr:1  (lane i <- lane i-1)
+        else if constexpr (T == 4 || T == 8) r = dpp_mov<0x111>(v);   // row_shr:1  (lane i <- lane i-1 inside a 16-lane row)
         else if constexpr (T >= 16) r = dpp_mov<0x138>(v);       // wave_shr:1 (lane i <- lane i-1 across the whole wave)
         else r = (uint32_t)__shfl_up((int)v, 1, 64);
         return (group_lane<T>() == 0) ? 0u : r;
@@ -290,6 +295,78 @@ PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32
         if (++since == NORM_BLOCKS && blk != NB - 1) { RW::normalize(acc); since = 0; }   // finish() takes lazy columns
     }
     RW::finish(acc, r);
+}
+
+// ---- digit pairs with base M on the lane-group engine ---------------------------------------------------------
+// An element x of Z/M^2 is the pair (a, b), a + b M == x R (mod M^2) with R = 2^(29 NL) (mont_padic.hpp has the
+// algebra): (a, b) (x) (c, d) = (w, v),  w = (a c + m M) / R,  v = (a d + b c - m + R M + m' M) / R — both
+// reductions modulo M (NL limbs) instead of M^2 (2 NL limbs): 5 NL^2 limb products per multiplication instead of the
+// 8 NL^2 of a Montgomery product modulo M^2.  Both halves run FUSED, row by row: row i of the first half yields the
+// quotient digit m_i, which is exactly what column i of the second half still needs, so it enters the second window
+// (group lane 0, as 2^29 - 1 - m_i; the + 1 and the (M - 1) R that complete R M - m enter at column 0 and at the top
+// of the group's last lane) and is never stored.
+// (a, b) in registers (lane slices), (c, d) as LDS rows c_ptr / d_ptr [limb * stride], M - 1 as LDS limbs (uniform).
+// Inputs lazy (< 2M + eps), outputs lazy; R / M >= 2^20 required.
+constexpr int PAIR_NORM_MAX = 16;              // three 2^58 products per row and column: 16 rows stay below 2^64
+template <int NLL, int U, int T, class NM>
+PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_ptr, const uint32_t* d_ptr, int stride,
+                      const uint32_t* mm1, const NM& nm, uint32_t n0inv) {
+    static_assert(NLL % U == 0 && U <= PAIR_NORM_MAX, "row-block size");
+    using RW = Rows<NLL, U, T>;
+    constexpr int NW = RW::NW;
+    uint64_t acc1[NW], acc2[NW];
+    RW::zero(acc1);
+    RW::zero(acc2);
+    const bool lane0 = (group_lane<T>() == 0), top = (group_lane<T>() == T - 1);
+    if (lane0) acc2[0] = 1;
+    constexpr int NB = RW::NL / U;
+    constexpr int NORM_BLOCKS = PAIR_NORM_MAX / U;
+    int since = 0;
+#pragma unroll 1
+    for (int blk = 0; blk < NB; ++blk) {
+        uint32_t cv[U], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cv[u] = c_ptr[(blk * U + u) * stride];
+            dv[u] = d_ptr[(blk * U + u) * stride];
+            const uint32_t f = mm1[blk * U + u];
+            acc2[NLL + u] += top ? (uint64_t)f : 0ull;           // (M - 1) R: column NL + row
+        }
+        uint32_t low1[U], low2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < NLL; ++j) acc1[j + u] += (uint64_t)a[j] * cv[u];
+            const uint32_t q1 = bcast0<T>(((uint32_t)acc1[u] * n0inv) & RMASK);
+            nm.template mac<NLL>(acc1, u, q1);
+            acc1[u + 1] += acc1[u] >> RB;
+            low1[u] = (uint32_t)acc1[u] & RMASK;
+            acc2[u] += lane0 ? (uint64_t)(RMASK - q1) : 0ull;
+#pragma unroll
+            for (int j = 0; j < NLL; ++j) {
+                acc2[j + u] += (uint64_t)a[j] * dv[u];
+                acc2[j + u] += (uint64_t)b[j] * cv[u];
+            }
+            const uint32_t q2 = bcast0<T>(((uint32_t)acc2[u] * n0inv) & RMASK);
+            nm.template mac<NLL>(acc2, u, q2);
+            acc2[u + 1] += acc2[u] >> RB;
+            low2[u] = (uint32_t)acc2[u] & RMASK;
+        }
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) { acc1[j] = acc1[j + U]; acc2[j] = acc2[j + U]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (T > 1) {
+                acc1[NLL - U + u] += (uint64_t)from_next<T>(low1[u]);
+                acc2[NLL - U + u] += (uint64_t)from_next<T>(low2[u]);
+            }
+            acc1[NLL + u] = 0;
+            acc2[NLL + u] = 0;
+        }
+        if (++since == NORM_BLOCKS && blk != NB - 1) { RW::normalize(acc1); RW::normalize(acc2); since = 0; }
+    }
+    RW::finish(acc1, a);
+    RW::finish(acc2, b);
 }
 
 // Plain product with an additive constant: a*b + init, where `init` (this lane's slice, < 2^(29*NL))

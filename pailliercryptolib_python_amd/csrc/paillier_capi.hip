@@ -15,6 +15,7 @@
 #include "hostbn.hpp"
 #include "kernels_padic.hpp"
 #include "kernels_padic_enc.hpp"
+#include "kernels_pair.hpp"
 #include "kernels_codec.hpp"
 
 using namespace pai;
@@ -303,6 +304,13 @@ struct pai_pubkey {
     uint32_t* d_one_dig = nullptr;     // digit pair of R mod n^2 (the element 1 in Montgomery digit form)
     uint32_t* d_ct_kdig = nullptr;     // [ct_nd][2][NL] digit pairs of R^(i+2) mod n^2
     int ct_nd = 0;
+    // digit pairs with base n on the lane-group engine (kernels_pair.hpp): DJN obfuscator for n beyond the digit engine
+    int pair_nl = 0;
+    ModSetup npair;                    // n at pair_nl limbs
+    uint32_t* d_pair_nm1 = nullptr;
+    uint32_t* d_pair_fb = nullptr;     // [J][2^wb][2][pair_nl]
+    int pair_windows = 0, pair_wbits = 0, pair_out_words = 0;
+    mutable DevBuf pair_wv;            // plain digit pairs on their way to k_encrypt mode 5 / 6
     uint16_t* d_pow_ops = nullptr;     // sliding-window schedule of the exponent n (standard scheme)
     int pow_nops = 0;
     mutable DevBuf ctmul_table;        // per-slot window tables of k_ctmul_padic
@@ -640,6 +648,59 @@ uint32_t* build_lane_group_fb(const pai_pubkey* pk, const ModSetup& ms, int wb, 
     return d_fb;
 }
 
+// Digit-pair fixed-base table for the lane-group pair kernels: T[j][d] = pair(hs^(d 2^(wb j)) R), R = 2^(29 pair_nl).
+// The host supplies pair(hs R) and pair(R); the window bases (squarings), the half-width windows (one sequential chain
+// per window) and the full table (one product per entry) are computed on the device.
+void build_pair_fb(pai_pubkey* pk, int wb, int J) {
+    const int nl = pk->pair_nl;
+    const bool two_level = (wb % 2 == 0) && wb >= 8;
+    const int h = two_level ? wb / 2 : wb;
+    const int J1 = two_level ? 2 * J : J;
+    auto pair_of = [&](const Limbs& v, uint32_t* dst) {
+        Limbs rem;
+        Limbs quo = hbn::divq(v, pk->n, &rem);
+        auto ra = hbn::to_r29(rem, nl), rb = hbn::to_r29(quo, nl);
+        std::memcpy(dst, ra.data(), (size_t)nl * 4);
+        std::memcpy(dst + nl, rb.data(), (size_t)nl * 4);
+    };
+    const Limbs Rm = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * nl), pk->nsq);
+    std::vector<uint32_t> bases(2 * (size_t)nl, 0), one(2 * (size_t)nl, 0);
+    pair_of(Rm, one.data());
+    pair_of(hbn::mulmod(pk->hs, Rm, pk->nsq), bases.data());        // B_0; the other window bases are squared on the device
+    DevBuf d_bases, d_one, d_half;
+    d_bases.ensure(bases.size() * 4);
+    d_one.ensure(one.size() * 4);
+    HIP_CHECK(hipMemcpy(d_bases.p, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_one.p, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+    const size_t ent_words = 2 * (size_t)nl;
+    const size_t NE = (size_t)J << wb, NE1 = (size_t)J1 << h;
+    HIP_CHECK(hipMalloc((void**)&pk->d_pair_fb, NE * ent_words * 4));
+    uint32_t* level1 = pk->d_pair_fb;
+    if (two_level) {
+        d_half.ensure(NE1 * ent_words * 4);
+        level1 = d_half.as<uint32_t>();
+    }
+    const int epb = pair_epb(nl);
+    const int g1 = std::max(1, (J1 + epb - 1) / epb);
+    bool ok = launch_pair_fb_chain(nl, nullptr, g1, pk->npair.d_ctx, pk->d_pair_nm1, d_bases.as<uint32_t>(), d_one.as<uint32_t>(),
+                                   level1, J1, h);
+    hipError_t e1 = hipGetLastError();
+    if (ok && two_level && e1 == hipSuccess) {
+        const int g2 = (int)std::max<size_t>(1, std::min<size_t>((NE + epb - 1) / epb, (size_t)pk->dev.ncu * 2));
+        ok = launch_pair_fb_expand(nl, nullptr, g2, pk->npair.d_ctx, pk->d_pair_nm1, level1, pk->d_pair_fb, J, h);
+        e1 = hipGetLastError();
+    }
+    hipError_t e2 = hipDeviceSynchronize();
+    d_bases.release();
+    d_one.release();
+    d_half.release();
+    if (!ok) throw PaiError(PAI_E_INTERNAL, "no digit-pair table kernel for this limb count");
+    HIP_CHECK(e1);
+    HIP_CHECK(e2);
+    pk->pair_windows = J;
+    pk->pair_wbits = wb;
+}
+
 // Fixed-base tables of the DJN obfuscator hs^r, built by the FIRST call that obfuscates (pai_encrypt with
 // randomness / pai_obfuscate), under pk->mu: a handle that only adds, multiplies or decrypts — every unpickled
 // ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
@@ -666,7 +727,9 @@ void build_fb_tables(const pai_pubkey* cpk) {
     const int J = (randbits + wb - 1) / wb;
     const size_t ENT = (size_t)1 << wb;
     pk->fb_windows = J;
-    if (!pk->penc_nl) {
+    if (pk->pair_nl) {
+        build_pair_fb(pk, wb, J);
+    } else if (!pk->penc_nl) {
         pk->d_fb = build_lane_group_fb(pk, pk->msq, wb, J);
     } else {
         // digit-form fixed-base table for the base-n digit engine
@@ -791,6 +854,17 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             }
             pk->d_ct_kdig = upload_vec(kd);
         }
+        if (!pk->penc_nl) {
+            // wider moduli: DJN obfuscation on base-n digit pairs spread over lane groups (PAI_DISABLE_PAIR=1: lane-group
+            // products modulo n^2 as in round 1)
+            pk->pair_nl = pair_nl_for_n_bits(hbn::bitlen(pk->n));
+            if (const char* env = std::getenv("PAI_DISABLE_PAIR")) { if (env[0] == '1') pk->pair_nl = 0; }
+            if (pk->pair_nl) {
+                pk->npair.init(pk->n, pk->pair_nl);
+                pk->d_pair_nm1 = upload_r29(hbn::sub(pk->n, Limbs{1u}), pk->pair_nl);
+                pk->pair_out_words = (hbn::RB * pk->pair_nl + 31) / 32;
+            }
+        }
         if (h_hs) {
             require(hs_words > 0 && randbits > 0, "DJN key needs hs and randbits");
             pk->djn = true;
@@ -831,6 +905,10 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_one_dig) (void)hipFree(pk->d_one_dig);
     if (pk->d_ct_kdig) (void)hipFree(pk->d_ct_kdig);
     if (pk->d_pow_ops) (void)hipFree(pk->d_pow_ops);
+    pk->npair.release();
+    if (pk->d_pair_nm1) (void)hipFree(pk->d_pair_nm1);
+    if (pk->d_pair_fb) (void)hipFree(pk->d_pair_fb);
+    pk->pair_wv.release();
     pk->ctmul_table.release();
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
     if (pk->d_tree_c) (void)hipFree(pk->d_tree_c);
@@ -933,6 +1011,27 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         ScopedKernelTimer t(!from_plain ? "k_encrypt(obfuscate)" : (d_r ? "k_encrypt(djn)" : "k_encrypt(raw)"), s);
         if (!launch_encrypt_padic(pk->penc_nl, s, pgrid, Q, d_m, d_r, d_ct_in, d_ct_out, (int)N, !from_plain ? 2 : (d_r ? 1 : 0)))
             throw PaiError(PAI_E_INTERNAL, "no digit-engine encrypt kernel for this limb count");
+        t.stop();
+    } else if (pk->pair_nl && d_r && pk->djn) {
+        // DJN encryption / obfuscation on lane-group digit pairs: (w, v) = plain pair of hs^r (1 + m n) [or hs^r], then
+        // ct = w + v n [or ct_in (w + v n)] as one product on the n^2 geometry (k_pair_finish)
+        PairParams Q;
+        Q.nctx = pk->npair.d_ctx;
+        Q.nm1 = pk->d_pair_nm1;
+        Q.fb_table = pk->d_pair_fb;
+        Q.fb_windows = pk->pair_windows;
+        Q.fb_wbits = pk->pair_wbits;
+        Q.pt_words = pk->n_words;
+        Q.r_words = pk->r_words;
+        Q.out_words = pk->pair_out_words;
+        pk->pair_wv.ensure(N * 2 * (size_t)pk->pair_out_words * 4);
+        const int epb = pair_epb(pk->pair_nl);
+        const size_t tiles = (N + epb - 1) / epb;
+        const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu * 2));
+        ScopedKernelTimer t(from_plain ? "k_encrypt(djn)" : "k_encrypt(obfuscate)", s);
+        if (!launch_pair_fixed_base(pk->pair_nl, s, pgrid, Q, d_m, d_r, pk->pair_wv.as<uint32_t>(), (int)N, from_plain ? 1 : 0))
+            throw PaiError(PAI_E_INTERNAL, "no digit-pair kernel for this limb count");
+        g->pair_finish(s, grid, P, pk->pair_wv.as<uint32_t>(), pk->pair_out_words, d_ct_in, d_ct_out, (int)N, from_plain ? 0 : 1);
         t.stop();
     } else if (d_r == nullptr) {
         require(from_plain, "obfuscation needs randomness");

@@ -1,0 +1,70 @@
+// Instantiations of the lane-group digit-pair kernels (kernels_pair.hpp): 112 limbs on 4 lanes x 28 (n up to 3228 bits:
+// 3072-bit keys; one wave per SIMD — two accumulator windows, both digits and the modulus slice are ~240 registers) and
+// 144 limbs on 8 lanes x 18 (n up to 4156 bits: 4096-bit keys; ~150 registers, two waves per SIMD.  4 lanes x 36 needs
+// ~310 registers: 1.6 KB of scratch per lane with the table prefetch).
+#include "geo_ops.hpp"
+#include "kernels_pair.hpp"
+
+namespace pai {
+
+template <class G>
+struct PairLaunch {
+    static constexpr int BYTES = PairLds<G>::BYTES;
+    static void set_lds(const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES); }
+    static void chain(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
+                      const uint32_t* one_pair, uint32_t* S, int nwin, int h) {
+        set_lds((const void*)k_pair_fb_chain<G>);
+        hipLaunchKernelGGL(k_pair_fb_chain<G>, dim3(grid), dim3(BLOCK_THREADS), BYTES, s, nctx, nm1, bases, one_pair, S, nwin, h);
+    }
+    static void expand(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S, uint32_t* T, int J, int h) {
+        set_lds((const void*)k_pair_fb_expand<G>);
+        hipLaunchKernelGGL(k_pair_fb_expand<G>, dim3(grid), dim3(BLOCK_THREADS), BYTES, s, nctx, nm1, S, T, J, h);
+    }
+    static void fixed_base(hipStream_t s, int grid, const PairParams& P, const uint32_t* m, const uint32_t* r, uint32_t* wv_out,
+                           int n, int with_m) {
+        set_lds((const void*)k_pair_fixed_base<G>);
+        hipLaunchKernelGGL(k_pair_fixed_base<G>, dim3(grid), dim3(BLOCK_THREADS), BYTES, s, P, m, r, wv_out, n, with_m);
+    }
+};
+#ifndef PAIR_G112
+#define PAIR_G112 Geo<28, 4, 7, false>     // 7-row blocks: 17.9 ms per 65536 at 3072-bit keys (4 rows: 18.9; 8 lanes x 14: 18.5)
+#endif
+#ifndef PAIR_G144
+#define PAIR_G144 Geo<18, 8, 6, false>     // 44.3 ms at 4096-bit keys (3 / 9 rows: 44.1 / 44.0; 4 lanes x 36 without prefetch: 58.1)
+#endif
+using G112 = PAIR_G112;
+using G144 = PAIR_G144;
+static_assert(G112::NL == 112 && G144::NL == 144, "pair geometries");
+using P112 = PairLaunch<G112>;
+using P144 = PairLaunch<G144>;
+
+int pair_nl_for_n_bits(int bits) {
+    if (bits <= 2048) return 0;                    // the one-element-per-lane digit engine serves those
+    if (RB * 112 >= bits + 20) return 112;
+    if (RB * 144 >= bits + 20) return 144;
+    return 0;
+}
+int pair_epb(int nl) { return nl == 112 ? G112::EPB : (nl == 144 ? G144::EPB : 0); }
+bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
+                          const uint32_t* one_pair, uint32_t* S, int nwin, int h) {
+    if (nl == 112) P112::chain(s, grid, nctx, nm1, bases, one_pair, S, nwin, h);
+    else if (nl == 144) P144::chain(s, grid, nctx, nm1, bases, one_pair, S, nwin, h);
+    else return false;
+    return true;
+}
+bool launch_pair_fb_expand(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
+                           uint32_t* T, int J, int h) {
+    if (nl == 112) P112::expand(s, grid, nctx, nm1, S, T, J, h);
+    else if (nl == 144) P144::expand(s, grid, nctx, nm1, S, T, J, h);
+    else return false;
+    return true;
+}
+bool launch_pair_fixed_base(int nl, hipStream_t s, int grid, const PairParams& P, const uint32_t* m, const uint32_t* r,
+                            uint32_t* wv_out, int n, int with_m) {
+    if (nl == 112) P112::fixed_base(s, grid, P, m, r, wv_out, n, with_m);
+    else if (nl == 144) P144::fixed_base(s, grid, P, m, r, wv_out, n, with_m);
+    else return false;
+    return true;
+}
+
+}  // namespace pai

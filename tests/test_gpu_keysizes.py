@@ -51,3 +51,45 @@ def test_key_size_boundaries(bits, monkeypatch):
     assert ([int(c) for c in tot.ciphertextBN()], tot.exponent()) == (want[0], want[1])
     if not small:
         assert abs(sk.decrypt(tot) - sum(vals)) < 1e-6
+
+
+@pytest.mark.parametrize("bits,wbits", [(2304, "6"), (3072, "7"), (3072, None), (3200, "8"), (3264, "5"), (4096, "10"), (4128, "8"),
+                                        (4160, "6")])
+def test_lane_group_digit_pair_obfuscator(bits, wbits, monkeypatch):
+    """DJN encryption and apply_obfuscator on lane-group digit pairs (kernels_pair.hpp: n of 2049..3228 bits on 112
+    limbs, up to 4156 bits on 144 limbs; wider moduli keep the products modulo n^2) on the THROUGHPUT path (small
+    batches would take the latency kernels): ciphertext bits against the oracle for one- and two-level table builds
+    (odd / even window widths; None = the default 16 bits), and the same bits with the pair path switched off."""
+    import ctypes as C
+
+    from pailliercryptolib_python_amd import _native
+    from tests._util import DevArray, ints_to_limbs, limbs_to_ints
+    from tests.test_gpu_paillier_abi import NativeKey, plaintexts
+
+    monkeypatch.setenv("PAI_LATENCY_MAX", "0")
+    if wbits is not None:
+        monkeypatch.setenv("PAI_FB_WBITS", wbits)
+    key, _, _ = make(bits)
+    N = 70                                                # a full and a ragged workgroup tile at either geometry
+    m = plaintexts(key, N, bits)
+    r = orc.synth_r_limbs(bits + 1, N, key.randbits)
+    r[0] = 0
+    r[1] = 0xFFFFFFFF
+    if key.randbits % 32:
+        r[1, -1] = (1 << (key.randbits % 32)) - 1
+    r_int = orc.limbs_to_ints(r)
+    want = [orc.encrypt(key, x, rr) for x, rr in zip(m, r_int)]
+    want2 = [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, r_int)]
+    for disable in ("0", "1"):
+        monkeypatch.setenv("PAI_DISABLE_PAIR", disable)
+        nk = NativeKey(key)
+        dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
+        ct = DevArray(shape=(N, nk.cw))
+        _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+        assert limbs_to_ints(ct.get()) == want, (bits, wbits, disable)
+        _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
+        assert limbs_to_ints(ct.get()) == want2, (bits, wbits, disable)
+        out = DevArray(shape=(N, nk.nw))
+        _native.check(nk.lib.pai_decrypt(nk.sk, ct.ptr, N, out.ptr, None))
+        assert limbs_to_ints(out.get()) == m
+        del nk

@@ -46,3 +46,9 @@ ls -la $OUT
 # ct*pt 5.36 -> 4.82; DJN encrypt per 2^20: 8-row fused 69.8 (no gain), 12-row fused 64-67 (adopted, -DPAI_ENCRYPT_U);
 # rejected: -DPADIC_U72=12 (1127 ms, spills), -DPADIC_SQR_SYM_MAX_NL=72 fused (887 ms), -DPAI_XLDS_ENCRYPT=true (70.2),
 # fused r^n at 36 limbs (29.0 vs 25.1 ms), 12-row r^n (within noise).
+# Lane-group digit pairs (tools/variant_tu.sh <tag> pair_kernels <flags>), DJN encrypt per 65536 at 3072 / 4096 bits:
+# default (28x4 7 rows / 18x8 6 rows, prefetch, 2 waves per SIMD at 8 lanes) 17.9 / 44.3 ms; -DPAIR_PREFETCH=0 19.3 / 45.4;
+# -DPAIR_WAVES_T8=1 - / 49.3; -DPAIR_G112=Geo<28,4,4,false> 18.9; Geo<14,8,7,false> 18.5; Geo<28,4,2,false> 18.7;
+# -DPAIR_G144=Geo<18,8,9,false> 44.0; Geo<18,8,3,false> 44.1; Geo<36,4,6,false> without prefetch 58.1 (spills).
+# PAI_DISABLE_PAIR=1 (products modulo n^2): 24.5 / 61.7.  Finishing as extra modes of k_encrypt instead of k_pair_finish
+# cost k_encrypt<36x8> 61 -> 94 ms.
