@@ -66,12 +66,18 @@ while time.time() - t0 < budget:
     e = [int.from_bytes(rng.bytes(ebits // 8 + 1), "little") % (1 << ebits) for _ in range(n2)]
     ew = (ebits + 31) // 32
     de = DevArray(ints_to_limbs(e, ew)); oc = DevArray(shape=(n2, nk.cw))
+    rr = pattern(1 << key.randbits, n2)
+    want_enc = [orc.encrypt(key, x, y) for x, y in zip(m, rr)]
+    dmm, drr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(ints_to_limbs(rr, nk.rw))
+    oe = DevArray(shape=(n2, nk.cw))
     for sw in ("0", "100000"):
         os.environ["PAI_LATENCY_MAX"] = sw
+        _native.check(lib.pai_encrypt(nk.pk, dmm.ptr, drr.ptr, n2, oe.ptr, None))
+        assert limbs_to_ints(oe.get()) == want_enc, ("encrypt", bits, n2, sw)
         _native.check(lib.pai_decrypt(nk.sk, dct.ptr, n2, om.ptr, None))
         assert limbs_to_ints(om.get()) == m, ("decrypt", bits, n2, sw)
         _native.check(lib.pai_ct_mul(nk.pk, dct.ptr, de.ptr, ew, ebits, 0, n2, oc.ptr, None))
         assert limbs_to_ints(oc.get()) == [pow(c, x, M) for c, x in zip(cts, e)], ("ct_mul", bits, n2, ebits, sw)
     os.environ.pop("PAI_LATENCY_MAX", None)
-    rounds += 1; checks += 6
+    rounds += 1; checks += 8
 print(json.dumps({"rounds": rounds, "checks": checks, "seconds": round(time.time() - t0, 1), "failures": 0}))
