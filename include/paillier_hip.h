@@ -133,7 +133,9 @@ int pai_ct_add_aligned(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t
 int pai_ct_prod(const pai_pubkey* pk, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out, void* stream);
 
 /* Exponent alignment, ipcl_python.py:570-741 (ct * 2^delta as ciphertext^(2^delta)):
- * for delta_i > 0: d_ct[i] <- d_ct[i]^(2^delta_i) mod n^2; other elements are left untouched. */
+ * for delta_i > 0: d_ct[i] <- d_ct[i]^(2^delta_i) mod n^2; other elements are left untouched.
+ * Batches of >= 16384 elements (PAI_POW2_DIGIT_MIN) on keys up to 2048 bits read the largest shift back first (this
+ * synchronises `stream`) and run shifts of 8..62 as ct^e with the one-bit exponent 2^delta on the base-n digit engine. */
 int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N,
                 void* stream);
 

@@ -143,4 +143,26 @@ k_draw_r(ChaChaKey K, uint32_t* __restrict__ out, size_t total_words, int r_word
     }
 }
 
+// ---- exponent alignment through the digit engine: delta_i -> the exponent 2^max(delta_i, 0) as two words -----------
+// (pai_ct_pow2 for large shifts: ct^(2^delta) is ct * pt with a one-bit exponent).  *dmax receives max(delta_i).
+__global__ void __launch_bounds__(256)
+k_pow2_expo(const int32_t* __restrict__ delta, int bcast, size_t n, uint32_t* __restrict__ e_out, int* __restrict__ dmax) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int d = 0;
+    if (i < n) {
+        d = delta[bcast ? 0 : i];
+        d = d > 0 ? d : 0;
+        const uint64_t e = d < 64 ? (1ull << d) : 0ull;
+        e_out[2 * i] = (uint32_t)e;
+        e_out[2 * i + 1] = (uint32_t)(e >> 32);
+    }
+    // wave maximum, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(d, off, 64);
+        d = o > d ? o : d;
+    }
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(dmax, d);
+}
+
 }  // namespace pai

@@ -249,6 +249,14 @@ size_t latency_max_elements() {
     return (size_t)2048;
 }
 
+// pai_ct_pow2 goes through the digit engine from this batch size on (PAI_POW2_DIGIT_MIN) when the largest shift is
+// at least POW2_DIGIT_MIN_SHIFT
+constexpr int POW2_DIGIT_MIN_SHIFT = 8;
+size_t pow2_digit_min_elements() {
+    if (const char* env = std::getenv("PAI_POW2_DIGIT_MIN")) return (size_t)std::strtoull(env, nullptr, 10);
+    return (size_t)16384;
+}
+
 int grid_for(const GeoOps* g, size_t N, int ncu, int blocks_per_cu = 2) {
     size_t tiles = (N + g->epb - 1) / g->epb;
     size_t cap = (size_t)ncu * blocks_per_cu;
@@ -314,6 +322,7 @@ struct pai_pubkey {
     uint16_t* d_pow_ops = nullptr;     // sliding-window schedule of the exponent n (standard scheme)
     int pow_nops = 0;
     mutable DevBuf ctmul_table;        // per-slot window tables of k_ctmul_padic
+    mutable DevBuf pow2_expo;          // one-bit exponents of pai_ct_pow2's digit-engine path
     uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
     mutable DevBuf inv_prod, inv_inv, inv_fail;
@@ -910,6 +919,7 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_pair_fb) (void)hipFree(pk->d_pair_fb);
     pk->pair_wv.release();
     pk->ctmul_table.release();
+    pk->pow2_expo.release();
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
     if (pk->d_tree_c) (void)hipFree(pk->d_tree_c);
     if (pk->d_tree_fix) (void)hipFree(pk->d_tree_fix);
@@ -1175,6 +1185,35 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
     });
 }
 
+// ct^e on the base-n digit engine (k_ctmul_padic); the caller holds pk->mu
+static void ctmul_padic_locked(const pai_pubkey* pk, hipStream_t s, const uint32_t* d_ct, const uint32_t* d_e, int e_words,
+                               int ebits_max, int e_bcast, size_t N, uint32_t* d_out, int wbits, const char* timer_name) {
+    const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+    pk->ctmul_table.ensure(ctmul_padic_table_words(pk->penc_nl, wbits, (size_t)grid) * 4);
+    CtMulPadicParams Q;
+    Q.nctx = pk->nmod.d_ctx;
+    Q.nm1 = pk->d_nm1;
+    Q.nsq = pk->d_nsq29;
+    Q.kdig = pk->d_ct_kdig;
+    Q.one_dig = pk->d_one_dig;
+    Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
+    Q.table = pk->ctmul_table.as<uint4>();
+    Q.nd = pk->ct_nd;
+    Q.wbits = wbits;
+    Q.ct_words = pk->ct_words;
+    Q.e_words = e_words;
+    Q.ebits_max = ebits_max;
+    Q.e_bcast = e_bcast;
+    pk->order.begin(s);
+    ScopedKernelTimer t(timer_name, s);
+    if (!launch_ctmul_padic(pk->penc_nl, s, grid, Q, d_ct, d_e, d_out, (int)N))
+        throw PaiError(PAI_E_INTERNAL, "no digit-engine ct*pt kernel for this limb count");
+    t.stop();
+    HIP_CHECK(hipGetLastError());
+    pk->order.end(s);
+}
+
 int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, int e_words, int ebits_max,
                int e_bcast, size_t N, uint32_t* d_out, void* stream) {
     return guarded([&] {
@@ -1213,31 +1252,7 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
             // base-n digit engine: fixed windows sized to the exponent width (table build 2^w - 2 products, then
             // w squarings + 1 product per window)
             std::lock_guard<std::mutex> lk(pk->mu);
-            const int wbits = var_window_bits(ebits_max);
-            const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
-            const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
-            pk->ctmul_table.ensure(ctmul_padic_table_words(pk->penc_nl, wbits, (size_t)grid) * 4);
-            CtMulPadicParams Q;
-            Q.nctx = pk->nmod.d_ctx;
-            Q.nm1 = pk->d_nm1;
-            Q.nsq = pk->d_nsq29;
-            Q.kdig = pk->d_ct_kdig;
-            Q.one_dig = pk->d_one_dig;
-            Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
-            Q.table = pk->ctmul_table.as<uint4>();
-            Q.nd = pk->ct_nd;
-            Q.wbits = wbits;
-            Q.ct_words = pk->ct_words;
-            Q.e_words = e_words;
-            Q.ebits_max = ebits_max;
-            Q.e_bcast = e_bcast;
-            pk->order.begin(s);
-            ScopedKernelTimer t("k_ctmul", s);
-            if (!launch_ctmul_padic(pk->penc_nl, s, grid, Q, d_ct, d_e, d_out, (int)N))
-                throw PaiError(PAI_E_INTERNAL, "no digit-engine ct*pt kernel for this limb count");
-            t.stop();
-            HIP_CHECK(hipGetLastError());
-            pk->order.end(s);
+            ctmul_padic_locked(pk, s, d_ct, d_e, e_words, ebits_max, e_bcast, N, d_out, var_window_bits(ebits_max), "k_ctmul");
             return;
         }
         const GeoOps* g = pk->msq.geo;
@@ -1269,6 +1284,31 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
         DeviceScope scope_(pk->device);
         const GeoOps* g = pk->msq.geo;
         g_last_times.clear();
+        if (pk->penc_nl && N >= pow2_digit_min_elements()) {
+            // Large batches on keys the digit engine serves: ct^(2^delta) is ct * pt with the one-bit exponent 2^delta —
+            // delta squarings at 4 NL^2 limb products on base-n digit pairs (+ ~4 products of conversions) against
+            // delta + 2 products of 8 NL^2 on the lane-group engine.  Worth it from shifts of ~8 on (ct - ct aligns by
+            // up to 52: 88 -> ~55 ms per 2^20); the largest shift is read back first (one 4-byte copy: this path
+            // synchronises the stream), smaller shifts keep the lane-group kernel.
+            hipStream_t s = (hipStream_t)stream;
+            std::unique_lock<std::mutex> lk(pk->mu);
+            pk->pow2_expo.ensure(N * 8 + 16);
+            int* d_max = reinterpret_cast<int*>(pk->pow2_expo.as<uint32_t>() + 2 * N);
+            pk->order.begin(s);
+            HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int), s));
+            hipLaunchKernelGGL(k_pow2_expo, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_delta, delta_bcast, N,
+                               pk->pow2_expo.as<uint32_t>(), d_max);
+            HIP_CHECK(hipGetLastError());
+            int dmax = 0;
+            HIP_CHECK(hipMemcpyAsync(&dmax, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            pk->order.end(s);
+            if (dmax >= POW2_DIGIT_MIN_SHIFT && dmax <= 62) {
+                ctmul_padic_locked(pk, s, d_ct, pk->pow2_expo.as<uint32_t>(), 2, dmax + 1, 0, N, d_ct, 1, "k_pow2");
+                return;
+            }
+            if (dmax == 0) return;
+        }
         ScopedKernelTimer t("k_pow2", (hipStream_t)stream);
         g->pow2((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words);
         t.stop();

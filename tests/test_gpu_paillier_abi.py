@@ -146,6 +146,34 @@ def test_ct_add_mul_pow2_2048(k2048):
     assert limbs_to_ints(da.get()) == [orc.ct_mul(x, 2 ** int(d), key.nsq) if d > 0 else x for x, d in zip(a, delta)]
 
 
+@pytest.mark.parametrize("bits", [1024, 2048])
+def test_ct_pow2_through_the_digit_engine(bits, monkeypatch):
+    """Large batches with shifts of 8 and more run ct^(2^delta) as ct * pt with a one-bit exponent on the base-n digit
+    engine (PAI_POW2_DIGIT_MIN lowers the batch threshold for the test): per-element shifts incl. <= 0 and the maximum
+    62, a broadcast shift, and shift sets that stay on the lane-group kernel (all < 8, none positive, one of 63)."""
+    monkeypatch.setenv("PAI_POW2_DIGIT_MIN", "1")
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key, N = nk.key, 300
+    rng = np.random.default_rng(bits)
+    a = rand_below(rng, key.nsq, N)
+    a[0], a[1] = 1, key.nsq - 1
+    cases = []
+    d = rng.integers(-5, 62, size=N).astype(np.int32)
+    d[:5] = [0, 1, -3, 62, 8]
+    cases.append((d, 0))
+    cases.append((np.array([52], dtype=np.int32), 1))
+    cases.append((rng.integers(-2, 8, size=N).astype(np.int32), 0))
+    cases.append((np.zeros(N, dtype=np.int32) - 1, 0))
+    d63 = rng.integers(0, 20, size=N).astype(np.int32)
+    d63[7] = 63
+    cases.append((d63, 0))
+    for delta, bc in cases:
+        da, dd = DevArray(ints_to_limbs(a, nk.cw)), DevArray(delta)
+        _native.check(nk.lib.pai_ct_pow2(nk.pk, da.ptr, dd.ptr, bc, N, None))
+        dl = [int(delta[0])] * N if bc else [int(v) for v in delta]
+        assert limbs_to_ints(da.get()) == [pow(x, 1 << v, key.nsq) if v > 0 else x for x, v in zip(a, dl)], (bits, bc, int(delta.max()))
+
+
 @pytest.mark.parametrize("ebits", [1, 2, 24, 25, 80, 81, 240, 241, 2048, 4096])
 def test_ct_mul_every_window_width_and_exponent_shape(k2048, ebits):
     """ct^e on the base-n digit engine: the window width follows ebits_max (2/3/4/5 bits), exponents of every
