@@ -703,6 +703,10 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
     d_bases.release();
     d_one.release();
     d_half.release();
+    if (!ok || e1 != hipSuccess || e2 != hipSuccess) {
+        (void)hipFree(pk->d_pair_fb);
+        pk->d_pair_fb = nullptr;
+    }
     if (!ok) throw PaiError(PAI_E_INTERNAL, "no digit-pair table kernel for this limb count");
     HIP_CHECK(e1);
     HIP_CHECK(e2);
