@@ -393,6 +393,10 @@ def main() -> None:
             "ct_add_roofline": {"bound": "valu_int", "canonical_frac": CANON_MAC_ADD * B / t_add / PEAK_MAC32_PER_S,
                                 "executed_frac": 2 * 2 * 144 * 144 * B / t_add / PEAK_MAC32_PER_S,
                                 "hbm_GBs": BYTES_ADD * B / t_add / 1e9, "hbm_frac": BYTES_ADD * B / t_add / 1e9 / HBM_PEAK_GBS},
+            # k_ctmul_padic on 72-limb base-n digit pairs, 53-bit exponents, 3-bit windows: 52 squarings of 4 NL^2, ~18 window
+            # products + 6 table products + 4 conversion products of 5 NL^2 (canonical: SURVEY 8d's 3.16 M MAC32)
+            "ct_mul_roofline": {"bound": "valu_int", "canonical_frac": 3.16e6 * B / t_mul / PEAK_MAC32_PER_S,
+                                "executed_frac": (52 * 4 + 28 * 5) * 72 * 72 * B / t_mul / PEAK_MAC32_PER_S},
             "note": "BASELINE configs[2] operations on the same resident batch (wall clock around the C-ABI call); results "
                     "checked against the oracle on 3 elements each",
         }

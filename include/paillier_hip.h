@@ -65,6 +65,15 @@ int pai_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes, voi
 int pai_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
 int pai_stream_sync(int device, void* stream);
 
+/* ---- container operations on device rows (no arithmetic) -----------------------------------------
+ * ipclPlainText / ipclCipherText __getitem__ with a slice and rotate (bindings/ipcl_bindings_classes.cpp:224-262,328-366;
+ * rotate is what the reference's reductions are built from, ipcl_python.py:810-827).  Rows of `row_words` words.
+ * slice:  d_out[i] = d_src[start + i * step] for i < count (step >= 1);  rotate:  d_out[i] = d_src[(i + shift) mod N]
+ * (any sign of shift; d_out must not alias d_src).  Asynchronous on `stream`. */
+int pai_buf_slice(int device, const uint32_t* d_src, int row_words, size_t start, size_t count, size_t step, uint32_t* d_out,
+                  void* stream);
+int pai_buf_rotate(int device, const uint32_t* d_src, int row_words, size_t N, long long shift, uint32_t* d_out, void* stream);
+
 /* ---- keys ------------------------------------------------------------------------------------- */
 /* ipclPublicKey(n, bits, enableDJN) — classes.cpp:24-27 — and the pickle form
  * (scheme, n, bits, hs, randbits) — ipcl_bindings.cpp:66-98.  h_hs == NULL selects the standard

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "pai_free": (C.c_int, [C.c_int, voidp]),
     "pai_memcpy_h2d": (C.c_int, [C.c_int, voidp, voidp, C.c_size_t, voidp]),
     "pai_memcpy_d2h": (C.c_int, [C.c_int, voidp, voidp, C.c_size_t, voidp]),
+    "pai_buf_slice": (C.c_int, [C.c_int, voidp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, voidp, voidp]),
+    "pai_buf_rotate": (C.c_int, [C.c_int, voidp, C.c_int, C.c_size_t, C.c_longlong, voidp, voidp]),
     "pai_stream_sync": (C.c_int, [C.c_int, voidp]),
     "pai_pubkey_create": (C.c_int, [voidp, C.c_int, C.c_int, voidp, C.c_int, C.c_int, C.c_int, C.POINTER(voidp)]),
     "pai_pubkey_destroy": (None, [voidp]),

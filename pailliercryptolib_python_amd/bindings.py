@@ -529,7 +529,7 @@ class ipclPlainText(_Container):
     def __getitem__(self, key):
         if isinstance(key, slice):
             a, b = _slice_bounds(key, len(self))
-            return ipclPlainText(self._t[a:b].contiguous()) if self._t is not None else ipclPlainText(self._ints[a:b])
+            return ipclPlainText(engine.rows_slice(self._t, a, b - a)) if self._t is not None else ipclPlainText(self._ints[a:b])
         if self._t is None:
             return ipclBigNumber(self._ints[key])
         return ipclBigNumber(engine.to_host_words(self._row(int(key)))[0])
@@ -539,7 +539,7 @@ class ipclPlainText(_Container):
         k = shift % n if n else 0
         if self._t is None:
             return ipclPlainText(self._ints[k:] + self._ints[:k])
-        return ipclPlainText(torch.roll(self._t, -k, dims=0).contiguous())
+        return ipclPlainText(engine.rows_rotate(self._t, k))
 
     def __eq__(self, other):
         if len(self) != len(other):
@@ -621,13 +621,13 @@ class ipclCipherText(_Container):
     def __getitem__(self, key):
         if isinstance(key, slice):
             a, b = _slice_bounds(key, len(self))
-            return ipclCipherText(self._pk, self._t[a:b].contiguous())
+            return ipclCipherText(self._pk, engine.rows_slice(self._t, a, b - a))
         return ipclBigNumber(engine.to_host_words(self._row(int(key)))[0])
 
     def rotate(self, shift: int) -> "ipclCipherText":
         n = len(self)
         k = shift % n if n else 0
-        return ipclCipherText(self._pk, torch.roll(self._t, -k, dims=0).contiguous())
+        return ipclCipherText(self._pk, engine.rows_rotate(self._t, k))
 
     def __add__(self, other):
         h = self._pk.handle

@@ -459,6 +459,38 @@ int pai_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes, voi
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     });
 }
+// Container operations of ipclPlainText / ipclCipherText on device rows (bindings/ipcl_bindings_classes.cpp:224-262,
+// 328-366: __getitem__ with an index or a slice, rotate): pure copies, no arithmetic.
+int pai_buf_slice(int device, const uint32_t* d_src, int row_words, size_t start, size_t count, size_t step, uint32_t* d_out,
+                  void* stream) {
+    return guarded([&] {
+        require(d_src && d_out && row_words > 0 && step >= 1, "bad arguments");
+        if (count == 0) return;
+        DeviceScope scope_(device);
+        const size_t row_bytes = (size_t)row_words * 4;
+        const uint32_t* src = d_src + start * (size_t)row_words;
+        if (step == 1) {
+            HIP_CHECK(hipMemcpyAsync(d_out, src, count * row_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        } else {
+            HIP_CHECK(hipMemcpy2DAsync(d_out, row_bytes, src, step * row_bytes, row_bytes, count, hipMemcpyDeviceToDevice,
+                                       (hipStream_t)stream));
+        }
+    });
+}
+// out[i] = src[(i + shift) mod N]   (std::rotate to the left by `shift`, as CipherText::rotate)
+int pai_buf_rotate(int device, const uint32_t* d_src, int row_words, size_t N, long long shift, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(d_src && d_out && row_words > 0 && d_src != d_out, "bad arguments");
+        if (N == 0) return;
+        DeviceScope scope_(device);
+        const long long n = (long long)N;
+        const size_t k = (size_t)(((shift % n) + n) % n);
+        const size_t row_bytes = (size_t)row_words * 4;
+        HIP_CHECK(hipMemcpyAsync(d_out, d_src + k * (size_t)row_words, (N - k) * row_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (k)
+            HIP_CHECK(hipMemcpyAsync(d_out + (N - k) * (size_t)row_words, d_src, k * row_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    });
+}
 int pai_stream_sync(int device, void* stream) {
     return guarded([&] {
         DeviceScope scope_(device);

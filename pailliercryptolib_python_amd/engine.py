@@ -62,6 +62,26 @@ def to_host_words(t: torch.Tensor) -> np.ndarray:
     return t.detach().cpu().contiguous().numpy().view(np.uint32)
 
 
+def rows_slice(t: torch.Tensor, start: int, count: int, step: int = 1) -> torch.Tensor:
+    """out[i] = t[start + i*step] on the device (pai_buf_slice: the containers' slice __getitem__, classes.cpp:224-262,328-366)."""
+    t = t.contiguous()
+    out = torch.empty((count, t.shape[1]), dtype=t.dtype, device=t.device)
+    if count:
+        _native.check(_native.load().pai_buf_slice(t.device.index or 0, _ptr(t), t.shape[1], int(start), int(count), int(step),
+                                                   _ptr(out), _stream(t.device)))
+    return out
+
+
+def rows_rotate(t: torch.Tensor, shift: int) -> torch.Tensor:
+    """out[i] = t[(i + shift) mod N] on the device (pai_buf_rotate: CipherText::rotate / PlainText::rotate)."""
+    t = t.contiguous()
+    out = torch.empty_like(t)
+    if t.shape[0]:
+        _native.check(_native.load().pai_buf_rotate(t.device.index or 0, _ptr(t), t.shape[1], t.shape[0], int(shift), _ptr(out),
+                                                    _stream(t.device)))
+    return out
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -566,3 +566,24 @@ def test_ct_add_aligned_matches_the_two_step_definition(bits):
         assert limbs_to_ints(out.get()) == want_b, (bits, N, "bcast")
         _native.check(nk.lib.pai_ct_add_aligned(nk.pk, da.ptr, db.ptr, 0, dd.ptr, N, da.ptr, None))
         assert limbs_to_ints(da.get()) == want, (bits, N, "in place")
+
+
+def test_buf_slice_and_rotate_are_row_copies():
+    """pai_buf_slice / pai_buf_rotate (SURVEY 8b's container exports; classes.cpp:224-262,328-366): slices with a step,
+    rotations by any signed amount, against numpy."""
+    lib = _native.load()
+    rng = np.random.default_rng(77)
+    N, W = 37, 13
+    src = rng.integers(0, 1 << 32, size=(N, W), dtype=np.uint64).astype(np.uint32)
+    ds = DevArray(src)
+    for start, count, step in ((0, N, 1), (5, 20, 1), (3, 11, 3), (36, 1, 1), (0, 0, 1), (1, 18, 2)):
+        out = DevArray(shape=(max(count, 1), W))
+        _native.check(lib.pai_buf_slice(0, ds.ptr, W, start, count, step, out.ptr, None))
+        _native.check(lib.pai_stream_sync(0, None))
+        assert np.array_equal(out.get()[:count], src[start:start + count * step:step][:count])
+    for shift in (0, 1, 5, N - 1, N, N + 3, -1, -40):
+        out = DevArray(shape=(N, W))
+        _native.check(lib.pai_buf_rotate(0, ds.ptr, W, N, shift, out.ptr, None))
+        _native.check(lib.pai_stream_sync(0, None))
+        assert np.array_equal(out.get(), np.roll(src, -shift, axis=0)), shift
+    assert lib.pai_buf_rotate(0, ds.ptr, W, N, 1, ds.ptr, None) != 0          # in place is refused
