@@ -141,6 +141,20 @@ int pai_ct_add_aligned(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t
  * upstream's rotate-and-add result.  count must be a positive multiple of groups; groups == 1 is sum(). */
 int pai_ct_prod(const pai_pubkey* pk, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out, void* stream);
 
+/* The matrix products PaillierEncryptedNumber.__matmul__ / __rmatmul__ / dot (ipcl_python.py:829-930): every output
+ * element is a sum of ciphertext * plaintext terms aligned to a common exponent, i.e. the product of powers
+ *     d_out[r * M + j] = prod_{l < K}  base(r, l, j)^(e[r][l][j])  mod n^2,
+ * base(r, l, j) = d_ct[r * K + l], or d_ct_inv[r * K + l] (the caller's pai_ct_invert of d_ct) where d_sign[l * M + j] != 0
+ * (negative multipliers, ipcl_python.py:426-437); e = |mantissa| << alignment shift, e_words words each, little endian,
+ * laid out [R][K][M][e_words]; ebits_max bounds every exponent.  d_sign and d_ct_inv are both NULL or both given.
+ * One chain of squarings per output element and chunk of members instead of one per term (Straus, 4-bit windows over
+ * per-base power tables built on the fly).  Keys the base-n digit engine serves (n up to 2048 bits) only:
+ * PAI_E_UNSUPPORTED otherwise, or when the power tables (18 KB per base with signs) do not fit — the caller then takes
+ * the term-by-term route (pai_ct_mul + pai_ct_add_aligned / pai_ct_prod).  The bits equal that route's: the result is the
+ * canonical residue of the same product. */
+int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_ct_inv, size_t R, size_t K, size_t M,
+                    const uint32_t* d_e, int e_words, int ebits_max, const uint8_t* d_sign, uint32_t* d_out, void* stream);
+
 /* Exponent alignment, ipcl_python.py:570-741 (ct * 2^delta as ciphertext^(2^delta)):
  * for delta_i > 0: d_ct[i] <- d_ct[i]^(2^delta_i) mod n^2; other elements are left untouched.
  * Batches of >= 16384 elements (PAI_POW2_DIGIT_MIN) on keys up to 2048 bits read the largest shift back first (this

@@ -60,6 +60,8 @@ PROTOTYPES = {
     "pai_ct_invert": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_add_aligned": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_prod": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp]),
+    "pai_ct_multiexp": (C.c_int, [voidp, voidp, voidp, C.c_size_t, C.c_size_t, C.c_size_t, voidp, C.c_int, C.c_int, voidp, voidp,
+                                  voidp]),
     "pai_shard_plan": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "pai_gather": (C.c_int, [C.c_int, i32p, C.POINTER(voidp), C.POINTER(C.c_size_t), C.c_int, C.c_int, voidp]),
     "pai_scatter": (C.c_int, [C.c_int, i32p, C.POINTER(voidp), C.POINTER(C.c_size_t), C.c_int, C.c_int, voidp]),

@@ -94,6 +94,9 @@ struct CtMulPadicParams;
 size_t ctmul_padic_table_words(int nl, int wbits, size_t blocks);
 bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e,
                         uint32_t* out, int n);
+struct MexpPadicParams;
+bool launch_mexp_table_padic(int nl, hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* ct, const uint32_t* ct_inv, int nlanes);
+bool launch_mexp_padic(int nl, hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* e, const uint8_t* sign, uint32_t* out, int nlanes);
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
                           const uint32_t* ct_in, uint32_t* ct_out, int n, int mode);
 

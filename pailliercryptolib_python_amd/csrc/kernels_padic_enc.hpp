@@ -596,4 +596,204 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
     }
 }
 
+// ---- multi-exponentiation: out[r][j] = prod_l base[r][l]^(e[r][l][j]) mod n^2 ---------------------------------------------
+// The matrix products of the API (PaillierEncryptedNumber.__matmul__ / __rmatmul__ / dot, ipcl_python.py:829-930) are sums
+// of ciphertext * plaintext terms, i.e. products of powers that share their bases across the output columns and their
+// squarings across the members of a sum (Straus): every base gets a table of its powers 0 .. 15 once
+// (k_mexp_table_padic; both the ciphertext and, for negative multipliers, its inverse), and a lane computes the partial
+// product over a chunk of members for one output element with ONE chain of squarings: per 4-bit window, four squarings,
+// then one table product per member.  ct * pt on its own spends 52 squarings + ~28 products per term; here a term costs
+// ~14-20 table products.  The partial products leave as canonical residues [chunk][r * M + j] for pai_ct_prod.
+struct MexpPadicParams {
+    const MontCtx* nctx;
+    const uint32_t* nm1;
+    const uint32_t* nsq;
+    const uint32_t* kdig;        // [nd][2][NL]
+    const uint32_t* one_dig;     // [2][NL]
+    uint4* mscratch;
+    uint4* table;                // [R * K][nsigns][16][2][NC]
+    int nd, ct_words;
+    int R, K, M, chunk, nsigns;
+    int e_words, ebits_max;
+};
+constexpr int MEXP_WBITS = 4, MEXP_NT = 1 << MEXP_WBITS;
+
+// one lane per (base, sign): powers 0 .. 15 of the ciphertext (sign 0) or of its inverse (sign 1), digit form
+template <int NL, int U>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_mexp_table_padic(MexpPadicParams P, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ ct_inv, int nlanes) {
+    using E = Padic<NL, U, PAI_XLDS_CTMUL>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
+    __syncthreads();
+    uint32_t sn[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
+    const uint32_t* nm = sn;
+    const uint32_t* nm1 = ldsn + NL;
+    const uint32_t n0inv = P.nctx->n0inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* A = reinterpret_cast<uint4*>(lds + wave * 2 * E::DIGIT_WORDS) + lane;
+    uint4* B = A + E::NC * 64;
+    const size_t nslots = (size_t)gridDim.x * BLOCK_THREADS;
+    const size_t slot = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const typename E::MBuf M{P.mscratch + slot, nslots};
+    const typename E::MBuf Wb{P.mscratch + (size_t)E::NC * nslots + slot, nslots};
+    const int tiles = (nlanes + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int idx = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = idx < nlanes;
+        const int is = live ? idx : nlanes - 1;
+        const int b = is / P.nsigns, sg = is - b * P.nsigns;
+        const uint32_t* row = (sg ? ct_inv : ct) + (size_t)b * P.ct_words;
+        uint4* ent = P.table + (size_t)is * MEXP_NT * 2 * E::NC;          // [d][2][NC]
+        padic_to_digit_form<E>(A, B, M, row, P.ct_words, P.kdig, P.nd, nm, nm1, n0inv);
+        if (live) {
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c) {
+                ent[c] = make_uint4(P.one_dig[4 * c], P.one_dig[4 * c + 1], P.one_dig[4 * c + 2], P.one_dig[4 * c + 3]);
+                ent[E::NC + c] = make_uint4(P.one_dig[NL + 4 * c], P.one_dig[NL + 4 * c + 1], P.one_dig[NL + 4 * c + 2], P.one_dig[NL + 4 * c + 3]);
+                ent[2 * E::NC + c] = E::ld(A, c);
+                ent[3 * E::NC + c] = E::ld(B, c);
+            }
+        }
+        __threadfence();
+        const uint4* x1 = ent + 2 * E::NC;            // the base itself, read back as the multiplier (dead lanes: the last live entry)
+        auto from_x = [&](int dg) {
+            return [=](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int c = 0; c < E::UC; ++c) {
+                    const uint4 t = x1[dg * E::NC + E::UC * blk + c];
+                    xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                }
+            };
+        };
+#pragma unroll 1
+        for (int d = 2; d < MEXP_NT; ++d) {
+            E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_x(0), from_x(1), nm, nm1, n0inv);
+            if (live) {
+#pragma unroll 1
+                for (int c = 0; c < E::NC; ++c) { ent[(size_t)(2 * d) * E::NC + c] = E::ld(A, c); ent[(size_t)(2 * d + 1) * E::NC + c] = E::ld(B, c); }
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// lane = (chunk c, output g = r * M + j): partial product over members l in [c * chunk, min(K, (c + 1) * chunk))
+// e: [R][K][M][e_words] exponents (|mantissa| << alignment shift), sign: [K][M] bytes (1 = use the inverse's table) or NULL
+template <int NL, int U>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_mexp_padic(MexpPadicParams P, const uint32_t* __restrict__ e, const uint8_t* __restrict__ sign, uint32_t* __restrict__ out, int nlanes) {
+    using E = Padic<NL, U, PAI_XLDS_CTMUL>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
+    __syncthreads();
+    uint32_t sn[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
+    const uint32_t* nm = sn;
+    const uint32_t* nm_lds = ldsn;
+    const uint32_t* nm1 = ldsn + NL;
+    const uint32_t n0inv = P.nctx->n0inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* A = reinterpret_cast<uint4*>(lds + wave * 2 * E::DIGIT_WORDS) + lane;
+    uint4* B = A + E::NC * 64;
+    const size_t nslots = (size_t)gridDim.x * BLOCK_THREADS;
+    const size_t slot = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const typename E::MBuf M{P.mscratch + slot, nslots};
+    const typename E::MBuf Wb{P.mscratch + (size_t)E::NC * nslots + slot, nslots};
+    const int G = P.R * P.M;
+    const int nwin = (P.ebits_max + MEXP_WBITS - 1) / MEXP_WBITS;
+    const int tiles = (nlanes + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int idx = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = idx < nlanes;
+        const int is = live ? idx : nlanes - 1;
+        const int ch = is / G, g = is - ch * G, r = g / P.M, j = g - r * P.M;
+        const int l0 = ch * P.chunk, l1 = min(P.K, l0 + P.chunk);
+        // the longest chunk of the wave sets the trip count (chunks are equal except the last)
+        const int lcount = P.chunk;
+        wave_lds_fence();
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) {
+            E::st(A, c, make_uint4(P.one_dig[4 * c], P.one_dig[4 * c + 1], P.one_dig[4 * c + 2], P.one_dig[4 * c + 3]));
+            E::st(B, c, make_uint4(P.one_dig[NL + 4 * c], P.one_dig[NL + 4 * c + 1], P.one_dig[NL + 4 * c + 2], P.one_dig[NL + 4 * c + 3]));
+        }
+        wave_lds_fence();
+        bool started = false;                         // wave-uniform: nothing but ones so far, squarings can be skipped
+#pragma unroll 1
+        for (int wi = nwin - 1; wi >= 0; --wi) {
+            if (started) {
+#pragma unroll 1
+                for (int sq = 0; sq < MEXP_WBITS; ++sq) E::template sqr_rolled_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);
+            }
+            const int bit = wi * MEXP_WBITS, k = bit >> 5, sh = bit & 31;        // a 4-bit window never straddles a word
+#pragma unroll 1
+            for (int li = 0; li < lcount; ++li) {
+                const int l = l0 + li;
+                const bool has = live && l < l1;
+                const int ls = l < P.K ? l : P.K - 1;
+                const size_t eoff = (((size_t)r * P.K + ls) * P.M + j) * P.e_words;
+                const uint32_t word = k < P.e_words ? e[eoff + k] : 0u;
+                const int d = has ? (int)((word >> sh) & (MEXP_NT - 1)) : 0;
+                if (__any(d != 0)) {
+                    const int sg = (sign && P.nsigns > 1) ? (int)sign[(size_t)ls * P.M + j] : 0;
+                    const uint4* ent = P.table + ((((size_t)r * P.K + ls) * P.nsigns + sg) * MEXP_NT + d) * 2 * E::NC;
+                    auto from_ent = [&](int dg) {
+                        return [=](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                            for (int c = 0; c < E::UC; ++c) {
+                                const uint4 t = ent[dg * E::NC + E::UC * blk + c];
+                                xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                            }
+                        };
+                    };
+                    E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_ent(0), from_ent(1), nm, nm1, n0inv);
+                    started = true;
+                }
+            }
+        }
+        // leave Montgomery form (times the plain pair (1, 0)), then ct = w + v n as one integer, canonical
+        uint32_t w[NL], v[NL];
+        {
+            auto one = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = 0;
+                if (blk == 0) xv[0] = 1;
+            };
+            auto zero = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = 0;
+            };
+            E::mm1_mul(w, M, A, one, nm, n0inv);
+            E::mm2_mul(v, M, A, B, zero, one, nm, nm1, n0inv);
+        }
+        wave_lds_fence();
+        E::store_digit(B, v);
+        wave_lds_fence();
+        uint32_t hi[NL];
+        E::mul_plain(hi, A, w, B, [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(nm_lds, blk, xv); });
+        wave_lds_fence();
+        E::store_digit(B, hi);
+        wave_lds_fence();
+        cond_sub_2nl<E>(A, B, P.nsq);
+        cond_sub_2nl<E>(A, B, P.nsq);
+        if (live) {
+            uint32_t* orow = out + (size_t)idx * P.ct_words;
+#pragma unroll 1
+            for (int k2 = 0; k2 < P.ct_words; ++k2) {
+                const int j0 = (32 * k2) / RB, s0 = 32 * k2 - RB * j0;
+                uint64_t t = (uint64_t)lds_limb<E>(A, B, j0) >> s0;
+                t |= (uint64_t)lds_limb<E>(A, B, j0 + 1) << (RB - s0);
+                t |= (uint64_t)lds_limb<E>(A, B, j0 + 2) << (2 * RB - s0);
+                orow[k2] = (uint32_t)t;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
 }  // namespace pai

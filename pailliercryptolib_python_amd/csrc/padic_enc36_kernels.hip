@@ -15,4 +15,11 @@ void enc36_ctmul(hipStream_t s, int grid, const CtMulPadicParams& P, const uint3
 }
 void enc36_pow(hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n) { L36::pow(s, grid, P, base, out, n); }
 
+void enc36_mexp_table(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* ct, const uint32_t* ct_inv, int nlanes) {
+    L36::mexp_table(s, grid, P, ct, ct_inv, nlanes);
+}
+void enc36_mexp(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* e, const uint8_t* sign, uint32_t* out, int nlanes) {
+    L36::mexp(s, grid, P, e, sign, out, nlanes);
+}
+
 }  // namespace pai

@@ -58,4 +58,17 @@ bool launch_pow_padic(int nl, hipStream_t s, int grid, const PowPadicParams& P, 
     return true;
 }
 
+bool launch_mexp_table_padic(int nl, hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* ct, const uint32_t* ct_inv, int nlanes) {
+    if (nl == 72) L72::mexp_table(s, grid, P, ct, ct_inv, nlanes);
+    else if (nl == 36) enc36_mexp_table(s, grid, P, ct, ct_inv, nlanes);
+    else return false;
+    return true;
+}
+bool launch_mexp_padic(int nl, hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* e, const uint8_t* sign, uint32_t* out, int nlanes) {
+    if (nl == 72) L72::mexp(s, grid, P, e, sign, out, nlanes);
+    else if (nl == 36) enc36_mexp(s, grid, P, e, sign, out, nlanes);
+    else return false;
+    return true;
+}
+
 }  // namespace pai

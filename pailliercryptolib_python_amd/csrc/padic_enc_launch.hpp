@@ -36,6 +36,14 @@ struct EncLaunch {
         (void)hipFuncSetAttribute((const void*)k_ctmul_padic<NL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
         hipLaunchKernelGGL((k_ctmul_padic<NL, U>), dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, P, ct, e, out, n);
     }
+    static void mexp_table(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* ct, const uint32_t* ct_inv, int nlanes) {
+        (void)hipFuncSetAttribute((const void*)k_mexp_table_padic<NL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
+        hipLaunchKernelGGL((k_mexp_table_padic<NL, U>), dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, P, ct, ct_inv, nlanes);
+    }
+    static void mexp(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* e, const uint8_t* sign, uint32_t* out, int nlanes) {
+        (void)hipFuncSetAttribute((const void*)k_mexp_padic<NL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
+        hipLaunchKernelGGL((k_mexp_padic<NL, U>), dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, P, e, sign, out, nlanes);
+    }
     static void pow(hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n) {
         (void)hipFuncSetAttribute((const void*)k_pow_padic<NL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
         hipLaunchKernelGGL((k_pow_padic<NL, U>), dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, P, base, out, n);
@@ -51,5 +59,7 @@ void enc36_encrypt(hipStream_t s, int grid, const EncPadicParams& P, const uint3
                    uint32_t* ct_out, int n, int mode);
 void enc36_ctmul(hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e, uint32_t* out, int n);
 void enc36_pow(hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n);
+void enc36_mexp_table(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* ct, const uint32_t* ct_inv, int nlanes);
+void enc36_mexp(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* e, const uint8_t* sign, uint32_t* out, int nlanes);
 
 }  // namespace pai

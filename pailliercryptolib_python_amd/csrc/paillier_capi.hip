@@ -323,6 +323,7 @@ struct pai_pubkey {
     int pow_nops = 0;
     mutable DevBuf ctmul_table;        // per-slot window tables of k_ctmul_padic
     mutable DevBuf pow2_expo;          // one-bit exponents of pai_ct_pow2's digit-engine path
+    mutable DevBuf mexp_table, mexp_partial;   // power tables and partial products of pai_ct_multiexp
     uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
     mutable DevBuf inv_prod, inv_inv, inv_fail;
@@ -956,6 +957,8 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->pair_wv.release();
     pk->ctmul_table.release();
     pk->pow2_expo.release();
+    pk->mexp_table.release();
+    pk->mexp_partial.release();
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
     if (pk->d_tree_c) (void)hipFree(pk->d_tree_c);
     if (pk->d_tree_fix) (void)hipFree(pk->d_tree_fix);
@@ -1376,13 +1379,9 @@ static void tree_mul(const pai_pubkey* pk, hipStream_t s, const uint32_t* a, con
     HIP_CHECK(hipGetLastError());
 }
 
-int pai_ct_prod(const pai_pubkey* pk, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out, void* stream) {
-    return guarded([&] {
-        require(pk && d_ct && d_out, "NULL argument");
-        require(groups > 0 && count >= groups && count % groups == 0, "count must be a positive multiple of groups");
-        std::lock_guard<std::mutex> lk(pk->mu);
-        DeviceScope scope_(pk->device);
-        hipStream_t s = (hipStream_t)stream;
+// the caller holds pk->mu and has selected the device
+static void ct_prod_locked(const pai_pubkey* pk, hipStream_t s, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out) {
+    {
         const size_t W = (size_t)pk->ct_words, ROW = W * 4;
         size_t members = count / groups;
         if (members == 1) {
@@ -1414,6 +1413,82 @@ int pai_ct_prod(const pai_pubkey* pk, const uint32_t* d_ct, size_t count, size_t
         tree_mul(pk, s, src, pk->d_tree_fix + (size_t)level * W, 1, d_out, groups);     // R^(1 - 2^L) * R^(2^L) * R^-1 = 1
         t.stop();
         pk->order.end(s);
+    }
+}
+
+int pai_ct_prod(const pai_pubkey* pk, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && d_ct && d_out, "NULL argument");
+        require(groups > 0 && count >= groups && count % groups == 0, "count must be a positive multiple of groups");
+        std::lock_guard<std::mutex> lk(pk->mu);
+        DeviceScope scope_(pk->device);
+        ct_prod_locked(pk, (hipStream_t)stream, d_ct, count, groups, d_out);
+    });
+}
+
+// Multi-exponentiation behind the matrix products (kernels_padic_enc.hpp: k_mexp_table_padic, k_mexp_padic)
+int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_ct_inv, size_t R, size_t K, size_t M,
+                    const uint32_t* d_e, int e_words, int ebits_max, const uint8_t* d_sign, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && d_ct && d_e && d_out, "NULL argument");
+        require(R > 0 && K > 0 && M > 0 && e_words > 0 && ebits_max > 0 && ebits_max <= 32 * e_words, "bad shape");
+        require((d_sign == nullptr) == (d_ct_inv == nullptr), "signs and inverses come together");
+        if (!pk->penc_nl) throw PaiError(PAI_E_UNSUPPORTED, "multi-exponentiation needs the base-n digit engine (keys up to 2048 bits)");
+        const size_t G = R * M, bases = R * K;
+        require(G * K < ((size_t)1 << 31) && bases < ((size_t)1 << 28), "matrix product too large for one call");
+        std::lock_guard<std::mutex> lk(pk->mu);
+        DeviceScope scope_(pk->device);
+        hipStream_t s = (hipStream_t)stream;
+        const int pnl = pk->penc_nl, nsigns = d_sign ? 2 : 1;
+        // members per lane: enough lanes to fill the device (one workgroup of 256 lanes per CU, several rounds), the
+        // rest of the sharing goes into longer chunks (the squarings are shared by a chunk)
+        size_t want_lanes = (size_t)pk->dev.ncu * BLOCK_THREADS * 2;
+        if (const char* env = std::getenv("PAI_MEXP_LANES")) { const size_t v = (size_t)std::strtoull(env, nullptr, 10); if (v) want_lanes = v; }
+        size_t chunk = std::max<size_t>(1, (G * K + want_lanes - 1) / want_lanes);
+        chunk = std::min(chunk, K);
+        const size_t chunks = (K + chunk - 1) / chunk;
+        const size_t nlanes = chunks * G;
+        const size_t table_bytes = bases * nsigns * MEXP_NT * 2 * (size_t)pnl * 4;
+        size_t mem_free = 0, mem_total = 0;
+        HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
+        if (table_bytes > mem_total / 8 || table_bytes + nlanes * (size_t)pk->ct_words * 4 > mem_free + pk->mexp_table.bytes + pk->mexp_partial.bytes)
+            throw PaiError(PAI_E_UNSUPPORTED, "power tables of this matrix product do not fit the device");
+        pk->mexp_table.ensure(table_bytes);
+        pk->mexp_partial.ensure(nlanes * (size_t)pk->ct_words * 4);
+        MexpPadicParams Q;
+        Q.nctx = pk->nmod.d_ctx;
+        Q.nm1 = pk->d_nm1;
+        Q.nsq = pk->d_nsq29;
+        Q.kdig = pk->d_ct_kdig;
+        Q.one_dig = pk->d_one_dig;
+        Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
+        Q.table = pk->mexp_table.as<uint4>();
+        Q.nd = pk->ct_nd;
+        Q.ct_words = pk->ct_words;
+        Q.R = (int)R; Q.K = (int)K; Q.M = (int)M; Q.chunk = (int)chunk; Q.nsigns = nsigns;
+        Q.e_words = e_words;
+        Q.ebits_max = ebits_max;
+        g_last_times.clear();
+        pk->order.begin(s);
+        {
+            const size_t tl = bases * nsigns, tiles = (tl + BLOCK_THREADS - 1) / BLOCK_THREADS;
+            const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+            ScopedKernelTimer t("k_mexp_table", s);
+            if (!launch_mexp_table_padic(pnl, s, grid, Q, d_ct, d_ct_inv, (int)tl))
+                throw PaiError(PAI_E_INTERNAL, "no multi-exponentiation kernel for this limb count");
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+        }
+        {
+            const size_t tiles = (nlanes + BLOCK_THREADS - 1) / BLOCK_THREADS;
+            const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+            ScopedKernelTimer t("k_mexp", s);
+            launch_mexp_padic(pnl, s, grid, Q, d_e, d_sign, pk->mexp_partial.as<uint32_t>(), (int)nlanes);
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+        }
+        pk->order.end(s);
+        ct_prod_locked(pk, s, pk->mexp_partial.as<uint32_t>(), nlanes, G, d_out);
     });
 }
 

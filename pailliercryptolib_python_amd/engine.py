@@ -203,6 +203,22 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_ct_prod(self.h, _ptr(ct), ct.shape[0], int(groups), _ptr(out), _stream(self.device)))
         return out
 
+    def ct_multiexp(self, ct: torch.Tensor, ct_inv: Optional[torch.Tensor], R: int, K: int, M: int, e: torch.Tensor,
+                    ebits_max: int, sign: Optional[torch.Tensor]) -> torch.Tensor:
+        """out[r*M + j] = prod_l base(r, l, j)^e[r, l, j] mod n^2 (pai_ct_multiexp); ct [R*K, W], e int32 [R, K, M, ew],
+        sign uint8 [K, M] or None.  Raises NativeError(PAI_E_UNSUPPORTED) when the key / sizes are not served."""
+        self._chk(ct, self.ct_words, "ct")
+        if ct.shape[0] != R * K or e.dtype != torch.int32 or tuple(e.shape[:3]) != (R, K, M) or not e.is_contiguous():
+            raise ValueError("ct_multiexp: shape mismatch")
+        if (sign is None) != (ct_inv is None):
+            raise ValueError("ct_multiexp: signs and inverses come together")
+        if sign is not None and (sign.dtype != torch.uint8 or tuple(sign.shape) != (K, M) or not sign.is_contiguous()):
+            raise ValueError("ct_multiexp: sign must be contiguous uint8 [K, M]")
+        out = self.empty_ct(R * M)
+        _native.check(self.lib.pai_ct_multiexp(self.h, _ptr(ct), _ptr(ct_inv), R, K, M, _ptr(e), e.shape[3], int(ebits_max),
+                                               _ptr(sign), _ptr(out), _stream(self.device)))
+        return out
+
     def ct_invert(self, ct: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(ct, self.ct_words, "ct")
         out = self.empty_ct(ct.shape[0]) if out is None else out

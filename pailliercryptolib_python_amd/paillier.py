@@ -578,12 +578,93 @@ class PaillierEncryptedNumber:
     def dot(self, other: Union[np.ndarray, list]) -> "PaillierEncryptedNumber":
         if len(other) != len(self):
             raise ValueError("PaillierEncryptedNumber.dot: input size mismatch with ciphertext")
+        fast = self._matmul_multiexp(np.asarray(other), 1, len(self), 1, False) if _fp.is_float_batch(other) else None
+        if fast is not None:
+            return fast
         return (self * other).sum()
+
+    # matrix products with at least this many ciphertext * plaintext terms go through pai_ct_multiexp (PAI_MEXP_MIN_TERMS)
+    MEXP_MIN_TERMS = 1 << 19
+
+    def _matmul_multiexp(self, other: np.ndarray, m: int, n: int, k: int, rhs: bool):
+        """The same output as __matmul below for float matrices, as ONE multi-exponentiation per output element
+        (pai_ct_multiexp): out(i, j) = prod_l base^(|mantissa| << shift), the shift being the exponent alignment of
+        ipcl_python.py:868-870 and the base the ciphertext or — negative multipliers, :426-437 — its inverse.  The bits
+        are those of the term-by-term route (a canonical residue of the same product).  Returns None when the shape,
+        the key or the exponent spread are not served; the caller then goes term by term."""
+        import os
+
+        from . import _native
+        h = self._h()
+        try:
+            min_terms = int(os.environ.get("PAI_MEXP_MIN_TERMS", self.MEXP_MIN_TERMS))
+        except ValueError:
+            min_terms = self.MEXP_MIN_TERMS
+        if m * n * k < min_terms or other.dtype.kind != "f" or self.public_key.n.bit_length() > 2048 + 20 \
+                or self.public_key.n.bit_length() <= 66:
+            return None
+        dev = h.device
+        if rhs:
+            # out(i, j) = sum_l other[i, l] * self[l*k + j]: rows of bases <-> j, members <-> l, columns <-> i
+            R, K, M = k, n, m
+            idx = (np.arange(n)[None, :] * k + np.arange(k)[:, None]).reshape(-1)             # [j][l] -> l*k + j
+            bases = self.words[torch.from_numpy(idx).to(dev)].contiguous()
+            e_a = np.asarray(self._expo, dtype=np.int64)[idx].reshape(R, K)
+            w = (other.T if other.ndim == 2 else other.reshape(1, n).T)                         # [l][i]
+        else:
+            R, K, M = m, n, k
+            bases = self.words
+            e_a = np.asarray(self._expo, dtype=np.int64).reshape(R, K)
+            w = other if other.ndim == 2 else other.reshape(n, 1)                               # [l][j]
+        mant, pexpo = _fp.float64_mantissas(_fp.checked_float64(np.ascontiguousarray(w, dtype=np.float64).reshape(-1)))
+        mant_t = torch.from_numpy(mant.reshape(K, M)).to(dev)
+        total = torch.from_numpy(e_a).to(dev)[:, :, None] + torch.from_numpy(pexpo.astype(np.int64).reshape(K, M)).to(dev)[None]
+        big_e = total.amax(dim=1)                                                               # [R, M]
+        mag = mant_t.abs()
+        shift = torch.where(mag[None] == 0, torch.zeros_like(total), big_e[:, None, :] - total)
+        del total
+        bitlen = torch.frexp(mag.to(torch.float64))[1].to(torch.int64)                          # exact below 2^53
+        ebits = int((bitlen[None] + shift).max().item())
+        if ebits > 128:
+            return None
+        ebits = max(ebits, 1)
+        ew = (ebits + 31) // 32
+        m32 = 0xFFFFFFFF
+        mag_b = mag[None].expand_as(shift)
+        words = []
+        for wi in range(ew):
+            pos = 32 * wi - shift                                                               # bit of mag at the word's bit 0
+            right = (mag_b >> pos.clamp(0, 63)) & m32
+            left = ((mag_b & m32) << (-pos).clamp(0, 31)) & m32
+            words.append(torch.where(pos >= 0, right, torch.where(pos > -32, left, torch.zeros_like(left))))
+        e_t = torch.stack(words, dim=3)
+        e_t = torch.where(e_t >= (1 << 31), e_t - (1 << 32), e_t).to(torch.int32).contiguous()
+        del words, shift
+        neg = mant_t < 0
+        sign = inv = None
+        if bool(neg.any().item()):
+            sign = neg.to(torch.uint8).contiguous()
+            inv = h.ct_invert(bases)
+        try:
+            out = h.ct_multiexp(bases, inv, R, K, M, e_t, ebits, sign)
+        except _native.NativeError as exc:
+            if exc.code == _native.PAI_E_UNSUPPORTED:
+                return None
+            raise
+        expo = big_e.cpu().numpy().astype(np.int32)                                             # [R, M]
+        if rhs:
+            perm = (np.arange(k)[None, :] * m + np.arange(m)[:, None]).reshape(-1)              # (i, j) <- j*m + i
+            out = out[torch.from_numpy(perm).to(dev)].contiguous()
+            expo = expo.T
+        return self._wrap(out, np.ascontiguousarray(expo).reshape(-1), m * k)
 
     def __matmul(self, other: np.ndarray, m: int, n: int, k: int, rhs: bool = False) -> "PaillierEncryptedNumber":
         """ipcl_python.py:829-880.  self is (m x n) row-major when rhs is False (result = self @ other,
         other n x k), or (n x k) when rhs is True (result = other @ self, other m x n).  Output element
         (i, j) = sum_l ct[.] * pt[.], one aligned tree product per output element."""
+        fast = self._matmul_multiexp(other, m, n, k, rhs)
+        if fast is not None:
+            return fast
         h = self._h()
         # member-major order (l, i, j): the n addends of output element (i, j) are n rows that lie m*k apart, which is
         # the layout pai_ct_prod reduces with contiguous halves

@@ -235,10 +235,15 @@ def test_random_expression_chains_match_the_oracle_bit_for_bit(fixed, seed):
     assert np.allclose(got, val, rtol=1e-9, atol=1e-9 * max(1.0, float(np.abs(val).max())))
 
 
-def test_reductions_match_the_oracle_bit_for_bit(fixed):
+@pytest.mark.parametrize("mexp_min", [None, "1"])
+def test_reductions_match_the_oracle_bit_for_bit(fixed, mexp_min, monkeypatch):
     """sum / mean / dot / @ / r@ / @= against the oracle's restatement of ipcl_python.py:746-930: the padded
     rotate-and-add tree (:810-827), the index maps (:777-808) and the per-row maximum-exponent alignment
-    (:868-870) fix the ciphertext bits and the exponents; mixed int / float inputs make the exponents differ."""
+    (:868-870) fix the ciphertext bits and the exponents; mixed int / float inputs make the exponents differ.
+    mexp_min = "1" sends every float matrix product through pai_ct_multiexp (large products take it by default)."""
+    if mexp_min is not None:
+        monkeypatch.setenv("PAI_MEXP_MIN_TERMS", mexp_min)
+        monkeypatch.setenv("PAI_MEXP_LANES", "3")                        # chunks of several members on these small shapes
     pk, sk, okey = fixed
     rng = np.random.default_rng(77)
     for N in (1, 2, 5, 8, 13):

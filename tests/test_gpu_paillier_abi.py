@@ -587,3 +587,53 @@ def test_buf_slice_and_rotate_are_row_copies():
         _native.check(lib.pai_stream_sync(0, None))
         assert np.array_equal(out.get(), np.roll(src, -shift, axis=0)), shift
     assert lib.pai_buf_rotate(0, ds.ptr, W, N, 1, ds.ptr, None) != 0          # in place is refused
+
+
+@pytest.mark.parametrize("bits,R,K,M,lanes", [(2048, 2, 37, 5, None), (2048, 1, 64, 3, "40"), (1024, 3, 9, 4, "7"), (2048, 1, 1, 1, None)])
+def test_ct_multiexp_matches_the_product_of_powers(bits, R, K, M, lanes, monkeypatch):
+    """pai_ct_multiexp: out[r*M + j] = prod_l base(r, l, j)^e[r][l][j] with the inverse's table where the sign byte is
+    set; exponents of up to 75 bits with zero windows, zeros and ones; PAI_MEXP_LANES forces chunks of several members
+    (shared squarings) on these small shapes."""
+    if lanes is not None:
+        monkeypatch.setenv("PAI_MEXP_LANES", lanes)
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    key = nk.key
+    rng = np.random.default_rng(1000 * R + K)
+    base = rand_below(rng, key.nsq, R * K)
+    base = [b if (b % key.p and b % key.q) else 3 for b in base]
+    inv = [pow(b, -1, key.nsq) for b in base]
+    ew = 3
+    e = [[[int.from_bytes(rng.bytes(10), "little") >> int(rng.integers(5, 80)) for _ in range(M)] for _ in range(K)] for _ in range(R)]
+    e[0][0][0] = 0
+    if K > 1:
+        e[0][1][0] = 1
+    sign = rng.integers(0, 2, size=(K, M)).astype(np.uint8)
+    ebits = max(1, max(v.bit_length() for a in e for b in a for v in b))
+    e_l = np.zeros((R, K, M, ew), dtype=np.uint32)
+    for r in range(R):
+        for l in range(K):
+            for j in range(M):
+                for w in range(ew):
+                    e_l[r, l, j, w] = (e[r][l][j] >> (32 * w)) & 0xFFFFFFFF
+    want = []
+    for r in range(R):
+        for j in range(M):
+            acc = 1
+            for l in range(K):
+                b = inv[r * K + l] if sign[l, j] else base[r * K + l]
+                acc = acc * pow(b, e[r][l][j], key.nsq) % key.nsq
+            want.append(acc)
+    dc, di, de, dsg = DevArray(ints_to_limbs(base, nk.cw)), DevArray(ints_to_limbs(inv, nk.cw)), DevArray(e_l), DevArray(sign)
+    out = DevArray(shape=(R * M, nk.cw))
+    _native.check(nk.lib.pai_ct_multiexp(nk.pk, dc.ptr, di.ptr, R, K, M, de.ptr, ew, ebits, dsg.ptr, out.ptr, None))
+    assert limbs_to_ints(out.get()) == want
+    # without signs: every base is the ciphertext itself
+    _native.check(nk.lib.pai_ct_multiexp(nk.pk, dc.ptr, None, R, K, M, de.ptr, ew, ebits, None, out.ptr, None))
+    want0 = []
+    for r in range(R):
+        for j in range(M):
+            acc = 1
+            for l in range(K):
+                acc = acc * pow(base[r * K + l], e[r][l][j], key.nsq) % key.nsq
+            want0.append(acc)
+    assert limbs_to_ints(out.get()) == want0
