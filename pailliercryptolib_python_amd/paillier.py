@@ -643,8 +643,14 @@ class PaillierEncryptedNumber:
         neg = mant_t < 0
         sign = inv = None
         if bool(neg.any().item()):
-            sign = neg.to(torch.uint8).contiguous()
-            inv = h.ct_invert(bases)
+            if M == 1:
+                # one column: every base is used with one sign only — swap the inverted ciphertexts in (half the tables)
+                rows = torch.nonzero(neg[:, 0].repeat(R)).reshape(-1)
+                bases = bases.clone()
+                bases[rows] = h.ct_invert(bases[rows].contiguous())
+            else:
+                sign = neg.to(torch.uint8).contiguous()
+                inv = h.ct_invert(bases)
         try:
             out = h.ct_multiexp(bases, inv, R, K, M, e_t, ebits, sign)
         except _native.NativeError as exc:
