@@ -79,5 +79,38 @@ while time.time() - t0 < budget:
         _native.check(lib.pai_ct_mul(nk.pk, dct.ptr, de.ptr, ew, ebits, 0, n2, oc.ptr, None))
         assert limbs_to_ints(oc.get()) == [pow(c, x, M) for c, x in zip(cts, e)], ("ct_mul", bits, n2, ebits, sw)
     os.environ.pop("PAI_LATENCY_MAX", None)
-    rounds += 1; checks += 8
+    # multi-exponentiation (keys the digit engine serves) with forced chunking, and pow2 on the digit engine
+    if bits <= 2048:
+        R, K, Mc = int(rng.integers(1, 4)), int(rng.integers(1, 24)), int(rng.integers(1, 6))
+        base = [x if (x % key.p and x % key.q) else 5 for x in pattern(M, R * K)]
+        inv = [pow(x, -1, M) for x in base]
+        eb = int(rng.choice([1, 7, 53, 64, 75, 100]))
+        ew2 = (eb + 31) // 32
+        ee = [[[int.from_bytes(rng.bytes(eb // 8 + 1), "little") % (1 << eb) for _ in range(Mc)] for _ in range(K)] for _ in range(R)]
+        sg = rng.integers(0, 2, size=(K, Mc)).astype(np.uint8)
+        e_l = np.zeros((R, K, Mc, ew2), dtype=np.uint32)
+        for r_ in range(R):
+            for l_ in range(K):
+                for j_ in range(Mc):
+                    for w_ in range(ew2): e_l[r_, l_, j_, w_] = (ee[r_][l_][j_] >> (32 * w_)) & 0xFFFFFFFF
+        os.environ["PAI_MEXP_LANES"] = str(int(rng.integers(1, 50)))
+        dcb, dib, deb, dsb = DevArray(ints_to_limbs(base, nk.cw)), DevArray(ints_to_limbs(inv, nk.cw)), DevArray(e_l), DevArray(sg)
+        ob = DevArray(shape=(R * Mc, nk.cw))
+        _native.check(lib.pai_ct_multiexp(nk.pk, dcb.ptr, dib.ptr, R, K, Mc, deb.ptr, ew2, eb, dsb.ptr, ob.ptr, None))
+        wantb = []
+        for r_ in range(R):
+            for j_ in range(Mc):
+                acc = 1
+                for l_ in range(K): acc = acc * pow(inv[r_ * K + l_] if sg[l_, j_] else base[r_ * K + l_], ee[r_][l_][j_], M) % M
+                wantb.append(acc)
+        assert limbs_to_ints(ob.get()) == wantb, ("multiexp", bits, R, K, Mc, eb)
+        os.environ["PAI_POW2_DIGIT_MIN"] = "1"
+        dl2 = rng.integers(-3, 63, N).astype(np.int32)
+        dd2 = DevArray(dl2); dc2 = DevArray(ints_to_limbs(a, nk.cw))
+        _native.check(lib.pai_ct_pow2(nk.pk, dc2.ptr, dd2.ptr, 0, N, None))
+        got2 = limbs_to_ints(dc2.get())
+        for i in range(0, N, max(1, N // 30)):
+            assert got2[i] == (pow(a[i], 1 << int(dl2[i]), M) if dl2[i] > 0 else a[i]), ("pow2_digit", bits, N, i)
+        os.environ.pop("PAI_POW2_DIGIT_MIN", None)
+    rounds += 1; checks += 10
 print(json.dumps({"rounds": rounds, "checks": checks, "seconds": round(time.time() - t0, 1), "failures": 0}))
