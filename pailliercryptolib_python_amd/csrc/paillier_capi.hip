@@ -1435,7 +1435,7 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
         require((d_sign == nullptr) == (d_ct_inv == nullptr), "signs and inverses come together");
         if (!pk->penc_nl) throw PaiError(PAI_E_UNSUPPORTED, "multi-exponentiation needs the base-n digit engine (keys up to 2048 bits)");
         const size_t G = R * M, bases = R * K;
-        require(G * K < ((size_t)1 << 31) && bases < ((size_t)1 << 28), "matrix product too large for one call");
+        if (G * K >= ((size_t)1 << 31) || bases >= ((size_t)1 << 28)) throw PaiError(PAI_E_UNSUPPORTED, "matrix product too large for one call");
         std::lock_guard<std::mutex> lk(pk->mu);
         DeviceScope scope_(pk->device);
         hipStream_t s = (hipStream_t)stream;
