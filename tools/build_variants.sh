@@ -52,3 +52,5 @@ ls -la $OUT
 # -DPAIR_G144=Geo<18,8,9,false> 44.0; Geo<18,8,3,false> 44.1; Geo<36,4,6,false> without prefetch 58.1 (spills).
 # PAI_DISABLE_PAIR=1 (products modulo n^2): 24.5 / 61.7.  Finishing as extra modes of k_encrypt instead of k_pair_finish
 # cost k_encrypt<36x8> 61 -> 94 ms.
+# Row-block size of the 36x4 lane-group kernels (tools/variant_tu.sh u12 geo_36x4 -DPAI_U_36X4=12): ct+ct 3.43 (6 rows) /
+# 3.65 (12) / 3.47 (4) ms per 2^20, k_pow2 (delta 12) 22.7 / 24.7 / 21.3, k_add_aligned 13.7 / 13.8 / 13.6: 6 rows kept.
