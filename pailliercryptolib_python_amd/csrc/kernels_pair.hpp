@@ -36,7 +36,8 @@ struct PairParams {
 // LDS: [c rows][d rows] ([limb][element] operand buffers, G::LDS_WORDS each), then the NL limbs of n - 1
 template <class G>
 struct PairLds {
-    static constexpr int BYTES = (2 * G::LDS_WORDS + G::NL) * 4;
+    static constexpr int BYTES = (2 * G::LDS_WORDS + 2 * G::NL) * 4;
+    PAI_DEV static uint32_t* mod(uint32_t* lds) { return lds + 2 * G::LDS_WORDS + G::NL; }   // modulus copy (NMLDS geometries)
     PAI_DEV static uint32_t* c(uint32_t* lds) { return lds; }
     PAI_DEV static uint32_t* d(uint32_t* lds) { return lds + G::LDS_WORDS; }
     PAI_DEV static uint32_t* nm1(uint32_t* lds) { return lds + 2 * G::LDS_WORDS; }
@@ -44,10 +45,21 @@ struct PairLds {
 
 template <class G>
 PAI_DEV void pair_setup(uint32_t* lds, const uint32_t* __restrict__ nm1) {
-    static_assert(!G::NMLDS, "the pair kernels keep the modulus slice in registers");
     uint32_t* dst = PairLds<G>::nm1(lds);
     for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) dst[i] = nm1[i];
     __syncthreads();
+}
+// this lane's view of the modulus: registers, or (NMLDS) a copy behind the operand buffers
+template <class G>
+PAI_DEV void pair_load_modulus(typename G::NM& nm, const MontCtx* __restrict__ ctx, uint32_t* lds) {
+    if constexpr (G::NMLDS) {
+        uint32_t* dst = PairLds<G>::mod(lds);
+        for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) dst[i] = ctx->n[i];
+        __syncthreads();
+        nm.p = dst + G::NLL * G::gl();
+    } else {
+        load_modulus<G>(nm, ctx, lds);
+    }
 }
 
 // this lane's slices of a raw digit pair [2][NL] (16-byte vectors when the slice length allows, else 8-byte)
@@ -119,7 +131,7 @@ k_pair_fb_chain(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ n
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     pair_setup<G>(lds, nm1);
     typename G::NM nm;
-    load_modulus<G>(nm, nctx, lds);
+    pair_load_modulus<G>(nm, nctx, lds);
     const uint32_t n0inv = nctx->n0inv;
     const int E1 = 1 << h;
     const int tiles = (nwin + G::EPB - 1) / G::EPB;
@@ -161,7 +173,7 @@ k_pair_fb_expand(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     pair_setup<G>(lds, nm1);
     typename G::NM nm;
-    load_modulus<G>(nm, nctx, lds);
+    pair_load_modulus<G>(nm, nctx, lds);
     const uint32_t n0inv = nctx->n0inv;
     const size_t half = (size_t)1 << h, per_window = half * half, total = (size_t)J * per_window;
     const size_t tiles = (total + G::EPB - 1) / G::EPB;
@@ -189,7 +201,7 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     pair_setup<G>(lds, P.nm1);
     typename G::NM nm;
-    load_modulus<G>(nm, P.nctx, lds);
+    pair_load_modulus<G>(nm, P.nctx, lds);
     const uint32_t n0inv = P.nctx->n0inv;
     const int tiles = (n + G::EPB - 1) / G::EPB;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {

@@ -54,3 +54,5 @@ ls -la $OUT
 # cost k_encrypt<36x8> 61 -> 94 ms.
 # Row-block size of the 36x4 lane-group kernels (tools/variant_tu.sh u12 geo_36x4 -DPAI_U_36X4=12): ct+ct 3.43 (6 rows) /
 # 3.65 (12) / 3.47 (4) ms per 2^20, k_pow2 (delta 12) 22.7 / 24.7 / 21.3, k_add_aligned 13.7 / 13.8 / 13.6: 6 rows kept.
+# 144-limb pair kernel on 4 lanes x 36 with the modulus slice re-read from LDS (-DPAIR_G144=Geo<36,4,6,true>): 55.8 ms
+# without / 57.8 with the table prefetch, 12-row blocks 93.4 (1.4-1.8 KB of scratch per lane either way) vs 45.7 for 8 x 18.
