@@ -615,6 +615,7 @@ struct MexpPadicParams {
     int nd, ct_words;
     int R, K, M, chunk, nsigns;
     int e_words, ebits_max;
+    int by_rows;                 // lane order inside a chunk: 0 = (r, j) with j fastest, 1 = (j, r) with r fastest
 };
 constexpr int MEXP_WBITS = 4, MEXP_NT = 1 << MEXP_WBITS;
 
@@ -712,7 +713,10 @@ k_mexp_padic(MexpPadicParams P, const uint32_t* __restrict__ e, const uint8_t* _
         const int idx = tile * BLOCK_THREADS + threadIdx.x;
         const bool live = idx < nlanes;
         const int is = live ? idx : nlanes - 1;
-        const int ch = is / G, g = is - ch * G, r = g / P.M, j = g - r * P.M;
+        // lanes of a wave walk the output columns of one row (they share their bases' tables), or — by_rows — the rows
+        // of one column (they share the multipliers, so their windows line up when the rows' exponents agree)
+        const int ch = is / G, g = is - ch * G;
+        const int r = P.by_rows ? g % P.R : g / P.M, j = P.by_rows ? g / P.R : g - (g / P.M) * P.M;
         const int l0 = ch * P.chunk, l1 = min(P.K, l0 + P.chunk);
         // the longest chunk of the wave sets the trip count (chunks are equal except the last)
         const int lcount = P.chunk;
@@ -782,7 +786,7 @@ k_mexp_padic(MexpPadicParams P, const uint32_t* __restrict__ e, const uint8_t* _
         cond_sub_2nl<E>(A, B, P.nsq);
         cond_sub_2nl<E>(A, B, P.nsq);
         if (live) {
-            uint32_t* orow = out + (size_t)idx * P.ct_words;
+            uint32_t* orow = out + ((size_t)ch * G + (size_t)r * P.M + j) * P.ct_words;
 #pragma unroll 1
             for (int k2 = 0; k2 < P.ct_words; ++k2) {
                 const int j0 = (32 * k2) / RB, s0 = 32 * k2 - RB * j0;

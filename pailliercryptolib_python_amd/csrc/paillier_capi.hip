@@ -1468,6 +1468,8 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
         Q.R = (int)R; Q.K = (int)K; Q.M = (int)M; Q.chunk = (int)chunk; Q.nsigns = nsigns;
         Q.e_words = e_words;
         Q.ebits_max = ebits_max;
+        Q.by_rows = 0;
+        if (const char* env = std::getenv("PAI_MEXP_BY_ROWS")) Q.by_rows = env[0] == '1';
         g_last_times.clear();
         pk->order.begin(s);
         {

@@ -56,3 +56,5 @@ ls -la $OUT
 # 3.65 (12) / 3.47 (4) ms per 2^20, k_pow2 (delta 12) 22.7 / 24.7 / 21.3, k_add_aligned 13.7 / 13.8 / 13.6: 6 rows kept.
 # 144-limb pair kernel on 4 lanes x 36 with the modulus slice re-read from LDS (-DPAIR_G144=Geo<36,4,6,true>): 55.8 ms
 # without / 57.8 with the table prefetch, 12-row blocks 93.4 (1.4-1.8 KB of scratch per lane either way) vs 45.7 for 8 x 18.
+# pai_ct_multiexp lane order (PAI_MEXP_BY_ROWS=1: lanes of a wave walk the rows of one output column instead of the columns
+# of one row): 64x1024 @ 1024x64 0.0986 vs 0.0967 s, 1024x64 @ 64x64 0.1004 vs 0.1009 s — no difference, columns kept.
