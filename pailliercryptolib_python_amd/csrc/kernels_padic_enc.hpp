@@ -599,9 +599,9 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
 // ---- multi-exponentiation: out[r][j] = prod_l base[r][l]^(e[r][l][j]) mod n^2 ---------------------------------------------
 // The matrix products of the API (PaillierEncryptedNumber.__matmul__ / __rmatmul__ / dot, ipcl_python.py:829-930) are sums
 // of ciphertext * plaintext terms, i.e. products of powers that share their bases across the output columns and their
-// squarings across the members of a sum (Straus): every base gets a table of its powers 0 .. 15 once
+// squarings across the members of a sum (Straus): every base gets a table of its powers 0 .. 2^w - 1 once
 // (k_mexp_table_padic; both the ciphertext and, for negative multipliers, its inverse), and a lane computes the partial
-// product over a chunk of members for one output element with ONE chain of squarings: per 4-bit window, four squarings,
+// product over a chunk of members for one output element with ONE chain of squarings: per w-bit window, w squarings,
 // then one table product per member.  ct * pt on its own spends 52 squarings + ~28 products per term; here a term costs
 // ~14-20 table products.  The partial products leave as canonical residues [chunk][r * M + j] for pai_ct_prod.
 struct MexpPadicParams {
@@ -611,13 +611,13 @@ struct MexpPadicParams {
     const uint32_t* kdig;        // [nd][2][NL]
     const uint32_t* one_dig;     // [2][NL]
     uint4* mscratch;
-    uint4* table;                // [R * K][nsigns][16][2][NC]
+    uint4* table;                // [R * K][nsigns][2^wbits][2][NC]
     int nd, ct_words;
     int R, K, M, chunk, nsigns;
     int e_words, ebits_max;
     int by_rows;                 // lane order inside a chunk: 0 = (r, j) with j fastest, 1 = (j, r) with r fastest
+    int wbits;                   // window width (2 .. 7): tables of 2^wbits powers per base and sign
 };
-constexpr int MEXP_WBITS = 4, MEXP_NT = 1 << MEXP_WBITS;
 
 // one lane per (base, sign): powers 0 .. 15 of the ciphertext (sign 0) or of its inverse (sign 1), digit form
 template <int NL, int U>
@@ -648,7 +648,8 @@ k_mexp_table_padic(MexpPadicParams P, const uint32_t* __restrict__ ct, const uin
         const int is = live ? idx : nlanes - 1;
         const int b = is / P.nsigns, sg = is - b * P.nsigns;
         const uint32_t* row = (sg ? ct_inv : ct) + (size_t)b * P.ct_words;
-        uint4* ent = P.table + (size_t)is * MEXP_NT * 2 * E::NC;          // [d][2][NC]
+        const int NT = 1 << P.wbits;
+        uint4* ent = P.table + (size_t)is * NT * 2 * E::NC;               // [d][2][NC]
         padic_to_digit_form<E>(A, B, M, row, P.ct_words, P.kdig, P.nd, nm, nm1, n0inv);
         if (live) {
 #pragma unroll 1
@@ -671,7 +672,7 @@ k_mexp_table_padic(MexpPadicParams P, const uint32_t* __restrict__ ct, const uin
             };
         };
 #pragma unroll 1
-        for (int d = 2; d < MEXP_NT; ++d) {
+        for (int d = 2; d < NT; ++d) {
             E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_x(0), from_x(1), nm, nm1, n0inv);
             if (live) {
 #pragma unroll 1
@@ -707,7 +708,8 @@ k_mexp_padic(MexpPadicParams P, const uint32_t* __restrict__ e, const uint8_t* _
     const typename E::MBuf M{P.mscratch + slot, nslots};
     const typename E::MBuf Wb{P.mscratch + (size_t)E::NC * nslots + slot, nslots};
     const int G = P.R * P.M;
-    const int nwin = (P.ebits_max + MEXP_WBITS - 1) / MEXP_WBITS;
+    const int W = P.wbits, NT = 1 << W;
+    const int nwin = (P.ebits_max + W - 1) / W;
     const int tiles = (nlanes + BLOCK_THREADS - 1) / BLOCK_THREADS;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int idx = tile * BLOCK_THREADS + threadIdx.x;
@@ -732,20 +734,21 @@ k_mexp_padic(MexpPadicParams P, const uint32_t* __restrict__ e, const uint8_t* _
         for (int wi = nwin - 1; wi >= 0; --wi) {
             if (started) {
 #pragma unroll 1
-                for (int sq = 0; sq < MEXP_WBITS; ++sq) E::template sqr_rolled_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);
+                for (int sq = 0; sq < W; ++sq) E::template sqr_rolled_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);
             }
-            const int bit = wi * MEXP_WBITS, k = bit >> 5, sh = bit & 31;        // a 4-bit window never straddles a word
+            const int bit = wi * W, k = bit >> 5, sh = bit & 31;
 #pragma unroll 1
             for (int li = 0; li < lcount; ++li) {
                 const int l = l0 + li;
                 const bool has = live && l < l1;
                 const int ls = l < P.K ? l : P.K - 1;
                 const size_t eoff = (((size_t)r * P.K + ls) * P.M + j) * P.e_words;
-                const uint32_t word = k < P.e_words ? e[eoff + k] : 0u;
-                const int d = has ? (int)((word >> sh) & (MEXP_NT - 1)) : 0;
+                uint64_t bits2 = k < P.e_words ? e[eoff + k] : 0u;
+                if (k + 1 < P.e_words) bits2 |= (uint64_t)e[eoff + k + 1] << 32;
+                const int d = has ? (int)((uint32_t)(bits2 >> sh) & (uint32_t)(NT - 1)) : 0;
                 if (__any(d != 0)) {
                     const int sg = (sign && P.nsigns > 1) ? (int)sign[(size_t)ls * P.M + j] : 0;
-                    const uint4* ent = P.table + ((((size_t)r * P.K + ls) * P.nsigns + sg) * MEXP_NT + d) * 2 * E::NC;
+                    const uint4* ent = P.table + ((((size_t)r * P.K + ls) * P.nsigns + sg) * NT + d) * 2 * E::NC;
                     auto from_ent = [&](int dg) {
                         return [=](int blk, uint32_t (&xv)[U]) {
 #pragma unroll

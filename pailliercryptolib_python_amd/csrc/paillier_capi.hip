@@ -1380,7 +1380,8 @@ static void tree_mul(const pai_pubkey* pk, hipStream_t s, const uint32_t* a, con
 }
 
 // the caller holds pk->mu and has selected the device
-static void ct_prod_locked(const pai_pubkey* pk, hipStream_t s, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out) {
+static void ct_prod_locked(const pai_pubkey* pk, hipStream_t s, const uint32_t* d_ct, size_t count, size_t groups, uint32_t* d_out,
+                           bool clear_times = true) {
     {
         const size_t W = (size_t)pk->ct_words, ROW = W * 4;
         size_t members = count / groups;
@@ -1395,7 +1396,7 @@ static void ct_prod_locked(const pai_pubkey* pk, hipStream_t s, const uint32_t* 
         pk->prod_a.ensure(h0 * groups * ROW);
         pk->prod_b.ensure(((h0 + 1) / 2) * groups * ROW);
         pk->order.begin(s);
-        g_last_times.clear();
+        if (clear_times) g_last_times.clear();
         ScopedKernelTimer t("k_modmul(tree)", s);
         const uint32_t* src = d_ct;
         uint32_t* bufs[2] = {pk->prod_a.as<uint32_t>(), pk->prod_b.as<uint32_t>()};
@@ -1448,9 +1449,22 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
         chunk = std::min(chunk, K);
         const size_t chunks = (K + chunk - 1) / chunk;
         const size_t nlanes = chunks * G;
-        const size_t table_bytes = bases * nsigns * MEXP_NT * 2 * (size_t)pnl * 4;
         size_t mem_free = 0, mem_total = 0;
         HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
+        // window width: a term costs ebits / w table products and every base (2^w - 2) products per sign for its table,
+        // which M output columns share; the widest tables must fit 1/16 of the device memory
+        int wbits = 2;
+        {
+            double best = 1e300;
+            for (int w = 2; w <= 7; ++w) {
+                const double tb = (double)bases * nsigns * (double)((size_t)1 << w) * 2.0 * pnl * 4.0;
+                if (w > 2 && tb > (double)mem_total / 16.0) break;
+                const double cost = (double)((ebits_max + w - 1) / w) + (double)nsigns * (double)(((size_t)1 << w) - 2) / (double)M;
+                if (cost < best) { best = cost; wbits = w; }
+            }
+            if (const char* env = std::getenv("PAI_MEXP_WBITS")) { const int v = std::atoi(env); if (v >= 1 && v <= 8) wbits = v; }
+        }
+        const size_t table_bytes = bases * nsigns * ((size_t)1 << wbits) * 2 * (size_t)pnl * 4;
         if (table_bytes > mem_total / 8 || table_bytes + nlanes * (size_t)pk->ct_words * 4 > mem_free + pk->mexp_table.bytes + pk->mexp_partial.bytes)
             throw PaiError(PAI_E_UNSUPPORTED, "power tables of this matrix product do not fit the device");
         pk->mexp_table.ensure(table_bytes);
@@ -1469,6 +1483,7 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
         Q.e_words = e_words;
         Q.ebits_max = ebits_max;
         Q.by_rows = 0;
+        Q.wbits = wbits;
         if (const char* env = std::getenv("PAI_MEXP_BY_ROWS")) Q.by_rows = env[0] == '1';
         g_last_times.clear();
         pk->order.begin(s);
@@ -1490,7 +1505,7 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
             HIP_CHECK(hipGetLastError());
         }
         pk->order.end(s);
-        ct_prod_locked(pk, s, pk->mexp_partial.as<uint32_t>(), nlanes, G, d_out);
+        ct_prod_locked(pk, s, pk->mexp_partial.as<uint32_t>(), nlanes, G, d_out, false);
     });
 }
 

@@ -589,13 +589,16 @@ def test_buf_slice_and_rotate_are_row_copies():
     assert lib.pai_buf_rotate(0, ds.ptr, W, N, 1, ds.ptr, None) != 0          # in place is refused
 
 
-@pytest.mark.parametrize("bits,R,K,M,lanes", [(2048, 2, 37, 5, None), (2048, 1, 64, 3, "40"), (1024, 3, 9, 4, "7"), (2048, 1, 1, 1, None)])
-def test_ct_multiexp_matches_the_product_of_powers(bits, R, K, M, lanes, monkeypatch):
+@pytest.mark.parametrize("bits,R,K,M,lanes,wbits", [(2048, 2, 37, 5, None, None), (2048, 1, 64, 3, "40", "5"), (1024, 3, 9, 4, "7", "3"),
+                                                    (2048, 1, 1, 1, None, "1"), (2048, 2, 11, 7, "9", "7"), (1024, 1, 20, 2, "5", "6")])
+def test_ct_multiexp_matches_the_product_of_powers(bits, R, K, M, lanes, wbits, monkeypatch):
     """pai_ct_multiexp: out[r*M + j] = prod_l base(r, l, j)^e[r][l][j] with the inverse's table where the sign byte is
     set; exponents of up to 75 bits with zero windows, zeros and ones; PAI_MEXP_LANES forces chunks of several members
-    (shared squarings) on these small shapes."""
+    (shared squarings) on these small shapes, PAI_MEXP_WBITS the table width (windows that straddle exponent words)."""
     if lanes is not None:
         monkeypatch.setenv("PAI_MEXP_LANES", lanes)
+    if wbits is not None:
+        monkeypatch.setenv("PAI_MEXP_WBITS", wbits)                     # the default follows the shape (2 .. 7 bits)
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     key = nk.key
     rng = np.random.default_rng(1000 * R + K)

@@ -26,6 +26,17 @@ for name, env in (("multiexp", None), ("term_by_term", str(1 << 60))):
     out[name] = {"s": round(t, 4), "terms_per_s": round(m * n * k / t), "checksum": int(r.words.to(torch.int64).sum().item()),
                  "expo_sum": int(np.asarray(r.exponent()).astype(np.int64).sum())}
     if env is None:
+        import pailliercryptolib_python_amd.paillier as _pm
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _orig = engine.PublicKeyHandle.ct_multiexp
+        tt = {}
+        def _timed(self, *a, **kw):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            r_ = _orig(self, *a, **kw); torch.cuda.synchronize(); tt["ct_multiexp_s"] = round(time.perf_counter() - t1, 4); return r_
+        engine.PublicKeyHandle.ct_multiexp = _timed
+        en @ w; torch.cuda.synchronize(); tt["total_s"] = round(time.perf_counter() - t0, 4)
+        engine.PublicKeyHandle.ct_multiexp = _orig
+        out[name]["split"] = tt
         engine.profile_enable(True); en @ w; out[name]["kernels_ms"] = {a: round(b, 2) for a, b in engine.profile_last().items()}; engine.profile_enable(False)
 big = pk.encrypt(rng.uniform(-10, 10, 1 << 20))
 v = rng.standard_normal(1 << 20)
