@@ -148,8 +148,8 @@ int pai_ct_prod(const pai_pubkey* pk, const uint32_t* d_ct, size_t count, size_t
  * (negative multipliers, ipcl_python.py:426-437); e = |mantissa| << alignment shift, e_words words each, little endian,
  * laid out [R][K][M][e_words]; ebits_max bounds every exponent.  d_sign and d_ct_inv are both NULL or both given.
  * One chain of squarings per output element and chunk of members instead of one per term (Straus; windows of 2..7 bits
- * over per-base power tables built on the fly, the width chosen from the shape).  Keys the base-n digit engine serves (n up to 2048 bits) only:
- * PAI_E_UNSUPPORTED otherwise, or when the power tables (2^w digit pairs per base and sign) do not fit — the caller then takes
+ * over per-base power tables built on the fly, the width chosen from the shape; on base-n digit pairs for keys up to 2048 bits,
+ * on lane groups above).  PAI_E_UNSUPPORTED when the power tables (2^w entries per base and sign) do not fit — the caller then takes
  * the term-by-term route (pai_ct_mul + pai_ct_add_aligned / pai_ct_prod).  The bits equal that route's: the result is the
  * canonical residue of the same product. */
 int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_ct_inv, size_t R, size_t K, size_t M,

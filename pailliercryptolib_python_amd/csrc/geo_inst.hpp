@@ -82,11 +82,21 @@ struct GeoInst {
         set_lds((const void*)k_add_aligned<GM>, bytes);
         hipLaunchKernelGGL(k_add_aligned<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, b_bcast, delta, out, n, w32);
     }
+    static void mexp_table(hipStream_t s, int grid, const MontCtx* c, const uint32_t* ct, const uint32_t* ct_inv, int w32,
+                           uint32_t* table, int nentries, int nsigns, int wbits) {
+        set_lds((const void*)k_mexp_table<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_mexp_table<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, ct, ct_inv, w32, table, nentries, nsigns, wbits);
+    }
+    static void mexp(hipStream_t s, int grid, const MontCtx* c, MexpParams P, const uint32_t* table, const uint32_t* e,
+                     const uint8_t* sign, uint32_t* out, int nlanes) {
+        set_lds((const void*)k_mexp<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_mexp<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, P, table, e, sign, out, nlanes);
+    }
     static size_t table_words(size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * G::NL * blocks * G::EPB; }
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &add_aligned, &table_words, &pair_finish};
+                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &add_aligned, &table_words, &pair_finish, &mexp_table, &mexp};
         return &o;
     }
 };

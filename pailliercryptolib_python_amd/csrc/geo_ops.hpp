@@ -42,6 +42,11 @@ struct GeoOps {
     // ct = w + v n [or ct_in (w + v n)] from the plain digit pairs of the lane-group pair kernels (rows [2][wv_words])
     void (*pair_finish)(hipStream_t, int grid, EncParams, const uint32_t* wv, int wv_words, const uint32_t* ct_in,
                         uint32_t* ct_out, int n, int mul_ct);
+    // multi-exponentiation (k_mexp_table / k_mexp): power tables per (base, sign), then chunks of members per output
+    void (*mexp_table)(hipStream_t, int grid, const MontCtx*, const uint32_t* ct, const uint32_t* ct_inv, int w32, uint32_t* table,
+                       int nentries, int nsigns, int wbits);
+    void (*mexp)(hipStream_t, int grid, const MontCtx*, MexpParams, const uint32_t* table, const uint32_t* e, const uint8_t* sign,
+                 uint32_t* out, int nlanes);
 };
 
 const GeoOps* geo_ops_36x1();

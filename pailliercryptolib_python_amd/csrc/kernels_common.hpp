@@ -10,6 +10,11 @@ namespace pai {
 constexpr int BLOCK_THREADS = 256;
 constexpr int MODMUL_FULL = 0, MODMUL_MONT = 1;      // k_modmul modes (kernels_modexp.hpp)
 
+// shape of a multi-exponentiation on the lane-group engine (kernels_modexp.hpp: k_mexp)
+struct MexpParams {
+    int R, K, M, chunk, nsigns, e_words, ebits_max, wbits, w32;
+};
+
 // Geometry of one kernel instance: NLL limbs per lane, T lanes per element, U rows per block,
 // NMLDS = the modulus slice is re-read from LDS during the q*n step instead of living in VGPRs.
 template <int NLL_, int T_, int U_, bool NMLDS_ = false>

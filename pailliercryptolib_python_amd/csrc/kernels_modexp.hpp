@@ -343,4 +343,113 @@ k_modexp_var_win(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ b
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-exponentiation on the lane-group engine (keys the base-n digit engine does not serve; see k_mexp_padic in
+// kernels_padic_enc.hpp for the scheme): per (base, sign) a table of the powers 0 .. 2^wbits - 1 in Montgomery form (raw
+// radix-29 rows of NL limbs), then one lane group per (chunk of members, output element) with one chain of squarings.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_mexp_table(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ ct_inv, int w32,
+             uint32_t* __restrict__ table, int nentries, int nsigns, int wbits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int t = G::gl();
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t n0inv = ctx->n0inv;
+    const int NT = 1 << wbits;
+    const int tiles = (nentries + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int idx = tile * G::EPB + G::elem();
+        const bool live = idx < nentries;
+        const int is = live ? idx : nentries - 1;
+        const int b = is / nsigns, sg = is - b * nsigns;
+        uint32_t* ent = table + (size_t)is * NT * G::NL + G::NLL * t;
+        uint32_t bR[G::NLL], x[G::NLL], c[G::NLL];
+        load_elem<G>(bR, (sg ? ct_inv : ct) + (size_t)b * w32, w32);
+        load_const_slice<G>(c, ctx->r2);
+        mm_times<G>(bR, c, lds, nm, n0inv);
+        load_const_slice<G>(c, ctx->one);
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) x[j] = bR[j];
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) { ent[j] = c[j]; ent[G::NL + j] = bR[j]; }
+        }
+#pragma unroll 1
+        for (int k = 2; k < NT; ++k) {
+            mm_times<G>(x, bR, lds, nm, n0inv);
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) ent[(size_t)k * G::NL + j] = x[j];
+            }
+        }
+    }
+}
+
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_mexp(const MontCtx* __restrict__ ctx, MexpParams P, const uint32_t* __restrict__ table, const uint32_t* __restrict__ e,
+       const uint8_t* __restrict__ sign, uint32_t* __restrict__ out, int nlanes) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int t = G::gl();
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t n0inv = ctx->n0inv;
+    const int W = P.wbits, NT = 1 << W;
+    const int nwin = (P.ebits_max + W - 1) / W;
+    const int Gn = P.R * P.M;
+    const int tiles = (nlanes + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int idx = tile * G::EPB + G::elem();
+        const bool live = idx < nlanes;
+        const int is = live ? idx : nlanes - 1;
+        const int ch = is / Gn, g = is - ch * Gn, r = g / P.M, j = g - r * P.M;
+        const int l0 = ch * P.chunk, l1 = min(P.K, l0 + P.chunk);
+        uint32_t x[G::NLL];
+        load_const_slice<G>(x, ctx->one);
+        bool started = false;                         // wave-uniform: only ones so far
+#pragma unroll 1
+        for (int wi = nwin - 1; wi >= 0; --wi) {
+            if (started) {
+#pragma unroll 1
+                for (int sq = 0; sq < W; ++sq) mm_square<G>(x, lds, nm, n0inv);
+            }
+            const int bit = wi * W, k = bit >> 5, sh = bit & 31;
+#pragma unroll 1
+            for (int li = 0; li < P.chunk; ++li) {
+                const int l = l0 + li;
+                const bool has = live && l < l1;
+                const int ls = l < P.K ? l : P.K - 1;
+                const size_t eoff = (((size_t)r * P.K + ls) * P.M + j) * P.e_words;
+                uint64_t bits2 = k < P.e_words ? e[eoff + k] : 0u;
+                if (k + 1 < P.e_words) bits2 |= (uint64_t)e[eoff + k + 1] << 32;
+                const int d = has ? (int)((uint32_t)(bits2 >> sh) & (uint32_t)(NT - 1)) : 0;
+                if (__any(d != 0)) {
+                    const int sg = (sign && P.nsigns > 1) ? (int)sign[(size_t)ls * P.M + j] : 0;
+                    const uint32_t* ent = table + ((((size_t)r * P.K + ls) * P.nsigns + sg) * NT + d) * G::NL + G::NLL * t;
+                    uint32_t y[G::NLL];
+                    if constexpr (G::NLL % 4 == 0) {                 // limb slices move as 16-byte vectors
+                        const uint4* e4 = reinterpret_cast<const uint4*>(ent);
+#pragma unroll
+                        for (int c = 0; c < G::NLL / 4; ++c) {
+                            const uint4 v = e4[c];
+                            y[4 * c] = v.x; y[4 * c + 1] = v.y; y[4 * c + 2] = v.z; y[4 * c + 3] = v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < G::NLL; ++jj) y[jj] = ent[jj];
+                    }
+                    mm_times<G>(x, y, lds, nm, n0inv);
+                    started = true;
+                }
+            }
+        }
+        uint32_t one[G::NLL];
+        set_plain_one<G>(one);
+        mm_times<G>(x, one, lds, nm, n0inv);
+        cond_sub<G::NLL, G::T>(x, nm);
+        if (live) store_elem<G>(x, out + (size_t)idx * P.w32, P.w32, lds);
+    }
+}
+
 }  // namespace pai

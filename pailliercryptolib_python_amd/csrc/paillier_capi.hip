@@ -1434,16 +1434,20 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
         require(pk && d_ct && d_e && d_out, "NULL argument");
         require(R > 0 && K > 0 && M > 0 && e_words > 0 && ebits_max > 0 && ebits_max <= 32 * e_words, "bad shape");
         require((d_sign == nullptr) == (d_ct_inv == nullptr), "signs and inverses come together");
-        if (!pk->penc_nl) throw PaiError(PAI_E_UNSUPPORTED, "multi-exponentiation needs the base-n digit engine (keys up to 2048 bits)");
         const size_t G = R * M, bases = R * K;
         if (G * K >= ((size_t)1 << 31) || bases >= ((size_t)1 << 28)) throw PaiError(PAI_E_UNSUPPORTED, "matrix product too large for one call");
         std::lock_guard<std::mutex> lk(pk->mu);
         DeviceScope scope_(pk->device);
         hipStream_t s = (hipStream_t)stream;
-        const int pnl = pk->penc_nl, nsigns = d_sign ? 2 : 1;
+        const GeoOps* lg = pk->msq.geo;                   // lane-group engine when the digit engine does not serve the key
+        const bool digit = pk->penc_nl != 0;
+        const int nsigns = d_sign ? 2 : 1;
+        // words of one table entry: a digit pair of 2 pnl limbs, or a Montgomery residue of nl limbs
+        const int pnl = digit ? pk->penc_nl : (lg->nl + 1) / 2;
+        const int lanes_per_wg = digit ? BLOCK_THREADS : lg->epb;
         // members per lane: enough lanes to fill the device (one workgroup of 256 lanes per CU, several rounds), the
         // rest of the sharing goes into longer chunks (the squarings are shared by a chunk)
-        size_t want_lanes = (size_t)pk->dev.ncu * BLOCK_THREADS * 2;
+        size_t want_lanes = (size_t)pk->dev.ncu * lanes_per_wg * (digit ? 2 : 4);
         if (const char* env = std::getenv("PAI_MEXP_LANES")) { const size_t v = (size_t)std::strtoull(env, nullptr, 10); if (v) want_lanes = v; }
         size_t chunk = std::max<size_t>(1, (G * K + want_lanes - 1) / want_lanes);
         chunk = std::min(chunk, K);
@@ -1469,40 +1473,62 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
             throw PaiError(PAI_E_UNSUPPORTED, "power tables of this matrix product do not fit the device");
         pk->mexp_table.ensure(table_bytes);
         pk->mexp_partial.ensure(nlanes * (size_t)pk->ct_words * 4);
-        MexpPadicParams Q;
-        Q.nctx = pk->nmod.d_ctx;
-        Q.nm1 = pk->d_nm1;
-        Q.nsq = pk->d_nsq29;
-        Q.kdig = pk->d_ct_kdig;
-        Q.one_dig = pk->d_one_dig;
-        Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
-        Q.table = pk->mexp_table.as<uint4>();
-        Q.nd = pk->ct_nd;
-        Q.ct_words = pk->ct_words;
-        Q.R = (int)R; Q.K = (int)K; Q.M = (int)M; Q.chunk = (int)chunk; Q.nsigns = nsigns;
-        Q.e_words = e_words;
-        Q.ebits_max = ebits_max;
-        Q.by_rows = 0;
-        Q.wbits = wbits;
-        if (const char* env = std::getenv("PAI_MEXP_BY_ROWS")) Q.by_rows = env[0] == '1';
         g_last_times.clear();
         pk->order.begin(s);
-        {
-            const size_t tl = bases * nsigns, tiles = (tl + BLOCK_THREADS - 1) / BLOCK_THREADS;
-            const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
-            ScopedKernelTimer t("k_mexp_table", s);
-            if (!launch_mexp_table_padic(pnl, s, grid, Q, d_ct, d_ct_inv, (int)tl))
-                throw PaiError(PAI_E_INTERNAL, "no multi-exponentiation kernel for this limb count");
-            t.stop();
-            HIP_CHECK(hipGetLastError());
-        }
-        {
-            const size_t tiles = (nlanes + BLOCK_THREADS - 1) / BLOCK_THREADS;
-            const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
-            ScopedKernelTimer t("k_mexp", s);
-            launch_mexp_padic(pnl, s, grid, Q, d_e, d_sign, pk->mexp_partial.as<uint32_t>(), (int)nlanes);
-            t.stop();
-            HIP_CHECK(hipGetLastError());
+        if (digit) {
+            MexpPadicParams Q;
+            Q.nctx = pk->nmod.d_ctx;
+            Q.nm1 = pk->d_nm1;
+            Q.nsq = pk->d_nsq29;
+            Q.kdig = pk->d_ct_kdig;
+            Q.one_dig = pk->d_one_dig;
+            Q.mscratch = reinterpret_cast<uint4*>(pk->d_mscratch);
+            Q.table = pk->mexp_table.as<uint4>();
+            Q.nd = pk->ct_nd;
+            Q.ct_words = pk->ct_words;
+            Q.R = (int)R; Q.K = (int)K; Q.M = (int)M; Q.chunk = (int)chunk; Q.nsigns = nsigns;
+            Q.e_words = e_words;
+            Q.ebits_max = ebits_max;
+            Q.by_rows = 0;
+            Q.wbits = wbits;
+            if (const char* env = std::getenv("PAI_MEXP_BY_ROWS")) Q.by_rows = env[0] == '1';
+            {
+                const size_t tl = bases * nsigns, tiles = (tl + BLOCK_THREADS - 1) / BLOCK_THREADS;
+                const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+                ScopedKernelTimer t("k_mexp_table", s);
+                if (!launch_mexp_table_padic(pnl, s, grid, Q, d_ct, d_ct_inv, (int)tl))
+                    throw PaiError(PAI_E_INTERNAL, "no multi-exponentiation kernel for this limb count");
+                t.stop();
+                HIP_CHECK(hipGetLastError());
+            }
+            {
+                const size_t tiles = (nlanes + BLOCK_THREADS - 1) / BLOCK_THREADS;
+                const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+                ScopedKernelTimer t("k_mexp", s);
+                launch_mexp_padic(pnl, s, grid, Q, d_e, d_sign, pk->mexp_partial.as<uint32_t>(), (int)nlanes);
+                t.stop();
+                HIP_CHECK(hipGetLastError());
+            }
+        } else {
+            // lane-group engine (keys above 2048 bits): Montgomery residues modulo n^2 as table entries
+            MexpParams P;
+            P.R = (int)R; P.K = (int)K; P.M = (int)M; P.chunk = (int)chunk; P.nsigns = nsigns;
+            P.e_words = e_words; P.ebits_max = ebits_max; P.wbits = wbits; P.w32 = pk->ct_words;
+            {
+                const size_t tl = bases * nsigns;
+                ScopedKernelTimer t("k_mexp_table", s);
+                lg->mexp_table(s, grid_for(lg, tl, pk->dev.ncu), pk->msq.d_ctx, d_ct, d_ct_inv, pk->ct_words, pk->mexp_table.as<uint32_t>(),
+                               (int)tl, nsigns, wbits);
+                t.stop();
+                HIP_CHECK(hipGetLastError());
+            }
+            {
+                ScopedKernelTimer t("k_mexp", s);
+                lg->mexp(s, grid_for(lg, nlanes, pk->dev.ncu), pk->msq.d_ctx, P, pk->mexp_table.as<uint32_t>(), d_e, d_sign,
+                         pk->mexp_partial.as<uint32_t>(), (int)nlanes);
+                t.stop();
+                HIP_CHECK(hipGetLastError());
+            }
         }
         pk->order.end(s);
         ct_prod_locked(pk, s, pk->mexp_partial.as<uint32_t>(), nlanes, G, d_out, false);

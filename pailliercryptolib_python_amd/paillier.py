@@ -600,8 +600,7 @@ class PaillierEncryptedNumber:
             min_terms = int(os.environ.get("PAI_MEXP_MIN_TERMS", self.MEXP_MIN_TERMS))
         except ValueError:
             min_terms = self.MEXP_MIN_TERMS
-        if m * n * k < min_terms or other.dtype.kind != "f" or self.public_key.n.bit_length() > 2048 + 20 \
-                or self.public_key.n.bit_length() <= 66:
+        if m * n * k < min_terms or other.dtype.kind != "f" or self.public_key.n.bit_length() <= 66:
             return None
         dev = h.device
         if rhs:

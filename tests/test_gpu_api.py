@@ -305,6 +305,32 @@ def test_reductions_match_the_oracle_bit_for_bit(fixed, mexp_min, monkeypatch):
         assert np.allclose(np.array(sk.decrypt(resi)).reshape(m, k), x @ yi)
 
 
+@pytest.mark.parametrize("bits", [1024, 3072, 4096])
+def test_matrix_product_routes_agree_at_other_key_sizes(bits, monkeypatch):
+    """`@`, `r@` and dot through pai_ct_multiexp (base-n digit pairs up to 2048-bit keys, lane groups above) give the
+    bits and exponents of the term-by-term route, and decrypt to the plain product."""
+    from tests.test_gpu_paillier_abi import seeded_key
+    okey = seeded_key(bits)
+    pk = PaillierPublicKey(ipclPublicKey(okey.n, bits, True, hs=okey.hs, randbits=okey.randbits))
+    sk = PaillierPrivateKey(pk, okey.p, okey.q)
+    rng = np.random.default_rng(bits)
+    m, n, k = 3, 7, 4
+    x, y = rng.uniform(-10, 10, (m, n)), rng.standard_normal((n, k))
+    y[2, 1] = 0.0
+    en = pk.encrypt(x.flatten())
+    en_y = pk.encrypt(y.flatten())
+    v = rng.standard_normal(m * n)
+    got = {}
+    for route, env in (("multiexp", "1"), ("terms", str(1 << 60))):
+        monkeypatch.setenv("PAI_MEXP_MIN_TERMS", env)
+        monkeypatch.setenv("PAI_MEXP_LANES", "5")
+        a, b, c = en @ y, x @ en_y, en.dot(v)
+        got[route] = [(ct_ints(t), list(np.atleast_1d(t.exponent()))) for t in (a, b, c)]
+        assert np.allclose(np.array(sk.decrypt(a)).reshape(m, k), x @ y) and np.allclose(np.array(sk.decrypt(b)).reshape(m, k), x @ y)
+        assert abs(sk.decrypt(c) - float(np.dot(x.flatten(), v))) < 1e-6
+    assert got["multiexp"] == got["terms"]
+
+
 def test_broadcast_rules(fixed):
     pk, sk, okey = fixed
     vec = pk.encrypt([1.0, 2.0, 3.0], r=orc.synth_r_limbs(1, 3, okey.randbits))

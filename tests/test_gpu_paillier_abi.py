@@ -590,7 +590,8 @@ def test_buf_slice_and_rotate_are_row_copies():
 
 
 @pytest.mark.parametrize("bits,R,K,M,lanes,wbits", [(2048, 2, 37, 5, None, None), (2048, 1, 64, 3, "40", "5"), (1024, 3, 9, 4, "7", "3"),
-                                                    (2048, 1, 1, 1, None, "1"), (2048, 2, 11, 7, "9", "7"), (1024, 1, 20, 2, "5", "6")])
+                                                    (2048, 1, 1, 1, None, "1"), (2048, 2, 11, 7, "9", "7"), (1024, 1, 20, 2, "5", "6"),
+                                                    (3072, 2, 13, 3, "6", None), (4096, 1, 9, 5, "4", "5"), (3072, 1, 3, 2, None, "2")])
 def test_ct_multiexp_matches_the_product_of_powers(bits, R, K, M, lanes, wbits, monkeypatch):
     """pai_ct_multiexp: out[r*M + j] = prod_l base(r, l, j)^e[r][l][j] with the inverse's table where the sign byte is
     set; exponents of up to 75 bits with zero windows, zeros and ones; PAI_MEXP_LANES forces chunks of several members
