@@ -3,6 +3,9 @@
 #include "geo_ops.hpp"
 #include "kernels_modexp.hpp"
 
+#ifndef PAI_MEXP_NMLDS
+#define PAI_MEXP_NMLDS false
+#endif
 #ifndef PAI_TILE_NMLDS
 #define PAI_TILE_NMLDS false
 #endif
@@ -89,8 +92,9 @@ struct GeoInst {
     }
     static void mexp(hipStream_t s, int grid, const MontCtx* c, MexpParams P, const uint32_t* table, const uint32_t* e,
                      const uint8_t* sign, uint32_t* out, int nlanes) {
-        set_lds((const void*)k_mexp<G>, G::LDS_BYTES);
-        hipLaunchKernelGGL(k_mexp<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, P, table, e, sign, out, nlanes);
+        using GX = Geo<G::NLL, G::T, G::U, PAI_MEXP_NMLDS>;
+        set_lds((const void*)k_mexp<GX>, GX::LDS_BYTES);
+        hipLaunchKernelGGL(k_mexp<GX>, dim3(grid), dim3(BLOCK_THREADS), GX::LDS_BYTES, s, c, P, table, e, sign, out, nlanes);
     }
     static size_t table_words(size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * G::NL * blocks * G::EPB; }
 

@@ -10,6 +10,17 @@ namespace pai {
 constexpr int BLOCK_THREADS = 256;
 constexpr int MODMUL_FULL = 0, MODMUL_MONT = 1;      // k_modmul modes (kernels_modexp.hpp)
 
+// Waves per SIMD the exponentiation-type lane-group kernels are compiled for.  At two waves per SIMD the 8-lane geometries
+// (28x8, 36x8: keys above 2048 bits) spill around their product loops; measured per kernel with -DPAI_WAVES_T8=1 (one wave,
+// 512 registers): k_mexp<36x8> 101 -> 54 ms (its spills sat INSIDE the row blocks), k_modexp_var_win<28x8> 22.1 -> 20.6 ms
+// per 65536, but k_modexp_var_win<36x8> 32.2 -> 34.4 and k_mexp<28x8> 31.7 -> 33.8 — hence per kernel and geometry.
+#ifndef PAI_WAVES_T8
+#define PAI_WAVES_T8 2
+#endif
+#define PAI_LG_WAVES(G) ((G::T) >= 8 ? PAI_WAVES_T8 : 2)
+#define PAI_MEXP_WAVES(G) (((G::T) >= 8 && (G::NLL) >= 36) ? 1 : PAI_LG_WAVES(G))
+#define PAI_VARWIN_WAVES(G) (((G::T) >= 8 && (G::NLL) < 36) ? 1 : PAI_LG_WAVES(G))
+
 // shape of a multi-exponentiation on the lane-group engine (kernels_modexp.hpp: k_mexp)
 struct MexpParams {
     int R, K, M, chunk, nsigns, e_words, ebits_max, wbits, w32;

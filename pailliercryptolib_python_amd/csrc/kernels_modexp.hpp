@@ -132,7 +132,7 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
 // resident element lives in a global scratch area laid out [entry][limb][slot] so that a wave reads
 // one entry with coalesced 128/256-byte rows; slot = blockIdx.x*EPB + element.
 template <class G, int W>
-__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_LG_WAVES(G))
 k_modexp_fixed(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, int base_w32,
                const uint32_t* __restrict__ expo, int ewords, int ebits,
                uint32_t* __restrict__ out, int out_w32, int n, uint32_t* __restrict__ table, int keep_mont) {
@@ -202,7 +202,7 @@ k_modexp_fixed(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ bas
 // Per-element exponents (e_i packed [N][EW] words, at most ebits_max significant bits): left-to-right
 // binary method; the multiply step is skipped when no element of the wave needs it.
 template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_LG_WAVES(G))
 k_modexp_var(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, int base_w32, int base_shift,
              const uint32_t* __restrict__ expo, int ew, int ebits_max, int exp_bcast,
              uint32_t* __restrict__ out, int out_w32, int n, int keep_mont, int out_raw) {
@@ -274,7 +274,7 @@ k_modexp_var(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base,
 // full-size exponents (negative multipliers, n - |x|) 4 944 against 8 192.  Windows in which every element of the
 // wave has digit zero are skipped.
 template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_VARWIN_WAVES(G))
 k_modexp_var_win(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, int base_w32,
                  const uint32_t* __restrict__ expo, int ew, int ebits_max, int exp_bcast,
                  uint32_t* __restrict__ out, int out_w32, int n, uint32_t* __restrict__ table, int wbits) {
@@ -348,7 +348,7 @@ k_modexp_var_win(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ b
 // kernels_padic_enc.hpp for the scheme): per (base, sign) a table of the powers 0 .. 2^wbits - 1 in Montgomery form (raw
 // radix-29 rows of NL limbs), then one lane group per (chunk of members, output element) with one chain of squarings.
 template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_LG_WAVES(G))
 k_mexp_table(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ ct_inv, int w32,
              uint32_t* __restrict__ table, int nentries, int nsigns, int wbits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -387,7 +387,7 @@ k_mexp_table(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ ct, c
 }
 
 template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_MEXP_WAVES(G))
 k_mexp(const MontCtx* __restrict__ ctx, MexpParams P, const uint32_t* __restrict__ table, const uint32_t* __restrict__ e,
        const uint8_t* __restrict__ sign, uint32_t* __restrict__ out, int nlanes) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];

@@ -63,7 +63,7 @@ struct EncParams {
 // mode 3: ct = (1 + m n) * obf         (obf = precomputed r^n mod n^2, standard scheme, read from `r`)
 // mode 4: ct = ct_in * obf
 template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_LG_WAVES(G))
 k_encrypt(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
           const uint32_t* __restrict__ ct_in, uint32_t* __restrict__ ct_out, int n, int mode) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -234,7 +234,7 @@ struct DecAParams {
 };
 
 template <class G, int W>
-__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_LG_WAVES(G))
 k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out /*[2][n][u_words]*/, int n,
         uint32_t* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -325,7 +325,7 @@ struct DecBParams {
 };
 
 template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_LG_WAVES(G))
 k_dec_b(DecBParams P, const uint32_t* __restrict__ u_in /*[2][n][u_words]*/, uint32_t* __restrict__ m_out, int n) {
     static_assert(!G::NMLDS, "stage B keeps the (small) prime moduli in registers");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];       // 2 operand buffers

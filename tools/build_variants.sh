@@ -58,3 +58,7 @@ ls -la $OUT
 # without / 57.8 with the table prefetch, 12-row blocks 93.4 (1.4-1.8 KB of scratch per lane either way) vs 45.7 for 8 x 18.
 # pai_ct_multiexp lane order (PAI_MEXP_BY_ROWS=1: lanes of a wave walk the rows of one output column instead of the columns
 # of one row): 64x1024 @ 1024x64 0.0986 vs 0.0967 s, 1024x64 @ 64x64 0.1004 vs 0.1009 s — no difference, columns kept.
+# One wave per SIMD for the 8-lane exponentiation kernels (-DPAI_WAVES_T8=1 on geo_28x8 / geo_36x8): k_mexp<36x8> 101 -> 54 ms
+# (adopted), k_modexp_var_win<28x8> 22.1 -> 20.6 ms per 65536 (adopted), k_modexp_var_win<36x8> 32.2 -> 34.4, k_mexp<28x8>
+# 31.7 -> 33.8, k_encrypt<36x8> 61.5 -> 59.4 (kept at two).  Modulus from LDS in k_mexp<36x8> (-DPAI_MEXP_NMLDS=true) 108 ms;
+# digit / sign of the next member prefetched 120 ms.
