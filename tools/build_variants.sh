@@ -62,3 +62,4 @@ ls -la $OUT
 # (adopted), k_modexp_var_win<28x8> 22.1 -> 20.6 ms per 65536 (adopted), k_modexp_var_win<36x8> 32.2 -> 34.4, k_mexp<28x8>
 # 31.7 -> 33.8, k_encrypt<36x8> 61.5 -> 59.4 (kept at two).  Modulus from LDS in k_mexp<36x8> (-DPAI_MEXP_NMLDS=true) 108 ms;
 # digit / sign of the next member prefetched 120 ms.
+# Row-block size of the 36x8 kernels (-DPAI_U_36X8): ct*pt at 4096 bits 31.5 (6 rows) / 33.5 (4) / 35.0 (3) / 43.4 (12) ms per 65536.
