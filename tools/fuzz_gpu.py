@@ -79,8 +79,9 @@ while time.time() - t0 < budget:
         _native.check(lib.pai_ct_mul(nk.pk, dct.ptr, de.ptr, ew, ebits, 0, n2, oc.ptr, None))
         assert limbs_to_ints(oc.get()) == [pow(c, x, M) for c, x in zip(cts, e)], ("ct_mul", bits, n2, ebits, sw)
     os.environ.pop("PAI_LATENCY_MAX", None)
-    # multi-exponentiation (keys the digit engine serves) with forced chunking, and pow2 on the digit engine
-    if bits <= 2048:
+    # multi-exponentiation (digit engine up to 2048-bit keys, lane groups above) with forced chunking and random table
+    # widths, and pow2 on the digit engine
+    if True:
         R, K, Mc = int(rng.integers(1, 4)), int(rng.integers(1, 24)), int(rng.integers(1, 6))
         base = [x if (x % key.p and x % key.q) else 5 for x in pattern(M, R * K)]
         inv = [pow(x, -1, M) for x in base]
@@ -94,6 +95,7 @@ while time.time() - t0 < budget:
                 for j_ in range(Mc):
                     for w_ in range(ew2): e_l[r_, l_, j_, w_] = (ee[r_][l_][j_] >> (32 * w_)) & 0xFFFFFFFF
         os.environ["PAI_MEXP_LANES"] = str(int(rng.integers(1, 50)))
+        os.environ["PAI_MEXP_WBITS"] = str(int(rng.integers(1, 8)))
         dcb, dib, deb, dsb = DevArray(ints_to_limbs(base, nk.cw)), DevArray(ints_to_limbs(inv, nk.cw)), DevArray(e_l), DevArray(sg)
         ob = DevArray(shape=(R * Mc, nk.cw))
         _native.check(lib.pai_ct_multiexp(nk.pk, dcb.ptr, dib.ptr, R, K, Mc, deb.ptr, ew2, eb, dsb.ptr, ob.ptr, None))
@@ -104,6 +106,7 @@ while time.time() - t0 < budget:
                 for l_ in range(K): acc = acc * pow(inv[r_ * K + l_] if sg[l_, j_] else base[r_ * K + l_], ee[r_][l_][j_], M) % M
                 wantb.append(acc)
         assert limbs_to_ints(ob.get()) == wantb, ("multiexp", bits, R, K, Mc, eb)
+    if bits <= 2048:
         os.environ["PAI_POW2_DIGIT_MIN"] = "1"
         dl2 = rng.integers(-3, 63, N).astype(np.int32)
         dd2 = DevArray(dl2); dc2 = DevArray(ints_to_limbs(a, nk.cw))
