@@ -63,3 +63,4 @@ ls -la $OUT
 # 31.7 -> 33.8, k_encrypt<36x8> 61.5 -> 59.4 (kept at two).  Modulus from LDS in k_mexp<36x8> (-DPAI_MEXP_NMLDS=true) 108 ms;
 # digit / sign of the next member prefetched 120 ms.
 # Row-block size of the 36x8 kernels (-DPAI_U_36X8): ct*pt at 4096 bits 31.5 (6 rows) / 33.5 (4) / 35.0 (3) / 43.4 (12) ms per 65536.
+# pai_ct_multiexp window width for dot of 2^20 (one column): auto = 3 bits 59.7 ms; PAI_MEXP_WBITS=2 / 4 / 5: 66.0 / 63.2 / 78.1.
