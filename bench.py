@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: Paillier encrypt+decrypt ops/sec, 2048-bit key, batch = 1 M.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scaling weak|strong] [--no-cpu-baseline] [--no-extras]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scaling strong|weak] [--no-cpu-baseline] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches the N ranks itself (one process per GPU under
+torch.distributed.run, rendezvous on 127.0.0.1) and fails loudly when fewer than N GPUs are visible.
 
 One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
 DJN-obfuscated encryption of the plaintext residues (pai_encrypt) followed by CRT decryption of the
 ciphertexts (pai_decrypt).  One op = one element encrypted AND decrypted (BASELINE.json metric,
 SURVEY.md §8d).  The path shards by independent elements (no data-path collective):
-  --scaling weak   (default) every rank runs B elements on its own device;
-  --scaling strong the B elements are split over the ranks by the contiguous block partition of
-                   pai_shard_plan (BASELINE's "batch = 1 M on 1/2/4/8 GPUs"); the final RCCL gather of the
-                   ciphertext shards is timed separately and reported as gather_ms (it is not part of an op).
+  --scaling strong (default) BASELINE's "batch = 1 M on 1/2/4/8 GPUs": the B elements are split over the ranks by
+                   the contiguous block partition of pai_shard_plan; the final RCCL gather of the ciphertext shards
+                   is timed separately and reported as gather_ms (it is not part of an op).  With N > 1 the line
+                   also carries the other arrangement under "weak_scaling" (same K steps, timed the same way);
+  --scaling weak   every rank runs B elements on its own device ("strong_scaling" then carries the other one).
 The timed region is bracketed by a barrier + torch.cuda.synchronize() and the maximum over ranks is taken.
 
 Inputs: key = the reference's bench constants P, Q (bench/bench_ipcl_python.py:83-97, stored in
@@ -58,6 +62,8 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md
 # canonical MAC32 per op at 2048-bit keys (CIOS 2L^2+L, 5-bit window)
 CANON_MAC_ENC, CANON_MAC_DEC, CANON_MAC_ADD, CANON_MAC_MUL53 = 41.52e6, 20.86e6, 65.8e3, 3.16e6
 BYTES_ENC, BYTES_DEC, BYTES_ADD = 648, 520, 1536   # algorithmic bytes per op
+BASELINE_METRIC = json.loads((ROOT / "BASELINE.json").read_text())["metric"] if (ROOT / "BASELINE.json").exists() else \
+    "Paillier encrypt+decrypt ops/sec, 2048-bit key, batch=1M; 1/2/4/8 MI355X"
 PMC_FILES = ["profiles/r02/pmc_bench_r02.json", "profiles/r01/pmc_bench_r01d.json"]   # newest first
 
 
@@ -129,17 +135,44 @@ def pmc_traffic(kernel_prefix: str, batch: int):
     return None
 
 
+def _self_launch(args) -> None:
+    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1 and hand its exit code back.  Fails loudly when the box has fewer GPUs."""
+    import socket
+    import subprocess
+
+    import torch
+
+    backend = os.environ.get("PAI_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus and backend == "nccl":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible (RCCL needs one device per rank; "
+                         f"PAI_BENCH_BACKEND=gloo shares devices for plumbing tests only)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PAI_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="elements per GPU (weak) or in total (strong) per step")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--batch", type=int, default=1 << 20, help="elements in total (strong) or per GPU (weak) per step")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the second (weak resp. strong) arrangement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip api_level / other_ops / small_batch (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -147,19 +180,33 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     # PAI_BENCH_BACKEND=gloo (plumbing test on a box with fewer GPUs than ranks): ranks share the visible devices and the
     # collectives go through the host; the product path is the same
     backend = os.environ.get("PAI_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    ranks_seen = [{"rank": 0, "device": dev_index, "name": torch.cuda.get_device_name(dev_index)}]
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
+        # every rank reports through the collective backend itself (RCCL on GPUs): N distinct ranks must answer
+        ids = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank, dev_index], dtype=torch.int64, device=device))
+        ranks_seen = [{"rank": int(t[0]), "device": int(t[1])} for t in ids]
+        if sorted(r_["rank"] for r_ in ranks_seen) != list(range(world)):
+            raise SystemExit(f"bench.py: the {backend} communicator reports ranks {ranks_seen}, expected {world} distinct ranks")
+        if backend == "nccl" and len({r_["device"] for r_ in ranks_seen}) != world:
+            raise SystemExit(f"bench.py: ranks share devices under RCCL: {ranks_seen}")
 
     from pailliercryptolib_python_amd import engine, fixedpoint, sharding
 
@@ -171,65 +218,73 @@ def main() -> None:
     okey = orc.make_key(key.p, key.q, djn_x=DJN_X, bits=KEY_BITS)
     assert okey.n == key.n and okey.hs == key.hs and okey.randbits == key.randbits
 
-    if args.scaling == "strong":
-        begin, B = engine.shard_plan(args.batch, world)[rank]        # this rank's contiguous block of the global batch
-        x_all = np.random.default_rng(1002).uniform(-1000.0, 1000.0, args.batch)
-        x = x_all[begin:begin + B]
-        total_per_step = float(args.batch)
-    else:
-        B = args.batch
-        x = np.random.default_rng(1002 + rank).uniform(-1000.0, 1000.0, B)
-        total_per_step = float(B) * world
-    res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
-    m = engine.to_device_words(res, device)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(4002 + rank)
-    r = pub.random_r(max(B, 1), generator=gen)[:B].contiguous()
-    ct = pub.empty_ct(B)
-    out = pub.empty_pt(B)
-    torch.cuda.synchronize()
-
-    def step():
-        if B:
-            pub.encrypt(m, r, out=ct)
-            priv.decrypt(ct, out=out)
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_leg(scaling: str):
+        """Inputs of this rank for one arrangement, W warm-up steps, K timed steps (barrier + synchronize on both sides,
+        maximum over ranks), then the parity check of what was timed."""
+        if scaling == "strong":
+            begin, B = engine.shard_plan(args.batch, world)[rank]        # this rank's contiguous block of the global batch
+            x = np.random.default_rng(1002).uniform(-1000.0, 1000.0, args.batch)[begin:begin + B]
+            total_per_step = float(args.batch)
+        else:
+            begin, B = 0, args.batch
+            x = np.random.default_rng(1002 + rank).uniform(-1000.0, 1000.0, B)
+            total_per_step = float(B) * world
+        res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
+        m = engine.to_device_words(res, device)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(4002 + rank)
+        r = pub.random_r(max(B, 1), generator=gen)[:B].contiguous()
+        ct = pub.empty_ct(B)
+        out = pub.empty_pt(B)
+        torch.cuda.synchronize()
 
-    # ---- correctness of what was just timed (outside the timed region) ---------------------------
-    ok = bool(torch.equal(out, m))
-    nchk = min(B, 4096)
-    got_x = fixedpoint.decode_float64_array(engine.to_host_words(out[:nchk]), expo[:nchk], key.n, key.max_int)
-    ok = ok and bool(np.array_equal(got_x, x[:nchk]))
-    if B:
-        idx = sorted({0, min(1, B - 1), B // 2, B - 1})
-        ct_h = engine.to_host_words(ct[idx])
-        r_h = engine.words_to_ints(engine.to_host_words(r[idx]))
-        m_h = engine.words_to_ints(res[idx])
-        ok = ok and engine.words_to_ints(ct_h) == [orc.encrypt(okey, mm, rr) for mm, rr in zip(m_h, r_h)]
-    if world > 1:
-        flag = torch.tensor([1 if ok else 0], device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = bool(flag.item())
-    if not ok:
-        raise SystemExit("bench.py: parity check failed (decrypt(encrypt(m)) != m or ciphertext bits differ from the oracle)")
+        def step():
+            if B:
+                pub.encrypt(m, r, out=ct)
+                priv.decrypt(ct, out=out)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- correctness of what was just timed (outside the timed region) ---------------------------
+        ok = bool(torch.equal(out, m))
+        nchk = min(B, 4096)
+        got_x = fixedpoint.decode_float64_array(engine.to_host_words(out[:nchk]), expo[:nchk], key.n, key.max_int)
+        ok = ok and bool(np.array_equal(got_x, x[:nchk]))
+        if B:
+            idx = sorted({0, min(1, B - 1), B // 2, B - 1})
+            ct_h = engine.to_host_words(ct[idx])
+            r_h = engine.words_to_ints(engine.to_host_words(r[idx]))
+            m_h = engine.words_to_ints(res[idx])
+            ok = ok and engine.words_to_ints(ct_h) == [orc.encrypt(okey, mm, rr) for mm, rr in zip(m_h, r_h)]
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+        if not ok:
+            raise SystemExit("bench.py: parity check failed (decrypt(encrypt(m)) != m or ciphertext bits differ from the oracle)")
+        return SimpleNamespace(scaling=scaling, begin=begin, B=B, x=x, res=res, expo=expo, m=m, r=r, ct=ct, out=out,
+                               elapsed=elapsed, total_per_step=total_per_step)
+
+    leg = run_leg(args.scaling)
+    begin, B, x, res, expo, m, r, ct, out = leg.begin, leg.B, leg.x, leg.res, leg.expo, leg.m, leg.r, leg.ct, leg.out
+    elapsed, total_per_step = leg.elapsed, leg.total_per_step
 
     # ---- the final gather of the sharded result (strong scaling; RCCL all-gather over xGMI) ------
     gather_ms = None
@@ -264,6 +319,15 @@ def main() -> None:
     if world > 1:
         per_rank_kern = [None] * world
         dist.all_gather_object(per_rank_kern, kern)
+
+    # ---- N > 1: the other arrangement, timed the same way (same K, same barriers, same parity check) ----
+    other_leg = None
+    if world > 1 and not args.no_other_scaling:
+        o = run_leg("weak" if args.scaling == "strong" else "strong")
+        other_leg = {"scaling": o.scaling, "value": o.total_per_step * args.steps / o.elapsed, "unit": "ops/s",
+                     "ms_per_step": 1e3 * o.elapsed / args.steps, "batch_total": int(o.total_per_step),
+                     "batch_this_rank": o.B, "steps": args.steps, "parity_checked": True}
+        del o
 
     single = rank == 0 and world == 1
     extras = single and not args.no_extras
@@ -305,8 +369,33 @@ def main() -> None:
             "value": sample / t_cpu, "unit": "encrypt+decrypt ops/s", "cores": threads, "kind": kind,
             "sample": f"{sample} elements of the same batch, same key and randomness; {how}, OpenMP over {threads} host "
                       f"threads, {t_cpu:.1f} s (encrypt {t_enc_cpu:.1f} s)",
+            "cores_detail": {"used": threads, "host_total": os.cpu_count(),
+                             "note": "used = min(OpenMP default, CPU affinity, cgroup cpu.max quota) of this process"},
             "reference_kernel_library": mb_lib or "libcrypto_mb / libippcp not present on this box (IPP-Crypto is un-vendored upstream)",
         }
+        # the reference's own benchmark sizes (bench/bench_ipcl_python.py:24-25,34-35,45-46,56-57,67-68: 16 and 64 elements),
+        # same port, one thread and all threads, beside the GPU latencies of small_batch
+        if co.ifma_available():
+            def cpu_wall(f, reps=3):
+                f()
+                t1_ = time.perf_counter()
+                for _ in range(reps):
+                    f()
+                return 1e3 * (time.perf_counter() - t1_) / reps
+
+            e53_h = [int(v) | 1 << 52 for v in np.random.default_rng(5).integers(0, 1 << 52, 64)]
+            cpu_small = {"kind": kind, "unit": "ms per batch", "threads_all": threads}
+            for nb in (16, 64):
+                ct_s = c_ct[:nb]
+                cpu_small[str(nb)] = {}
+                for label, th in (("1_thread", 1), ("all_threads", threads)):
+                    cpu_small[str(nb)][label] = {
+                        "encrypt_ms": cpu_wall(lambda: enc(res[:nb], r_host[:nb], threads=th)),
+                        "decrypt_ms": cpu_wall(lambda: dec(ct_s, threads=th)),
+                        "ct_add_ms": cpu_wall(lambda: co.modmul(key.nsq, ct_s, ct_s, threads=th)),
+                        "ct_mul_53bit_ms": cpu_wall(lambda: co.ifma_modexp(key.nsq, ct_s, e53_h[:nb], threads=th)),
+                    }
+            cpu["small_batch"] = cpu_small
 
     # ---- API level: host float64 -> encrypt -> decrypt -> host float64 (rank 0, N = 1) ----------
     api = None
@@ -423,7 +512,7 @@ def main() -> None:
         executed = (executed_macs_decrypt(key.p, key.q) * B / t_deca) if t_deca > 0 else None
         traffic = pmc_traffic("k_dec_a_padic", B)
         line = {
-            "metric": "Paillier encrypt+decrypt ops/sec, 2048-bit key",
+            "metric": BASELINE_METRIC,
             "value": value,
             "unit": "ops/s",
             "n_gpus": world,
@@ -468,6 +557,9 @@ def main() -> None:
             },
             "per_rank_kernel_ms": per_rank_kern if world > 1 else None,
             "gather_ms": gather_ms,
+            "ranks_seen": ranks_seen,
+            "collective_backend": (backend if world > 1 else None),
+            ("weak_scaling" if args.scaling == "strong" else "strong_scaling"): other_leg,
             "cpu_baseline": cpu,
             "api_level": api,
             "other_ops": other,

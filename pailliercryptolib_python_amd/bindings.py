@@ -18,6 +18,7 @@ import enum
 import math
 import os
 import secrets
+import threading
 from typing import List, Optional, Sequence, Union
 
 import numpy as np
@@ -185,6 +186,8 @@ class ipclPublicKey:
         elif device is not None:
             self._devices = [torch.device(device)]
         self._handles: dict = {}
+        self._obf_pool: Optional[torch.Tensor] = None
+        self._obf_lock = threading.Lock()        # pooled obfuscators are single-use: take and fill are atomic
 
     # -- lazily created device handles (cached per key material and device: engine.public_handle) ----
     def _device_list(self) -> List[torch.device]:
@@ -271,6 +274,7 @@ class ipclPublicKey:
         self._devices = None
         self._handles = {}
         self._obf_pool = None
+        self._obf_lock = threading.Lock()
 
     # randomness for the obfuscator: OS CSPRNG on the host, expanded / uploaded as limbs
     def _draw_r(self, count: int, h: Optional[engine.PublicKeyHandle] = None) -> torch.Tensor:
@@ -302,19 +306,25 @@ class ipclPublicKey:
         h = self.handle
         one = torch.zeros((count, h.n_words), dtype=torch.int32, device=h.device)      # E(0; r) = 1 * obf(r)
         fresh = h.encrypt(one, self._draw_r(count))
-        pool = getattr(self, "_obf_pool", None)
-        self._obf_pool = fresh if pool is None or pool.shape[0] == 0 else torch.cat([pool, fresh], dim=0)
+        with self._obf_lock:
+            pool = self._obf_pool
+            self._obf_pool = fresh if pool is None or pool.shape[0] == 0 else torch.cat([pool, fresh], dim=0)
 
     def obfuscator_pool_size(self) -> int:
-        pool = getattr(self, "_obf_pool", None)
-        return 0 if pool is None else int(pool.shape[0])
+        with self._obf_lock:
+            return 0 if self._obf_pool is None else int(self._obf_pool.shape[0])
 
     def _take_obfuscators(self, count: int) -> Optional[torch.Tensor]:
-        pool = getattr(self, "_obf_pool", None)
-        if pool is None or pool.shape[0] < count or count == 0:
+        """`count` pooled obfuscators, removed from the pool under the key's lock: two concurrent encryptions can never
+        receive the same value (reuse would make ct1 * ct2^-1 = 1 + (m1 - m2) n, i.e. leak the plaintext difference)."""
+        if count == 0:
             return None
-        taken, self._obf_pool = pool[:count].contiguous(), pool[count:]
-        return taken
+        with self._obf_lock:
+            pool = self._obf_pool
+            if pool is None or pool.shape[0] < count:
+                return None
+            taken, self._obf_pool = pool[:count], pool[count:]
+        return taken.contiguous()
 
     def encrypt_words(self, m: torch.Tensor, make_secure: bool = True, r: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Residues [N, n_words] on the home device -> ciphertexts [N, ct_words] on the home device; large batches
@@ -361,6 +371,10 @@ class ipclPublicKey:
     def encrypt(self, pt: "ipclPlainText", make_secure: bool = True, *, r: Optional[torch.Tensor] = None) -> "ipclCipherText":
         """classes.cpp:53-60.  ``r`` (extension) injects the obfuscator randomness for reproducible runs."""
         return ipclCipherText(self, self.encrypt_words(pt._device_words(self.handle), make_secure, r))
+
+    def encrypt_tolist(self, pt: "ipclPlainText", make_secure: bool = True, *, r: Optional[torch.Tensor] = None) -> list:
+        """classes.cpp:61-70: encrypt, then the ciphertexts as a list of ipclBigNumber (CipherText.getTexts())."""
+        return self.encrypt(pt, make_secure, r=r).getTexts()
 
     def apply_obfuscator(self, x, *, r: Optional[torch.Tensor] = None):
         """classes.cpp:71-83: BigNumber -> BigNumber, CipherText -> list of BigNumber (as upstream)."""
@@ -445,6 +459,10 @@ class ipclPrivateKey:
         if ct.public_key._n != self._pk._n:
             raise RuntimeError("ipclPrivateKey.decrypt: public key mismatch")
         return ipclPlainText(self.decrypt_words(ct._t))
+
+    def decrypt_tolist(self, ct: "ipclCipherText") -> list:
+        """classes.cpp:134-141: decrypt, then the residues as a list of ipclBigNumber (PlainText.getTexts())."""
+        return self.decrypt(ct).getTexts()
 
     def __getstate__(self):
         return (ipclBigNumber(self._pk._n).to_bytes(), ipclBigNumber(self._p).to_bytes(), ipclBigNumber(self._q).to_bytes())

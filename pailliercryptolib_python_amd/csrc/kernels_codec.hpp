@@ -114,10 +114,11 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) 
 
 struct ChaChaKey { uint32_t k[8]; uint32_t nonce[3]; uint32_t counter0; };
 
-// word w of the key stream (block = w / 16) goes to out[w]; rows of r_words words get their top word masked to
-// randbits.  The stream is the RFC's: state = constants | key | counter | nonce, 20 rounds, feed-forward.
+// word w of the key stream (block = w / 16) goes to out[w]; in every row of r_words words the word with index top_word
+// is masked with top_mask and the words above it are zero (r < 2^rbits even when rbits is more than a word short of
+// the row width).  The stream is the RFC's: state = constants | key | counter | nonce, 20 rounds, feed-forward.
 __global__ void __launch_bounds__(256)
-k_draw_r(ChaChaKey K, uint32_t* __restrict__ out, size_t total_words, int r_words, uint32_t top_mask) {
+k_draw_r(ChaChaKey K, uint32_t* __restrict__ out, size_t total_words, int r_words, int top_word, uint32_t top_mask) {
     const size_t blk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blk * 16 >= total_words) return;
     uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, K.k[0], K.k[1], K.k[2], K.k[3], K.k[4], K.k[5], K.k[6], K.k[7],
@@ -137,7 +138,9 @@ k_draw_r(ChaChaKey K, uint32_t* __restrict__ out, size_t total_words, int r_word
         const size_t w = blk * 16 + i;
         if (w < total_words) {
             uint32_t v = x[i] + s[i];
-            if ((int)(w % (size_t)r_words) == r_words - 1) v &= top_mask;
+            const int col = (int)(w % (size_t)r_words);
+            if (col == top_word) v &= top_mask;
+            if (col > top_word) v = 0;
             out[w] = v;
         }
     }

@@ -128,6 +128,24 @@ struct ScratchOrder {
     }
 };
 
+// begin() now, end() when the scope is left — also by an exception, so that work already queued on the stream stays ordered
+// before the next user of the scratch.  done() ends early (before a host synchronisation).
+struct OrderScope {
+    ScratchOrder& o;
+    hipStream_t s;
+    bool open = true;
+    OrderScope(ScratchOrder& o_, hipStream_t s_) : o(o_), s(s_) { o.begin(s); }
+    void done() {
+        if (open) { open = false; o.end(s); }
+    }
+    ~OrderScope() {
+        if (!open) return;
+        try { o.end(s); } catch (...) {}
+    }
+    OrderScope(const OrderScope&) = delete;
+    OrderScope& operator=(const OrderScope&) = delete;
+};
+
 // grow-only device buffer
 struct DevBuf {
     void* p = nullptr;
@@ -1177,10 +1195,12 @@ int pai_draw_r(const pai_pubkey* pk, const uint32_t* h_key8, const uint32_t* h_n
         // DJN keys: r < 2^randbits.  Standard keys: candidates of bits(n) bits — the caller keeps those in [1, n)
         // (rejection sampling, bindings.py) so that r is uniform there.
         const int rbits = pk->djn ? pk->randbits : hbn::bitlen(pk->n);
-        const int top = rbits - 32 * (pk->r_words - 1);
+        require(rbits >= 1 && rbits <= 32 * pk->r_words, "randomness width does not fit the r rows");
+        const int top_word = (rbits - 1) / 32;                  // the live top word; n may be words shorter than key_bits
+        const int top = rbits - 32 * top_word;                  // 1 ... 32
         const uint32_t mask = top >= 32 ? 0xFFFFFFFFu : ((1u << top) - 1u);
         hipLaunchKernelGGL(k_draw_r, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, d_r, total,
-                           pk->r_words, mask);
+                           pk->r_words, top_word, mask);
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -1474,7 +1494,7 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
         pk->mexp_table.ensure(table_bytes);
         pk->mexp_partial.ensure(nlanes * (size_t)pk->ct_words * 4);
         g_last_times.clear();
-        pk->order.begin(s);
+        OrderScope order_(pk->order, s);
         if (digit) {
             MexpPadicParams Q;
             Q.nctx = pk->nmod.d_ctx;
@@ -1505,7 +1525,8 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
                 const size_t tiles = (nlanes + BLOCK_THREADS - 1) / BLOCK_THREADS;
                 const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
                 ScopedKernelTimer t("k_mexp", s);
-                launch_mexp_padic(pnl, s, grid, Q, d_e, d_sign, pk->mexp_partial.as<uint32_t>(), (int)nlanes);
+                if (!launch_mexp_padic(pnl, s, grid, Q, d_e, d_sign, pk->mexp_partial.as<uint32_t>(), (int)nlanes))
+                    throw PaiError(PAI_E_INTERNAL, "no multi-exponentiation kernel for this limb count");
                 t.stop();
                 HIP_CHECK(hipGetLastError());
             }
@@ -1530,7 +1551,7 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
                 HIP_CHECK(hipGetLastError());
             }
         }
-        pk->order.end(s);
+        order_.done();
         ct_prod_locked(pk, s, pk->mexp_partial.as<uint32_t>(), nlanes, G, d_out, false);
     });
 }
@@ -1565,7 +1586,7 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
         pk->inv_prod.ensure(std::max<size_t>(1, upper + (alias ? N : 0)) * ROW);
         pk->inv_inv.ensure(std::max<size_t>(1, upper + (L == 0 ? N : 0)) * ROW);
         pk->inv_fail.ensure(4);
-        pk->order.begin(s);
+        OrderScope order_(pk->order, s);
         HIP_CHECK(hipMemsetAsync(pk->inv_fail.p, 0, 4, s));
         uint32_t* prod = pk->inv_prod.as<uint32_t>();
         uint32_t* inv = pk->inv_inv.as<uint32_t>();
@@ -1604,7 +1625,7 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
         t.stop();
         int fail = 0;
         HIP_CHECK(hipMemcpyAsync(&fail, pk->inv_fail.p, 4, hipMemcpyDeviceToHost, s));
-        pk->order.end(s);
+        order_.done();
         HIP_CHECK(hipStreamSynchronize(s));
         if (fail) throw PaiError(PAI_E_INVALID, "ct_invert: a ciphertext is not invertible modulo n^2");
     });

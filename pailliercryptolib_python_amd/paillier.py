@@ -202,24 +202,28 @@ class PaillierPrivateKey:
         needs the exact big-integer path (|mantissa| >= 2^63, overflow zone, corrupt residue).  Large batches are
         sharded over the key's devices: ciphertext shards go out by peer copy, every device decrypts and decodes
         its block, and only 8-byte mantissas come back."""
-        pub = enc.public_key.pubkey
+        # one device list for decryption AND decoding: the private key's own (the ciphertext's key object may name other
+        # devices; the codec only depends on n, which the two share)
+        pub = self.prikey._pk
+        home = pub.handle.device
+        words = enc.words if enc.words.device == home else enc.words.to(home)
         devs = pub.fanout_devices(len(enc)) if self.__n.bit_length() > 66 else None
         if devs is not None:
-            ct_sh = engine.scatter_shards(enc.words, devs)
+            ct_sh = engine.scatter_shards(words, devs)
 
             def work(g, dev, begin, count):
                 if count == 0:
                     return np.zeros(0, dtype=np.int64), False, None
                 t = self.prikey.handle_on(dev).decrypt(ct_sh[g])
                 mant, flag = pub.handle_on(dev).fp_decode_i64(t)
-                bad = bool(flag.any())
-                return mant.cpu().numpy(), bad, (engine.to_host_words(t) if bad else None)
+                return mant.cpu().numpy(), bool(flag.any()), t
 
             parts = engine.fan_out(devs, work, len(enc))
             if not any(p[1] for p in parts):
                 return np.concatenate([p[0] for p in parts]), None
-            return None, self._decrypt_words(enc)
-        t = self.prikey.decrypt_words(enc.words)
+            # some element needs the exact host path: the residues of every shard are already there
+            return None, np.concatenate([engine.to_host_words(p[2]) for p in parts if p[2] is not None], axis=0)
+        t = self.prikey.decrypt_words(words)
         if self.__n.bit_length() > 66:
             mant, flag = pub.handle.fp_decode_i64(t)
             if not bool(flag.any()):
@@ -602,6 +606,22 @@ class PaillierEncryptedNumber:
             min_terms = self.MEXP_MIN_TERMS
         if m * n * k < min_terms or other.dtype.kind != "f" or self.public_key.n.bit_length() <= 66:
             return None
+        dev = h.device
+        # the limits pai_ct_multiexp enforces (terms < 2^31, bases < 2^28) and a memory estimate are checked BEFORE the
+        # per-term exponent tensors are built (~80 bytes per term live at the peak): a shape that cannot be served goes
+        # term by term instead of dying in the allocator
+        terms = m * n * k
+        if terms >= 1 << 31 or (k * n if rhs else m * n) >= 1 << 28:
+            return None
+        if dev.type == "cuda" and 96 * terms > torch.cuda.mem_get_info(dev)[0]:
+            return None
+        try:
+            return self._matmul_multiexp_build(other, m, n, k, rhs, h)
+        except torch.cuda.OutOfMemoryError:
+            return None
+
+    def _matmul_multiexp_build(self, other: np.ndarray, m: int, n: int, k: int, rhs: bool, h):
+        from . import _native
         dev = h.device
         if rhs:
             # out(i, j) = sum_l other[i, l] * self[l*k + j]: rows of bases <-> j, members <-> l, columns <-> i

@@ -308,7 +308,7 @@ def test_reductions_match_the_oracle_bit_for_bit(fixed, mexp_min, monkeypatch):
 @pytest.mark.parametrize("bits", [1024, 3072, 4096])
 def test_matrix_product_routes_agree_at_other_key_sizes(bits, monkeypatch):
     """`@`, `r@` and dot through pai_ct_multiexp (base-n digit pairs up to 2048-bit keys, lane groups above) give the
-    bits and exponents of the term-by-term route, and decrypt to the plain product."""
+    bits and exponents of the term-by-term route AND of the oracle's api_matmul / api_dot, and decrypt to the plain product."""
     from tests.test_gpu_paillier_abi import seeded_key
     okey = seeded_key(bits)
     pk = PaillierPublicKey(ipclPublicKey(okey.n, bits, True, hs=okey.hs, randbits=okey.randbits))
@@ -317,9 +317,15 @@ def test_matrix_product_routes_agree_at_other_key_sizes(bits, monkeypatch):
     m, n, k = 3, 7, 4
     x, y = rng.uniform(-10, 10, (m, n)), rng.standard_normal((n, k))
     y[2, 1] = 0.0
-    en = pk.encrypt(x.flatten())
-    en_y = pk.encrypt(y.flatten())
+    rx, ry = orc.synth_r_limbs(bits + 1, m * n, okey.randbits), orc.synth_r_limbs(bits + 2, n * k, okey.randbits)
+    en = pk.encrypt(x.flatten(), r=rx)
+    en_y = pk.encrypt(y.flatten(), r=ry)
     v = rng.standard_normal(m * n)
+    # the oracle's restatement of ipcl_python.py:829-880 / :767-775 at this key size (bits AND exponents)
+    oc, oe = orc.api_encrypt(okey, list(x.flatten()), orc.limbs_to_ints(rx))
+    oyc, oye = orc.api_encrypt(okey, list(y.flatten()), orc.limbs_to_ints(ry))
+    want = [tuple(orc.api_matmul(okey, oc, oe, y)), tuple(orc.api_matmul(okey, oyc, oye, x, rhs=True)),
+            tuple(orc.api_dot(okey, oc, oe, list(v)))]
     got = {}
     for route, env in (("multiexp", "1"), ("terms", str(1 << 60))):
         monkeypatch.setenv("PAI_MEXP_MIN_TERMS", env)
@@ -329,6 +335,7 @@ def test_matrix_product_routes_agree_at_other_key_sizes(bits, monkeypatch):
         assert np.allclose(np.array(sk.decrypt(a)).reshape(m, k), x @ y) and np.allclose(np.array(sk.decrypt(b)).reshape(m, k), x @ y)
         assert abs(sk.decrypt(c) - float(np.dot(x.flatten(), v))) < 1e-6
     assert got["multiexp"] == got["terms"]
+    assert got["terms"] == [(w[0], list(w[1])) for w in want]
 
 
 def test_broadcast_rules(fixed):
@@ -502,3 +509,30 @@ def test_standard_scheme_randomness_is_drawn_on_the_device_inside_1_n():
     bad = _rows_not_in_1_n(r, n_w)
     want = [not (0 < v < n_small) for v in vals]
     assert bad.cpu().tolist() == want and 0.05 < sum(want) / len(want) < 0.8       # n >= 0.5625 * 2^1024: at least 11 % lie above n_small
+
+
+def test_standard_scheme_key_declared_wider_than_its_modulus():
+    """ipclPublicKey(n, bits) only rejects n WIDER than bits: a modulus more than a 32-bit word shorter than the declared
+    length must still draw its randomness inside [1, n) (the rows are key-length wide, the live top word is bits(n)'s)."""
+    okey = orc.make_key(orc.seeded_prime(480, 91), orc.seeded_prime(480, 92))
+    n = okey.n
+    assert n.bit_length() <= 1024 - 32
+    raw = ipclPublicKey(n, 1024, False)
+    pk = PaillierPublicKey(raw)
+    sk = PaillierPrivateKey(pk, okey.p, okey.q)
+    r = raw._draw_r(3000)
+    vals = engine.words_to_ints(engine.to_host_words(r))
+    assert all(0 < v < n for v in vals) and len(set(vals)) == 3000 and max(vals).bit_length() == n.bit_length()
+    x = np.random.default_rng(4).uniform(-50, 50, 200)
+    en = pk.encrypt(x)
+    assert np.array_equal(sk.decrypt_to_numpy(en), x)
+    en.apply_obfuscator()
+    assert np.array_equal(sk.decrypt_to_numpy(en), x)
+    # the binding-level list forms (ipcl_bindings_classes.cpp:61-70,134-141)
+    from pailliercryptolib_python_amd.bindings import ipclCipherText, ipclPlainText, ipclPrivateKey
+    from pailliercryptolib_python_amd.paillier import BNUtils
+    pt = ipclPlainText([BNUtils.int2BN(v) for v in (0, 1, 2, 12345, n - 1)])
+    cts = raw.encrypt_tolist(pt, True)
+    assert len(cts) == 5 and all(0 < int(c) < n * n for c in cts)
+    back = ipclPrivateKey(raw, okey.p, okey.q).decrypt_tolist(ipclCipherText(raw, cts))
+    assert [int(b) for b in back] == [0, 1, 2, 12345, n - 1]

@@ -1,7 +1,7 @@
 """GPU: bench.py's multi-rank code path (rendezvous, barriers, max-over-ranks timing, per-rank kernel times, the final
 gather of the strong-scaling mode) with two ranks on the one GPU of the test box.  RCCL refuses two ranks on one device,
-so the collectives go through gloo here (PAI_BENCH_BACKEND=gloo); everything else is the path `torchrun ... bench.py
---gpus N` takes on an 8-GPU node."""
+so the collectives go through gloo here (PAI_BENCH_BACKEND=gloo); everything else is the path `python bench.py --gpus N`
+(self-launching) or `torchrun ... bench.py --gpus N` takes on an 8-GPU node."""
 import json
 import os
 import subprocess
@@ -14,20 +14,38 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
 def test_bench_two_ranks_on_one_gpu(scaling):
+    """`python bench.py --gpus 2` with no torchrun around it: bench.py starts the two ranks itself."""
     env = dict(os.environ, PAI_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29700 + os.getpid() % 200 + (1 if scaling == "strong" else 0)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "6000",
-           "--scaling", scaling, "--no-cpu-baseline", "--no-extras"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "6000",
+           "--no-cpu-baseline", "--no-extras"] + (["--scaling", "weak"] if scaling == "weak" else [])     # strong is the default
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["parity_checked"] is True
+    assert line["metric"] == json.loads((ROOT / "BASELINE.json").read_text())["metric"]
+    assert sorted(r["rank"] for r in line["ranks_seen"]) == [0, 1] and line["collective_backend"] == "gloo"
     assert len(line["per_rank_kernel_ms"]) == 2 and all("k_dec_a" in k for k in line["per_rank_kernel_ms"])
     if scaling == "strong":
         assert line["config"]["batch_total"] == 6000 and line["gather_ms"] is not None
+        other = line["weak_scaling"]
+        assert other["scaling"] == "weak" and other["batch_total"] == 12000
     else:
         assert line["config"]["batch_total"] == 12000 and line["gather_ms"] is None
-    assert line["value"] > 0
+        other = line["strong_scaling"]
+        assert other["scaling"] == "strong" and other["batch_total"] == 6000
+    assert line["value"] > 0 and other["value"] > 0 and other["parity_checked"] is True
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """RCCL needs one device per rank: asking for more GPUs than the box has must fail loudly, not run fewer ranks."""
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PAI_BENCH_BACKEND")}
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "1", "--no-extras",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+    assert res.returncode != 0 and "GPU(s) are visible" in res.stderr
