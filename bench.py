@@ -456,6 +456,17 @@ def main() -> None:
         t_add_b = wall(lambda: pub.ct_add(ct, ct_b[:1], out=ct2))
         if rows(ct2) != [orc.ct_add(a, engine.words_to_ints(engine.to_host_words(ct_b[:1]))[0], key.nsq) for a in ca]:
             raise SystemExit("bench.py: broadcast ct_add parity check failed")
+        # the same addition inside a chain (lazy Montgomery domain, include/paillier_hip.h pai_ct_mont_mul): ONE product, the
+        # stray R^-1 kept as the buffer's tag; checked as a b R^-1 and, after the retag product, as a b (the wire form)
+        t_add_1 = wall(lambda: pub.ct_mont_mul(ct, ct_b, out=ct2))
+        r_inv = pow(pow(2, pub.mont_bits, key.nsq), -1, key.nsq)
+        if rows(ct2) != [a * b * r_inv % key.nsq for a, b in zip(ca, cb)]:
+            raise SystemExit("bench.py: ct_mont_mul parity check failed")
+        t_retag = wall(lambda: pub.ct_retag(ct2, -1, 0, out=ct2), reps=1)
+        pub.ct_mont_mul(ct, ct_b, out=ct2)
+        pub.ct_retag(ct2, -1, 0, out=ct2)
+        if rows(ct2) != [orc.ct_add(a, b, key.nsq) for a, b in zip(ca, cb)]:
+            raise SystemExit("bench.py: ct_mont_mul + retag parity check failed")
         t_mul = wall(lambda: pub.ct_mul(ct, e53, 53, out=ct2), reps=2)
         e_h = [int(v[0]) & 0xFFFFFFFF | (int(v[1]) & 0xFFFFFFFF) << 32 for v in e53[chk].cpu().numpy()]
         if rows(ct2) != [orc.ct_mul(a, e, key.nsq) for a, e in zip(ca, e_h)]:
@@ -477,6 +488,12 @@ def main() -> None:
         engine.profile_enable(False)
         other = {
             "ct_add_ops_per_s": B / t_add, "ct_add_bcast_ops_per_s": B / t_add_b, "ct_mul_53bit_ops_per_s": B / t_mul,
+            "ct_add_in_chain_ops_per_s": B / t_add_1, "ct_retag_ops_per_s": B / t_retag,
+            "ct_add_in_chain_roofline": {"bound": "valu_int", "canonical_frac": CANON_MAC_ADD * B / t_add_1 / PEAK_MAC32_PER_S,
+                                         "executed_frac": 2 * 144 * 144 * B / t_add_1 / PEAK_MAC32_PER_S,
+                                         "hbm_GBs": BYTES_ADD * B / t_add_1 / 1e9,
+                                         "note": "one Montgomery product per addition; the wire form costs one more product "
+                                                 "(ct_retag) once per chain, at the boundary"},
             "ct_invert_ops_per_s": B / t_inv, "ct_sum_elements_per_s": nsum / t_sum, "batch": B,
             "k_modmul_ms": k_add,
             "ct_add_roofline": {"bound": "valu_int", "canonical_frac": CANON_MAC_ADD * B / t_add / PEAK_MAC32_PER_S,

@@ -133,6 +133,21 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
 int pai_ct_add_aligned(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
                        size_t N, uint32_t* d_out, void* stream);
 
+/* Lazy Montgomery domain for chains of additions (extension).  A ciphertext buffer may hold x R^k mod n^2
+ * instead of x (R = 2^bits of pai_pubkey_mont_bits; the caller tracks the integer k per buffer — k = 0 is the wire form).
+ * pai_ct_mont_mul: d_out[i] = d_a[i] * d_b[i] * R^-1 mod n^2 (canonical residue), ONE Montgomery product per element where
+ * pai_ct_add needs two: operands with tags ka, kb give ciphertext-addition with tag ka + kb - 1.  Multiplying by the
+ * broadcast constant R^(1 + k' - k) mod n^2 (b_bcast != 0) moves a buffer from tag k to tag k', e.g. back to the wire
+ * form before decryption, export or pickling — the bits at every boundary are those of CipherText::operator+
+ * (classes.cpp:318-321).  d_out may alias d_a. */
+int pai_ct_mont_mul(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N, uint32_t* d_out,
+                    void* stream);
+int pai_pubkey_mont_bits(const pai_pubkey* pk, int* bits);
+/* pai_ct_add_aligned on buffers that share a tag k: d_entry = one packed row holding R^(2 - k) mod n^2 (for k = 0 this
+ * is what pai_ct_add_aligned uses); the result carries tag k. */
+int pai_ct_add_aligned_dom(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
+                           size_t N, uint32_t* d_out, const uint32_t* d_entry, void* stream);
+
 /* The reductions of PaillierEncryptedNumber.sum / __matmul__ (ipcl_python.py:746-762, 810-880): upstream pads to a
  * power of two with E_raw(0) = 1 and runs log2 steps of CipherText::rotate + operator+ (__padded_ct, :810-827),
  * i.e. computes the product of a group of ciphertexts modulo n^2.  Here: d_ct holds `count` rows read as
@@ -161,6 +176,10 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
  * synchronises `stream`) and run shifts of 8..62 as ct^e with the one-bit exponent 2^delta on the base-n digit engine. */
 int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N,
                 void* stream);
+/* The same with the caller's knowledge of max_i delta_i (the Python layer builds delta on the host and knows it): no
+ * read-back, the call is asynchronous for every batch size.  max_delta must be >= every delta_i (0: nothing to do). */
+int pai_ct_pow2_hint(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N, int max_delta,
+                     void* stream);
 
 /* ---- data formats either side of the path --------------------------------------------------------------
  * Fixed-point codec of bindings/fixedpoint.py:54-115 for float64 arrays (the hot Python loops of

@@ -59,6 +59,9 @@ PROTOTYPES = {
     "pai_ct_mul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_int, C.c_int, C.c_size_t, voidp, voidp]),
     "pai_ct_invert": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_add_aligned": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp]),
+    "pai_ct_add_aligned_dom": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp, voidp]),
+    "pai_ct_mont_mul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp, voidp]),
+    "pai_pubkey_mont_bits": (C.c_int, [voidp, C.POINTER(C.c_int)]),
     "pai_ct_prod": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp]),
     "pai_ct_multiexp": (C.c_int, [voidp, voidp, voidp, C.c_size_t, C.c_size_t, C.c_size_t, voidp, C.c_int, C.c_int, voidp, voidp,
                                   voidp]),
@@ -66,6 +69,7 @@ PROTOTYPES = {
     "pai_gather": (C.c_int, [C.c_int, i32p, C.POINTER(voidp), C.POINTER(C.c_size_t), C.c_int, C.c_int, voidp]),
     "pai_scatter": (C.c_int, [C.c_int, i32p, C.POINTER(voidp), C.POINTER(C.c_size_t), C.c_int, C.c_int, voidp]),
     "pai_ct_pow2": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp]),
+    "pai_ct_pow2_hint": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, C.c_int, voidp]),
     "pai_fp_encode_f64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_fp_encode_i64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_fp_decode_i64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),

@@ -580,18 +580,23 @@ class ipclPlainText(_Container):
 class ipclCipherText(_Container):
     """bindings/ipcl_bindings_classes.cpp:268-378: ciphertext container bound to a public key."""
 
-    def __init__(self, pubkey: ipclPublicKey, data=None):
+    def __init__(self, pubkey: ipclPublicKey, data=None, *, dom: int = 0):
         self._pk = pubkey
         self._ints: List[int] = []
         self._dev: Optional[torch.Tensor] = None      # limb matrix on the key's home device ...
         self._host: Optional[np.ndarray] = None       # ... or host words that have not been needed on a device yet
+        # Lazy Montgomery domain (extension, DESIGN.md §2.5): the device rows hold x R^_dom mod n^2.  Additions are ONE
+        # Montgomery product (tags ka, kb -> ka + kb - 1); whoever needs the wire form (getTexts, pickling, decryption,
+        # ct * pt, every `_t` / `words` access) gets it through one more product, done once and cached in place.
+        self._dom = 0
         W = 2 * ((pubkey._bits + 31) // 32)
         if isinstance(data, torch.Tensor):
             if data.shape[1] != W:
                 raise RuntimeError("ipclCipherText: width does not match the key")
             self._dev = data
+            self._dom = int(dom)
         elif isinstance(data, ipclCipherText):
-            self._dev, self._host = data._dev, data._host
+            self._dev, self._host, self._dom = data._dev, data._host, data._dom
         elif isinstance(data, np.ndarray) and data.dtype == np.uint32 and data.ndim == 2:
             if data.shape[1] != W:
                 raise RuntimeError("ipclCipherText: width does not match the key")
@@ -606,22 +611,29 @@ class ipclCipherText(_Container):
                     raise RuntimeError("ipclCipherText: width does not match the key")
             self._host = engine.ints_to_words(vals, W) if vals else np.zeros((0, W), dtype=np.uint32)
 
-    @property
-    def _t(self) -> torch.Tensor:
-        """The limb matrix on the home device; host-built containers (pickles, lists of BigNumbers) are uploaded —
-        and the key's device handle created — only when an operation first needs them."""
+    def _raw(self):
+        """(limb matrix on the home device, domain tag): rows hold x R^tag mod n^2.  Host-built containers (pickles, lists
+        of BigNumbers) are uploaded — and the key's device handle created — only when an operation first needs them."""
         if self._dev is None:
             self._dev = engine.to_device_words(self._host, self._pk.handle.device)
             self._host = None
         elif self._dev.device != self._pk.handle.device:
             self._dev = self._dev.to(self._pk.handle.device)
+        return self._dev, self._dom
+
+    @property
+    def _t(self) -> torch.Tensor:
+        """The limb matrix on the home device in the wire form (canonical residues of the ciphertexts themselves)."""
+        t, k = self._raw()
+        if k != 0:
+            self._dev, self._dom = self._pk.handle.ct_retag(t, k, 0), 0
         return self._dev
 
     def getSize(self) -> int:
         return int(self._host.shape[0]) if self._dev is None else int(self._dev.shape[0])
 
     def getTexts(self) -> List[ipclBigNumber]:
-        words = self._host if self._dev is None else engine.to_host_words(self._dev)
+        words = self._host if self._dev is None else engine.to_host_words(self._t)
         return [ipclBigNumber(v) for v in engine.words_to_ints(words)]
 
     @property
@@ -639,13 +651,15 @@ class ipclCipherText(_Container):
     def __getitem__(self, key):
         if isinstance(key, slice):
             a, b = _slice_bounds(key, len(self))
-            return ipclCipherText(self._pk, engine.rows_slice(self._t, a, b - a))
+            t, dom = self._raw()
+            return ipclCipherText(self._pk, engine.rows_slice(t, a, b - a), dom=dom)
         return ipclBigNumber(engine.to_host_words(self._row(int(key)))[0])
 
     def rotate(self, shift: int) -> "ipclCipherText":
         n = len(self)
         k = shift % n if n else 0
-        return ipclCipherText(self._pk, engine.rows_rotate(self._t, k))
+        t, dom = self._raw()
+        return ipclCipherText(self._pk, engine.rows_rotate(t, k), dom=dom)
 
     def __add__(self, other):
         h = self._pk.handle
@@ -655,7 +669,8 @@ class ipclCipherText(_Container):
             return NotImplemented
         if len(other) != len(self) and len(other) != 1:
             raise RuntimeError("Size mismatch")
-        return ipclCipherText(self._pk, h.ct_add(self._t, other._t))
+        (ta, ka), (tb, kb) = self._raw(), other._raw()
+        return ipclCipherText(self._pk, h.ct_mont_mul(ta, tb), dom=ka + kb - 1)        # one product; the tag remembers the R^-1
 
     def __mul__(self, other: ipclPlainText):
         if not isinstance(other, ipclPlainText):

@@ -74,8 +74,8 @@ struct GeoInst {
                                int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits) {
         // 8-lane geometries: modulus slice from LDS (3072 / 4096-bit ct * pt 20.8 -> 20.5 / 32.7 -> 31.8 ms per 65536)
         using GV = Geo<G::NLL, G::T, G::U, (G::T >= 8 && G::NLL % 4 == 0) ? PAI_VARWIN_NMLDS : false>;
-        set_lds((const void*)k_modexp_var_win<GV>, GV::LDS_BYTES);
-        hipLaunchKernelGGL(k_modexp_var_win<GV>, dim3(grid), dim3(BLOCK_THREADS), GV::LDS_BYTES, s, c, base, base_w32, expo, ew,
+        set_lds((const void*)k_modexp_var_win<GV>, VarWinCfg<GV>::LDS_BYTES);
+        hipLaunchKernelGGL(k_modexp_var_win<GV>, dim3(grid), dim3(BLOCK_THREADS), VarWinCfg<GV>::LDS_BYTES, s, c, base, base_w32, expo, ew,
                            ebits_max, exp_bcast, out, out_w32, n, table, wbits);
     }
     static void pow2(hipStream_t s, int grid, const MontCtx* c, uint32_t* ct, const int32_t* delta, int delta_bcast,
@@ -85,10 +85,10 @@ struct GeoInst {
         hipLaunchKernelGGL(k_pow2<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, ct, delta, delta_bcast, n, w32);
     }
     static void add_aligned(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, int b_bcast,
-                            const int32_t* delta, uint32_t* out, int n, int w32) {
+                            const int32_t* delta, uint32_t* out, int n, int w32, const uint32_t* entry) {
         constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;
         set_lds((const void*)k_add_aligned<GM>, bytes);
-        hipLaunchKernelGGL(k_add_aligned<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, b_bcast, delta, out, n, w32);
+        hipLaunchKernelGGL(k_add_aligned<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, b_bcast, delta, out, n, w32, entry);
     }
     static void mexp_table(hipStream_t s, int grid, const MontCtx* c, const uint32_t* ct, const uint32_t* ct_inv, int w32,
                            uint32_t* table, int nentries, int nsigns, int wbits) {

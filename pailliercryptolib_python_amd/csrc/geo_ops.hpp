@@ -36,7 +36,7 @@ struct GeoOps {
                  int w32);
     // out_i = a_i * b_i with the lower-exponent side raised by ^(2^|delta_i|) first (delta = exponent(a) - exponent(b))
     void (*add_aligned)(hipStream_t, int grid, const MontCtx*, const uint32_t* a, const uint32_t* b, int b_bcast,
-                        const int32_t* delta, uint32_t* out, int n, int w32);
+                        const int32_t* delta, uint32_t* out, int n, int w32, const uint32_t* entry);
     // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups
     size_t (*table_words)(size_t blocks);
     // ct = w + v n [or ct_in (w + v n)] from the plain digit pairs of the lane-group pair kernels (rows [2][wv_words])

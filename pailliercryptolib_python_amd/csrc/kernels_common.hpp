@@ -19,7 +19,10 @@ constexpr int MODMUL_FULL = 0, MODMUL_MONT = 1;      // k_modmul modes (kernels_
 #endif
 #define PAI_LG_WAVES(G) ((G::T) >= 8 ? PAI_WAVES_T8 : 2)
 #define PAI_MEXP_WAVES(G) (((G::T) >= 8 && (G::NLL) >= 36) ? 1 : PAI_LG_WAVES(G))
-#define PAI_VARWIN_WAVES(G) (((G::T) >= 8 && (G::NLL) < 36) ? 1 : PAI_LG_WAVES(G))
+#ifndef PAI_VARWIN_WAVES_28X8
+#define PAI_VARWIN_WAVES_28X8 1
+#endif
+#define PAI_VARWIN_WAVES(G) (((G::T) >= 8 && (G::NLL) < 36) ? PAI_VARWIN_WAVES_28X8 : PAI_LG_WAVES(G))
 
 // shape of a multi-exponentiation on the lane-group engine (kernels_modexp.hpp: k_mexp)
 struct MexpParams {

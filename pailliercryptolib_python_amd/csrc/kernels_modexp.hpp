@@ -273,6 +273,21 @@ k_modexp_var(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base,
 // instead of one per bit: 53-bit exponents 6 + 51 + 17 = 74 products at 3 bits against 53 + 53 for the binary method,
 // full-size exponents (negative multipliers, n - |x|) 4 944 against 8 192.  Windows in which every element of the
 // wave has digit zero are skipped.
+//
+// Lane groups of 4 and 8 (keys above 2048 bits: BASELINE configs 4 and 5) keep the table ROW-major per slot —
+// [slot][entry][NL], every lane reading / writing its contiguous slice with 16-byte accesses — and never hold a table
+// entry in registers: the entry of the coming multiplication is STREAMED into a second LDS operand buffer, four words per
+// row block, while the window's last squaring runs (RowStream, mont_dev.hpp), and the multiplication takes it from
+// there as its right operand.  (Round 2 gathered 36 single dwords per lane from the [entry][limb][slot] layout right
+// before each multiplication: 27 GB fetched for 67 MB of ciphertexts, 27 % of the wave cycles waiting —
+// profiles/r02/pmc_k4096_r02.json.)
+template <class G>
+struct VarWinCfg {
+    static constexpr bool STREAM = (G::T == 4 || G::T == 8) && G::NLL % 4 == 0;
+    static constexpr int BUF1 = G::LDS_WORDS + G::NL;                     // second operand buffer, behind the modulus copy
+    static constexpr int LDS_BYTES = G::LDS_BYTES + (STREAM ? G::LDS_WORDS * 4 : 0);
+};
+
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, PAI_VARWIN_WAVES(G))
 k_modexp_var_win(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, int base_w32,
@@ -283,6 +298,87 @@ k_modexp_var_win(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ b
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
     const uint32_t n0inv = ctx->n0inv;
+    if constexpr (VarWinCfg<G>::STREAM) {
+        constexpr int CH = 4, NCH = G::NLL / 4;
+        using RS = RowStream<CH, NCH, 0>;
+        const int NT = 1 << wbits;
+        const int nwin = (ebits_max + wbits - 1) / wbits;
+        const size_t slot = (size_t)blockIdx.x * G::EPB + G::elem();
+        uint32_t* trow = table + slot * (size_t)NT * G::NL + G::NLL * t;       // this lane's slice of entry 0
+        auto tload = [&](uint32_t (&v)[G::NLL], int entry) {
+            const uint4* p4 = reinterpret_cast<const uint4*>(trow + (size_t)entry * G::NL);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { const uint4 q = p4[c]; v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w; }
+        };
+        auto tstore = [&](const uint32_t (&v)[G::NLL], int entry) {
+            uint4* p4 = reinterpret_cast<uint4*>(trow + (size_t)entry * G::NL);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) p4[c] = make_uint4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+        };
+        const int col = (G::NLL * t) * G::EPB + G::elem();
+        const int tiles = (n + G::EPB - 1) / G::EPB;
+        for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+            const int ei = tile * G::EPB + G::elem();
+            const bool live = ei < n;
+            const int es = live ? ei : n - 1;
+            const uint32_t* erow = expo + (size_t)(exp_bcast ? 0 : es) * ew;
+            auto window = [&](int wi) -> int {
+                const int bit = wi * wbits, k = bit >> 5;
+                uint64_t bits2 = k < ew ? erow[k] : 0u;
+                if (k + 1 < ew) bits2 |= (uint64_t)erow[k + 1] << 32;
+                return (int)((uint32_t)(bits2 >> (bit & 31)) & (uint32_t)(NT - 1));
+            };
+            uint32_t x[G::NLL];
+            {   // base -> Montgomery form; table[k] = base^k, table[0] = 1
+                uint32_t bR[G::NLL], c[G::NLL];
+                load_elem<G>(bR, base + (size_t)es * base_w32, base_w32);
+                load_const_slice<G>(c, ctx->r2);
+                mm_times<G>(bR, c, lds, nm, n0inv);
+                load_const_slice<G>(c, ctx->one);
+                tstore(c, 0);
+                tstore(bR, 1);
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) x[j] = bR[j];
+#pragma unroll 1
+                for (int k = 2; k < NT; ++k) {
+                    mm_times<G>(x, bR, lds, nm, n0inv);
+                    tstore(x, k);
+                }
+            }
+            tload(x, window(nwin - 1));
+#pragma unroll 1
+            for (int wi = nwin - 2; wi >= 0; --wi) {
+                const int d = window(wi);
+                const bool any = __any(d != 0);
+                RS pf;
+                pf.src0 = trow + (size_t)d * G::NL;
+                pf.src1 = pf.src0;
+                pf.dst0 = lds + VarWinCfg<G>::BUF1 + col;
+                pf.dst1 = pf.dst0;
+                pf.stride = G::EPB;
+                // one rolled body for the window's products: wbits squarings (x staged as its own right operand), then —
+                // if some element of the wave has a non-zero digit — the multiplication by the streamed table entry
+                const int nsteps = wbits + (any ? 1 : 0);
+#pragma unroll 1
+                for (int s = 0; s < nsteps; ++s) {
+                    const bool is_mul = s == wbits;
+                    if (!is_mul) stage_b<G>(x, lds);
+                    else wave_lds_fence();
+                    pf.on = any && s == wbits - 1;
+                    uint32_t r[G::NLL];
+                    mont_mul<G::NLL, G::U, G::T>(r, x, lds + (is_mul ? VarWinCfg<G>::BUF1 : 0) + G::elem(), G::EPB, nm, n0inv, &pf);
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
+                }
+            }
+            uint32_t one[G::NLL];
+            set_plain_one<G>(one);
+            mm_times<G>(x, one, lds, nm, n0inv);
+            cond_sub<G::NLL, G::T>(x, nm);
+            if (live) store_elem<G>(x, out + (size_t)ei * out_w32, out_w32, lds);
+        }
+        return;
+    }
     const size_t nslots = (size_t)gridDim.x * G::EPB;
     const size_t slot = (size_t)blockIdx.x * G::EPB + G::elem();
     auto tbl = [&](int entry, int j) -> uint32_t& {

@@ -478,19 +478,30 @@ k_pow2(const MontCtx* __restrict__ ctx, uint32_t* ct, const int32_t* __restrict_
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_add_aligned(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, int b_bcast,
-              const int32_t* __restrict__ delta, uint32_t* out, int n, int w32) {
+              const int32_t* __restrict__ delta, uint32_t* out, int n, int w32, const uint32_t* __restrict__ entry) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using WT = WaveTile<G>;
     uint32_t* stage = lds + G::LDS_WORDS + G::NL;
-    uint32_t* r2_lds = stage + G::STAGE_WORDS;           // R^2 mod M, one copy per workgroup
+    uint32_t* r2_lds = stage + G::STAGE_WORDS;           // the domain-entry constant (R^2 mod M), one copy per workgroup
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
-    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) r2_lds[i] = ctx->r2[i];
-    __syncthreads();
     const uint32_t n0inv = ctx->n0inv;
     constexpr int WPB = BLOCK_THREADS / 64;
     const int wtiles = (n + WT::EPW - 1) / WT::EPW;
     clear_stage<G>(stage);
+    if (entry == nullptr) {
+        for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) r2_lds[i] = ctx->r2[i];
+    } else {
+        // operands stored as x R^k (pai_ct_add_aligned_dom): the caller's constant R^(2-k), one packed row, replaces R^2
+        uint32_t cc[G::NLL];
+        load_tile<G>(stage, entry, 1, w32, true);
+        unpack_row<G>(cc, stage);
+        if (threadIdx.x < G::T) {
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) r2_lds[G::NLL * G::gl() + j] = cc[j];
+        }
+    }
+    __syncthreads();
     const uint32_t* o_lds = lds + G::elem();             // column of this element in the [limb][element] operand buffer (staged x)
     const int per_wave = (wtiles + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
     const int wt_begin = ((int)blockIdx.x * WPB + WT::wave()) * per_wave;

@@ -34,9 +34,20 @@ struct PairParams {
 };
 
 // LDS: [c rows][d rows] ([limb][element] operand buffers, G::LDS_WORDS each), then the NL limbs of n - 1
+// Groups of 8 lanes (4096-bit keys) run two waves per SIMD and have no registers to spare for a prefetched table entry
+// (the compiler spilled it straight after the load, i.e. waited for HBM once per window: 26 % of the wave cycles in
+// profiles/r02/pmc_k4096_r02.json): there the next entry is STREAMED into a second pair of LDS operand buffers, two words per
+// row block (RowStream, mont_dev.hpp).
+#ifndef PAIR_STREAM_T
+#define PAIR_STREAM_T 8
+#endif
 template <class G>
 struct PairLds {
+    static constexpr bool STREAM = G::T >= PAIR_STREAM_T;
     static constexpr int BYTES = (2 * G::LDS_WORDS + 2 * G::NL) * 4;
+    static constexpr int BYTES_FB = BYTES + (STREAM ? 2 * G::LDS_WORDS * 4 : 0);      // k_pair_fixed_base: + the second buffer pair
+    PAI_DEV static uint32_t* c2(uint32_t* lds) { return lds + 2 * G::LDS_WORDS + 2 * G::NL; }
+    PAI_DEV static uint32_t* d2(uint32_t* lds) { return lds + 3 * G::LDS_WORDS + 2 * G::NL; }
     PAI_DEV static uint32_t* mod(uint32_t* lds) { return lds + 2 * G::LDS_WORDS + G::NL; }   // modulus copy (NMLDS geometries)
     PAI_DEV static uint32_t* c(uint32_t* lds) { return lds; }
     PAI_DEV static uint32_t* d(uint32_t* lds) { return lds + G::LDS_WORDS; }
@@ -218,6 +229,34 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
         };
         uint32_t a[G::NLL], b[G::NLL], c[G::NLL], d[G::NLL];
         pair_load<G>(a, b, entry(0));
+        if constexpr (PairLds<G>::STREAM) {
+            constexpr int CH = (G::NLL % 4 == 0) ? 4 : 2, NCH = G::NLL / CH;
+            // buffer pair k lives at lds + k * PAIR_OFF (c rows, then d rows): plain offsets from the shared base — a runtime
+            // choice between two POINTERS makes the compiler lose the LDS address space (flat_load in the row loop)
+            constexpr int PAIR_OFF = 2 * G::LDS_WORDS + 2 * G::NL;
+            if (P.fb_windows > 1) {
+                pair_load<G>(c, d, entry(1));
+                stage_b<G>(c, lds + PAIR_OFF);
+                stage_b<G>(d, lds + PAIR_OFF + G::LDS_WORDS);
+            }
+            const int col = (G::NLL * G::gl()) * G::EPB + G::elem();
+#pragma unroll 1
+            for (int jw = 1; jw < P.fb_windows; ++jw) {
+                const int cur = (jw & 1) * PAIR_OFF, nxt = PAIR_OFF - cur;
+                // the next window's entry streams into the other buffer pair while this product runs (the last window
+                // re-reads its own entry: harmless, keeps the loop body uniform)
+                const uint32_t* ent = entry(jw + 1 < P.fb_windows ? jw + 1 : jw);
+                RowStream<CH, NCH, NCH> pf;
+                pf.src0 = ent + G::NLL * G::gl();
+                pf.src1 = ent + G::NL + G::NLL * G::gl();
+                pf.dst0 = lds + nxt + col;
+                pf.dst1 = lds + nxt + G::LDS_WORDS + col;
+                pf.stride = G::EPB;
+                pair_mul<G::NLL, G::U, G::T>(a, b, lds + cur + G::elem(), lds + cur + G::LDS_WORDS + G::elem(), G::EPB,
+                                             PairLds<G>::nm1(lds), nm, n0inv, &pf);
+                wave_lds_fence();
+            }
+        } else {
         if (P.fb_windows > 1) pair_load<G>(c, d, entry(1));
 #pragma unroll 1
         for (int jw = 1; jw < P.fb_windows; ++jw) {
@@ -233,6 +272,7 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
 #endif
             pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
                                          PairLds<G>::nm1(lds), nm, n0inv);
+        }
         }
         set_plain_one<G>(c);
         if (with_m) load_elem<G>(d, m + (size_t)es * P.pt_words, P.pt_words);

@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace pai {
 
@@ -272,11 +273,62 @@ struct NmLds {
     PAI_DEV uint32_t limb(int j) const { return p[j]; }
 };
 
+// Hook called once per row block of a product (pair_mul / mont_mul_pf): lets a kernel stream the NEXT operand from HBM
+// into LDS a few words per block, through a register or two, while the multiplier runs (RowStream below).
+struct NoStream {
+    PAI_DEV void step(int) {}
+    PAI_DEV void drain() {}
+};
+
+// Streams `NCH` chunks of CH words (this lane's contiguous slice of a row in global memory, CH * 4-byte aligned) into LDS
+// column storage dst[w * stride] for word w of the slice: block k of the running product issues the load of chunk k and
+// stores chunk k - 1, so a chunk has a whole row block (thousands of cycles) to arrive and occupies CH registers.
+// Two consecutive slices (digit pairs: the c part then the d part) are served by the split at chunk NCH0.
+template <int CH, int NCH0, int NCH1>
+struct RowStream {
+    static_assert(CH == 1 || CH == 2 || CH == 4, "chunk width");
+    const uint32_t* src0;
+    const uint32_t* src1;
+    uint32_t* dst0;
+    uint32_t* dst1;
+    int stride;
+    bool on = true;            // wave-uniform: a product that has nothing to stream
+    uint32_t r[CH];
+    PAI_DEV void load(int k) {
+        const uint32_t* p = k < NCH0 ? src0 + k * CH : src1 + (k - NCH0) * CH;
+        if constexpr (CH == 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else if constexpr (CH == 2) {
+            const uint2 v = *reinterpret_cast<const uint2*>(p);
+            r[0] = v.x; r[1] = v.y;
+        } else {
+            r[0] = *p;
+        }
+    }
+    PAI_DEV void store(int k) {
+        uint32_t* q = k < NCH0 ? dst0 + (k * CH) * stride : dst1 + ((k - NCH0) * CH) * stride;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) q[i * stride] = r[i];
+    }
+    PAI_DEV void step(int blk) {
+        if (!on) return;
+        if (blk >= 1 && blk <= NCH0 + NCH1) store(blk - 1);
+        if (blk < NCH0 + NCH1) load(blk);
+    }
+    // after the product's last block: whatever is still in flight (products with fewer blocks than chunks + 1)
+    template <int NB>
+    PAI_DEV void drain_from() {
+#pragma unroll 1
+        for (int k = NB; k <= NCH0 + NCH1; ++k) step(k);
+    }
+};
+
 // r = a * b * R^-1 mod M (lazy: < 2M when a,b < 2M).  b limbs are read from b_ptr[i * bstride]
 // (LDS, [limb][element]); nm = this lane's slice of the modulus.
-template <int NLL, int U, int T, class NM>
+template <int NLL, int U, int T, class NM, class PF = NoStream>
 PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32_t* b_ptr, int bstride,
-                      const NM& nm, uint32_t n0inv) {
+                      const NM& nm, uint32_t n0inv, PF* pf = nullptr) {
     static_assert(NLL % U == 0, "NLL must be a multiple of the row-block size U");
     static_assert(NORM_ROWS % U == 0, "NORM_ROWS must be a multiple of U");
     using RW = Rows<NLL, U, T>;
@@ -287,6 +339,7 @@ PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32
     int since = 0;
 #pragma unroll 1
     for (int blk = 0; blk < NB; ++blk) {
+        if constexpr (!std::is_same<PF, NoStream>::value) pf->step(blk);
         uint32_t bv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) bv[u] = b_ptr[(blk * U + u) * bstride];
@@ -294,6 +347,7 @@ PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32
         RW::template block<true, true>(acc, a, bv, nm, n0inv, low);
         if (++since == NORM_BLOCKS && blk != NB - 1) { RW::normalize(acc); since = 0; }   // finish() takes lazy columns
     }
+    if constexpr (!std::is_same<PF, NoStream>::value) pf->template drain_from<NB>();
     RW::finish(acc, r);
 }
 
@@ -308,9 +362,10 @@ PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32
 // (a, b) in registers (lane slices), (c, d) as LDS rows c_ptr / d_ptr [limb * stride], M - 1 as LDS limbs (uniform).
 // Inputs lazy (< 2M + eps), outputs lazy; R / M >= 2^20 required.
 constexpr int PAIR_NORM_MAX = 16;              // three 2^58 products per row and column: 16 rows stay below 2^64
-template <int NLL, int U, int T, class NM>
+
+template <int NLL, int U, int T, class NM, class PF = NoStream>
 PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_ptr, const uint32_t* d_ptr, int stride,
-                      const uint32_t* mm1, const NM& nm, uint32_t n0inv) {
+                      const uint32_t* mm1, const NM& nm, uint32_t n0inv, PF* pf = nullptr) {
     static_assert(NLL % U == 0 && U <= PAIR_NORM_MAX, "row-block size");
     using RW = Rows<NLL, U, T>;
     constexpr int NW = RW::NW;
@@ -324,6 +379,7 @@ PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_
     int since = 0;
 #pragma unroll 1
     for (int blk = 0; blk < NB; ++blk) {
+        if constexpr (!std::is_same<PF, NoStream>::value) pf->step(blk);
         uint32_t cv[U], dv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -365,6 +421,7 @@ PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_
         }
         if (++since == NORM_BLOCKS && blk != NB - 1) { RW::normalize(acc1); RW::normalize(acc2); since = 0; }
     }
+    if constexpr (!std::is_same<PF, NoStream>::value) pf->template drain_from<NB>();
     RW::finish(acc1, a);
     RW::finish(acc2, b);
 }

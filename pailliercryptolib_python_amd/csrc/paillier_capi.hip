@@ -1335,11 +1335,25 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
     });
 }
 
+static int ct_pow2_impl(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N, int dmax_hint,
+                        void* stream);
+
 int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N,
                 void* stream) {
+    return ct_pow2_impl(pk, d_ct, d_delta, delta_bcast, N, -1, stream);
+}
+
+int pai_ct_pow2_hint(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N, int max_delta,
+                     void* stream) {
+    return ct_pow2_impl(pk, d_ct, d_delta, delta_bcast, N, max_delta < 0 ? 0 : max_delta, stream);
+}
+
+static int ct_pow2_impl(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N, int dmax_hint,
+                        void* stream) {
     return guarded([&] {
         require(pk && d_ct && d_delta, "NULL argument");
         if (N == 0) return;
+        if (dmax_hint == 0) return;                                       // the caller knows that nothing is to be raised
         DeviceScope scope_(pk->device);
         const GeoOps* g = pk->msq.geo;
         g_last_times.clear();
@@ -1347,8 +1361,9 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
             // Large batches on keys the digit engine serves: ct^(2^delta) is ct * pt with the one-bit exponent 2^delta —
             // delta squarings at 4 NL^2 limb products on base-n digit pairs (+ ~4 products of conversions) against
             // delta + 2 products of 8 NL^2 on the lane-group engine.  Worth it from shifts of ~8 on (ct - ct aligns by
-            // up to 52: 88 -> ~55 ms per 2^20); the largest shift is read back first (one 4-byte copy: this path
-            // synchronises the stream), smaller shifts keep the lane-group kernel.
+            // up to 52: 88 -> ~55 ms per 2^20); the largest shift decides — the caller's hint (pai_ct_pow2_hint: fully
+            // asynchronous) or, without one, a 4-byte read-back that synchronises the stream; smaller shifts keep the
+            // lane-group kernel.
             hipStream_t s = (hipStream_t)stream;
             std::unique_lock<std::mutex> lk(pk->mu);
             pk->pow2_expo.ensure(N * 8 + 16);
@@ -1358,9 +1373,11 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
             hipLaunchKernelGGL(k_pow2_expo, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_delta, delta_bcast, N,
                                pk->pow2_expo.as<uint32_t>(), d_max);
             HIP_CHECK(hipGetLastError());
-            int dmax = 0;
-            HIP_CHECK(hipMemcpyAsync(&dmax, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            int dmax = dmax_hint;
+            if (dmax_hint < 0) {                                          // no hint: read the largest shift back (synchronises)
+                HIP_CHECK(hipMemcpyAsync(&dmax, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+            }
             pk->order.end(s);
             if (dmax >= POW2_DIGIT_MIN_SHIFT && dmax <= 62) {
                 ctmul_padic_locked(pk, s, d_ct, pk->pow2_expo.as<uint32_t>(), 2, dmax + 1, 0, N, d_ct, 1, "k_pow2");
@@ -1375,19 +1392,53 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
     });
 }
 
+static void add_aligned_common(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
+                               size_t N, uint32_t* d_out, const uint32_t* d_entry, void* stream) {
+    require(pk && d_a && d_b && d_delta && d_out, "NULL argument");
+    if (N == 0) return;
+    DeviceScope scope_(pk->device);
+    const GeoOps* g = pk->msq.geo;
+    g_last_times.clear();
+    ScopedKernelTimer t("k_add_aligned", (hipStream_t)stream);
+    g->add_aligned((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, b_bcast, d_delta, d_out, (int)N,
+                   pk->ct_words, d_entry);
+    t.stop();
+    HIP_CHECK(hipGetLastError());
+}
+
 int pai_ct_add_aligned(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
                        size_t N, uint32_t* d_out, void* stream) {
+    return guarded([&] { add_aligned_common(pk, d_a, d_b, b_bcast, d_delta, N, d_out, nullptr, stream); });
+}
+
+int pai_ct_add_aligned_dom(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
+                           size_t N, uint32_t* d_out, const uint32_t* d_entry, void* stream) {
     return guarded([&] {
-        require(pk && d_a && d_b && d_delta && d_out, "NULL argument");
+        require(d_entry != nullptr, "NULL entry constant");
+        add_aligned_common(pk, d_a, d_b, b_bcast, d_delta, N, d_out, d_entry, stream);
+    });
+}
+
+int pai_ct_mont_mul(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N, uint32_t* d_out,
+                    void* stream) {
+    return guarded([&] {
+        require(pk && d_a && d_b && d_out, "NULL argument");
         if (N == 0) return;
         DeviceScope scope_(pk->device);
         const GeoOps* g = pk->msq.geo;
         g_last_times.clear();
-        ScopedKernelTimer t("k_add_aligned", (hipStream_t)stream);
-        g->add_aligned((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, b_bcast, d_delta, d_out, (int)N,
-                       pk->ct_words);
+        ScopedKernelTimer t("k_modmul", (hipStream_t)stream);
+        g->modmul((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
+                  MODMUL_MONT);
         t.stop();
         HIP_CHECK(hipGetLastError());
+    });
+}
+
+int pai_pubkey_mont_bits(const pai_pubkey* pk, int* bits) {
+    return guarded([&] {
+        require(pk && bits, "NULL argument");
+        *bits = RB * pk->msq.geo->nl;
     });
 }
 

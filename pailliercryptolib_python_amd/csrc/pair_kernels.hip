@@ -22,8 +22,8 @@ struct PairLaunch {
     }
     static void fixed_base(hipStream_t s, int grid, const PairParams& P, const uint32_t* m, const uint32_t* r, uint32_t* wv_out,
                            int n, int with_m) {
-        set_lds((const void*)k_pair_fixed_base<G>);
-        hipLaunchKernelGGL(k_pair_fixed_base<G>, dim3(grid), dim3(BLOCK_THREADS), BYTES, s, P, m, r, wv_out, n, with_m);
+        (void)hipFuncSetAttribute((const void*)k_pair_fixed_base<G>, hipFuncAttributeMaxDynamicSharedMemorySize, PairLds<G>::BYTES_FB);
+        hipLaunchKernelGGL(k_pair_fixed_base<G>, dim3(grid), dim3(BLOCK_THREADS), PairLds<G>::BYTES_FB, s, P, m, r, wv_out, n, with_m);
     }
 };
 #ifndef PAIR_G112

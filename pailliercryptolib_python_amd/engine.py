@@ -166,9 +166,50 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_ct_add(self.h, _ptr(a), _ptr(b), bcast, a.shape[0], _ptr(out), _stream(self.device)))
         return out
 
-    def ct_add_aligned(self, a: torch.Tensor, b: torch.Tensor, delta: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    # ---- lazy Montgomery domain (include/paillier_hip.h: pai_ct_mont_mul).  A buffer with tag k holds x R^k mod n^2. ----
+    @property
+    def mont_bits(self) -> int:
+        """log2 of the Montgomery radix R of the ciphertext engine (n^2 geometry)."""
+        if getattr(self, "_mont_bits", None) is None:
+            v = C.c_int(0)
+            _native.check(self.lib.pai_pubkey_mont_bits(self.h, C.byref(v)))
+            self._mont_bits = int(v.value)
+        return self._mont_bits
+
+    def dom_const(self, k: int) -> torch.Tensor:
+        """R^k mod n^2 as one packed device row (k any integer), cached per handle."""
+        cache = self.__dict__.setdefault("_dom_consts", {})
+        t = cache.get(k)
+        if t is None:
+            nsq = self.n * self.n
+            r = pow(2, self.mont_bits, nsq)
+            v = pow(r, k, nsq) if k >= 0 else pow(pow(r, -1, nsq), -k, nsq)
+            t = to_device_words(int_to_words(v, self.ct_words)[None, :], self.device)
+            cache[k] = t
+        return t
+
+    def ct_mont_mul(self, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """a_i * b_i * R^-1 mod n^2: ONE Montgomery product per element (tags ka, kb -> ka + kb - 1); b of one row broadcasts."""
+        self._chk(a, self.ct_words, "a")
+        self._chk(b, self.ct_words, "b")
+        bcast = 1 if (b.shape[0] == 1 and a.shape[0] != 1) else 0
+        if not bcast and a.shape[0] != b.shape[0]:
+            raise RuntimeError("Size mismatch")
+        out = self.empty_ct(a.shape[0]) if out is None else out
+        _native.check(self.lib.pai_ct_mont_mul(self.h, _ptr(a), _ptr(b), bcast, a.shape[0], _ptr(out), _stream(self.device)))
+        return out
+
+    def ct_retag(self, a: torch.Tensor, k_from: int, k_to: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x R^k_from -> x R^k_to (one product with the broadcast constant R^(1 + k_to - k_from)); k_to = 0 is the wire form."""
+        if k_from == k_to:
+            return a
+        return self.ct_mont_mul(a, self.dom_const(1 + k_to - k_from), out=out)
+
+    def ct_add_aligned(self, a: torch.Tensor, b: torch.Tensor, delta: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       dom: int = 0) -> torch.Tensor:
         """a_i * b_i mod n^2 after raising the lower-exponent side by ^(2^|delta_i|), delta = exponent(a) - exponent(b)
-        (int32 [N] on the device): __raw_add with its alignment in one pass (ipcl_python.py:490-526, 570-741)."""
+        (int32 [N] on the device): __raw_add with its alignment in one pass (ipcl_python.py:490-526, 570-741).
+        dom: the common domain tag of a and b (and of the result)."""
         self._chk(a, self.ct_words, "a")
         self._chk(b, self.ct_words, "b")
         bcast = 1 if (b.shape[0] == 1 and a.shape[0] != 1) else 0
@@ -177,8 +218,12 @@ class PublicKeyHandle:
         if delta.dtype != torch.int32 or delta.dim() != 1 or delta.shape[0] != a.shape[0] or not delta.is_contiguous():
             raise ValueError("delta: expected contiguous int32 [N]")
         out = self.empty_ct(a.shape[0]) if out is None else out
-        _native.check(self.lib.pai_ct_add_aligned(self.h, _ptr(a), _ptr(b), bcast, _ptr(delta), a.shape[0], _ptr(out),
-                                                  _stream(self.device)))
+        if dom == 0:
+            _native.check(self.lib.pai_ct_add_aligned(self.h, _ptr(a), _ptr(b), bcast, _ptr(delta), a.shape[0], _ptr(out),
+                                                      _stream(self.device)))
+        else:
+            _native.check(self.lib.pai_ct_add_aligned_dom(self.h, _ptr(a), _ptr(b), bcast, _ptr(delta), a.shape[0], _ptr(out),
+                                                          _ptr(self.dom_const(2 - dom)), _stream(self.device)))
         return out
 
     def ct_mul(self, ct: torch.Tensor, e: torch.Tensor, ebits_max: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -225,12 +270,22 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_ct_invert(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.device)))
         return out
 
-    def ct_pow2_(self, ct: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
+    def ct_pow2_(self, ct: torch.Tensor, delta, max_delta: Optional[int] = None) -> torch.Tensor:
+        """ct_i <- ct_i^(2^delta_i) in place for delta_i > 0.  delta: int32 device tensor, or a host numpy array (then the
+        largest shift is known here and the call never reads anything back: asynchronous for every batch size)."""
         self._chk(ct, self.ct_words, "ct")
+        if isinstance(delta, np.ndarray):
+            delta = np.ascontiguousarray(delta, dtype=np.int32).reshape(-1)
+            max_delta = int(delta.max()) if delta.size else 0
+            delta = torch.from_numpy(delta).to(self.device)
         if delta.dtype != torch.int32 or delta.dim() != 1 or not delta.is_contiguous():
             raise ValueError("delta: expected contiguous int32 [N] or [1]")
         bcast = 1 if (delta.shape[0] == 1 and ct.shape[0] != 1) else 0
-        _native.check(self.lib.pai_ct_pow2(self.h, _ptr(ct), _ptr(delta), bcast, ct.shape[0], _stream(self.device)))
+        if max_delta is None:
+            _native.check(self.lib.pai_ct_pow2(self.h, _ptr(ct), _ptr(delta), bcast, ct.shape[0], _stream(self.device)))
+        else:
+            _native.check(self.lib.pai_ct_pow2_hint(self.h, _ptr(ct), _ptr(delta), bcast, ct.shape[0], int(max_delta),
+                                                    _stream(self.device)))
         return ct
 
     # -- data formats either side of the path (device codec, obfuscator randomness) ----------------

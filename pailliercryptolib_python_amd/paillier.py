@@ -278,8 +278,8 @@ class PaillierEncryptedNumber:
     def _h(self) -> engine.PublicKeyHandle:
         return self.public_key.pubkey.handle
 
-    def _wrap(self, ct: torch.Tensor, expo, length: Optional[int] = None) -> "PaillierEncryptedNumber":
-        return PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, ct), expo,
+    def _wrap(self, ct: torch.Tensor, expo, length: Optional[int] = None, dom: int = 0) -> "PaillierEncryptedNumber":
+        return PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, ct, dom=dom), expo,
                                        ct.shape[0] if length is None else length)
 
     def __repr__(self):
@@ -333,8 +333,8 @@ class PaillierEncryptedNumber:
             raise IndexError("__getitem__: key out of range")
         if key.step not in (None, 1):
             raise RuntimeError("Step size not supported")
-        sub = self.words[start:stop].contiguous()
-        return self._wrap(sub, self._expo[start:stop])
+        t, dom = self.__ipclCipherText._raw()                    # a slice keeps its container's domain tag
+        return self._wrap(t[start:stop].contiguous(), self._expo[start:stop], dom=dom)
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
@@ -376,7 +376,7 @@ class PaillierEncryptedNumber:
         t = h.ct_add_aligned(self.words, b_inv, delta)
         k = (E - m).astype(np.int32)
         if (k > 0).any():
-            h.ct_pow2_(t, torch.from_numpy(np.ascontiguousarray(k)).to(h.device))
+            h.ct_pow2_(t, k)
         return self._wrap(t, E.astype(np.int32), self.__length)
 
     def __rsub__(self, other):
@@ -493,11 +493,15 @@ class PaillierEncryptedNumber:
         if other.words.shape[0] == 1 and self.words.shape[0] > 1:
             ye = np.broadcast_to(ye, xe.shape)
         delta = (xe - ye).astype(np.int32)
+        # lazy Montgomery domain (bindings.ipclCipherText._raw): operands hold x R^k; the sum is ONE product and its tag
+        # remembers the stray R^-1 — whoever needs the wire form pays the second product once, chains of sums never do
+        (ta, ka), (tb, kb) = self.__ipclCipherText._raw(), other.ciphertext()._raw()
         if not delta.any():
-            res = h.ct_add(self.words, other.words)
-        else:
-            res = h.ct_add_aligned(self.words, other.words, torch.from_numpy(np.ascontiguousarray(delta)).to(h.device))
-        return self._wrap(res, np.maximum(xe, ye).astype(np.int32), self.__length)
+            return self._wrap(h.ct_mont_mul(ta, tb), np.maximum(xe, ye).astype(np.int32), self.__length, dom=ka + kb - 1)
+        if kb != ka:
+            tb = h.ct_retag(tb, kb, ka)
+        res = h.ct_add_aligned(ta, tb, torch.from_numpy(np.ascontiguousarray(delta)).to(h.device), dom=ka)
+        return self._wrap(res, np.maximum(xe, ye).astype(np.int32), self.__length, dom=ka)
 
     def increase_exponent_to(self, x_ct, x_expo, exponent: int):
         """ipcl_python.py:528-568: raise every element of x to `exponent` (ct^(2^delta) where delta > 0)."""
@@ -506,7 +510,7 @@ class PaillierEncryptedNumber:
         if (delta > 0).any():
             h = self._h()
             words = words.clone()
-            h.ct_pow2_(words, torch.from_numpy(np.ascontiguousarray(delta)).to(h.device))
+            h.ct_pow2_(words, delta)
         return ipclCipherText(self.public_key.pubkey, words) if isinstance(x_ct, ipclCipherText) else words
 
     def __align_exponent(self, x_ct: torch.Tensor, x_expo, y_ct: torch.Tensor, y_expo):
@@ -522,13 +526,13 @@ class PaillierEncryptedNumber:
         dy = (res - ye).astype(np.int32)
         if (dx > 0).any():
             x_ct = x_ct.clone()
-            h.ct_pow2_(x_ct, torch.from_numpy(np.ascontiguousarray(dx)).to(h.device))
+            h.ct_pow2_(x_ct, dx)
         if (dy > 0).any():
             if y_ct.shape[0] == 1 and x_ct.shape[0] > 1:
                 y_ct = y_ct.expand(x_ct.shape[0], -1).contiguous()
             else:
                 y_ct = y_ct.clone()
-            h.ct_pow2_(y_ct, torch.from_numpy(np.ascontiguousarray(dy)).to(h.device))
+            h.ct_pow2_(y_ct, dy)
         return x_ct, y_ct, res.astype(np.int32)
 
     def length(self) -> int:

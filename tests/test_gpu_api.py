@@ -536,3 +536,63 @@ def test_standard_scheme_key_declared_wider_than_its_modulus():
     assert len(cts) == 5 and all(0 < int(c) < n * n for c in cts)
     back = ipclPrivateKey(raw, okey.p, okey.q).decrypt_tolist(ipclCipherText(raw, cts))
     assert [int(b) for b in back] == [0, 1, 2, 12345, n - 1]
+
+
+def test_lazy_domain_tags_never_change_the_bits(fixed):
+    """Sums are single Montgomery products whose stray R^-1 is remembered per container (bindings.ipclCipherText._raw);
+    every boundary (ciphertextBN, pickling, decryption, slices, further mixed-exponent additions, products, the
+    binding-level CipherText + CipherText and rotate) shows the bits of the reference's composition."""
+    pk, sk, okey = fixed
+    rng = np.random.default_rng(17)
+    N = 9
+    vals = [np.round(rng.uniform(-100, 100, N), 3) for _ in range(4)]
+    rs = [orc.synth_r_limbs(900 + i, N, okey.randbits) for i in range(4)]
+    ens = [pk.encrypt(v, r=r) for v, r in zip(vals, rs)]
+    ocs = [orc.api_encrypt(okey, list(v), orc.limbs_to_ints(r)) for v, r in zip(vals, rs)]
+    # equal exponents inside each array pair? force it: integers encode with exponent 0
+    ints = [list(range(i, i + N)) for i in (1, 50, 700)]
+    ei = [pk.encrypt(v, r=orc.synth_r_limbs(950 + i, N, okey.randbits)) for i, v in enumerate(ints)]
+    oi = [orc.api_encrypt(okey, v, orc.limbs_to_ints(orc.synth_r_limbs(950 + i, N, okey.randbits))) for i, v in enumerate(ints)]
+    s2 = ei[0] + ei[1]
+    s3 = s2 + ei[2]
+    assert s2.ciphertext()._raw()[1] == -1 and s3.ciphertext()._raw()[1] == -2           # one product each, tags drift
+    w2 = orc.api_add_ct(okey, *oi[0], *oi[1])
+    w3 = orc.api_add_ct(okey, *w2, *oi[2])
+    part = s3[2:5]                                                                        # a slice keeps the tag ...
+    assert part.ciphertext()._raw()[1] == -2
+    assert ct_ints(part) == w3[0][2:5]                                                    # ... and canonicalises on export
+    assert ct_ints(s3) == w3[0] and s3.ciphertext()._raw()[1] == 0                       # exported once, cached in place
+    assert sk.decrypt(s2) == [a + b for a, b in zip(ints[0], ints[1])]
+    # mixed exponents on tagged operands: (float + float) + (int + int) aligns inside pai_ct_add_aligned_dom
+    f2 = ens[0] + ens[1]
+    mix = f2 + (ei[0] + ei[1])
+    wf2 = orc.api_add_ct(okey, *ocs[0], *ocs[1])
+    wmix = orc.api_add_ct(okey, *wf2, *w2)
+    assert (ct_ints(mix), mix.exponent()) == (wmix[0], wmix[1])
+    # tagged operand into a product, a difference, a reduction and a pickle
+    s2b = ei[0] + ei[1]
+    prod = s2b * 2.5
+    wprod = orc.api_mul_plain(okey, *w2, 2.5)
+    assert (ct_ints(prod), prod.exponent()) == (wprod[0], wprod[1])
+    s2c = ei[0] + ei[1]
+    diff = s2c - ei[2]
+    wdiff = orc.api_sub_ct(okey, *w2, *oi[2])
+    assert (ct_ints(diff), diff.exponent()) == (wdiff[0], wdiff[1])
+    s2d = ei[0] + ei[1]
+    tot = s2d.sum()
+    wtot = orc.api_sum(okey, *w2)
+    assert (ct_ints(tot), tot.exponent()) == (wtot[0], wtot[1])
+    s2e = ei[0] + ei[1]
+    back = pickle.loads(pickle.dumps(s2e))
+    assert ct_ints(back) == w2[0]
+    # binding level: CipherText + CipherText (classes.cpp:318-321), rotate keeps the tag, getTexts is the wire form
+    ca, cb = ei[0].ciphertext(), ei[1].ciphertext()
+    cs = ca + cb
+    assert cs._raw()[1] == -1
+    rot = cs.rotate(2)
+    assert rot._raw()[1] == -1 and [int(b) for b in rot.getTexts()] == w2[0][2:] + w2[0][:2]
+    assert [int(b) for b in cs.getTexts()] == w2[0]
+    one = pk.encrypt(5, r=orc.synth_r_limbs(990, 1, okey.randbits))
+    bs = ei[0] + one                                                                      # broadcast addend
+    wb = orc.api_add_ct(okey, *oi[0], *orc.api_encrypt(okey, [5], orc.limbs_to_ints(orc.synth_r_limbs(990, 1, okey.randbits))))
+    assert ct_ints(bs) == wb[0]

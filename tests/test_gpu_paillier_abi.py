@@ -641,3 +641,50 @@ def test_ct_multiexp_matches_the_product_of_powers(bits, R, K, M, lanes, wbits, 
                 acc = acc * pow(base[r * K + l], e[r][l][j], key.nsq) % key.nsq
             want0.append(acc)
     assert limbs_to_ints(out.get()) == want0
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
+def test_lazy_montgomery_domain_exports(bits):
+    """pai_ct_mont_mul / pai_pubkey_mont_bits / pai_ct_add_aligned_dom (include/paillier_hip.h, 'lazy Montgomery domain'):
+    the single product a b R^-1 against CPython ints, the tag algebra (ka, kb -> ka + kb - 1; retag by a broadcast
+    constant), a chain of three single-product additions brought back to the wire form with one more product = the bits of
+    three pai_ct_add calls, and the aligned addition on operands stored as x R^k for k in {-2, -1, 1, 3}."""
+    nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
+    M = nk.key.nsq
+    rb = C.c_int(0)
+    _native.check(nk.lib.pai_pubkey_mont_bits(nk.pk, C.byref(rb)))
+    assert rb.value % 29 == 0 and (1 << rb.value) > 4 * M
+    R = pow(2, rb.value, M)
+    Ri = pow(R, -1, M)
+    rng = np.random.default_rng(bits + 31)
+
+    def rk(k):
+        return pow(R, k, M) if k >= 0 else pow(Ri, -k, M)
+
+    for N in (1, 17, 130):
+        a, b, c, d = (rand_below(rng, M, N) for _ in range(4))
+        a[0] = M - 1
+        da, db, dc, dd = (DevArray(ints_to_limbs(v, nk.cw)) for v in (a, b, c, d))
+        out = DevArray(shape=(N, nk.cw))
+        _native.check(nk.lib.pai_ct_mont_mul(nk.pk, da.ptr, db.ptr, 0, N, out.ptr, None))
+        assert limbs_to_ints(out.get()) == [x * y * Ri % M for x, y in zip(a, b)], (bits, N)
+        _native.check(nk.lib.pai_ct_mont_mul(nk.pk, da.ptr, db.ptr, 1, N, out.ptr, None))
+        assert limbs_to_ints(out.get()) == [x * b[0] * Ri % M for x in a], (bits, N, "bcast")
+        # ((a + b) + c) + d with one product each: tag -3; one product with R^4 returns to the wire form
+        _native.check(nk.lib.pai_ct_mont_mul(nk.pk, da.ptr, db.ptr, 0, N, out.ptr, None))
+        _native.check(nk.lib.pai_ct_mont_mul(nk.pk, out.ptr, dc.ptr, 0, N, out.ptr, None))       # in place
+        _native.check(nk.lib.pai_ct_mont_mul(nk.pk, out.ptr, dd.ptr, 0, N, out.ptr, None))
+        k4 = DevArray(ints_to_limbs([rk(4)], nk.cw))
+        _native.check(nk.lib.pai_ct_mont_mul(nk.pk, out.ptr, k4.ptr, 1, N, out.ptr, None))
+        assert limbs_to_ints(out.get()) == [w * x * y * z % M for w, x, y, z in zip(a, b, c, d)], (bits, N, "chain")
+        # aligned addition on a common tag k
+        delta = rng.integers(-5, 6, N).astype(np.int32)
+        delta[0] = 0
+        ddl = DevArray(delta)
+        plain = [x * pow(y, 1 << int(t), M) % M if t > 0 else pow(x, 1 << int(-t), M) * y % M for x, y, t in zip(a, b, delta)]
+        for k in (-2, -1, 1, 3):
+            ak, bk = [x * rk(k) % M for x in a], [y * rk(k) % M for y in b]
+            dak, dbk = DevArray(ints_to_limbs(ak, nk.cw)), DevArray(ints_to_limbs(bk, nk.cw))
+            ent = DevArray(ints_to_limbs([rk(2 - k)], nk.cw))
+            _native.check(nk.lib.pai_ct_add_aligned_dom(nk.pk, dak.ptr, dbk.ptr, 0, ddl.ptr, N, out.ptr, ent.ptr, None))
+            assert limbs_to_ints(out.get()) == [v * rk(k) % M for v in plain], (bits, N, k)
