@@ -61,8 +61,10 @@ struct GeoInst {
     }
     static void dec_a(hipStream_t s, int gridx, DecAParams P, const uint32_t* ct, uint32_t* u_out, int n,
                       uint32_t* table) {
-        set_lds((const void*)k_dec_a<G, MODEXP_WINDOW>, G::LDS_BYTES);
-        hipLaunchKernelGGL((k_dec_a<G, MODEXP_WINDOW>), dim3(gridx, 2), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, ct,
+        // the wide-group (latency) geometries run stage A on minus-one contexts (mont_dev.hpp: Rows::block_m1)
+        using GD = Geo<G::NLL, G::T, G::U, G::NMLDS, (G::T >= 16)>;
+        set_lds((const void*)k_dec_a<GD, MODEXP_WINDOW>, GD::LDS_BYTES);
+        hipLaunchKernelGGL((k_dec_a<GD, MODEXP_WINDOW>), dim3(gridx, 2), dim3(BLOCK_THREADS), GD::LDS_BYTES, s, P, ct,
                            u_out, n, table);
     }
     static void dec_b(hipStream_t s, int grid, DecBParams P, const uint32_t* u_in, uint32_t* m_out, int n) {

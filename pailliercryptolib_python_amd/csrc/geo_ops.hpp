@@ -107,6 +107,7 @@ bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams&
 
 // digit pairs with base n on the lane-group engine (kernels_pair.hpp): DJN obfuscator / encryption for n of 2049 .. 4156 bits
 struct PairParams;
+struct PairCtMulParams;
 int pair_nl_for_n_bits(int bits);                 // 112 / 144 limbs, 0 = not served
 int pair_epb(int nl);                             // elements per workgroup
 bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
@@ -115,6 +116,8 @@ bool launch_pair_fb_expand(int nl, hipStream_t s, int grid, const MontCtx* nctx,
                            uint32_t* T, int J, int h);
 bool launch_pair_fixed_base(int nl, hipStream_t s, int grid, const PairParams& P, const uint32_t* m, const uint32_t* r,
                             uint32_t* wv_out, int n, int with_m);
+bool launch_pair_ctmul(int nl, hipStream_t s, int grid, const PairCtMulParams& P, const uint32_t* ct, const uint32_t* e,
+                       uint32_t* wv_out, int n);
 
 // x = a^-1 mod M for `count` values of `words` 32-bit words each (words in {64,128,192,256}); *fail counts
 // non-invertible inputs.  Returns false if `words` has no instantiation.

@@ -31,10 +31,12 @@ struct MexpParams {
 
 // Geometry of one kernel instance: NLL limbs per lane, T lanes per element, U rows per block,
 // NMLDS = the modulus slice is re-read from LDS during the q*n step instead of living in VGPRs.
-template <int NLL_, int T_, int U_, bool NMLDS_ = false>
+// M1 = "minus-one" Montgomery contexts (mont_dev.hpp: Rows::block_m1) — the wide-group latency kernels.
+template <int NLL_, int T_, int U_, bool NMLDS_ = false, bool M1_ = false>
 struct Geo {
     static constexpr int NLL = NLL_, T = T_, U = U_;
     static constexpr bool NMLDS = NMLDS_;
+    static constexpr bool M1 = M1_;
     static constexpr int NL = NLL * T;                 // limbs per element
     static constexpr int EPB = BLOCK_THREADS / T;      // elements per workgroup
     static constexpr int LDS_WORDS = NL * EPB;         // one [limb][element] operand buffer
@@ -62,8 +64,9 @@ PAI_DEV void load_modulus(typename G::NM& nm, const MontCtx* __restrict__ ctx, u
         nm.p = dst + G::NLL * G::gl();
     } else {
         const int t = G::gl();
+        const uint32_t* src = G::M1 ? ctx->npp : ctx->n;     // minus-one contexts multiply the quotient digits by (M + 1) / 2^(29 U)
 #pragma unroll
-        for (int j = 0; j < G::NLL; ++j) nm.v[j] = ctx->n[G::NLL * t + j];
+        for (int j = 0; j < G::NLL; ++j) nm.v[j] = src[G::NLL * t + j];
     }
 }
 
@@ -293,10 +296,12 @@ PAI_DEV void stage_b(const uint32_t (&x)[G::NLL], uint32_t* lds) {
 }
 
 // r = a * b mod-Montgomery with b taken from the element's LDS column
+// (minus-one geometries: nm is the (M + 1) / 2^(29 U) slice and the scalar next to it the number of row blocks)
 template <class G>
 PAI_DEV void mm_lds(uint32_t (&r)[G::NLL], const uint32_t (&a)[G::NLL], const uint32_t* lds,
                     const typename G::NM& nm, uint32_t n0inv) {
-    mont_mul<G::NLL, G::U, G::T>(r, a, lds + G::elem(), G::EPB, nm, n0inv);
+    if constexpr (G::M1) mont_mul_m1<G::NLL, G::U, G::T>(r, a, lds + G::elem(), G::EPB, nm, (int)n0inv);
+    else mont_mul<G::NLL, G::U, G::T>(r, a, lds + G::elem(), G::EPB, nm, n0inv);
 }
 
 // x = x * x (Montgomery) : stage x as b, multiply by itself

@@ -231,6 +231,8 @@ struct DecAParams {
     const uint32_t* expo[2];     // s - 1, packed u32 words
     int ewords[2], ebits[2];
     int ct_words, u_words;       // u_words = words of an s^2 residue
+    const MontCtx* fin[2];       // minus-one geometries: sq[] are contexts of s^2 * k (k = -s^-2 mod 2^(29 U)); the result
+                                 // is reduced modulo s^2 itself with these conventional contexts at the very end
 };
 
 template <class G, int W>
@@ -245,7 +247,8 @@ k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_
     const int t = G::gl();
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
-    const uint32_t n0inv = ctx->n0inv;
+    const uint32_t n0inv = G::M1 ? ctx->rows / G::U : ctx->n0inv;      // minus-one contexts: the number of row blocks instead
+    const int nrows = G::M1 ? (int)ctx->rows : G::NL;                   // limbs per chunk of the ciphertext (R = 2^(29 nrows))
     const size_t nslots = (size_t)gridDim.x * gridDim.y * G::EPB;
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * G::EPB + G::elem();
     auto tbl = [&](int entry, int j) -> uint32_t& {
@@ -263,15 +266,21 @@ k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_
             uint32_t bR[G::NLL];
             {
                 uint32_t hi[G::NLL], c[G::NLL];
-                load_elem_off<G>(hi, row, P.ct_words, G::NL);
+                load_elem_off<G>(hi, row, P.ct_words, nrows);
                 load_const_slice<G>(c, P.r3[which]);
                 mm_times<G>(hi, c, lds, nm, n0inv);                 // hi * R^2
                 load_elem_off<G>(bR, row, P.ct_words, 0);
+                if constexpr (G::M1) {                              // the low chunk is nrows limbs, not the geometry's NL
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) bR[j] = (G::NLL * t + j < nrows) ? bR[j] : 0u;
+                }
                 load_const_slice<G>(c, ctx->r2);
                 mm_times<G>(bR, c, lds, nm, n0inv);                 // lo * R
                 add_limbs<G>(bR, hi);
-                cond_sub<G::NLL, G::T>(bR, nm);                     // < 4M -> < 2M
-                cond_sub<G::NLL, G::T>(bR, nm);
+                if constexpr (!G::M1) {                             // (minus-one contexts have R > 16 M: < 4M is a valid operand)
+                    cond_sub<G::NLL, G::T>(bR, nm);                 // < 4M -> < 2M
+                    cond_sub<G::NLL, G::T>(bR, nm);
+                }
             }
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) { x[j] = bR[j]; tbl(1, j) = bR[j]; }
@@ -306,7 +315,22 @@ k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_
             uint32_t one[G::NLL];
             set_plain_one<G>(one);
             mm_times<G>(x, one, lds, nm, n0inv);
-            cond_sub<G::NLL, G::T>(x, nm);
+            if constexpr (G::M1) {
+                // x is the power modulo s^2 k (lazy); two conventional products with the context of s^2 itself reduce it:
+                // x * R^2 * R^-1 = x R (mod s^2), then * 1 * R^-1
+                const MontCtx* f = P.fin[which];
+                NmRegs<G::NLL> nf;
+                load_const_slice<G>(nf.v, f->n);
+                uint32_t c[G::NLL], r[G::NLL];
+                load_const_slice<G>(c, f->r2);
+                stage_b<G>(x, lds);
+                mont_mul<G::NLL, G::U, G::T>(r, c, lds + G::elem(), G::EPB, nf, f->n0inv);
+                stage_b<G>(r, lds);
+                mont_mul<G::NLL, G::U, G::T>(x, one, lds + G::elem(), G::EPB, nf, f->n0inv);
+                cond_sub<G::NLL, G::T>(x, nf);
+            } else {
+                cond_sub<G::NLL, G::T>(x, nm);
+            }
         }
         if (live) store_elem<G>(x, u_out + ((size_t)which * n + ei) * P.u_words, P.u_words, lds);
     }

@@ -46,6 +46,7 @@ struct PairLds {
     static constexpr bool STREAM = G::T >= PAIR_STREAM_T;
     static constexpr int BYTES = (2 * G::LDS_WORDS + 2 * G::NL) * 4;
     static constexpr int BYTES_FB = BYTES + (STREAM ? 2 * G::LDS_WORDS * 4 : 0);      // k_pair_fixed_base: + the second buffer pair
+    static constexpr int BYTES_CT = BYTES + 2 * G::LDS_WORDS * 4;                     // k_pair_ctmul: always two buffer pairs
     PAI_DEV static uint32_t* c2(uint32_t* lds) { return lds + 2 * G::LDS_WORDS + 2 * G::NL; }
     PAI_DEV static uint32_t* d2(uint32_t* lds) { return lds + 3 * G::LDS_WORDS + 2 * G::NL; }
     PAI_DEV static uint32_t* mod(uint32_t* lds) { return lds + 2 * G::LDS_WORDS + G::NL; }   // modulus copy (NMLDS geometries)
@@ -281,6 +282,128 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
             for (int j = 0; j < G::NLL; ++j) d[j] = 0;
         }
         pair_times<G>(a, b, c, d, lds, nm, n0inv);
+        if (live) {
+            uint32_t* row = wv_out + (size_t)ei * 2 * P.out_words;
+            store_elem<G>(a, row, P.out_words, PairLds<G>::c(lds));
+            store_elem<G>(b, row + P.out_words, P.out_words, PairLds<G>::c(lds));
+        }
+    }
+}
+
+// ---- ct^e for per-element exponents (ciphertext * plaintext, CipherText::operator*, classes.cpp:324-325) ------------------
+// The lane-group counterpart of k_ctmul_padic for n of 2049 .. 4156 bits (BASELINE configs 4 and 5).  Round 2 ran this
+// operation as Montgomery products modulo n^2 (k_modexp_var_win: 8 NL^2 limb products each, NL = limbs of n); a 53-bit
+// exponent is 52 squarings and ~22 multiplications, and on digit pairs a SQUARING is 4 NL^2 (a a, its reduction, 2 a b, its
+// reduction) and a multiplication 5 NL^2.  Flow: the ciphertext enters digit form through its base-R digits,
+// sum_i (D_i, 0) (x) pair(R^(i+2) mod n^2) (as stage A of decryption does); per-slot table of the powers 0 .. 2^w - 1,
+// row-major [slot][entry][2][NL]; per window w squarings and one multiplication whose table entry STREAMS into the second
+// LDS buffer pair during the window's last squaring (RowStream); the plain pair (1, 0) takes the power out of Montgomery
+// form and (w, v) leaves as two packed rows for k_pair_finish (w + v n on the n^2 geometry).
+struct PairCtMulParams {
+    const MontCtx* nctx;         // modulus n on the pair geometry
+    const uint32_t* nm1;         // n - 1
+    const uint32_t* kdig;        // [nd][2][NL] pairs of R^(i+2) mod n^2
+    const uint32_t* one_pair;    // pair(R mod n^2): the Montgomery digit form of 1
+    uint32_t* table;             // [grid * EPB][2^wbits][2][NL]
+    int nd, wbits, ct_words, e_words, ebits_max, e_bcast, out_words;
+};
+
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
+k_pair_ctmul(PairCtMulParams P, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ e, uint32_t* __restrict__ wv_out, int n) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    pair_setup<G>(lds, P.nm1);
+    typename G::NM nm;
+    pair_load_modulus<G>(nm, P.nctx, lds);
+    const uint32_t n0inv = P.nctx->n0inv;
+    constexpr int PAIR_OFF = 2 * G::LDS_WORDS + 2 * G::NL;          // second buffer pair (plain offsets: see k_pair_fixed_base)
+    constexpr int CH = (G::NLL % 4 == 0) ? 4 : 2, NCH = G::NLL / CH;
+    const int t = G::gl();
+    const int W = P.wbits, NT = 1 << W;
+    const int nwin = (P.ebits_max + W - 1) / W;
+    const size_t slot = (size_t)blockIdx.x * G::EPB + G::elem();
+    uint32_t* trow = P.table + slot * (size_t)NT * 2 * G::NL;
+    const int col = (G::NLL * t) * G::EPB + G::elem();
+    const uint32_t* mm1 = PairLds<G>::nm1(lds);
+    const int tiles = (n + G::EPB - 1) / G::EPB;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * G::EPB + G::elem();
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        const uint32_t* erow = e + (size_t)(P.e_bcast ? 0 : es) * P.e_words;
+        auto window = [&](int wi) -> int {
+            const int bit = wi * W, k = bit >> 5;
+            uint64_t bits2 = k < P.e_words ? erow[k] : 0u;
+            if (k + 1 < P.e_words) bits2 |= (uint64_t)erow[k + 1] << 32;
+            return (int)((uint32_t)(bits2 >> (bit & 31)) & (uint32_t)(NT - 1));
+        };
+        uint32_t a[G::NLL], b[G::NLL];
+        {   // digit form of the ciphertext (Montgomery digit form: the pair of ct R)
+            const uint32_t* row = ct + (size_t)es * P.ct_words;
+            uint32_t sa[G::NLL], sb[G::NLL], c[G::NLL], d[G::NLL];
+#pragma unroll 1
+            for (int i = 0; i < P.nd; ++i) {
+                load_elem_off<G>(a, row, P.ct_words, G::NL * i);
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) b[j] = 0;
+                pair_load<G>(c, d, P.kdig + (size_t)i * 2 * G::NL);
+                pair_times<G>(a, b, c, d, lds, nm, n0inv);
+                if (i == 0) {
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) { sa[j] = a[j]; sb[j] = b[j]; }
+                } else {
+                    add_limbs<G>(sa, a);
+                    add_limbs<G>(sb, b);
+                }
+            }
+            // table: T[0] = 1, T[1] = x, T[k] = T[k - 1] x  (x staged once as the right operand)
+            pair_load<G>(c, d, P.one_pair);
+            pair_store<G>(c, d, trow);
+            pair_store<G>(sa, sb, trow + 2 * G::NL);
+            stage_b<G>(sa, PairLds<G>::c(lds));
+            stage_b<G>(sb, PairLds<G>::d(lds));
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) { a[j] = sa[j]; b[j] = sb[j]; }
+#pragma unroll 1
+            for (int k = 2; k < NT; ++k) {
+                pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB, mm1, nm, n0inv);
+                pair_store<G>(a, b, trow + (size_t)k * 2 * G::NL);
+            }
+        }
+        pair_load<G>(a, b, trow + (size_t)window(nwin - 1) * 2 * G::NL);
+#pragma unroll 1
+        for (int wi = nwin - 2; wi >= 0; --wi) {
+            const int dg = window(wi);
+            const bool any = __any(dg != 0);
+            RowStream<CH, NCH, NCH> pf;
+            pf.src0 = trow + (size_t)dg * 2 * G::NL + G::NLL * t;
+            pf.src1 = pf.src0 + G::NL;
+            pf.dst0 = lds + PAIR_OFF + col;
+            pf.dst1 = lds + PAIR_OFF + G::LDS_WORDS + col;
+            pf.stride = G::EPB;
+            const int nsteps = W + (any ? 1 : 0);
+#pragma unroll 1
+            for (int s = 0; s < nsteps; ++s) {                 // one rolled body: W squarings, then the multiplication
+                const bool is_mul = s == W;
+                if (!is_mul) {
+                    stage_b<G>(a, PairLds<G>::c(lds));
+                    stage_b<G>(b, PairLds<G>::d(lds));
+                } else {
+                    wave_lds_fence();
+                }
+                pf.on = any && s == W - 1;
+                const int off = is_mul ? PAIR_OFF : 0;
+                pair_mul<G::NLL, G::U, G::T>(a, b, lds + off + G::elem(), lds + off + G::LDS_WORDS + G::elem(), G::EPB, mm1, nm, n0inv,
+                                             &pf, !is_mul);
+            }
+        }
+        {   // leave Montgomery form: times the plain pair (1, 0)
+            uint32_t c[G::NLL], d[G::NLL];
+            set_plain_one<G>(c);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) d[j] = 0;
+            pair_times<G>(a, b, c, d, lds, nm, n0inv);
+        }
         if (live) {
             uint32_t* row = wv_out + (size_t)ei * 2 * P.out_words;
             store_elem<G>(a, row, P.out_words, PairLds<G>::c(lds));

@@ -49,7 +49,8 @@ struct MontCtx {
     uint32_t n0inv;           // -M^-1 mod 2^29
     uint32_t nl;              // limbs in use (template instance must match)
     uint32_t bits;            // bit length of M
-    uint32_t pad_;
+    uint32_t rows;            // "minus-one" contexts (Rows::block_m1): rows per product, R = 2^(29 rows); else 0
+    uint32_t npp[NLMAX];      // "minus-one" contexts: (M + 1) / 2^(29 U), the multiplier of the quotient digits
 };
 
 // ---- lane-group helpers -------------------------------------------------------------------------
@@ -177,6 +178,40 @@ struct Rows {
             if constexpr (T > 1) acc[NLL - U + u] += (uint64_t)from_next<T>(low[u]);
             acc[NLL + u] = 0;
         }
+    }
+
+    // U rows for a modulus M == -1 (mod 2^(29 U)) ("minus-one" contexts: the caller's modulus times -M^-1 mod 2^(29 U)):
+    // T + q M with q = T mod 2^(29 U) is T - q + q (M + 1), so the U quotient digits of a block ARE the U limbs the
+    // block retires — no multiplication by -M^-1 and, what matters on a lone wave, no dependency of row u + 1's digit on
+    // row u's multiply-accumulates: all a*b of the block, one short carry chain, the broadcasts, all q*(M + 1)/2^(29 U).
+    // The wide-group (latency) geometries spend 80 % of their instructions outside the multiplier; this halves them.
+    template <class NM>
+    PAI_DEV static void block_m1(uint64_t (&acc)[NW], const uint32_t (&a)[NLL], const uint32_t (&bv)[U], const NM& npp) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < NLL; ++j) acc[j + u] += (uint64_t)a[j] * bv[u];
+        }
+        uint32_t low[U], q[U];
+        uint64_t c = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t t = acc[u] + c;
+            low[u] = (uint32_t)t & RMASK;
+            c = t >> RB;
+        }
+        acc[U] += c;
+#pragma unroll
+        for (int u = 0; u < U; ++u) q[u] = bcast0<T>(low[u]);            // group lane 0 retires the quotient digits
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) acc[j] = acc[j + U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[NLL + u] = 0;
+            if constexpr (T > 1) acc[NLL - U + u] += (uint64_t)from_next<T>(low[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) npp.template mac<NLL>(acc, u, q[u]);
     }
 
     // full carry propagation into canonical 29-bit limbs (across the T lanes of the group)
@@ -351,6 +386,39 @@ PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32
     RW::finish(acc, r);
 }
 
+// r = a * b * 2^(-29 U nblk) mod M for a "minus-one" context (Rows::block_m1): only the first U * nblk limbs of b are
+// read (b < 2^(29 U nblk) = R), a may use the whole geometry; npp = this lane's slice of (M + 1) / 2^(29 U).
+// Lazy in, lazy out (< 2M) for R > 16 M (the margin lets a sum of two lazy values in as an operand).
+template <int NLL, int U, int T, class NM>
+PAI_DEV void mont_mul_m1(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32_t* b_ptr, int bstride, const NM& npp,
+                         int nblk) {
+    static_assert(NORM_ROWS % U == 0, "NORM_ROWS must be a multiple of U");
+    using RW = Rows<NLL, U, T>;
+    uint64_t acc[RW::NW];
+    RW::zero(acc);
+    constexpr int NORM_BLOCKS = NORM_ROWS / U;          // two products per row and column, as in mont_mul
+    int since = 0;
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; ++blk) {
+        uint32_t bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) bv[u] = b_ptr[(blk * U + u) * bstride];
+        RW::block_m1(acc, a, bv, npp);
+        if (++since == NORM_BLOCKS && blk != nblk - 1) { RW::normalize(acc); since = 0; }
+    }
+    // block_m1 adds q (M + 1) / 2^(29 U) AFTER the slide, so the window's top U columns still hold partial sums when the
+    // last block ends (mont_mul's are zero there): they are the next lane's lowest columns — hand them over before finish()
+    if constexpr (T > 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t top = acc[NLL + u];
+            const uint32_t lo = from_prev<T>((uint32_t)top), hi = from_prev<T>((uint32_t)(top >> 32));
+            acc[u] += ((uint64_t)hi << 32) | lo;
+        }
+    }
+    RW::finish(acc, r);
+}
+
 // ---- digit pairs with base M on the lane-group engine ---------------------------------------------------------
 // An element x of Z/M^2 is the pair (a, b), a + b M == x R (mod M^2) with R = 2^(29 NL) (mont_padic.hpp has the
 // algebra): (a, b) (x) (c, d) = (w, v),  w = (a c + m M) / R,  v = (a d + b c - m + R M + m' M) / R — both
@@ -363,9 +431,11 @@ PAI_DEV void mont_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32
 // Inputs lazy (< 2M + eps), outputs lazy; R / M >= 2^20 required.
 constexpr int PAIR_NORM_MAX = 16;              // three 2^58 products per row and column: 16 rows stay below 2^64
 
+// sqr (wave-uniform): the rows at c_ptr / d_ptr are (a, b) themselves — a d + b c is then 2 a d, one multiply-accumulate
+// per limb pair less (4 NL^2 instead of 5 NL^2); both forms share this one body.
 template <int NLL, int U, int T, class NM, class PF = NoStream>
 PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_ptr, const uint32_t* d_ptr, int stride,
-                      const uint32_t* mm1, const NM& nm, uint32_t n0inv, PF* pf = nullptr) {
+                      const uint32_t* mm1, const NM& nm, uint32_t n0inv, PF* pf = nullptr, bool sqr = false) {
     static_assert(NLL % U == 0 && U <= PAIR_NORM_MAX, "row-block size");
     using RW = Rows<NLL, U, T>;
     constexpr int NW = RW::NW;
@@ -385,6 +455,7 @@ PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_
         for (int u = 0; u < U; ++u) {
             cv[u] = c_ptr[(blk * U + u) * stride];
             dv[u] = d_ptr[(blk * U + u) * stride];
+            dv[u] = sqr ? dv[u] << 1 : dv[u];
             const uint32_t f = mm1[blk * U + u];
             acc2[NLL + u] += top ? (uint64_t)f : 0ull;           // (M - 1) R: column NL + row
         }
@@ -399,9 +470,10 @@ PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_
             low1[u] = (uint32_t)acc1[u] & RMASK;
             acc2[u] += lane0 ? (uint64_t)(RMASK - q1) : 0ull;
 #pragma unroll
-            for (int j = 0; j < NLL; ++j) {
-                acc2[j + u] += (uint64_t)a[j] * dv[u];
-                acc2[j + u] += (uint64_t)b[j] * cv[u];
+            for (int j = 0; j < NLL; ++j) acc2[j + u] += (uint64_t)a[j] * dv[u];
+            if (!sqr) {
+#pragma unroll
+                for (int j = 0; j < NLL; ++j) acc2[j + u] += (uint64_t)b[j] * cv[u];
             }
             const uint32_t q2 = bcast0<T>(((uint32_t)acc2[u] * n0inv) & RMASK);
             nm.template mac<NLL>(acc2, u, q2);

@@ -220,6 +220,46 @@ struct ModSetup {
         HIP_CHECK(hipMalloc((void**)&d_ctx, sizeof(MontCtx)));
         HIP_CHECK(hipMemcpy(d_ctx, &h, sizeof(MontCtx), hipMemcpyHostToDevice));
     }
+    // "Minus-one" context of the wide-group (latency) kernels (mont_dev.hpp: Rows::block_m1): the modulus is replaced by
+    // M' = M k, k = -M^-1 mod 2^(29 U), so that M' == -1 (mod 2^(29 U)) and the quotient digits of a row block are the
+    // limbs the block retires.  Residues modulo M' are residues modulo M; R = 2^(29 rows) with rows = the limbs M' needs
+    // (+ 4 bits of head-room: R > 16 M'), not the geometry's capacity.  M, R, R2, R3 of this object then refer to M'.
+    void init_m1(const Limbs& mod_, const GeoOps* g) {
+        require(hbn::is_odd(mod_), "modulus must be odd");
+        geo = g;
+        nl = g->nl;
+        const int ub = hbn::RB * g->u;
+        const Limbs pow = hbn::shl(Limbs{1u}, ub);
+        const Limbs k = hbn::sub(pow, hbn::inv_mod_pow2(mod_, ub));           // -M^-1 mod 2^(29 U)
+        M = hbn::mul(mod_, k);
+        bits = hbn::bitlen(M);
+        w32 = words_for_bits(bits);
+        int rows = (bits + 4 + hbn::RB - 1) / hbn::RB;
+        rows = (rows + g->u - 1) / g->u * g->u;
+        require(rows <= nl, "minus-one modulus does not fit the geometry");
+        const Limbs mp1 = hbn::add(M, Limbs{1u});
+        require(hbn::is_zero(hbn::low_bits(mp1, ub)), "minus-one modulus: construction failed");
+        const Limbs npp = hbn::shr(mp1, ub);
+        R = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * rows), M);
+        R2 = hbn::mulmod(R, R, M);
+        R3 = hbn::mulmod(R2, R, M);
+        MontCtx h;
+        std::memset(&h, 0, sizeof(h));
+        auto put = [&](uint32_t* dst, const Limbs& v) {
+            auto r = hbn::to_r29(v, nl);
+            std::memcpy(dst, r.data(), (size_t)nl * 4);
+        };
+        put(h.n, M);
+        put(h.npp, npp);
+        put(h.r2, R2);
+        put(h.one, R);
+        h.n0inv = 1;
+        h.nl = (uint32_t)nl;
+        h.bits = (uint32_t)bits;
+        h.rows = (uint32_t)rows;
+        HIP_CHECK(hipMalloc((void**)&d_ctx, sizeof(MontCtx)));
+        HIP_CHECK(hipMemcpy(d_ctx, &h, sizeof(MontCtx), hipMemcpyHostToDevice));
+    }
     void release() {
         if (d_ctx) (void)hipFree(d_ctx);
         d_ctx = nullptr;
@@ -335,6 +375,10 @@ struct pai_pubkey {
     ModSetup npair;                    // n at pair_nl limbs
     uint32_t* d_pair_nm1 = nullptr;
     uint32_t* d_pair_fb = nullptr;     // [J][2^wb][2][pair_nl]
+    uint32_t* d_pair_kdig = nullptr;   // [pair_nd][2][pair_nl] pairs of R^(i+2) mod n^2 (ct * pt on lane-group digit pairs)
+    uint32_t* d_pair_one = nullptr;    // pair(R mod n^2)
+    int pair_nd = 0;
+    mutable DevBuf pair_ct_table;      // per-slot power tables of k_pair_ctmul
     int pair_windows = 0, pair_wbits = 0, pair_out_words = 0;
     mutable DevBuf pair_wv;            // plain digit pairs on their way to k_encrypt mode 5 / 6
     uint16_t* d_pow_ops = nullptr;     // sliding-window schedule of the exponent n (standard scheme)
@@ -407,6 +451,7 @@ struct pai_privkey {
     struct Lat {
         bool ready = false, usable = false;
         ModSetup sq[2], pr[2];
+        ModSetup sq_true[2];          // s^2 itself (sq[] are minus-one contexts of s^2 k): the last reduction of stage A
         uint32_t* d_r3[2] = {nullptr, nullptr};
         uint32_t* d_sinv2[2] = {nullptr, nullptr};
         uint32_t* d_nsinv2[2] = {nullptr, nullptr};
@@ -576,6 +621,10 @@ int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e
     });
 }
 // window width of the per-element-exponent kernels: table build 2^w - 2 products, then w squarings + 1 product per window
+static bool pair_ctmul_disabled() {                 // PAI_DISABLE_PAIR_CTMUL=1: ct * pt above 2048-bit keys as products modulo n^2
+    const char* env = std::getenv("PAI_DISABLE_PAIR_CTMUL");
+    return env && env[0] == '1';
+}
 static int var_window_bits(int ebits_max) { return ebits_max <= 24 ? 2 : (ebits_max <= 80 ? 3 : (ebits_max <= 240 ? 4 : 5)); }
 
 int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const uint32_t* d_e, int e_words,
@@ -927,6 +976,27 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
                 pk->npair.init(pk->n, pk->pair_nl);
                 pk->d_pair_nm1 = upload_r29(hbn::sub(pk->n, Limbs{1u}), pk->pair_nl);
                 pk->pair_out_words = (hbn::RB * pk->pair_nl + 31) / 32;
+                // ct * pt on digit pairs (k_pair_ctmul): a ciphertext enters digit form through its base-R digits D_i,
+                // sum_i (D_i, 0) (x) pair(R^(i+2) mod n^2); pair(x) = (x mod n, x div n)
+                const int pnl = pk->pair_nl;
+                auto pair_of = [&](const Limbs& v, std::vector<uint32_t>& dst) {
+                    Limbs rem;
+                    Limbs quo = hbn::divq(v, pk->n, &rem);
+                    auto ra = hbn::to_r29(rem, pnl), rb = hbn::to_r29(quo, pnl);
+                    dst.insert(dst.end(), ra.begin(), ra.end());
+                    dst.insert(dst.end(), rb.begin(), rb.end());
+                };
+                const Limbs Rm = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * pnl), pk->nsq);
+                pk->pair_nd = (32 * pk->ct_words + hbn::RB * pnl - 1) / (hbn::RB * pnl);
+                std::vector<uint32_t> kd, one;
+                Limbs K = hbn::mulmod(Rm, Rm, pk->nsq);
+                for (int i = 0; i < pk->pair_nd; ++i) {
+                    pair_of(K, kd);
+                    K = hbn::mulmod(K, Rm, pk->nsq);
+                }
+                pair_of(Rm, one);
+                pk->d_pair_kdig = upload_vec(kd);
+                pk->d_pair_one = upload_vec(one);
             }
         }
         if (h_hs) {
@@ -972,6 +1042,9 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->npair.release();
     if (pk->d_pair_nm1) (void)hipFree(pk->d_pair_nm1);
     if (pk->d_pair_fb) (void)hipFree(pk->d_pair_fb);
+    if (pk->d_pair_kdig) (void)hipFree(pk->d_pair_kdig);
+    if (pk->d_pair_one) (void)hipFree(pk->d_pair_one);
+    pk->pair_ct_table.release();
     pk->pair_wv.release();
     pk->ctmul_table.release();
     pk->pow2_expo.release();
@@ -1316,6 +1389,47 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         }
         const GeoOps* g = pk->msq.geo;
         const int grid = grid_for(g, N, pk->dev.ncu);
+        if (pk->pair_nl && pk->d_pair_kdig && ebits_max > 8 && !pair_ctmul_disabled()) {
+            // n of 2049 .. 4156 bits: squarings at 4 NL^2 and multiplications at 5 NL^2 limb products on lane-group digit
+            // pairs (k_pair_ctmul) instead of 8 NL^2 per Montgomery product modulo n^2, then w + v n (k_pair_finish)
+            std::lock_guard<std::mutex> lk(pk->mu);
+            const int wbits = var_window_bits(ebits_max);
+            const int epb = pair_epb(pk->pair_nl);
+            const size_t tiles = (N + epb - 1) / epb;
+            const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu * 2));
+            pk->pair_ct_table.ensure(((size_t)pgrid * epb << wbits) * 2 * (size_t)pk->pair_nl * 4);
+            pk->pair_wv.ensure(N * 2 * (size_t)pk->pair_out_words * 4);
+            PairCtMulParams Q;
+            Q.nctx = pk->npair.d_ctx;
+            Q.nm1 = pk->d_pair_nm1;
+            Q.kdig = pk->d_pair_kdig;
+            Q.one_pair = pk->d_pair_one;
+            Q.table = pk->pair_ct_table.as<uint32_t>();
+            Q.nd = pk->pair_nd;
+            Q.wbits = wbits;
+            Q.ct_words = pk->ct_words;
+            Q.e_words = e_words;
+            Q.ebits_max = ebits_max;
+            Q.e_bcast = e_bcast;
+            Q.out_words = pk->pair_out_words;
+            EncParams P;
+            P.nsq = pk->msq.d_ctx;
+            P.nR = pk->d_nR;
+            P.fb_table = nullptr;
+            P.fb_windows = 0;
+            P.fb_wbits = 0;
+            P.pt_words = pk->n_words;
+            P.ct_words = pk->ct_words;
+            P.r_words = pk->r_words;
+            OrderScope order_(pk->order, s);
+            ScopedKernelTimer t("k_ctmul", s);
+            if (!launch_pair_ctmul(pk->pair_nl, s, pgrid, Q, d_ct, d_e, pk->pair_wv.as<uint32_t>(), (int)N))
+                throw PaiError(PAI_E_INTERNAL, "no digit-pair ct * pt kernel for this limb count");
+            g->pair_finish(s, grid, P, pk->pair_wv.as<uint32_t>(), pk->pair_out_words, nullptr, d_out, (int)N, 0);
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         if (ebits_max > 8) {
             std::lock_guard<std::mutex> lk(pk->mu);
             const int wbits = var_window_bits(ebits_max);
@@ -1799,6 +1913,7 @@ void pai_privkey_destroy(pai_privkey* sk) {
     if (sk->d_pinvqR) (void)hipFree(sk->d_pinvqR);
     for (int w = 0; w < 2; ++w) {
         sk->lat.sq[w].release();
+        sk->lat.sq_true[w].release();
         sk->lat.pr[w].release();
         if (sk->lat.d_r3[w]) (void)hipFree(sk->lat.d_r3[w]);
         if (sk->lat.d_sinv2[w]) (void)hipFree(sk->lat.d_sinv2[w]);
@@ -1821,13 +1936,19 @@ static void build_latency_consts(pai_privkey* sk) {
     if (L.ready) return;
     L.ready = true;
     const Limbs prime[2] = {sk->p, sk->q};
-    const GeoOps* ga = geo_latency_for_bits(hbn::bitlen(hbn::mul(sk->q, sk->q)));
+    // stage A: one integer per wavefront (3 x 64) whenever s^2 k fits — the quotient digits then travel through
+    // v_readfirstlane into an SGPR operand (one instruction per digit; 32-lane groups need five), and a product runs
+    // over the limbs the modulus needs, not the geometry's capacity, so the idle lanes cost nothing
+    const int sq_bits = hbn::bitlen(hbn::mul(sk->q, sk->q));
+    const GeoOps* ga = geo_ops_3x64();
+    if (sq_bits + hbn::RB * ga->u + 8 > hbn::RB * ga->nl) ga = geo_latency_for_bits(sq_bits + hbn::RB * 3 + 8);
     const GeoOps* gb = geo_latency_for_bits(hbn::bitlen(sk->q));
     if (!ga || !gb) return;                                  // key too wide for the latency geometries: throughput path only
     const Limbs one{1u};
     for (int w = 0; w < 2; ++w) {
         const Limbs& s = prime[w];
-        L.sq[w].init(hbn::mul(s, s), 0, ga);
+        L.sq[w].init_m1(hbn::mul(s, s), ga);
+        L.sq_true[w].init(hbn::mul(s, s), 0, ga);
         L.pr[w].init(s, 0, gb);
         L.d_r3[w] = upload_r29(L.sq[w].R3, L.sq[w].nl);
         const int nl = gb->nl, k = hbn::RB * nl;
@@ -1857,7 +1978,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 pai_privkey::Lat& L = sk->lat;
                 const GeoOps* ga = L.sq[0].geo;
                 const GeoOps* gb = L.pr[0].geo;
-                const int u_words = std::max(L.sq[0].w32, L.sq[1].w32);
+                const int u_words = std::max(L.sq_true[0].w32, L.sq_true[1].w32);
                 const int gridx = (int)((N + ga->epb - 1) / ga->epb);
                 L.table.ensure(ga->table_words((size_t)gridx * 2) * 4);
                 sk->ubuf.ensure(2 * N * (size_t)u_words * 4);
@@ -1866,6 +1987,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 DecBParams B;
                 for (int w = 0; w < 2; ++w) {
                     A.sq[w] = L.sq[w].d_ctx;
+                    A.fin[w] = L.sq_true[w].d_ctx;
                     A.r3[w] = L.d_r3[w];
                     A.expo[w] = sk->d_expo[w];
                     A.ewords[w] = sk->ewords[w];
@@ -1919,6 +2041,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         DecAParams A;
         for (int w = 0; w < 2; ++w) {
             A.sq[w] = sk->sq[w].d_ctx;
+            A.fin[w] = nullptr;
             A.r3[w] = sk->d_r3[w];
             A.expo[w] = sk->d_expo[w];
             A.ewords[w] = sk->ewords[w];

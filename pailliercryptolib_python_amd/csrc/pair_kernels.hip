@@ -25,6 +25,10 @@ struct PairLaunch {
         (void)hipFuncSetAttribute((const void*)k_pair_fixed_base<G>, hipFuncAttributeMaxDynamicSharedMemorySize, PairLds<G>::BYTES_FB);
         hipLaunchKernelGGL(k_pair_fixed_base<G>, dim3(grid), dim3(BLOCK_THREADS), PairLds<G>::BYTES_FB, s, P, m, r, wv_out, n, with_m);
     }
+    static void ctmul(hipStream_t s, int grid, const PairCtMulParams& P, const uint32_t* ct, const uint32_t* e, uint32_t* wv_out, int n) {
+        (void)hipFuncSetAttribute((const void*)k_pair_ctmul<G>, hipFuncAttributeMaxDynamicSharedMemorySize, PairLds<G>::BYTES_CT);
+        hipLaunchKernelGGL(k_pair_ctmul<G>, dim3(grid), dim3(BLOCK_THREADS), PairLds<G>::BYTES_CT, s, P, ct, e, wv_out, n);
+    }
 };
 #ifndef PAIR_G112
 #define PAIR_G112 Geo<28, 4, 7, false>     // 7-row blocks: 17.9 ms per 65536 at 3072-bit keys (4 rows: 18.9; 8 lanes x 14: 18.5)
@@ -63,6 +67,14 @@ bool launch_pair_fixed_base(int nl, hipStream_t s, int grid, const PairParams& P
                             uint32_t* wv_out, int n, int with_m) {
     if (nl == 112) P112::fixed_base(s, grid, P, m, r, wv_out, n, with_m);
     else if (nl == 144) P144::fixed_base(s, grid, P, m, r, wv_out, n, with_m);
+    else return false;
+    return true;
+}
+
+bool launch_pair_ctmul(int nl, hipStream_t s, int grid, const PairCtMulParams& P, const uint32_t* ct, const uint32_t* e,
+                       uint32_t* wv_out, int n) {
+    if (nl == 112) P112::ctmul(s, grid, P, ct, e, wv_out, n);
+    else if (nl == 144) P144::ctmul(s, grid, P, ct, e, wv_out, n);
     else return false;
     return true;
 }

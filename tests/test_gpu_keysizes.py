@@ -93,3 +93,44 @@ def test_lane_group_digit_pair_obfuscator(bits, wbits, monkeypatch):
         _native.check(nk.lib.pai_decrypt(nk.sk, ct.ptr, N, out.ptr, None))
         assert limbs_to_ints(out.get()) == m
         del nk
+
+
+@pytest.mark.parametrize("bits", [2304, 3072, 3200, 3264, 4096, 4128])
+def test_lane_group_digit_pair_ct_times_pt(bits, monkeypatch):
+    """ciphertext * plaintext for n of 2049 .. 4156 bits on lane-group digit pairs (kernels_pair.hpp: k_pair_ctmul — digit
+    form through the base-R digits, per-slot power table, squarings at 4 NL^2 with the table entry streamed into LDS,
+    k_pair_finish) on the THROUGHPUT path: bits against CPython pow for every window width the exponent widths select
+    (2 / 3 / 4 / 5 bits), per-element and broadcast exponents, zero digits and zero exponents, a full and a ragged tile,
+    in place — and the same bits with the pair path switched off (products modulo n^2)."""
+    from pailliercryptolib_python_amd import _native
+    from tests._util import DevArray, ints_to_limbs, limbs_to_ints, rand_below
+    from tests.test_gpu_paillier_abi import NativeKey
+
+    monkeypatch.setenv("PAI_LATENCY_MAX", "0")
+    key, _, _ = make(bits)
+    M = key.nsq
+    rng = np.random.default_rng(bits + 5)
+    N = 70
+    c = rand_below(rng, M, N)
+    c[0], c[1] = 1, M - 1
+    for disable in ("0", "1"):
+        monkeypatch.setenv("PAI_DISABLE_PAIR_CTMUL", disable)
+        nk = NativeKey(key)
+        dc = DevArray(ints_to_limbs(c, nk.cw))
+        for ebits in (12, 53, 130, 300):
+            e = [int.from_bytes(rng.bytes(ebits // 8 + 1), "little") % (1 << ebits) for _ in range(N)]
+            e[0], e[2], e[3] = 0, (1 << ebits) - 1, 1 << (ebits - 1)
+            ew = (ebits + 31) // 32
+            de = DevArray(ints_to_limbs(e, ew))
+            out = DevArray(shape=(N, nk.cw))
+            _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
+            assert limbs_to_ints(out.get()) == [pow(a, b, M) for a, b in zip(c, e)], (bits, ebits, disable)
+            db = DevArray(ints_to_limbs([e[4]], ew))
+            _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, db.ptr, ew, ebits, 1, N, out.ptr, None))
+            assert limbs_to_ints(out.get()) == [pow(a, e[4], M) for a in c], (bits, ebits, disable, "bcast")
+        d2 = DevArray(ints_to_limbs(c, nk.cw))
+        e = [int(v) for v in rng.integers(1, 1 << 53, N)]
+        de = DevArray(ints_to_limbs(e, 2))
+        _native.check(nk.lib.pai_ct_mul(nk.pk, d2.ptr, de.ptr, 2, 53, 0, N, d2.ptr, None))                # in place
+        assert limbs_to_ints(d2.get()) == [pow(a, b, M) for a, b in zip(c, e)], (bits, disable, "in place")
+        del nk
