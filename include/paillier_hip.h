@@ -83,6 +83,10 @@ int pai_buf_rotate(int device, const uint32_t* d_src, int row_words, size_t N, l
 int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint32_t* h_hs, int hs_words,
                       int randbits, int device, pai_pubkey** out);
 void pai_pubkey_destroy(pai_pubkey* pk);
+/* Extension for many-key (federated) deployments: frees what the handle holds beyond its constants — the DJN fixed-base
+ * tables (8.6 GB at 2048-bit keys; the next obfuscating call rebuilds them, sized from the memory that is free THEN) and
+ * the grow-only scratch of the batch operations.  Synchronises the device.  *freed_bytes (optional): device memory returned. */
+int pai_pubkey_trim(pai_pubkey* pk, size_t* freed_bytes);
 /* fills any non-NULL out-parameter */
 int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_words, int* r_words,
                     int* randbits, int* is_djn, int* device);

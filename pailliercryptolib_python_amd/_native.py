@@ -69,6 +69,7 @@ PROTOTYPES = {
     "pai_gather": (C.c_int, [C.c_int, i32p, C.POINTER(voidp), C.POINTER(C.c_size_t), C.c_int, C.c_int, voidp]),
     "pai_scatter": (C.c_int, [C.c_int, i32p, C.POINTER(voidp), C.POINTER(C.c_size_t), C.c_int, C.c_int, voidp]),
     "pai_ct_pow2": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp]),
+    "pai_pubkey_trim": (C.c_int, [voidp, C.POINTER(C.c_size_t)]),
     "pai_ct_pow2_hint": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, C.c_int, voidp]),
     "pai_fp_encode_f64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_fp_encode_i64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),

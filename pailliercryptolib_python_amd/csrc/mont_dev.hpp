@@ -92,6 +92,7 @@ template <int T> PAI_DEV uint32_t from_next(uint32_t v) {
         else if constexpr (T == 4 || T == 8) r = dpp_mov<0x101>(v);   // row_shl:1  (lane i <- lane i+1 inside a 16-lane row)
         else if constexpr (T >= 16) r = dpp_mov<0x130>(v);       // wave_shl:1 (lane i <- lane i+1 across the whole wave)
         else r = (uint32_t)__shfl_down((int)v, 1, 64);
+        if constexpr (T == 64) return r;                         // bound_ctrl: the wave's last lane already reads 0
         return (group_lane<T>() == T - 1) ? 0u : r;
     }
 }
@@ -104,6 +105,7 @@ template <int T> PAI_DEV uint32_t from_prev(uint32_t v) {
         else if constexpr (T == 4 || T == 8) r = dpp_mov<0x111>(v);   // row_shr:1  (lane i <- lane i-1 inside a 16-lane row)
         else if constexpr (T >= 16) r = dpp_mov<0x138>(v);       // wave_shr:1 (lane i <- lane i-1 across the whole wave)
         else r = (uint32_t)__shfl_up((int)v, 1, 64);
+        if constexpr (T == 64) return r;                         // bound_ctrl: lane 0 already reads 0
         return (group_lane<T>() == 0) ? 0u : r;
     }
 }

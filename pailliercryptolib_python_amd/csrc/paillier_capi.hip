@@ -1069,6 +1069,41 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (prev_ >= 0) (void)hipSetDevice(prev_);
 }
 
+int pai_pubkey_trim(pai_pubkey* pk, size_t* freed_bytes) {
+    return guarded([&] {
+        require(pk != nullptr, "pk is NULL");
+        std::lock_guard<std::mutex> lk(pk->mu);
+        DeviceScope scope_(pk->device);
+        HIP_CHECK(hipDeviceSynchronize());                     // nothing in flight may still read the tables / scratch
+        size_t before = 0, after = 0, total = 0;
+        HIP_CHECK(hipMemGetInfo(&before, &total));
+        // the DJN fixed-base tables (rebuilt by the next obfuscating call) ...
+        if (pk->d_fb) { (void)hipFree(pk->d_fb); pk->d_fb = nullptr; }
+        if (pk->d_fb_dig) { (void)hipFree(pk->d_fb_dig); pk->d_fb_dig = nullptr; }
+        if (pk->d_pair_fb) { (void)hipFree(pk->d_pair_fb); pk->d_pair_fb = nullptr; }
+        pk->fb_ready = false;
+        if (pk->d_lat_fb) { (void)hipFree(pk->d_lat_fb); pk->d_lat_fb = nullptr; }
+        if (pk->d_lat_nR) { (void)hipFree(pk->d_lat_nR); pk->d_lat_nR = nullptr; }
+        pk->lat_fb_ready = false;
+        // ... and the grow-only scratch of the batch operations (re-grown on demand)
+        pk->table.release();
+        pk->tmp.release();
+        pk->lat_table.release();
+        pk->ctmul_table.release();
+        pk->pair_ct_table.release();
+        pk->pair_wv.release();
+        pk->pow2_expo.release();
+        pk->mexp_table.release();
+        pk->mexp_partial.release();
+        pk->inv_prod.release();
+        pk->inv_inv.release();
+        pk->prod_a.release();
+        pk->prod_b.release();
+        HIP_CHECK(hipMemGetInfo(&after, &total));
+        if (freed_bytes) *freed_bytes = after > before ? after - before : 0;
+    });
+}
+
 int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_words, int* r_words, int* randbits,
                     int* is_djn, int* device) {
     return guarded([&] {

@@ -166,6 +166,13 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_ct_add(self.h, _ptr(a), _ptr(b), bcast, a.shape[0], _ptr(out), _stream(self.device)))
         return out
 
+    def trim(self) -> int:
+        """Frees the fixed-base tables and the grow-only scratch of this handle (rebuilt / re-grown on demand); returns
+        the device bytes released.  For processes that hold many keys on one device."""
+        v = C.c_size_t(0)
+        _native.check(self.lib.pai_pubkey_trim(self.h, C.byref(v)))
+        return int(v.value)
+
     # ---- lazy Montgomery domain (include/paillier_hip.h: pai_ct_mont_mul).  A buffer with tag k holds x R^k mod n^2. ----
     @property
     def mont_bits(self) -> int:

@@ -688,3 +688,31 @@ def test_lazy_montgomery_domain_exports(bits):
             ent = DevArray(ints_to_limbs([rk(2 - k)], nk.cw))
             _native.check(nk.lib.pai_ct_add_aligned_dom(nk.pk, dak.ptr, dbk.ptr, 0, ddl.ptr, N, out.ptr, ent.ptr, None))
             assert limbs_to_ints(out.get()) == [v * rk(k) % M for v in plain], (bits, N, k)
+
+
+def test_pubkey_trim_releases_the_tables_and_the_next_call_rebuilds_them(k2048):
+    """pai_pubkey_trim (many-key deployments): after a DJN encryption the handle holds its fixed-base table (gigabytes at the
+    default window width); trim returns that memory, a second key's table fits next to the first, and the next encryption
+    rebuilds the table and produces the same bits."""
+    nk, key = k2048, k2048.key
+    N = 5000                                                      # beyond the latency path: the throughput kernel and its table
+    m = plaintexts(key, N, 4242)
+    r = orc.synth_r_limbs(4243, N, key.randbits)
+    want = [orc.encrypt(key, x, rr) for x, rr in zip(m[:8], orc.limbs_to_ints(r[:8]))]
+    dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
+    ct = DevArray(shape=(N, nk.cw))
+    _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+    first = ct.get()
+    assert limbs_to_ints(first[:8]) == want
+    freed = C.c_size_t(0)
+    _native.check(nk.lib.pai_pubkey_trim(nk.pk, C.byref(freed)))
+    assert freed.value >= 1 << 30, freed.value                   # 8.6 GB at the default 18-bit windows
+    other = NativeKey(seeded_key(1024))                           # a second DJN key on the same device builds its own table
+    m2 = plaintexts(other.key, 64, 1)
+    r2 = orc.synth_r_limbs(2, 64, other.key.randbits)
+    ct2 = DevArray(shape=(64, other.cw))
+    _native.check(other.lib.pai_encrypt(other.pk, DevArray(ints_to_limbs(m2, other.nw)).ptr, DevArray(r2).ptr, 64, ct2.ptr, None))
+    assert limbs_to_ints(ct2.get()[:2]) == [orc.encrypt(other.key, x, rr) for x, rr in zip(m2[:2], orc.limbs_to_ints(r2[:2]))]
+    _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))       # rebuilds
+    assert np.array_equal(ct.get(), first)
+    _native.check(nk.lib.pai_pubkey_trim(nk.pk, None))

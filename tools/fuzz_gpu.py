@@ -38,6 +38,20 @@ while time.time() - t0 < budget:
     bc = int(rng.integers(0, 2))
     _native.check(lib.pai_ct_add(nk.pk, da.ptr, db.ptr, bc, N, out.ptr, None))
     assert limbs_to_ints(out.get()) == [x * (b[0] if bc else y) % M for x, y in zip(a, b)], ("ct_add", bits, N, bc)
+    # lazy Montgomery domain: the single product, and the aligned addition on a random common tag
+    rb = C.c_int(0)
+    _native.check(lib.pai_pubkey_mont_bits(nk.pk, C.byref(rb)))
+    Rm = pow(2, rb.value, M); Ri = pow(Rm, -1, M)
+    _native.check(lib.pai_ct_mont_mul(nk.pk, da.ptr, db.ptr, bc, N, out.ptr, None))
+    assert limbs_to_ints(out.get()) == [x * (b[0] if bc else y) * Ri % M for x, y in zip(a, b)], ("ct_mont_mul", bits, N, bc)
+    kt = int(rng.integers(-3, 4))
+    rk = pow(Rm, kt, M) if kt >= 0 else pow(Ri, -kt, M)
+    r2k = pow(Rm, 2 - kt, M) if 2 - kt >= 0 else pow(Ri, kt - 2, M)
+    dlt = rng.integers(-4, 5, N).astype(np.int32)
+    dak, dbk = DevArray(ints_to_limbs([x * rk % M for x in a], nk.cw)), DevArray(ints_to_limbs([y * rk % M for y in b], nk.cw))
+    _native.check(lib.pai_ct_add_aligned_dom(nk.pk, dak.ptr, dbk.ptr, 0, DevArray(dlt).ptr, N, out.ptr, DevArray(ints_to_limbs([r2k], nk.cw)).ptr, None))
+    assert limbs_to_ints(out.get()) == [(x * pow(y, 1 << int(t), M) if t > 0 else pow(x, 1 << int(-t), M) * y) * rk % M
+                                        for x, y, t in zip(a, b, dlt)], ("add_aligned_dom", bits, N, kt)
     groups = int(rng.choice([g for g in (1, 2, 3, 5, 7, 16) if N % g == 0] or [1])) if N > 1 else 1
     if N % groups == 0:
         og = DevArray(shape=(groups, nk.cw))
@@ -50,7 +64,10 @@ while time.time() - t0 < budget:
         assert limbs_to_ints(og.get()) == want, ("ct_prod", bits, N, groups)
     delta = rng.integers(-3, 9, N).astype(np.int32)
     dd = DevArray(delta); dc = DevArray(ints_to_limbs(a, nk.cw))
-    _native.check(lib.pai_ct_pow2(nk.pk, dc.ptr, dd.ptr, 0, N, None))
+    if rng.integers(0, 2):
+        _native.check(lib.pai_ct_pow2(nk.pk, dc.ptr, dd.ptr, 0, N, None))
+    else:
+        _native.check(lib.pai_ct_pow2_hint(nk.pk, dc.ptr, dd.ptr, 0, N, int(max(0, delta.max())), None))
     assert limbs_to_ints(dc.get()) == [pow(x, 1 << int(d), M) if d > 0 else x for x, d in zip(a, delta)], ("pow2", bits, N)
     units = [x if (x % key.p and x % key.q) else 1 for x in a]
     du = DevArray(ints_to_limbs(units, nk.cw))
@@ -115,5 +132,5 @@ while time.time() - t0 < budget:
         for i in range(0, N, max(1, N // 30)):
             assert got2[i] == (pow(a[i], 1 << int(dl2[i]), M) if dl2[i] > 0 else a[i]), ("pow2_digit", bits, N, i)
         os.environ.pop("PAI_POW2_DIGIT_MIN", None)
-    rounds += 1; checks += 10
+    rounds += 1; checks += 12
 print(json.dumps({"rounds": rounds, "checks": checks, "seconds": round(time.time() - t0, 1), "failures": 0}))

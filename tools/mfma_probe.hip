@@ -10,7 +10,7 @@
 // Per reduction: limbs -> spread digits (VALU), 20 lane-half swaps, 30 MFMAs (lower-triangular p' Toeplitz), 80 swaps of
 // the accumulators, carry-normalisation of 160 column sums into digits (VALU), 20 swaps, 30 MFMAs (the high half of
 // m p), 80 swaps, recombination of 160 column sums into 29-bit limbs (VALU).
-// Against it: what the reduction costs on the vector multiplier today, 2 x 36^2 v_mad_u64_u32 with lazy 64-bit columns.
+// Against it: what ONE reduction costs on the vector multiplier today: 36^2 v_mad_u64_u32 (digit-serial, lazy 64-bit columns).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/mfma_probe tools/mfma_probe.hip && tools/mfma_probe
 // prints one JSON line: cycles per reduction and wave for both forms, a correctness check of the MFMA form against a
@@ -176,8 +176,10 @@ k_mfma_reduce(const v4i* __restrict__ frag_pinv, const v4i* __restrict__ frag_p,
     if (lane == 0 && blockIdx.x == 0) *cycles = t1 - t0;
 }
 
-// what the same reduction costs on the vector multiplier: 2 x 36^2 multiply-accumulates into lazy 64-bit columns with the
-// modulus limbs as SGPR operands (the digit-pair engine's arrangement), carries every 12 rows
+// what the same ONE reduction costs on the vector multiplier today: digit-serial Montgomery, 36^2 multiply-accumulates of the
+// quotient digits with the modulus limbs (SGPR operands, lazy 64-bit columns, carries every 12 rows — the digit-pair
+// engine's arrangement; the quotient digit is one v_mul_lo per row, no separate T_lo p' product exists there).  A squaring
+// of the digit-pair engine contains two such reductions (w and v): 2 x 36^2 = 57 % of its multiplies.
 __global__ void __launch_bounds__(64, 1)
 k_valu_reduce(const uint32_t* __restrict__ pl, const uint32_t* __restrict__ tlo, uint32_t* __restrict__ out, int iters, unsigned long long* cycles) {
     const int lane = threadIdx.x;
@@ -189,7 +191,7 @@ k_valu_reduce(const uint32_t* __restrict__ pl, const uint32_t* __restrict__ tlo,
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < 1; ++half) {          // ONE reduction: q p accumulated digit-serially (36^2 multiply-accumulates)
             uint64_t acc[NL + 12];
 #pragma unroll
             for (int j = 0; j < NL + 12; ++j) acc[j] = x[j % NL];
