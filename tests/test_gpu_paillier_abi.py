@@ -711,7 +711,8 @@ def test_pubkey_trim_releases_the_tables_and_the_next_call_rebuilds_them(k2048):
     m2 = plaintexts(other.key, 64, 1)
     r2 = orc.synth_r_limbs(2, 64, other.key.randbits)
     ct2 = DevArray(shape=(64, other.cw))
-    _native.check(other.lib.pai_encrypt(other.pk, DevArray(ints_to_limbs(m2, other.nw)).ptr, DevArray(r2).ptr, 64, ct2.ptr, None))
+    dm2, dr2 = DevArray(ints_to_limbs(m2, other.nw)), DevArray(r2)
+    _native.check(other.lib.pai_encrypt(other.pk, dm2.ptr, dr2.ptr, 64, ct2.ptr, None))
     assert limbs_to_ints(ct2.get()[:2]) == [orc.encrypt(other.key, x, rr) for x, rr in zip(m2[:2], orc.limbs_to_ints(r2[:2]))]
     _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))       # rebuilds
     assert np.array_equal(ct.get(), first)

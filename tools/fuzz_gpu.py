@@ -49,7 +49,8 @@ while time.time() - t0 < budget:
     r2k = pow(Rm, 2 - kt, M) if 2 - kt >= 0 else pow(Ri, kt - 2, M)
     dlt = rng.integers(-4, 5, N).astype(np.int32)
     dak, dbk = DevArray(ints_to_limbs([x * rk % M for x in a], nk.cw)), DevArray(ints_to_limbs([y * rk % M for y in b], nk.cw))
-    _native.check(lib.pai_ct_add_aligned_dom(nk.pk, dak.ptr, dbk.ptr, 0, DevArray(dlt).ptr, N, out.ptr, DevArray(ints_to_limbs([r2k], nk.cw)).ptr, None))
+    ddlt, dent = DevArray(dlt), DevArray(ints_to_limbs([r2k], nk.cw))
+    _native.check(lib.pai_ct_add_aligned_dom(nk.pk, dak.ptr, dbk.ptr, 0, ddlt.ptr, N, out.ptr, dent.ptr, None))
     assert limbs_to_ints(out.get()) == [(x * pow(y, 1 << int(t), M) if t > 0 else pow(x, 1 << int(-t), M) * y) * rk % M
                                         for x, y, t in zip(a, b, dlt)], ("add_aligned_dom", bits, N, kt)
     groups = int(rng.choice([g for g in (1, 2, 3, 5, 7, 16) if N % g == 0] or [1])) if N > 1 else 1
