@@ -64,7 +64,7 @@ CANON_MAC_ENC, CANON_MAC_DEC, CANON_MAC_ADD, CANON_MAC_MUL53 = 41.52e6, 20.86e6,
 BYTES_ENC, BYTES_DEC, BYTES_ADD = 648, 520, 1536   # algorithmic bytes per op
 BASELINE_METRIC = json.loads((ROOT / "BASELINE.json").read_text())["metric"] if (ROOT / "BASELINE.json").exists() else \
     "Paillier encrypt+decrypt ops/sec, 2048-bit key, batch=1M; 1/2/4/8 MI355X"
-PMC_FILES = ["profiles/r02/pmc_bench_r02.json", "profiles/r01/pmc_bench_r01d.json"]   # newest first
+PMC_FILES = ["profiles/r03/pmc_bench_r03.json", "profiles/r02/pmc_bench_r02.json", "profiles/r01/pmc_bench_r01d.json"]   # newest first
 
 
 def _sliding_counts(e: int, w: int = 6):

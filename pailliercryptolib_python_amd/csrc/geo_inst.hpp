@@ -73,12 +73,22 @@ struct GeoInst {
         hipLaunchKernelGGL(k_dec_b<G>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, u_in, m_out, n);
     }
     static void modexp_var_win(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32, const uint32_t* expo,
-                               int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits) {
+                               int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits,
+                               const MontCtx* fin) {
         // 8-lane geometries: modulus slice from LDS (3072 / 4096-bit ct * pt 20.8 -> 20.5 / 32.7 -> 31.8 ms per 65536)
         using GV = Geo<G::NLL, G::T, G::U, (G::T >= 8 && G::NLL % 4 == 0) ? PAI_VARWIN_NMLDS : false>;
+        if constexpr (G::T >= 16) {
+            if (fin != nullptr) {        // wide-group geometries with a minus-one context (c) and the true modulus' context (fin)
+                using GM1 = Geo<G::NLL, G::T, G::U, false, true>;
+                set_lds((const void*)k_modexp_var_win<GM1>, VarWinCfg<GM1>::LDS_BYTES);
+                hipLaunchKernelGGL(k_modexp_var_win<GM1>, dim3(grid), dim3(BLOCK_THREADS), VarWinCfg<GM1>::LDS_BYTES, s, c, base, base_w32,
+                                   expo, ew, ebits_max, exp_bcast, out, out_w32, n, table, wbits, fin);
+                return;
+            }
+        }
         set_lds((const void*)k_modexp_var_win<GV>, VarWinCfg<GV>::LDS_BYTES);
         hipLaunchKernelGGL(k_modexp_var_win<GV>, dim3(grid), dim3(BLOCK_THREADS), VarWinCfg<GV>::LDS_BYTES, s, c, base, base_w32, expo, ew,
-                           ebits_max, exp_bcast, out, out_w32, n, table, wbits);
+                           ebits_max, exp_bcast, out, out_w32, n, table, wbits, (const MontCtx*)nullptr);
     }
     static void pow2(hipStream_t s, int grid, const MontCtx* c, uint32_t* ct, const int32_t* delta, int delta_bcast,
                      int n, int w32) {

@@ -25,7 +25,8 @@ struct GeoOps {
                        int n, int keep_mont, int out_raw);
     // windowed variant: table scratch of var_table_words(blocks, wbits) words
     void (*modexp_var_win)(hipStream_t, int grid, const MontCtx*, const uint32_t* base, int base_w32, const uint32_t* expo,
-                           int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits);
+                           int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits,
+                           const MontCtx* fin /* minus-one context pairs on the wide-group geometries, else NULL */);
     void (*encrypt)(hipStream_t, int grid, EncParams, const uint32_t* m, const uint32_t* r, const uint32_t* ct_in,
                     uint32_t* ct_out, int n, int mode);
     // T[j][hi * 2^h + lo] = S[2 j + 1][hi] * S[2 j][lo]: second level of the fixed-base table build (raw Montgomery rows)

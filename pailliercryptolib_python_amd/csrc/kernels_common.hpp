@@ -325,6 +325,24 @@ PAI_DEV void mm_times(uint32_t (&x)[G::NLL], const uint32_t (&y)[G::NLL], uint32
     for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
 }
 
+// Minus-one geometries: x (lazy, a residue modulo M k) -> the canonical residue modulo M itself, by two conventional
+// Montgomery products with M's own context: x R^2 R^-1 = x R (mod M), then * 1 * R^-1.
+template <class G>
+PAI_DEV void m1_reduce_to_true_modulus(uint32_t (&x)[G::NLL], uint32_t* lds, const MontCtx* __restrict__ f) {
+    NmRegs<G::NLL> nf;
+    load_const_slice<G>(nf.v, f->n);
+    uint32_t c[G::NLL], r[G::NLL], one[G::NLL];
+    load_const_slice<G>(c, f->r2);
+#pragma unroll
+    for (int j = 0; j < G::NLL; ++j) one[j] = 0;
+    if (G::gl() == 0) one[0] = 1;
+    stage_b<G>(x, lds);
+    mont_mul<G::NLL, G::U, G::T>(r, c, lds + G::elem(), G::EPB, nf, f->n0inv);
+    stage_b<G>(r, lds);
+    mont_mul<G::NLL, G::U, G::T>(x, one, lds + G::elem(), G::EPB, nf, f->n0inv);
+    cond_sub<G::NLL, G::T>(x, nf);
+}
+
 // plain integer 1 spread over the group (lane 0, limb 0)
 template <class G>
 PAI_DEV void set_plain_one(uint32_t (&x)[G::NLL]) {

@@ -292,12 +292,15 @@ template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, PAI_VARWIN_WAVES(G))
 k_modexp_var_win(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, int base_w32,
                  const uint32_t* __restrict__ expo, int ew, int ebits_max, int exp_bcast,
-                 uint32_t* __restrict__ out, int out_w32, int n, uint32_t* __restrict__ table, int wbits) {
+                 uint32_t* __restrict__ out, int out_w32, int n, uint32_t* __restrict__ table, int wbits,
+                 const MontCtx* __restrict__ fin) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int t = G::gl();
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
-    const uint32_t n0inv = ctx->n0inv;
+    // minus-one geometries (small batches on one integer per wavefront): ctx is the context of M k, the scalar next to the
+    // modulus slice is the number of row blocks, and `fin` (M's own context) reduces the result at the end
+    const uint32_t n0inv = G::M1 ? ctx->rows / G::U : ctx->n0inv;
     if constexpr (VarWinCfg<G>::STREAM) {
         constexpr int CH = 4, NCH = G::NLL / 4;
         using RS = RowStream<CH, NCH, 0>;
@@ -434,7 +437,8 @@ k_modexp_var_win(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ b
         uint32_t one[G::NLL];
         set_plain_one<G>(one);
         mm_times<G>(x, one, lds, nm, n0inv);
-        cond_sub<G::NLL, G::T>(x, nm);
+        if constexpr (G::M1) m1_reduce_to_true_modulus<G>(x, lds, fin);
+        else cond_sub<G::NLL, G::T>(x, nm);
         if (live) store_elem<G>(x, out + (size_t)ei * out_w32, out_w32, lds);
     }
 }

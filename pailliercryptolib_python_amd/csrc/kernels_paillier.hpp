@@ -316,18 +316,8 @@ k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_
             set_plain_one<G>(one);
             mm_times<G>(x, one, lds, nm, n0inv);
             if constexpr (G::M1) {
-                // x is the power modulo s^2 k (lazy); two conventional products with the context of s^2 itself reduce it:
-                // x * R^2 * R^-1 = x R (mod s^2), then * 1 * R^-1
-                const MontCtx* f = P.fin[which];
-                NmRegs<G::NLL> nf;
-                load_const_slice<G>(nf.v, f->n);
-                uint32_t c[G::NLL], r[G::NLL];
-                load_const_slice<G>(c, f->r2);
-                stage_b<G>(x, lds);
-                mont_mul<G::NLL, G::U, G::T>(r, c, lds + G::elem(), G::EPB, nf, f->n0inv);
-                stage_b<G>(r, lds);
-                mont_mul<G::NLL, G::U, G::T>(x, one, lds + G::elem(), G::EPB, nf, f->n0inv);
-                cond_sub<G::NLL, G::T>(x, nf);
+                // x is the power modulo s^2 k (lazy): reduce it modulo s^2 itself
+                m1_reduce_to_true_modulus<G>(x, lds, P.fin[which]);
             } else {
                 cond_sub<G::NLL, G::T>(x, nm);
             }

@@ -400,6 +400,8 @@ struct pai_pubkey {
     // latency path of ct * pt (small batches): n^2 on a wide-group geometry, built by the first small call
     mutable bool lat_ready = false, lat_usable = false;
     mutable ModSetup lat_msq;
+    mutable ModSetup lat_msq_m1;       // minus-one context of n^2 for the small-batch ct * pt
+    mutable bool lat_m1_tried = false, lat_m1_ok = false;
     mutable DevBuf lat_table;
     // latency path of DJN encryption: n R and a 10-bit fixed-base table in the wide-group geometry (81 MB at 2048-bit keys)
     mutable bool lat_fb_ready = false;
@@ -642,7 +644,7 @@ int pai_modexp_var(pai_modulus* m, const uint32_t* d_base, int base_bcast, const
             m->table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
             m->order.begin((hipStream_t)stream);
             g->modexp_var_win((hipStream_t)stream, grid, m->ms.d_ctx, d_base, m->ms.w32, d_e, e_words, ebits_max, e_bcast, d_out,
-                              m->ms.w32, (int)N, m->table.as<uint32_t>(), wbits);
+                              m->ms.w32, (int)N, m->table.as<uint32_t>(), wbits, nullptr);
             HIP_CHECK(hipGetLastError());
             m->order.end((hipStream_t)stream);
             return;
@@ -1056,6 +1058,7 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->prod_a.release();
     pk->prod_b.release();
     pk->lat_msq.release();
+    pk->lat_msq_m1.release();
     pk->lat_table.release();
     if (pk->d_lat_nR) (void)hipFree(pk->d_lat_nR);
     if (pk->d_lat_fb) (void)hipFree(pk->d_lat_fb);
@@ -1407,8 +1410,17 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
                 pk->lat_table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
                 pk->order.begin(s);
                 ScopedKernelTimer t("k_ctmul", s);
-                g->modexp_var_win(s, grid, pk->lat_msq.d_ctx, d_ct, pk->ct_words, d_e, e_words, ebits_max, e_bcast, d_out,
-                                  pk->ct_words, (int)N, pk->lat_table.as<uint32_t>(), wbits);
+                if (!pk->lat_m1_tried) {                 // minus-one context of n^2 on the same geometry (mont_dev.hpp: block_m1)
+                    pk->lat_m1_tried = true;
+                    const int need = hbn::bitlen(pk->nsq) + hbn::RB * g->u + 4;
+                    if (g->t >= 16 && (need + hbn::RB - 1) / hbn::RB + g->u <= g->nl) {
+                        pk->lat_msq_m1.init_m1(pk->nsq, g);
+                        pk->lat_m1_ok = true;
+                    }
+                }
+                g->modexp_var_win(s, grid, pk->lat_m1_ok ? pk->lat_msq_m1.d_ctx : pk->lat_msq.d_ctx, d_ct, pk->ct_words, d_e, e_words,
+                                  ebits_max, e_bcast, d_out, pk->ct_words, (int)N, pk->lat_table.as<uint32_t>(), wbits,
+                                  pk->lat_m1_ok ? pk->lat_msq.d_ctx : nullptr);
                 t.stop();
                 HIP_CHECK(hipGetLastError());
                 pk->order.end(s);
@@ -1472,7 +1484,7 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
             pk->order.begin(s);
             ScopedKernelTimer t("k_ctmul", s);
             g->modexp_var_win(s, grid, pk->msq.d_ctx, d_ct, pk->ct_words, d_e, e_words, ebits_max, e_bcast, d_out,
-                              pk->ct_words, (int)N, pk->ctmul_table.as<uint32_t>(), wbits);
+                              pk->ct_words, (int)N, pk->ctmul_table.as<uint32_t>(), wbits, nullptr);
             t.stop();
             HIP_CHECK(hipGetLastError());
             pk->order.end(s);
