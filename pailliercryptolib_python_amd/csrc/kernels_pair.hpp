@@ -158,7 +158,10 @@ k_pair_fb_chain(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ n
         for (int sq = 0; sq < smax; ++sq) {
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) { a[j] = c[j]; b[j] = d[j]; }
-            pair_times<G>(a, b, c, d, lds, nm, n0inv);
+            stage_b<G>(c, PairLds<G>::c(lds));
+            stage_b<G>(d, PairLds<G>::d(lds));
+            pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
+                                         PairLds<G>::nm1(lds), nm, n0inv, (NoStream*)nullptr, true);       // a squaring: 4 NL^2
             const bool keep = sq < h * is;
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) { c[j] = keep ? a[j] : c[j]; d[j] = keep ? b[j] : d[j]; }
