@@ -233,6 +233,9 @@ struct DecAParams {
     int ct_words, u_words;       // u_words = words of an s^2 residue
     const MontCtx* fin[2];       // minus-one geometries: sq[] are contexts of s^2 * k (k = -s^-2 mod 2^(29 U)); the result
                                  // is reduced modulo s^2 itself with these conventional contexts at the very end
+    const uint16_t* ops[2];      // minus-one geometries: sliding-window schedule of s - 1 (squarings | table index << 8,
+    int nops[2];                 // index 0xFF = no multiplication), table of the odd powers base^(2i+1), i < tbl_entries;
+    int tbl_entries;             // slot tbl_entries keeps base^2.  NULL: fixed W-bit windows
 };
 
 template <class G, int W>
@@ -280,6 +283,50 @@ k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_
                 if constexpr (!G::M1) {                             // (minus-one contexts have R > 16 M: < 4M is a valid operand)
                     cond_sub<G::NLL, G::T>(bR, nm);                 // < 4M -> < 2M
                     cond_sub<G::NLL, G::T>(bR, nm);
+                }
+            }
+            if constexpr (G::M1) {
+                if (P.ops[which] != nullptr) {
+                    // small batches: the host-compiled sliding-window schedule of s - 1 over a table of odd powers (as in
+                    // k_dec_a_padic): ~1200 sequential products instead of ~1260, and every one of them is latency here
+                    const uint16_t* ops = P.ops[which];
+                    const int nops = P.nops[which], NT = P.tbl_entries;
+                    uint32_t x2[G::NLL];
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) { x[j] = bR[j]; tbl(0, j) = bR[j]; }
+                    mm_square<G>(x, lds, nm, n0inv);
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) { x2[j] = x[j]; x[j] = bR[j]; }
+#pragma unroll 1
+                    for (int k = 1; k < NT; ++k) {
+                        mm_times<G>(x, x2, lds, nm, n0inv);
+#pragma unroll
+                        for (int j = 0; j < G::NLL; ++j) tbl(k, j) = x[j];
+                    }
+                    {
+                        const int i0 = (int)(ops[0] >> 8);
+#pragma unroll
+                        for (int j = 0; j < G::NLL; ++j) x[j] = tbl(i0, j);
+                    }
+#pragma unroll 1
+                    for (int k = 1; k < nops; ++k) {
+                        const int op = (int)ops[k];
+                        const int nsq = op & 0xFF, idx = op >> 8;
+#pragma unroll 1
+                        for (int q = 0; q < nsq; ++q) mm_square<G>(x, lds, nm, n0inv);
+                        if (idx != 0xFF) {
+                            uint32_t y[G::NLL];
+#pragma unroll
+                            for (int j = 0; j < G::NLL; ++j) y[j] = tbl(idx, j);
+                            mm_times<G>(x, y, lds, nm, n0inv);
+                        }
+                    }
+                    uint32_t one[G::NLL];
+                    set_plain_one<G>(one);
+                    mm_times<G>(x, one, lds, nm, n0inv);
+                    m1_reduce_to_true_modulus<G>(x, lds, P.fin[which]);
+                    if (live) store_elem<G>(x, u_out + ((size_t)which * n + ei) * P.u_words, P.u_words, lds);
+                    continue;
                 }
             }
 #pragma unroll

@@ -454,6 +454,8 @@ struct pai_privkey {
         bool ready = false, usable = false;
         ModSetup sq[2], pr[2];
         ModSetup sq_true[2];          // s^2 itself (sq[] are minus-one contexts of s^2 k): the last reduction of stage A
+        uint16_t* d_ops[2] = {nullptr, nullptr};     // sliding-window schedule of s - 1
+        int nops[2] = {0, 0};
         uint32_t* d_r3[2] = {nullptr, nullptr};
         uint32_t* d_sinv2[2] = {nullptr, nullptr};
         uint32_t* d_nsinv2[2] = {nullptr, nullptr};
@@ -1963,6 +1965,7 @@ void pai_privkey_destroy(pai_privkey* sk) {
         sk->lat.sq_true[w].release();
         sk->lat.pr[w].release();
         if (sk->lat.d_r3[w]) (void)hipFree(sk->lat.d_r3[w]);
+        if (sk->lat.d_ops[w]) (void)hipFree(sk->lat.d_ops[w]);
         if (sk->lat.d_sinv2[w]) (void)hipFree(sk->lat.d_sinv2[w]);
         if (sk->lat.d_nsinv2[w]) (void)hipFree(sk->lat.d_nsinv2[w]);
         if (sk->lat.d_hR[w]) (void)hipFree(sk->lat.d_hR[w]);
@@ -1987,7 +1990,9 @@ static void build_latency_consts(pai_privkey* sk) {
     // v_readfirstlane into an SGPR operand (one instruction per digit; 32-lane groups need five), and a product runs
     // over the limbs the modulus needs, not the geometry's capacity, so the idle lanes cost nothing
     const int sq_bits = hbn::bitlen(hbn::mul(sk->q, sk->q));
-    const GeoOps* ga = geo_ops_3x64();
+    const GeoOps* ga = geo_ops_2x64();                       // two limbs per lane: the fewest instructions per row (13 vs 17)
+    if (sq_bits + hbn::RB * ga->u + 8 > hbn::RB * ga->nl) ga = geo_ops_3x64();
+    if (const char* env = std::getenv("PAI_LAT_GEO3")) { if (env[0] == '1') ga = geo_ops_3x64(); }
     if (sq_bits + hbn::RB * ga->u + 8 > hbn::RB * ga->nl) ga = geo_latency_for_bits(sq_bits + hbn::RB * 3 + 8);
     const GeoOps* gb = geo_latency_for_bits(hbn::bitlen(sk->q));
     if (!ga || !gb) return;                                  // key too wide for the latency geometries: throughput path only
@@ -1998,6 +2003,12 @@ static void build_latency_consts(pai_privkey* sk) {
         L.sq_true[w].init(hbn::mul(s, s), 0, ga);
         L.pr[w].init(s, 0, gb);
         L.d_r3[w] = upload_r29(L.sq[w].R3, L.sq[w].nl);
+        {
+            const std::vector<uint16_t> ops = compile_sliding_schedule(hbn::sub(s, one));
+            L.nops[w] = (int)ops.size();
+            HIP_CHECK(hipMalloc((void**)&L.d_ops[w], ops.size() * 2));
+            HIP_CHECK(hipMemcpy(L.d_ops[w], ops.data(), ops.size() * 2, hipMemcpyHostToDevice));
+        }
         const int nl = gb->nl, k = hbn::RB * nl;
         L.d_hR[w] = upload_r29(hbn::mulmod(sk->h_host[w], L.pr[w].R, s), nl);
         Limbs sinv2 = hbn::inv_mod_pow2(s, k);
@@ -2027,7 +2038,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 const GeoOps* gb = L.pr[0].geo;
                 const int u_words = std::max(L.sq_true[0].w32, L.sq_true[1].w32);
                 const int gridx = (int)((N + ga->epb - 1) / ga->epb);
-                L.table.ensure(ga->table_words((size_t)gridx * 2) * 4);
+                L.table.ensure(ga->table_words((size_t)gridx * 2) * 4 / 32 * (PADIC_TBL_ENTRIES + 2));    // odd powers + base^2
                 sk->ubuf.ensure(2 * N * (size_t)u_words * 4);
                 sk->order.begin(s);
                 DecAParams A;
@@ -2035,6 +2046,8 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 for (int w = 0; w < 2; ++w) {
                     A.sq[w] = L.sq[w].d_ctx;
                     A.fin[w] = L.sq_true[w].d_ctx;
+                    A.ops[w] = L.d_ops[w];
+                    A.nops[w] = L.nops[w];
                     A.r3[w] = L.d_r3[w];
                     A.expo[w] = sk->d_expo[w];
                     A.ewords[w] = sk->ewords[w];
@@ -2046,6 +2059,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 }
                 A.ct_words = pk->ct_words;
                 A.u_words = u_words;
+                A.tbl_entries = PADIC_TBL_ENTRIES;
                 B.pinvqR = L.d_pinvqR;
                 B.u_words = u_words;
                 B.pt_words = pk->n_words;
@@ -2089,6 +2103,8 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         for (int w = 0; w < 2; ++w) {
             A.sq[w] = sk->sq[w].d_ctx;
             A.fin[w] = nullptr;
+            A.ops[w] = nullptr;
+            A.nops[w] = 0;
             A.r3[w] = sk->d_r3[w];
             A.expo[w] = sk->d_expo[w];
             A.ewords[w] = sk->ewords[w];
