@@ -31,7 +31,6 @@ SOURCES = [
     "geo_3x16.hip",
     "geo_3x32.hip",
     "geo_3x64.hip",
-    "geo_2x64.hip",
     "geo_9x32.hip",
     "inv_eea.hip",
     "wide_kernels.hip",

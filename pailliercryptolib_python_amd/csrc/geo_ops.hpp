@@ -60,7 +60,6 @@ const GeoOps* geo_ops_36x8();
 const GeoOps* geo_ops_3x16();
 const GeoOps* geo_ops_3x32();
 const GeoOps* geo_ops_3x64();
-const GeoOps* geo_ops_2x64();       // stage A of small-batch decryption only (minus-one contexts)
 const GeoOps* geo_ops_9x32();
 
 // smallest geometry whose capacity covers a modulus of `bits` bits (R = 2^(29 NL) > 4 M), or nullptr

@@ -1990,9 +1990,7 @@ static void build_latency_consts(pai_privkey* sk) {
     // v_readfirstlane into an SGPR operand (one instruction per digit; 32-lane groups need five), and a product runs
     // over the limbs the modulus needs, not the geometry's capacity, so the idle lanes cost nothing
     const int sq_bits = hbn::bitlen(hbn::mul(sk->q, sk->q));
-    const GeoOps* ga = geo_ops_2x64();                       // two limbs per lane: the fewest instructions per row (13 vs 17)
-    if (sq_bits + hbn::RB * ga->u + 8 > hbn::RB * ga->nl) ga = geo_ops_3x64();
-    if (const char* env = std::getenv("PAI_LAT_GEO3")) { if (env[0] == '1') ga = geo_ops_3x64(); }
+    const GeoOps* ga = geo_ops_3x64();       // (2 limbs per lane, 2 x 64, measured slower: 4.46 vs 3.77 ms at 2048-bit keys)
     if (sq_bits + hbn::RB * ga->u + 8 > hbn::RB * ga->nl) ga = geo_latency_for_bits(sq_bits + hbn::RB * 3 + 8);
     const GeoOps* gb = geo_latency_for_bits(hbn::bitlen(sk->q));
     if (!ga || !gb) return;                                  // key too wide for the latency geometries: throughput path only
