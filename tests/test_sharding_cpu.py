@@ -52,3 +52,26 @@ def test_gather_rows_world2_gloo(n_total):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`python bench.py --gpus N` launches N ranks itself; with fewer visible GPUs than ranks (none, in the CPU container)
+    it must fail loudly instead of quietly measuring fewer devices — and a torchrun world that disagrees with --gpus too."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than two GPUs")
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PAI_BENCH_BACKEND")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=str(root))
+    assert res.returncode != 0 and "GPU(s) are visible" in res.stderr
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True,
+                         timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=str(root))
+    assert res.returncode != 0 and "launcher started 2 rank(s)" in res.stderr
