@@ -70,7 +70,7 @@ def test_lane_group_digit_pair_obfuscator(bits, wbits, monkeypatch):
     if wbits is not None:
         monkeypatch.setenv("PAI_FB_WBITS", wbits)
     key, _, _ = make(bits)
-    N = 70                                                # a full and a ragged workgroup tile at either geometry
+    N = 70 if bits < 4000 else 37                         # a full and a ragged workgroup tile at either geometry (64 / 32 elements)
     m = plaintexts(key, N, bits)
     r = orc.synth_r_limbs(bits + 1, N, key.randbits)
     r[0] = 0
@@ -110,7 +110,7 @@ def test_lane_group_digit_pair_ct_times_pt(bits, monkeypatch):
     key, _, _ = make(bits)
     M = key.nsq
     rng = np.random.default_rng(bits + 5)
-    N = 70
+    N = 70 if bits < 4000 else 37                         # a full and a ragged tile (64 / 32 elements per workgroup)
     c = rand_below(rng, M, N)
     c[0], c[1] = 1, M - 1
     for disable in ("0", "1"):

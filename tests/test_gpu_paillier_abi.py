@@ -490,10 +490,11 @@ def test_decrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
     ones on the digit-pair engine (throughput path); PAI_LATENCY_MAX moves the switch.  Both against the oracle."""
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     key = nk.key
-    for N in (3, 7, 33, 150):
+    for N in ((3, 7, 33, 150) if bits <= 2048 else (3, 33, 70)):
         m = plaintexts(key, N, bits + N)
         rng = np.random.default_rng(N)
-        ct = [orc.encrypt(key, x, int.from_bytes(rng.bytes(key.randbits // 8), "little")) for x in m]
+        # short randomness keeps the oracle's CPython pow cheap; decryption does not care how a ciphertext was obfuscated
+        ct = [orc.encrypt(key, x, int.from_bytes(rng.bytes(16), "little")) for x in m]
         dct = DevArray(ints_to_limbs(ct, nk.cw))
         for switch in ("0", "100000"):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
@@ -525,7 +526,7 @@ def test_djn_encrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
     """Small DJN batches encrypt (and re-obfuscate) on the wide-group geometry with its own 10-bit fixed-base table."""
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     key = nk.key
-    for N in (3, 20, 65):
+    for N in ((3, 20, 65) if bits <= 2048 else (3, 37)):          # the oracle's CPython pow dominates at the wide keys
         m = plaintexts(key, N, bits + 3 * N)
         r = orc.synth_r_limbs(bits + N, N, key.randbits)
         r[0] = 0                                                   # r = 0: obfuscator 1
