@@ -223,6 +223,11 @@ class ipclPublicKey:
     def device(self) -> torch.device:
         return self.handle.device
 
+    def trim(self) -> int:
+        """Extension (many keys per device): releases the fixed-base tables and grow-only scratch of every device handle of
+        this key (pai_pubkey_trim) — they are rebuilt / re-grown on demand.  Returns the device bytes released."""
+        return sum(h.trim() for h in self._handles.values())
+
     def fanout_devices(self, n_items: int) -> Optional[List[torch.device]]:
         """The device list to shard a batch of n_items over, or None when it should stay on the home device."""
         devs = self._device_list()

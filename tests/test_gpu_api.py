@@ -596,3 +596,18 @@ def test_lazy_domain_tags_never_change_the_bits(fixed):
     bs = ei[0] + one                                                                      # broadcast addend
     wb = orc.api_add_ct(okey, *oi[0], *orc.api_encrypt(okey, [5], orc.limbs_to_ints(orc.synth_r_limbs(990, 1, okey.randbits))))
     assert ct_ints(bs) == wb[0]
+
+
+def test_key_trim_at_the_api_level(fixed):
+    """ipclPublicKey.trim(): tables and scratch go, the next encryption rebuilds what it needs; results unchanged."""
+    import torch
+
+    pk, sk, okey = fixed
+    x = np.random.default_rng(8).uniform(-9, 9, 5000)
+    r = orc.synth_r_limbs(77, 5000, okey.randbits)
+    a = pk.encrypt(x, r=r)
+    first = a.words.clone()
+    assert pk.pubkey.trim() > 0
+    b = pk.encrypt(x, r=r)
+    assert torch.equal(b.words, first)
+    assert np.array_equal(sk.decrypt_to_numpy(b), x)
