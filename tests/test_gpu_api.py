@@ -611,3 +611,33 @@ def test_key_trim_at_the_api_level(fixed):
     b = pk.encrypt(x, r=r)
     assert torch.equal(b.words, first)
     assert np.array_equal(sk.decrypt_to_numpy(b), x)
+
+
+def test_large_mixed_exponent_sums_are_sorted_by_shift_and_bit_identical(fixed, monkeypatch):
+    """Batches of >= 2^15 elements run the fused aligned addition in the order of |exponent difference| (paillier._add_aligned)
+    and scatter the results back: the same ciphertext bits as the unsorted pass, a sample against the oracle's composition,
+    and `a - b` through the same helper."""
+    import torch
+
+    pk, sk, okey = fixed
+    rng = np.random.default_rng(99)
+    N = (1 << 15) + 37
+    x = rng.uniform(-1000, 1000, N)
+    y = rng.uniform(-1000, 1000, N) * np.ldexp(1.0, rng.integers(-6, 7, N))
+    ra, rb = orc.synth_r_limbs(1201, N, okey.randbits), orc.synth_r_limbs(1202, N, okey.randbits)
+    a, b = pk.encrypt(x, r=ra), pk.encrypt(y, r=rb)
+    got = {}
+    for tag, env in (("sorted", "1"), ("plain", str(1 << 40))):
+        monkeypatch.setenv("PAI_ALIGN_SORT_MIN", env)
+        s, d = a + b, a - b
+        got[tag] = (s.words.clone(), list(s.exponent()), d.words.clone(), list(d.exponent()))
+    assert torch.equal(got["sorted"][0], got["plain"][0]) and got["sorted"][1] == got["plain"][1]
+    assert torch.equal(got["sorted"][2], got["plain"][2]) and got["sorted"][3] == got["plain"][3]
+    idx = [0, 1, 17, N // 2, N - 1]
+    oa = orc.api_encrypt(okey, [float(x[i]) for i in idx], orc.limbs_to_ints(ra[idx]))
+    ob = orc.api_encrypt(okey, [float(y[i]) for i in idx], orc.limbs_to_ints(rb[idx]))
+    want = orc.api_add_ct(okey, *oa, *ob)
+    sw = engine.words_to_ints(engine.to_host_words(got["sorted"][0][idx]))
+    assert sw == want[0] and [got["sorted"][1][i] for i in idx] == want[1]
+    monkeypatch.delenv("PAI_ALIGN_SORT_MIN")
+    assert np.allclose(sk.decrypt_to_numpy(a + b), x + y, rtol=0, atol=1e-6 * np.abs(x + y).max())
