@@ -592,8 +592,8 @@ class PaillierEncryptedNumber:
             hh = (n + 1) // 2
             lo = n - hh
             ea, eb = e[:lo], e[hh:hh + lo]
-            delta = torch.from_numpy(np.ascontiguousarray((ea - eb).reshape(-1).astype(np.int32))).to(h.device)
-            prod = h.ct_add_aligned(x[:lo].reshape(-1, W).contiguous(), x[hh:hh + lo].reshape(-1, W).contiguous(), delta)
+            prod = _add_aligned(h, x[:lo].reshape(-1, W).contiguous(), x[hh:hh + lo].reshape(-1, W).contiguous(),
+                                (ea - eb).reshape(-1).astype(np.int32))
             prod = prod.reshape(lo, groups, W)
             em = np.maximum(ea, eb)
             if lo < hh:
