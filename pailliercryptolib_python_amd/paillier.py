@@ -275,7 +275,7 @@ def _add_aligned(h: engine.PublicKeyHandle, ta: torch.Tensor, tb: torch.Tensor, 
         sort_min = int(os.environ.get("PAI_ALIGN_SORT_MIN", ALIGN_SORT_MIN))
     except ValueError:
         sort_min = ALIGN_SORT_MIN
-    if n < sort_min or tb.shape[0] != n or int(np.abs(delta).max()) <= 1:
+    if n < sort_min or tb.shape[0] != n or delta.size == 0 or int(np.abs(delta).max()) <= 1:
         return h.ct_add_aligned(ta, tb, d_dev, dom=dom)
     # sort inside segments of 512 neighbours only: the kernel hands every wave one contiguous run of tiles (about that long at
     # 2^20 elements), so a global sort would pile the expensive tiles onto the last waves
