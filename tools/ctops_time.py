@@ -22,6 +22,7 @@ def tm(f, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3
 out = {}
 out['ct_add_ms'] = tm(lambda: pub.ct_add(ct, ct, out=ct2))
+out['ct_mont_mul_ms'] = tm(lambda: pub.ct_mont_mul(ct, ct, out=ct2))          # the addition inside a chain (lazy Montgomery domain)
 e = torch.randint(0, 1 << 30, (B, 2), dtype=torch.int32, device=dev); e[:, 1] &= (1 << 21) - 1; e[:, 1] |= (1 << 20)
 out['ct_mul_53bit_ms'] = tm(lambda: pub.ct_mul(ct, e, 53, out=ct2))
 e1 = e[:1].contiguous()
