@@ -90,6 +90,19 @@ struct GeoInst {
         hipLaunchKernelGGL(k_modexp_var_win<GV>, dim3(grid), dim3(BLOCK_THREADS), VarWinCfg<GV>::LDS_BYTES, s, c, base, base_w32, expo, ew,
                            ebits_max, exp_bcast, out, out_w32, n, table, wbits, (const MontCtx*)nullptr);
     }
+    static void sq_chain(hipStream_t s, const MontCtx* c, const MontCtx* fin, const uint32_t* base, int w32, uint32_t* out, int h,
+                         int nsnap) {
+        if constexpr (G::T >= 16) {
+            if (fin != nullptr) {
+                using GM1 = Geo<G::NLL, G::T, G::U, false, true>;
+                set_lds((const void*)k_sq_chain<GM1>, GM1::LDS_BYTES);
+                hipLaunchKernelGGL(k_sq_chain<GM1>, dim3(1), dim3(BLOCK_THREADS), GM1::LDS_BYTES, s, c, fin, base, w32, out, h, nsnap);
+                return;
+            }
+        }
+        set_lds((const void*)k_sq_chain<G>, G::LDS_BYTES);
+        hipLaunchKernelGGL(k_sq_chain<G>, dim3(1), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, (const MontCtx*)nullptr, base, w32, out, h, nsnap);
+    }
     static void pow2(hipStream_t s, int grid, const MontCtx* c, uint32_t* ct, const int32_t* delta, int delta_bcast,
                      int n, int w32) {
         constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
@@ -117,7 +130,7 @@ struct GeoInst {
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &add_aligned, &table_words, &pair_finish, &mexp_table, &mexp};
+                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &sq_chain, &add_aligned, &table_words, &pair_finish, &mexp_table, &mexp};
         return &o;
     }
 };

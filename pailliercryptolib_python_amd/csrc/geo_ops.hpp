@@ -36,6 +36,8 @@ struct GeoOps {
     void (*pow2)(hipStream_t, int grid, const MontCtx*, uint32_t* ct, const int32_t* delta, int delta_bcast, int n,
                  int w32);
     // out_i = a_i * b_i with the lower-exponent side raised by ^(2^|delta_i|) first (delta = exponent(a) - exponent(b))
+    // out[j] = base^(2^(h j)) mod M, j < nsnap, plain packed rows: one chain of squarings (fin: see modexp_var_win)
+    void (*sq_chain)(hipStream_t, const MontCtx*, const MontCtx* fin, const uint32_t* base, int w32, uint32_t* out, int h, int nsnap);
     void (*add_aligned)(hipStream_t, int grid, const MontCtx*, const uint32_t* a, const uint32_t* b, int b_bcast,
                         const int32_t* delta, uint32_t* out, int n, int w32, const uint32_t* entry);
     // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups
@@ -90,8 +92,15 @@ bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& 
 // digit engine with base n for raw/DJN encryption (kernels_padic_enc.hpp)
 struct EncPadicParams;
 int padic_enc_nl_for_n_bits(int bits);
+// optional precomputed window bases of a fixed-base table: plain residues modulo n^2, [windows][base_words], from k_sq_chain
+struct FbBases {
+    const uint32_t* bases_plain = nullptr;
+    int base_words = 0;
+    const uint32_t* kdig = nullptr;      // digit pairs of R^(i+2) mod n^2 (the ciphertext -> digit-form constants)
+    int nd = 0;
+};
 bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
-                           const uint32_t* one_dig, uint32_t* table, int J, int wb);
+                           const uint32_t* one_dig, uint32_t* table, int J, int wb, const FbBases& fb);
 bool launch_fb_expand_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
                             uint32_t* T, int J, int h, uint32_t* mscratch);
 struct PowPadicParams;

@@ -59,7 +59,8 @@ struct EncPadicParams {
 template <int NL, int U>
 __global__ void __launch_bounds__(64, 1)
 k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const uint32_t* __restrict__ hs_dig,
-                 const uint32_t* __restrict__ one_dig, uint4* __restrict__ table, int J, int wb) {
+                 const uint32_t* __restrict__ one_dig, uint4* __restrict__ table, int J, int wb,
+                 const uint32_t* __restrict__ bases_plain, int base_words, const uint32_t* __restrict__ kdig, int nd) {
     using E = Padic<NL, U>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* ldsn = lds + 3 * E::DIGIT_WORDS;
@@ -79,6 +80,13 @@ k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const ui
     auto self = [&](const uint4* X) {
         return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); };
     };
+    if (bases_plain != nullptr) {
+        // the window bases B_j = hs^(2^(wb j)) arrive as plain residues modulo n^2 (k_sq_chain: ONE chain of squarings on
+        // an integer-per-wavefront geometry, microseconds per product) and enter digit form the way ciphertexts do
+        padic_to_digit_form<E>(A, B, M, bases_plain + (size_t)js * base_words, base_words, kdig, nd, nm, nm1, n0inv);
+#pragma unroll 1
+        for (int c = 0; c < E::NC; ++c) { ent(1, 0, c) = E::ld(A, c); ent(1, 1, c) = E::ld(B, c); }
+    } else {
     // B_j = hs^(2^(wb j)): every lane walks the same squaring chain and snapshots its own window base
 #pragma unroll 1
     for (int c = 0; c < E::NC; ++c) {
@@ -95,6 +103,7 @@ k_fb_table_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1, const ui
         }
         if (s == wb * jmax) break;
         E::mul(A, B, M, self(A), self(B), nm, nm1, n0inv);            // x <- x^2
+    }
     }
     __threadfence();
     // T[j][0] = 1 (Montgomery digit form), T[j][d] = T[j][d-1] * B_j

@@ -529,6 +529,40 @@ k_pow2(const MontCtx* __restrict__ ctx, uint32_t* ct, const int32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// out[j] = base^(2^(h j)) mod M for j < nsnap, as plain packed rows: ONE chain of squarings — the window bases of a
+// fixed-base table.  Meant for the integer-per-wavefront geometries (a product takes microseconds there; the digit
+// engine's table kernel used to walk this chain on one lane per window, 50 us per squaring: 51 ms of every first
+// obfuscating call at 2048-bit keys).  Every element of the workgroup computes the same chain; element 0 stores.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_sq_chain(const MontCtx* __restrict__ ctx, const MontCtx* __restrict__ fin, const uint32_t* __restrict__ base, int w32,
+           uint32_t* __restrict__ out, int h, int nsnap) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t n0inv = G::M1 ? ctx->rows / G::U : ctx->n0inv;
+    uint32_t x[G::NLL], c[G::NLL];
+    load_elem<G>(x, base, w32);
+    load_const_slice<G>(c, ctx->r2);
+    mm_times<G>(x, c, lds, nm, n0inv);                               // base R
+#pragma unroll 1
+    for (int j = 0; j < nsnap; ++j) {
+        uint32_t y[G::NLL], one[G::NLL];
+#pragma unroll
+        for (int k = 0; k < G::NLL; ++k) y[k] = x[k];
+        set_plain_one<G>(one);
+        mm_times<G>(y, one, lds, nm, n0inv);                         // leave Montgomery form
+        if constexpr (G::M1) m1_reduce_to_true_modulus<G>(y, lds, fin);
+        else cond_sub<G::NLL, G::T>(y, nm);
+        if (G::elem() == 0) store_elem<G>(y, out + (size_t)j * w32, w32, lds);
+        if (j + 1 < nsnap) {
+#pragma unroll 1
+            for (int s = 0; s < h; ++s) mm_square<G>(x, lds, nm, n0inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exponent alignment fused with the addition: PaillierEncryptedNumber.__raw_add (ipcl_python.py:490-526) raises the
 // operand with the LOWER fixed-point exponent by ct^(2^delta) (:570-741) and then multiplies the two ciphertexts.
 //   delta_i = exponent(a_i) - exponent(b_i);   out_i = delta_i > 0 ? a_i * b_i^(2^delta_i) : a_i^(2^-delta_i) * b_i   (mod n^2)

@@ -5,7 +5,7 @@ namespace pai {
 
 using L36 = EncLaunch<36, 12>;
 void enc36_fb_table(hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig, const uint32_t* one_dig,
-                    uint32_t* table, int J, int wb) { L36::fb_table(s, nctx, nm1, hs_dig, one_dig, table, J, wb); }
+                    uint32_t* table, int J, int wb, const FbBases& fb) { L36::fb_table(s, nctx, nm1, hs_dig, one_dig, table, J, wb, fb); }
 void enc36_fb_expand(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S, uint32_t* T, int J, int h,
                      uint32_t* mscratch) { L36::fb_expand(s, grid, nctx, nm1, S, T, J, h, mscratch); }
 void enc36_encrypt(hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r, const uint32_t* ct_in,

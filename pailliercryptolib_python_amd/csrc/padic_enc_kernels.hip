@@ -23,9 +23,9 @@ int padic_enc_nl_for_n_bits(int bits) {
     return 0;
 }
 bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig,
-                           const uint32_t* one_dig, uint32_t* table, int J, int wb) {
-    if (nl == 72) L72::fb_table(s, nctx, nm1, hs_dig, one_dig, table, J, wb);
-    else if (nl == 36) enc36_fb_table(s, nctx, nm1, hs_dig, one_dig, table, J, wb);
+                           const uint32_t* one_dig, uint32_t* table, int J, int wb, const FbBases& fb) {
+    if (nl == 72) L72::fb_table(s, nctx, nm1, hs_dig, one_dig, table, J, wb, fb);
+    else if (nl == 36) enc36_fb_table(s, nctx, nm1, hs_dig, one_dig, table, J, wb, fb);
     else return false;
     return true;
 }

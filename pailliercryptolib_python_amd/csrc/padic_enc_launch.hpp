@@ -10,11 +10,11 @@ template <int NL, int U>
 struct EncLaunch {
     static constexpr int BYTES2 = 2 * NL * BLOCK_THREADS * 4 + 2 * NL * 4;      // digit pair per lane + modulus copies
     static void fb_table(hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig, const uint32_t* one_dig,
-                         uint32_t* table, int J, int wb) {
+                         uint32_t* table, int J, int wb, const FbBases& fb) {
         constexpr int bytes = 3 * NL * 64 * 4 + 2 * NL * 4;
         (void)hipFuncSetAttribute((const void*)k_fb_table_padic<NL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         hipLaunchKernelGGL((k_fb_table_padic<NL, U>), dim3((J + 63) / 64), dim3(64), bytes, s, nctx, nm1, hs_dig, one_dig,
-                           reinterpret_cast<uint4*>(table), J, wb);
+                           reinterpret_cast<uint4*>(table), J, wb, fb.bases_plain, fb.base_words, fb.kdig, fb.nd);
     }
     static void fb_expand(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S, uint32_t* T, int J,
                           int h, uint32_t* mscratch) {
@@ -52,7 +52,7 @@ struct EncLaunch {
 
 // 36-limb instantiations (padic_enc36_kernels.hip)
 void enc36_fb_table(hipStream_t s, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* hs_dig, const uint32_t* one_dig,
-                    uint32_t* table, int J, int wb);
+                    uint32_t* table, int J, int wb, const FbBases& fb);
 void enc36_fb_expand(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S, uint32_t* T, int J, int h,
                      uint32_t* mscratch);
 void enc36_encrypt(hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r, const uint32_t* ct_in,

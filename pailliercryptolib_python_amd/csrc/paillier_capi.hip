@@ -625,6 +625,10 @@ int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e
     });
 }
 // window width of the per-element-exponent kernels: table build 2^w - 2 products, then w squarings + 1 product per window
+static bool fb_chain_disabled() {                   // PAI_DISABLE_FB_CHAIN=1: window bases by the table kernel's own squaring chain
+    const char* env = std::getenv("PAI_DISABLE_FB_CHAIN");
+    return env && env[0] == '1';
+}
 static bool pair_ctmul_disabled() {                 // PAI_DISABLE_PAIR_CTMUL=1: ct * pt above 2048-bit keys as products modulo n^2
     const char* env = std::getenv("PAI_DISABLE_PAIR_CTMUL");
     return env && env[0] == '1';
@@ -818,6 +822,28 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
     pk->pair_wbits = wb;
 }
 
+// Contexts of n^2 on the integer-per-wavefront (latency) geometry, built on first need under pk->mu: the conventional one
+// (lat_msq) and, where it fits, the minus-one one (lat_msq_m1).  Returns false when no latency geometry is wide enough.
+static bool ensure_lat_ctx(const pai_pubkey* pk) {
+    if (!pk->lat_ready) {
+        pk->lat_ready = true;
+        if (const GeoOps* gl = geo_latency_for_bits(hbn::bitlen(pk->nsq))) {
+            pk->lat_msq.init(pk->nsq, 0, gl);
+            pk->lat_usable = true;
+        }
+    }
+    if (pk->lat_usable && !pk->lat_m1_tried) {
+        pk->lat_m1_tried = true;
+        const GeoOps* g = pk->lat_msq.geo;
+        const int need = hbn::bitlen(pk->nsq) + hbn::RB * g->u + 4;
+        if (g->t >= 16 && (need + hbn::RB - 1) / hbn::RB + g->u <= g->nl) {
+            pk->lat_msq_m1.init_m1(pk->nsq, g);
+            pk->lat_m1_ok = true;
+        }
+    }
+    return pk->lat_usable;
+}
+
 // Fixed-base tables of the DJN obfuscator hs^r, built by the FIRST call that obfuscates (pai_encrypt with
 // randomness / pai_obfuscate), under pk->mu: a handle that only adds, multiplies or decrypts — every unpickled
 // ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
@@ -883,20 +909,41 @@ void build_fb_tables(const pai_pubkey* cpk) {
         pk->fbd_windows = DJ;
         HIP_CHECK(hipMalloc((void**)&pk->d_fb_dig, ((size_t)DJ << dwb) * ent_bytes));
         bool ok = true;
+        // window bases hs^(2^(h j)): one chain of squarings on the integer-per-wavefront geometry (k_sq_chain, ~6 us per
+        // product) instead of the same chain walked by every lane of the table kernel at 50 us per product
+        const int h1 = dwb <= 12 ? dwb : dwb / 2, J1 = dwb <= 12 ? DJ : 2 * DJ;
+        FbBases fbb;
+        DevBuf d_bases, d_hs_plain;
+        if (pk->d_ct_kdig && ensure_lat_ctx(pk) && !fb_chain_disabled()) {
+            const std::vector<uint32_t> hw = [&] { std::vector<uint32_t> v((size_t)pk->ct_words, 0); std::memcpy(v.data(), pk->hs.data(), pk->hs.size() * 4); return v; }();
+            d_hs_plain.ensure(hw.size() * 4);
+            HIP_CHECK(hipMemcpy(d_hs_plain.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+            d_bases.ensure((size_t)J1 * pk->ct_words * 4);
+            const GeoOps* gl = pk->lat_msq.geo;
+            gl->sq_chain(nullptr, pk->lat_m1_ok ? pk->lat_msq_m1.d_ctx : pk->lat_msq.d_ctx, pk->lat_m1_ok ? pk->lat_msq.d_ctx : nullptr,
+                         d_hs_plain.as<uint32_t>(), pk->ct_words, d_bases.as<uint32_t>(), h1, J1);
+            HIP_CHECK(hipGetLastError());
+            fbb.bases_plain = d_bases.as<uint32_t>();
+            fbb.base_words = pk->ct_words;
+            fbb.kdig = pk->d_ct_kdig;
+            fbb.nd = pk->ct_nd;
+        }
         if (dwb <= 12) {
-            ok = launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs.as<uint32_t>(), d_one, pk->d_fb_dig, DJ, dwb);
+            ok = launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs.as<uint32_t>(), d_one, pk->d_fb_dig, DJ, dwb, fbb);
         } else {
             // two levels: half-width windows at twice the density (sequential chains of 2^h entries), then
             // one parallel pass of DJ * 2^dwb independent products
             const int h = dwb / 2;
             d_half.ensure(((size_t)(2 * DJ) << h) * ent_bytes);
-            ok = launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs.as<uint32_t>(), d_one, d_half.as<uint32_t>(), 2 * DJ, h) &&
+            ok = launch_fb_table_padic(pnl, nullptr, pk->nmod.d_ctx, pk->d_nm1, d_hs.as<uint32_t>(), d_one, d_half.as<uint32_t>(), 2 * DJ, h, fbb) &&
                  launch_fb_expand_padic(pnl, nullptr, pk->dev.ncu, pk->nmod.d_ctx, pk->d_nm1, d_half.as<uint32_t>(), pk->d_fb_dig, DJ, h,
                                         pk->d_mscratch);
         }
         hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
         d_hs.release();
         d_half.release();
+        d_bases.release();
+        d_hs_plain.release();
         if (!ok) throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
         HIP_CHECK(e1);
         HIP_CHECK(e2);
@@ -1398,28 +1445,13 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         if (N <= 4 * latency_max_elements() && ebits_max > 8) {          // 0.9 ms against 4.8 ms up to ~8192 elements
             // small batch: windowed exponentiation with n^2 spread over a whole wavefront per ciphertext
             std::lock_guard<std::mutex> lk(pk->mu);
-            if (!pk->lat_ready) {
-                pk->lat_ready = true;
-                if (const GeoOps* gl = geo_latency_for_bits(hbn::bitlen(pk->nsq))) {
-                    pk->lat_msq.init(pk->nsq, 0, gl);
-                    pk->lat_usable = true;
-                }
-            }
-            if (pk->lat_usable) {
+            if (ensure_lat_ctx(pk)) {
                 const GeoOps* g = pk->lat_msq.geo;
                 const int grid = (int)((N + g->epb - 1) / g->epb);
                 const int wbits = var_window_bits(ebits_max);
                 pk->lat_table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
                 pk->order.begin(s);
                 ScopedKernelTimer t("k_ctmul", s);
-                if (!pk->lat_m1_tried) {                 // minus-one context of n^2 on the same geometry (mont_dev.hpp: block_m1)
-                    pk->lat_m1_tried = true;
-                    const int need = hbn::bitlen(pk->nsq) + hbn::RB * g->u + 4;
-                    if (g->t >= 16 && (need + hbn::RB - 1) / hbn::RB + g->u <= g->nl) {
-                        pk->lat_msq_m1.init_m1(pk->nsq, g);
-                        pk->lat_m1_ok = true;
-                    }
-                }
                 g->modexp_var_win(s, grid, pk->lat_m1_ok ? pk->lat_msq_m1.d_ctx : pk->lat_msq.d_ctx, d_ct, pk->ct_words, d_e, e_words,
                                   ebits_max, e_bcast, d_out, pk->ct_words, (int)N, pk->lat_table.as<uint32_t>(), wbits,
                                   pk->lat_m1_ok ? pk->lat_msq.d_ctx : nullptr);
