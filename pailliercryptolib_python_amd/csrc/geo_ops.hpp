@@ -121,7 +121,7 @@ struct PairCtMulParams;
 int pair_nl_for_n_bits(int bits);                 // 112 / 144 limbs, 0 = not served
 int pair_epb(int nl);                             // elements per workgroup
 bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
-                          const uint32_t* one_pair, uint32_t* S, int nwin, int h);
+                          const uint32_t* one_pair, uint32_t* S, int nwin, int h, const FbBases& fb);
 bool launch_pair_fb_expand(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
                            uint32_t* T, int J, int h);
 bool launch_pair_fixed_base(int nl, hipStream_t s, int grid, const PairParams& P, const uint32_t* m, const uint32_t* r,

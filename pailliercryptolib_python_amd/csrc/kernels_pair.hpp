@@ -139,7 +139,8 @@ PAI_DEV void pair_times(uint32_t (&a)[G::NLL], uint32_t (&b)[G::NLL], const uint
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
 k_pair_fb_chain(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ nm1, const uint32_t* __restrict__ base0,
-                const uint32_t* __restrict__ one_pair, uint32_t* __restrict__ S, int nwin, int h) {
+                const uint32_t* __restrict__ one_pair, uint32_t* __restrict__ S, int nwin, int h,
+                const uint32_t* __restrict__ bases_plain, int base_words, const uint32_t* __restrict__ kdig, int nd) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     pair_setup<G>(lds, nm1);
     typename G::NM nm;
@@ -153,7 +154,29 @@ k_pair_fb_chain(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ n
         const int is = live ? i : nwin - 1;
         uint32_t a[G::NLL], b[G::NLL], c[G::NLL], d[G::NLL];
         pair_load<G>(c, d, base0);
-        const int smax = h * min(nwin - 1, tile * G::EPB + G::EPB - 1);
+        int smax = h * min(nwin - 1, tile * G::EPB + G::EPB - 1);
+        if (bases_plain != nullptr) {
+            // the window base B_i = hs^(2^(h i)) arrives as a plain residue modulo n^2 (k_sq_chain) and enters digit form
+            // through its base-R digits, as a ciphertext does in k_pair_ctmul
+            smax = 0;
+            const uint32_t* row = bases_plain + (size_t)is * base_words;
+#pragma unroll 1
+            for (int i = 0; i < nd; ++i) {
+                uint32_t kc[G::NLL], kd[G::NLL];
+                load_elem_off<G>(a, row, base_words, G::NL * i);
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) b[j] = 0;
+                pair_load<G>(kc, kd, kdig + (size_t)i * 2 * G::NL);
+                pair_times<G>(a, b, kc, kd, lds, nm, n0inv);
+                if (i == 0) {
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) { c[j] = a[j]; d[j] = b[j]; }
+                } else {
+                    add_limbs<G>(c, a);
+                    add_limbs<G>(d, b);
+                }
+            }
+        }
 #pragma unroll 1
         for (int sq = 0; sq < smax; ++sq) {
 #pragma unroll

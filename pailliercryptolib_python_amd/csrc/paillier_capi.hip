@@ -765,6 +765,8 @@ uint32_t* build_lane_group_fb(const pai_pubkey* pk, const ModSetup& ms, int wb, 
     return d_fb;
 }
 
+static bool ensure_lat_ctx(const pai_pubkey* pk);
+
 // Digit-pair fixed-base table for the lane-group pair kernels: T[j][d] = pair(hs^(d 2^(wb j)) R), R = 2^(29 pair_nl).
 // The host supplies pair(hs R) and pair(R); the window bases (squarings), the half-width windows (one sequential chain
 // per window) and the full table (one product per entry) are computed on the device.
@@ -799,8 +801,26 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
     }
     const int epb = pair_epb(nl);
     const int g1 = std::max(1, (J1 + epb - 1) / epb);
+    // window bases from one chain of squarings on the integer-per-wavefront geometry (k_sq_chain), as for the digit engine
+    FbBases fbb;
+    DevBuf d_plain, d_hs_plain;
+    if (pk->d_pair_kdig && ensure_lat_ctx(pk) && !fb_chain_disabled()) {
+        std::vector<uint32_t> hw((size_t)pk->ct_words, 0);
+        std::memcpy(hw.data(), pk->hs.data(), pk->hs.size() * 4);
+        d_hs_plain.ensure(hw.size() * 4);
+        HIP_CHECK(hipMemcpy(d_hs_plain.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        d_plain.ensure((size_t)J1 * pk->ct_words * 4);
+        const GeoOps* gl = pk->lat_msq.geo;
+        gl->sq_chain(nullptr, pk->lat_m1_ok ? pk->lat_msq_m1.d_ctx : pk->lat_msq.d_ctx, pk->lat_m1_ok ? pk->lat_msq.d_ctx : nullptr,
+                     d_hs_plain.as<uint32_t>(), pk->ct_words, d_plain.as<uint32_t>(), h, J1);
+        HIP_CHECK(hipGetLastError());
+        fbb.bases_plain = d_plain.as<uint32_t>();
+        fbb.base_words = pk->ct_words;
+        fbb.kdig = pk->d_pair_kdig;
+        fbb.nd = pk->pair_nd;
+    }
     bool ok = launch_pair_fb_chain(nl, nullptr, g1, pk->npair.d_ctx, pk->d_pair_nm1, d_bases.as<uint32_t>(), d_one.as<uint32_t>(),
-                                   level1, J1, h);
+                                   level1, J1, h, fbb);
     hipError_t e1 = hipGetLastError();
     if (ok && two_level && e1 == hipSuccess) {
         const int g2 = (int)std::max<size_t>(1, std::min<size_t>((NE + epb - 1) / epb, (size_t)pk->dev.ncu * 2));
@@ -811,6 +831,8 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
     d_bases.release();
     d_one.release();
     d_half.release();
+    d_plain.release();
+    d_hs_plain.release();
     if (!ok || e1 != hipSuccess || e2 != hipSuccess) {
         (void)hipFree(pk->d_pair_fb);
         pk->d_pair_fb = nullptr;

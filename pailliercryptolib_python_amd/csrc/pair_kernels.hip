@@ -12,9 +12,10 @@ struct PairLaunch {
     static constexpr int BYTES = PairLds<G>::BYTES;
     static void set_lds(const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES); }
     static void chain(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
-                      const uint32_t* one_pair, uint32_t* S, int nwin, int h) {
+                      const uint32_t* one_pair, uint32_t* S, int nwin, int h, const FbBases& fb) {
         set_lds((const void*)k_pair_fb_chain<G>);
-        hipLaunchKernelGGL(k_pair_fb_chain<G>, dim3(grid), dim3(BLOCK_THREADS), BYTES, s, nctx, nm1, bases, one_pair, S, nwin, h);
+        hipLaunchKernelGGL(k_pair_fb_chain<G>, dim3(grid), dim3(BLOCK_THREADS), BYTES, s, nctx, nm1, bases, one_pair, S, nwin, h,
+                           fb.bases_plain, fb.base_words, fb.kdig, fb.nd);
     }
     static void expand(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S, uint32_t* T, int J, int h) {
         set_lds((const void*)k_pair_fb_expand<G>);
@@ -50,9 +51,9 @@ int pair_nl_for_n_bits(int bits) {
 }
 int pair_epb(int nl) { return nl == 112 ? G112::EPB : (nl == 144 ? G144::EPB : 0); }
 bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
-                          const uint32_t* one_pair, uint32_t* S, int nwin, int h) {
-    if (nl == 112) P112::chain(s, grid, nctx, nm1, bases, one_pair, S, nwin, h);
-    else if (nl == 144) P144::chain(s, grid, nctx, nm1, bases, one_pair, S, nwin, h);
+                          const uint32_t* one_pair, uint32_t* S, int nwin, int h, const FbBases& fb) {
+    if (nl == 112) P112::chain(s, grid, nctx, nm1, bases, one_pair, S, nwin, h, fb);
+    else if (nl == 144) P144::chain(s, grid, nctx, nm1, bases, one_pair, S, nwin, h, fb);
     else return false;
     return true;
 }
