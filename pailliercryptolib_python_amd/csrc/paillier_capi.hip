@@ -301,7 +301,8 @@ struct ScopedKernelTimer {
 
 // Batches up to this many elements take the latency path: every integer spread over 16-64 lanes, (element, prime)
 // pairs filling the device instead of lanes (PAI_LATENCY_MAX overrides; 0 disables it).  Measured on MI355X at
-// 2048-bit keys: decrypt 7.3 ms up to 1024 elements, 10.2 ms at 2048, against 14.6 ms on the throughput kernels.
+// 2048-bit keys: decrypt 3.8 ms up to 512 elements, 7.0 ms at 2048, 12.2 ms at 4096 (decrypt takes the path up to twice
+// this value), against 14.7 ms on the throughput kernels.
 size_t latency_max_elements() {
     if (const char* env = std::getenv("PAI_LATENCY_MAX")) return (size_t)std::strtoull(env, nullptr, 10);
     return (size_t)2048;
@@ -462,6 +463,11 @@ struct pai_privkey {
         uint32_t* d_hR[2] = {nullptr, nullptr};
         uint32_t* d_pinvqR = nullptr;
         DevBuf table;
+        // mid-size batches (more than one wave per SIMD at one integer per wavefront): the densest wide-group geometry
+        // s^2 k fits (two integers per wavefront at 2048-bit keys) — the same stage A on its own contexts
+        bool dense = false;
+        ModSetup sq2[2], sq2_true[2];
+        uint32_t* d_r3_2[2] = {nullptr, nullptr};
     } lat;
     ScratchOrder order;
     std::mutex mu;
@@ -625,6 +631,10 @@ int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e
     });
 }
 // window width of the per-element-exponent kernels: table build 2^w - 2 products, then w squarings + 1 product per window
+static bool lat_dense_disabled() {                  // PAI_LAT_DENSE=0: small-batch stage A always on one integer per wavefront
+    const char* env = std::getenv("PAI_LAT_DENSE");
+    return env && env[0] == '0';
+}
 static bool fb_chain_disabled() {                   // PAI_DISABLE_FB_CHAIN=1: window bases by the table kernel's own squaring chain
     const char* env = std::getenv("PAI_DISABLE_FB_CHAIN");
     return env && env[0] == '1';
@@ -2017,6 +2027,9 @@ void pai_privkey_destroy(pai_privkey* sk) {
     for (int w = 0; w < 2; ++w) {
         sk->lat.sq[w].release();
         sk->lat.sq_true[w].release();
+        sk->lat.sq2[w].release();
+        sk->lat.sq2_true[w].release();
+        if (sk->lat.d_r3_2[w]) (void)hipFree(sk->lat.d_r3_2[w]);
         sk->lat.pr[w].release();
         if (sk->lat.d_r3[w]) (void)hipFree(sk->lat.d_r3[w]);
         if (sk->lat.d_ops[w]) (void)hipFree(sk->lat.d_ops[w]);
@@ -2069,6 +2082,16 @@ static void build_latency_consts(pai_privkey* sk) {
     }
     L.d_pinvqR = upload_r29(hbn::mulmod(sk->pinvq_host, L.pr[1].R, sk->q), gb->nl);
     L.usable = true;
+    const GeoOps* gd = geo_latency_for_bits(sq_bits + hbn::RB * 3 + 8);
+    if (gd && gd != ga && gd->t >= 16 && gd->t < ga->t) {
+        for (int w = 0; w < 2; ++w) {
+            const Limbs s2 = hbn::mul(prime[w], prime[w]);
+            L.sq2[w].init_m1(s2, gd);
+            L.sq2_true[w].init(s2, 0, gd);
+            L.d_r3_2[w] = upload_r29(L.sq2[w].R3, L.sq2[w].nl);
+        }
+        L.dense = true;
+    }
 }
 
 int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream) {
@@ -2080,13 +2103,19 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         DeviceScope scope_(pk->device);
         DeviceInfo dev = scope_.info;
         hipStream_t s = (hipStream_t)stream;
-        if (N <= latency_max_elements()) {
+        if (N <= 2 * latency_max_elements()) {                            // measured cross-over at 2048-bit keys: ~4900 elements
             build_latency_consts(sk);
             if (sk->lat.usable) {
                 // small batch: every integer is spread over 16-64 lanes, one product takes microseconds instead of
                 // tens of microseconds; (element, prime) pairs fill the device instead of lanes
                 pai_privkey::Lat& L = sk->lat;
-                const GeoOps* ga = L.sq[0].geo;
+                // one integer per wavefront while that leaves at most one wave per SIMD (2 N <= 4 x CUs), the denser
+                // geometry (two integers per wavefront at 2048-bit keys) beyond
+                const bool dense = L.dense && 2 * N > 4 * (size_t)dev.ncu && !lat_dense_disabled();
+                const ModSetup* SQ = dense ? L.sq2 : L.sq;
+                const ModSetup* SQT = dense ? L.sq2_true : L.sq_true;
+                uint32_t* const* R3 = dense ? L.d_r3_2 : L.d_r3;
+                const GeoOps* ga = SQ[0].geo;
                 const GeoOps* gb = L.pr[0].geo;
                 const int u_words = std::max(L.sq_true[0].w32, L.sq_true[1].w32);
                 const int gridx = (int)((N + ga->epb - 1) / ga->epb);
@@ -2096,11 +2125,11 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 DecAParams A;
                 DecBParams B;
                 for (int w = 0; w < 2; ++w) {
-                    A.sq[w] = L.sq[w].d_ctx;
-                    A.fin[w] = L.sq_true[w].d_ctx;
+                    A.sq[w] = SQ[w].d_ctx;
+                    A.fin[w] = SQT[w].d_ctx;
                     A.ops[w] = L.d_ops[w];
                     A.nops[w] = L.nops[w];
-                    A.r3[w] = L.d_r3[w];
+                    A.r3[w] = R3[w];
                     A.expo[w] = sk->d_expo[w];
                     A.ewords[w] = sk->ewords[w];
                     A.ebits[w] = sk->ebits[w];

@@ -490,7 +490,7 @@ def test_decrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
     ones on the digit-pair engine (throughput path); PAI_LATENCY_MAX moves the switch.  Both against the oracle."""
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     key = nk.key
-    for N in ((3, 7, 33, 150) if bits <= 2048 else (3, 33, 70)):
+    for N in ((3, 7, 33, 150, 700) if bits <= 2048 else (3, 33, 70, 600)):      # > 512: the denser wide-group geometry
         m = plaintexts(key, N, bits + N)
         rng = np.random.default_rng(N)
         # short randomness keeps the oracle's CPython pow cheap; decryption does not care how a ciphertext was obfuscated
