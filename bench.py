@@ -55,16 +55,51 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-KEY_BITS = 2048
 DJN_X = 0x1234567
-PEAK_MAC32_PER_S = 35.9e12        # measured v_mad_u64_u32 rate, 8 waves/SIMD (profiles/r01/ubench_valu_mi355x.jsonl)
+# v_mad_u64_u32 rate of the chip, 8 waves/SIMD: PEAK = an 18 ms burst on constant operands (profiles/r01/ubench_valu_mi355x.jsonl);
+# PEAK_SUSTAINED = seconds-long back-to-back launches on data-dependent operands with the clock the power management settles
+# at (2.29 GHz / 1290 W of the 1400 W cap; profiles/r04/ubench_valu_sustained.jsonl, form 1) - the two differ by 2.4 %
+PEAK_MAC32_PER_S = 35.9e12
+PEAK_SUSTAINED_MAC32_PER_S = 35.05e12
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md
-# canonical MAC32 per op at 2048-bit keys (CIOS 2L^2+L, 5-bit window)
-CANON_MAC_ENC, CANON_MAC_DEC, CANON_MAC_ADD, CANON_MAC_MUL53 = 41.52e6, 20.86e6, 65.8e3, 3.16e6
-BYTES_ENC, BYTES_DEC, BYTES_ADD = 648, 520, 1536   # algorithmic bytes per op
+# canonical MAC32 per op (CIOS 2L^2+L, 5-bit window): encrypt DJN, decrypt CRT, ct+ct, ct x pt (53-bit e)
+CANON = {1024: (5.35e6, 2.70e6, 16.5e3, 0.79e6), 2048: (41.52e6, 20.86e6, 65.8e3, 3.16e6),
+         3072: (138.76e6, 69.61e6, 147.8e3, 7.10e6), 4096: (327.15e6, 163.99e6, 262.7e3, 12.61e6)}
 BASELINE_METRIC = json.loads((ROOT / "BASELINE.json").read_text())["metric"] if (ROOT / "BASELINE.json").exists() else \
     "Paillier encrypt+decrypt ops/sec, 2048-bit key, batch=1M; 1/2/4/8 MI355X"
-PMC_FILES = ["profiles/r03/pmc_bench_r03.json", "profiles/r02/pmc_bench_r02.json", "profiles/r01/pmc_bench_r01d.json"]   # newest first
+# BASELINE.json configurations this tool can time (same step, same parity check, same roofline / cpu_baseline objects):
+# the metric's own configuration and the two sharded ones (cfg4 / cfg5 = BASELINE.json configs[3] / configs[4])
+CONFIGS = {
+    "headline": {"key_bits": 2048, "batch": 1 << 20, "baseline": "metric (configs[1]/[2] key and batch): 2048-bit key, batch 2^20"},
+    "cfg2": {"key_bits": 2048, "batch": 1 << 16, "baseline": "configs[1]: 2048-bit key, batch 65 536"},
+    "cfg4": {"key_bits": 3072, "batch": 1 << 20, "baseline": "configs[3]: 3072-bit key, batch 2^20 encrypt+decrypt sharded over the ranks"},
+    "cfg5": {"key_bits": 4096, "batch": 1 << 18, "baseline": "configs[4]: 4096-bit key, batch 2^18 encrypt with CRT decrypt"},
+}
+# PMC summaries by key size, newest first: (file, batch the profile was taken at)
+PMC_FILES = {2048: [("profiles/r03/pmc_bench_r03.json", 1 << 20), ("profiles/r02/pmc_bench_r02.json", 1 << 20),
+                    ("profiles/r01/pmc_bench_r01d.json", 1 << 20)],
+             3072: [("profiles/r03/pmc_k3072_r03.json", 1 << 16)], 4096: [("profiles/r03/pmc_k4096_r03.json", 1 << 16)]}
+
+
+def alg_bytes(bits: int):
+    """Algorithmic bytes per op: encrypt 8 + k/16 in, k/4 out; decrypt k/4 in, 8 out; add 3 k/4."""
+    return 8 + bits // 16 + bits // 4, bits // 4 + 8, 3 * bits // 4
+
+
+def padic_nl(prime_bits: int) -> int:
+    """Limbs of the digit engine serving a prime (csrc/padic_dec_kernels.hip: padic_nl_for_prime_bits)."""
+    for nl in (24, 36, 56, 72):
+        if 29 * nl >= prime_bits + 20 and prime_bits >= 400:
+            return nl
+    return 0
+
+
+def modmul_limbs(mod_bits: int) -> int:
+    """Limbs of the lane-group geometry serving a modulus (csrc/geo_inst.hpp: geo_for_bits)."""
+    for nl in (36, 72, 112, 144, 224, 288):
+        if 29 * nl >= mod_bits + 2:
+            return nl
+    return 0
 
 
 def _sliding_counts(e: int, w: int = 6):
@@ -100,12 +135,16 @@ def synthetic_key(bits: int = 2048, djn_x: Optional[int] = 0x1234567) -> SimpleN
                            max_int=n // 3 - 1, djn_x=djn_x)
 
 
-def executed_macs_decrypt(p: int, q: int, nl: int = 36, w: int = 6, ct_bits: int = 4096) -> float:
+def executed_macs_decrypt(p: int, q: int, w: int = 6) -> float:
     """29x29-bit MACs actually issued per decrypted element by k_dec_a_padic (both primes): on base-s digit
-    pairs a squaring takes 36*37/2 (a^2, every limb pair once) + 36^2 (its reduction) + 2*36^2 (2ab and
-    its reduction) MACs and a multiplication 5*36^2."""
-    sq = nl * (nl + 1) // 2 + nl * nl + 2 * nl * nl
+    pairs of NL limbs a multiplication takes 5 NL^2 MACs and a squaring NL^2 (reduction of a^2) + 2 NL^2 (2ab and its
+    reduction) + the a^2 half: NL (NL+1)/2 up to 36 limbs (every limb pair once), NL (NL+8)/2 at 56 limbs (limb-class
+    symmetric in 8-row blocks: csrc/mont_padic.hpp sqr_sym_fused), NL^2 at 72 limbs (sqr_fused)."""
+    nl = padic_nl(max(p.bit_length(), q.bit_length()))
+    half = {24: nl * (nl + 1) // 2, 36: nl * (nl + 1) // 2, 56: nl * (nl + 8) // 2, 72: nl * nl}[nl]
+    sq = half + 3 * nl * nl
     mul = 5 * nl * nl
+    ct_bits = 2 * (p * q).bit_length()
     nd = -(-ct_bits // (29 * nl))
     total = 0.0
     for s_ in (p, q):
@@ -116,11 +155,11 @@ def executed_macs_decrypt(p: int, q: int, nl: int = 36, w: int = 6, ct_bits: int
     return total
 
 
-def pmc_traffic(kernel_prefix: str, batch: int):
-    """HBM bytes per launch of a kernel from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes, KiB units; gfx950 FETCH_SIZE counts half of a wide streaming read => doubled, as
-    MI355X_MICROARCH.md prescribes).  The profiles were taken at batch 2^20; scaled linearly to `batch`."""
-    for rel in PMC_FILES:
+def pmc_traffic(kernel_prefix: str, batch: int, key_bits: int = 2048):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary of this key size (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, KiB units; gfx950 FETCH_SIZE counts half of a wide streaming read => doubled, as
+    MI355X_MICROARCH.md prescribes).  Scaled linearly from the batch the profile was taken at to `batch`."""
+    for rel, prof_batch in PMC_FILES.get(key_bits, []):
         f = ROOT / rel
         if not f.exists():
             continue
@@ -128,10 +167,10 @@ def pmc_traffic(kernel_prefix: str, batch: int):
         data = json.loads(raw)
         for name, c in data.items():
             if name.startswith(kernel_prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                scale = batch / float(1 << 20)
+                scale = batch / float(prof_batch)
                 return {"bytes": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * scale, "fetch_KiB": c["FETCH_SIZE"],
-                        "write_KiB": c["WRITE_SIZE"], "source": rel, "sha256": hashlib.sha256(raw).hexdigest()[:16],
-                        "kernel": name}
+                        "write_KiB": c["WRITE_SIZE"], "source": rel, "profile_batch": prof_batch,
+                        "sha256": hashlib.sha256(raw).hexdigest()[:16], "kernel": name}
     return None
 
 
@@ -162,13 +201,24 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="elements in total (strong) or per GPU (weak) per step")
+    ap.add_argument("--config", choices=tuple(CONFIGS), default="headline",
+                    help="BASELINE.json configuration: headline (2048-bit, 2^20), cfg2 (2048-bit, 65 536), cfg4 (3072-bit, 2^20), "
+                         "cfg5 (4096-bit, 2^18)")
+    ap.add_argument("--key-bits", type=int, default=None, choices=(1024, 2048, 3072, 4096), help="override the configuration's key size")
+    ap.add_argument("--batch", type=int, default=None, help="elements in total (strong) or per GPU (weak) per step "
+                                                            "(default: the configuration's batch)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the second (weak resp. strong) arrangement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip api_level / other_ops / small_batch (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    KEY_BITS = args.key_bits or cfg["key_bits"]
+    if args.batch is None:
+        args.batch = cfg["batch"]
+    CANON_MAC_ENC, CANON_MAC_DEC, CANON_MAC_ADD, CANON_MAC_MUL53 = CANON[KEY_BITS]
+    BYTES_ENC, BYTES_DEC, BYTES_ADD = alg_bytes(KEY_BITS)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -91,6 +91,20 @@ int pai_pubkey_trim(pai_pubkey* pk, size_t* freed_bytes);
 int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_words, int* r_words,
                     int* randbits, int* is_djn, int* device);
 
+/* ipclKeypair.generate_keypair(n_length, enable_DJN) — bindings/ipcl_bindings.cpp:12-15 -> ipcl::generateKeypair
+ * (timed by the reference's BM_KeyGen, bench/bench_ipcl_python.py:13-19).  Host-only (no device work): two random primes
+ * of key_bits/2 bits with the two top bits set (so p*q has exactly key_bits bits), p != q; djn != 0 adds upstream's DJN
+ * constraints p = q = 3 (mod 4), gcd(p-1, q-1) = 2.  Incremental search over a sieve of the primes below 2^16, Miller-
+ * Rabin with base 2 and 24 random bases, the two primes searched on two host threads.  key_bits: a multiple of 64,
+ * 128..8192.  h_seed == NULL: the kernel CSPRNG (getrandom); a seed makes the key reproducible (tests only — such a
+ * key is NOT secret).  h_p, h_q receive key_bits/64 words each, p < q not guaranteed. */
+int pai_keygen(int key_bits, int djn, const uint64_t* h_seed, uint32_t* h_p, uint32_t* h_q);
+/* Host big-integer modular exponentiation for key set-up (the DJN base hs = (-x^2)^n mod n^2 of ipcl::PublicKey's
+ * constructor, classes.cpp:24-27): h_out = h_base ^ h_exp mod h_mod for an odd modulus of mod_words words (<= 260);
+ * h_base: mod_words words, < modulus; h_out: mod_words words.  Host-only, synchronous. */
+int pai_host_modexp(const uint32_t* h_base, const uint32_t* h_exp, int exp_words, const uint32_t* h_mod, int mod_words,
+                    uint32_t* h_out);
+
 /* ipclPrivateKey(pubkey, p, q) — classes.cpp:96-101.  p and q may come in either order; n == p*q is
  * checked.  Derives p^2, q^2, hp, hq, p^-1 mod q. */
 int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, const uint32_t* h_q, int q_words,

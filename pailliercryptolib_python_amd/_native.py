@@ -48,6 +48,8 @@ PROTOTYPES = {
     "pai_stream_sync": (C.c_int, [C.c_int, voidp]),
     "pai_pubkey_create": (C.c_int, [voidp, C.c_int, C.c_int, voidp, C.c_int, C.c_int, C.c_int, C.POINTER(voidp)]),
     "pai_pubkey_destroy": (None, [voidp]),
+    "pai_keygen": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint64), voidp, voidp]),
+    "pai_host_modexp": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, voidp]),
     "pai_pubkey_info": (C.c_int, [voidp] + [C.POINTER(C.c_int)] * 7),
     "pai_privkey_create": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, C.POINTER(voidp)]),
     "pai_privkey_destroy": (None, [voidp]),
@@ -124,6 +126,32 @@ def check(code: int) -> None:
     if code != PAI_OK:
         msg = load().pai_last_error()
         raise NativeError(code, msg.decode("utf-8", "replace") if msg else "")
+
+
+def keygen(key_bits: int, djn: bool, seed=None):
+    """pai_keygen: two random primes (p, q) for a key of key_bits bits as Python ints (host-only native search)."""
+    import numpy as np
+
+    words = key_bits // 64
+    p = np.zeros(words, dtype=np.uint32)
+    q = np.zeros(words, dtype=np.uint32)
+    sd = C.byref(C.c_uint64(int(seed) & (2**64 - 1))) if seed is not None else None
+    check(load().pai_keygen(int(key_bits), 1 if djn else 0, sd, p.ctypes.data, q.ctypes.data))
+    return int.from_bytes(p.tobytes(), "little"), int.from_bytes(q.tobytes(), "little")
+
+
+def host_modexp(base: int, exp: int, mod: int) -> int:
+    """pai_host_modexp: base^exp mod an odd modulus on the host cores (key set-up; not a hot operation)."""
+    import numpy as np
+
+    mw = (mod.bit_length() + 31) // 32
+    ew = max(1, (exp.bit_length() + 31) // 32)
+    b = np.frombuffer((base % mod).to_bytes(4 * mw, "little"), dtype=np.uint32).copy()
+    e = np.frombuffer(exp.to_bytes(4 * ew, "little"), dtype=np.uint32).copy()
+    m = np.frombuffer(mod.to_bytes(4 * mw, "little"), dtype=np.uint32).copy()
+    out = np.zeros(mw, dtype=np.uint32)
+    check(load().pai_host_modexp(b.ctypes.data, e.ctypes.data, ew, m.ctypes.data, mw, out.ctypes.data))
+    return int.from_bytes(out.tobytes(), "little")
 
 
 def device_count() -> int:

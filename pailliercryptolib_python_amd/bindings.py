@@ -24,7 +24,7 @@ from typing import List, Optional, Sequence, Union
 import numpy as np
 import torch
 
-from . import engine
+from . import _native, engine
 
 # ------------------------------------------------------------------------------------------------
 # BigNumber
@@ -175,7 +175,7 @@ class ipclPublicKey:
                 # upstream DJN set-up: hs = (-x^2)^n mod n^2 for a random unit x
                 nsq = self._n * self._n
                 x = _random_unit(self._n)
-                hs = pow((-x * x) % nsq, self._n, nsq)
+                hs = _native.host_modexp((-x * x) % nsq, self._n, nsq) if self._n & 1 else pow((-x * x) % nsq, self._n, nsq)
             self._hs = int(hs)
             self._randbits = int(randbits) if randbits is not None else self._bits // 2
         else:
@@ -751,8 +751,12 @@ class ipclKeypair:
             raise RuntimeError("generate_keypair: n_length must be a multiple of 4 and at least 64")
         half = n_length // 2
         while True:
-            p = _random_prime(half, enable_DJN)
-            q = _random_prime(half, enable_DJN)
+            if n_length % 64 == 0 and n_length >= 128:
+                # native search (pai_keygen): sieve + Miller-Rabin on the host cores, both primes in parallel
+                p, q = _native.keygen(n_length, enable_DJN)
+            else:
+                p = _random_prime(half, enable_DJN)
+                q = _random_prime(half, enable_DJN)
             if p == q or (p * q).bit_length() != n_length:
                 continue
             if enable_DJN and math.gcd(p - 1, q - 1) != 2:

@@ -13,6 +13,7 @@
 
 #include "geo_ops.hpp"
 #include "hostbn.hpp"
+#include "host_keygen.hpp"
 #include "kernels_padic.hpp"
 #include "kernels_padic_enc.hpp"
 #include "kernels_pair.hpp"
@@ -482,6 +483,41 @@ extern "C" {
 int pai_version(void) { return 200; }
 
 const char* pai_last_error(void) { return g_err.c_str(); }
+
+int pai_keygen(int key_bits, int djn, const uint64_t* h_seed, uint32_t* h_p, uint32_t* h_q) {
+    return guarded([&] {
+        require(key_bits >= 128 && key_bits <= 8192 && key_bits % 64 == 0, "pai_keygen: key_bits must be a multiple of 64 in 128..8192");
+        require(h_p != nullptr && h_q != nullptr, "pai_keygen: output pointer is NULL");
+        const int half = key_bits / 2, L = (half + 63) / 64, words = half / 32;
+        uint64_t p[kg::MAXL] = {0}, q[kg::MAXL] = {0};
+        kg::generate_primes(key_bits, djn != 0, h_seed, p, q);
+        std::memcpy(h_p, p, 4 * (size_t)words);
+        std::memcpy(h_q, q, 4 * (size_t)words);
+        (void)L;
+    });
+}
+
+int pai_host_modexp(const uint32_t* h_base, const uint32_t* h_exp, int exp_words, const uint32_t* h_mod, int mod_words,
+                    uint32_t* h_out) {
+    return guarded([&] {
+        require(h_base && h_exp && h_mod && h_out, "pai_host_modexp: NULL pointer");
+        require(mod_words >= 1 && mod_words <= 2 * kg::MAXL && exp_words >= 1, "pai_host_modexp: bad word count");
+        require((h_mod[0] & 1u) != 0, "pai_host_modexp: modulus must be odd");
+        const int L = (mod_words + 1) / 2, eL = (exp_words + 1) / 2;
+        uint64_t m[kg::MAXL] = {0}, b[kg::MAXL] = {0}, out[kg::MAXL] = {0};
+        std::vector<uint64_t> e((size_t)eL, 0);
+        std::memcpy(m, h_mod, 4 * (size_t)mod_words);
+        std::memcpy(b, h_base, 4 * (size_t)mod_words);
+        std::memcpy(e.data(), h_exp, 4 * (size_t)exp_words);
+        int Lt = L;
+        while (Lt > 1 && m[Lt - 1] == 0) --Lt;                       // Montgomery radix from the modulus' own length
+        for (int i = Lt; i < L; ++i) require(b[i] == 0, "pai_host_modexp: base wider than the modulus");
+        kg::Mont mt(m, Lt);
+        require(kg::cmp(b, mt.m, Lt) < 0, "pai_host_modexp: base must be reduced modulo the modulus");
+        mt.pow(out, b, e.data(), eL);
+        std::memcpy(h_out, out, 4 * (size_t)mod_words);
+    });
+}
 
 int pai_device_count(int* count) {
     return guarded([&] {
