@@ -174,6 +174,95 @@ def pmc_traffic(kernel_prefix: str, batch: int, key_bits: int = 2048):
     return None
 
 
+def reference_bench(key, okey, device) -> dict:
+    """The reference's own benchmark suite (bench/bench_ipcl_python.py:13-78) through the PUBLIC API, with
+    its exact inputs and its fixed 2048-bit key: BM_KeyGen 1024 / 2048 and BM_Encrypt / BM_Decrypt / BM_Add_CTCT /
+    BM_Add_CTPT / BM_Mul_CTPT at 16 and 64 elements, microseconds per call (the unit the reference prints).  Every call is
+    followed by a device synchronisation (the reference's calls are synchronous).  Beside each row: the same
+    composition (ipcl_python.py's encode / align / raw-encrypt / modexp / modmul sequence, oracle/c_oracle.CApi) on the
+    CPU port's AVX512-IFMA mb8 kernels with one thread and with all granted threads.  The deterministic rows are checked
+    bit for bit: the CPU leg is fed the GPU's input ciphertexts and must return the GPU's output ciphertexts."""
+    import torch
+
+    from oracle import c_oracle as co
+    from pailliercryptolib_python_amd import PaillierKeypair, PaillierPrivateKey, PaillierPublicKey, engine
+    from pailliercryptolib_python_amd.bindings import ipclPublicKey
+
+    pk = PaillierPublicKey(ipclPublicKey(key.n, key.bits, True, hs=key.hs, randbits=key.randbits, device=device))
+    sk = PaillierPrivateKey(pk, key.p, key.q)
+    threads = co.max_threads()
+    capis = {"cpu_1_thread_us": co.CApi(okey, threads=1), f"cpu_{threads}_threads_us": co.CApi(okey, threads=threads)}
+
+    def us(f, sync: bool, budget_s: float = 0.4, min_reps: int = 3, max_reps: int = 200):
+        f()                                                      # warm (first call: tables, scratch, thread pool)
+        if sync:
+            torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            f()
+            if sync:
+                torch.cuda.synchronize()
+            n += 1
+            el = time.perf_counter() - t0
+            if n >= max_reps or (n >= min_reps and el > budget_s):
+                return 1e6 * el / n
+
+    def host(enc):
+        return engine.to_host_words(enc.words), enc.exponent()
+
+    out = {"unit": "microseconds per call (mean)", "key": "reference bench P, Q (2048 bits), DJN",
+           "source": "bench/bench_ipcl_python.py:13-78", "cpu_kind": "port (IFMA mb8) driven through ipcl_python.py's composition"
+           if co.ifma_available() else "port (plain C / CPython pow) driven through ipcl_python.py's composition", "rows": {}}
+    for bits in (1024, 2048):
+        out["rows"][f"BM_KeyGen/{bits}"] = {
+            "gpu_api_us": us(lambda: PaillierKeypair.generate_keypair(bits), sync=False, budget_s=1.0),
+            "note": "pai_keygen: host-side sieve + Miller-Rabin on two threads, DJN base through pai_host_modexp; no CPU-port "
+                    "counterpart (the reference's generator is IPP-Crypto's, absent here)"}
+    for nb in (16, 64):
+        ar = np.arange(nb)
+        x_enc, x_dec = (ar + 11) * 1234.5678, (ar + 1) * 1234.5678
+        x, y = (ar + 11) * 5111.2834, (32768 - ar) * 1.3872
+        ct_dec, ct_x, ct_y = pk.encrypt(x_dec), pk.encrypt(x), pk.encrypt(y)
+        ct_xx = ct_x * x
+        cases = {
+            "BM_Encrypt": (lambda: pk.encrypt(x_enc), lambda c: c.encrypt(x_enc)),
+            "BM_Decrypt": (lambda: sk.decrypt(ct_dec), None),
+            "BM_Add_CTCT": (lambda: ct_x + ct_y, None),
+            "BM_Add_CTPT": (lambda: ct_xx + y, None),
+            "BM_Mul_CTPT": (lambda: ct_x * y, None),
+        }
+        h_dec, h_x, h_y, h_xx = host(ct_dec), host(ct_x), host(ct_y), host(ct_xx)
+        cpu_f = {
+            "BM_Encrypt": lambda c: c.encrypt(x_enc),
+            "BM_Decrypt": lambda c: c.decrypt(*h_dec),
+            "BM_Add_CTCT": lambda c: c.add_ctct(*h_x, *h_y),
+            "BM_Add_CTPT": lambda c: c.add_ctpt(*h_xx, y),
+            "BM_Mul_CTPT": lambda c: c.mul_ctpt(*h_x, y),
+        }
+        # parity of the deterministic rows (and of decryption): GPU public API == the composition on the CPU port
+        c0 = next(iter(capis.values()))
+        assert sk.decrypt(ct_dec) == c0.decrypt(*h_dec) == [float(v) for v in x_dec], "reference_bench: decrypt parity"
+        for name, got in (("BM_Add_CTCT", ct_x + ct_y), ("BM_Add_CTPT", ct_xx + y), ("BM_Mul_CTPT", ct_x * y)):
+            want_w, want_e = cpu_f[name](c0)
+            got_w, got_e = host(got)
+            if not (np.array_equal(got_w, want_w) and list(got_e) == list(want_e)):
+                raise SystemExit(f"bench.py: reference_bench parity failed for {name}/{nb}")
+        if not np.array_equal(host(ct_x * x)[0], h_xx[0]):
+            raise SystemExit("bench.py: reference_bench ct * x is not deterministic")
+        for name, (gpu_call, _) in cases.items():
+            row = {"gpu_api_us": us(gpu_call, sync=True)}
+            for label, c in capis.items():
+                row[label] = us(lambda: cpu_f[name](c), sync=False)
+            best_cpu = min(v for k_, v in row.items() if k_.startswith("cpu_"))
+            row["gpu_over_best_cpu"] = row["gpu_api_us"] / best_cpu
+            out["rows"][f"{name}/{nb}"] = row
+    out["parity_checked"] = "decrypt values; Add_CTCT / Add_CTPT / Mul_CTPT ciphertext bits and exponents (GPU API vs CPU port), 16 and 64"
+    out["note"] = ("gpu_api_us: PaillierPublicKey / PaillierPrivateKey / PaillierEncryptedNumber calls, host ndarray in, each followed "
+                   "by torch.cuda.synchronize(); additions return lazily tagged ciphertexts (the wire form costs one more product at "
+                   "export).  cpu_*: c_oracle.CApi, Python glue of the reference's shape included")
+    return out
+
+
 def _self_launch(args) -> None:
     """`python bench.py --gpus N` outside a torchrun environment: start the N ranks (one process per GPU) under
     torch.distributed.run on 127.0.0.1 and hand its exit code back.  Fails loudly when the box has fewer GPUs."""
@@ -211,6 +300,7 @@ def main() -> None:
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the second (weak resp. strong) arrangement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip api_level / other_ops / small_batch (profiling runs)")
+    ap.add_argument("--no-reference-bench", action="store_true", help="skip the reproduction of bench/bench_ipcl_python.py")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -489,11 +579,12 @@ def main() -> None:
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / reps
 
-        chk = [0, B // 3, B - 1]
+        chk = sorted({int(v) for v in np.linspace(0, B - 1, 64)})      # 64 elements spread over the batch
 
         def rows(t_):
             return engine.words_to_ints(engine.to_host_words(t_[chk]))
 
+        NLSQ = modmul_limbs(2 * KEY_BITS)                 # limbs of the lane-group geometry serving n^2
         ct_b = torch.roll(ct, 1, dims=0).contiguous()
         ct2 = pub.empty_ct(B)
         e53 = torch.randint(0, 1 << 30, (B, 2), dtype=torch.int32, device=device)     # 53-bit multipliers (float mantissas)
@@ -540,21 +631,21 @@ def main() -> None:
             "ct_add_ops_per_s": B / t_add, "ct_add_bcast_ops_per_s": B / t_add_b, "ct_mul_53bit_ops_per_s": B / t_mul,
             "ct_add_in_chain_ops_per_s": B / t_add_1, "ct_retag_ops_per_s": B / t_retag,
             "ct_add_in_chain_roofline": {"bound": "valu_int", "canonical_frac": CANON_MAC_ADD * B / t_add_1 / PEAK_MAC32_PER_S,
-                                         "executed_frac": 2 * 144 * 144 * B / t_add_1 / PEAK_MAC32_PER_S,
+                                         "executed_frac": 2 * NLSQ * NLSQ * B / t_add_1 / PEAK_MAC32_PER_S,
                                          "hbm_GBs": BYTES_ADD * B / t_add_1 / 1e9,
                                          "note": "one Montgomery product per addition; the wire form costs one more product "
                                                  "(ct_retag) once per chain, at the boundary"},
             "ct_invert_ops_per_s": B / t_inv, "ct_sum_elements_per_s": nsum / t_sum, "batch": B,
             "k_modmul_ms": k_add,
             "ct_add_roofline": {"bound": "valu_int", "canonical_frac": CANON_MAC_ADD * B / t_add / PEAK_MAC32_PER_S,
-                                "executed_frac": 2 * 2 * 144 * 144 * B / t_add / PEAK_MAC32_PER_S,
+                                "executed_frac": 2 * 2 * NLSQ * NLSQ * B / t_add / PEAK_MAC32_PER_S,
                                 "hbm_GBs": BYTES_ADD * B / t_add / 1e9, "hbm_frac": BYTES_ADD * B / t_add / 1e9 / HBM_PEAK_GBS},
             # k_ctmul_padic on 72-limb base-n digit pairs, 53-bit exponents, 3-bit windows: 52 squarings of 4 NL^2, ~18 window
             # products + 6 table products + 4 conversion products of 5 NL^2 (canonical: SURVEY 8d's 3.16 M MAC32)
             "ct_mul_roofline": {"bound": "valu_int", "canonical_frac": 3.16e6 * B / t_mul / PEAK_MAC32_PER_S,
-                                "executed_frac": (52 * 4 + 28 * 5) * 72 * 72 * B / t_mul / PEAK_MAC32_PER_S},
+                                "executed_frac": ((52 * 4 + 28 * 5) * 72 * 72 * B / t_mul / PEAK_MAC32_PER_S) if KEY_BITS == 2048 else None},
             "note": "BASELINE configs[2] operations on the same resident batch (wall clock around the C-ABI call); results "
-                    "checked against the oracle on 3 elements each",
+                    "checked against the oracle on 64 elements each",
         }
         del ct_b, ct2, e53
         # latency at the reference's own batch sizes (bench/bench_ipcl_python.py:24-25,34-35,45-46)
@@ -562,13 +653,20 @@ def main() -> None:
         for nb in (16, 64):
             ms_, rs_ = m[:nb].contiguous(), r[:nb].contiguous()
             cts_ = pub.encrypt(ms_, rs_)
-            es_ = torch.full((nb, 2), 3, dtype=torch.int32, device=device)
+            # dense random 53-bit exponents: the SAME values the CPU leg of cpu_baseline.small_batch uses (default_rng(5))
+            e53_s = [int(v) | 1 << 52 for v in np.random.default_rng(5).integers(0, 1 << 52, 64)][:nb]
+            es_ = torch.from_numpy(np.array([[e & 0xFFFFFFFF, e >> 32] for e in e53_s], dtype=np.int64).astype(np.uint32)
+                                   .view(np.int32)).to(device)
             small[str(nb)] = {
                 "encrypt_ms": 1e3 * wall(lambda: pub.encrypt(ms_, rs_), reps=5),
                 "decrypt_ms": 1e3 * wall(lambda: priv.decrypt(cts_), reps=5),
                 "ct_add_ms": 1e3 * wall(lambda: pub.ct_add(cts_, cts_), reps=5),
                 "ct_mul_53bit_ms": 1e3 * wall(lambda: pub.ct_mul(cts_, es_, 53), reps=5),
             }
+
+    ref_bench = None
+    if extras and KEY_BITS == 2048 and not args.no_reference_bench:
+        ref_bench = reference_bench(key, okey, device)
 
     if rank == 0:
         total_ops = total_per_step * args.steps
@@ -577,9 +675,12 @@ def main() -> None:
         t_enc = kern.get("k_encrypt(djn)", 0.0) * 1e-3
         canonical = (CANON_MAC_DEC * B / t_deca) if t_deca > 0 else None
         executed = (executed_macs_decrypt(key.p, key.q) * B / t_deca) if t_deca > 0 else None
-        traffic = pmc_traffic("k_dec_a_padic", B)
+        macs_exec = executed_macs_decrypt(key.p, key.q)
+        traffic = pmc_traffic("k_dec_a_padic", B, KEY_BITS)
+        metric = BASELINE_METRIC if args.config == "headline" and KEY_BITS == 2048 else \
+            f"Paillier encrypt+decrypt ops/sec, {KEY_BITS}-bit key, batch={args.batch}; {world} MI355X ({cfg['baseline']})"
         line = {
-            "metric": BASELINE_METRIC,
+            "metric": metric,
             "value": value,
             "unit": "ops/s",
             "n_gpus": world,
@@ -592,20 +693,28 @@ def main() -> None:
             "dtype": "u32 limbs (radix-2^29 in 32-bit registers, 64-bit accumulators)",
             "data": "synthetic",
             "config": {
-                "workload": f"2048-bit key (reference bench P,Q), DJN encrypt + CRT decrypt, "
+                "workload": f"{KEY_BITS}-bit key ({'reference bench P,Q' if KEY_BITS == 2048 else 'seeded fixture primes'}), DJN encrypt + CRT decrypt, "
                             + (f"batch={args.batch} in total, block-sharded over {world} GPU(s)" if args.scaling == "strong"
                                else f"batch={B} per GPU")
                             + ", inputs resident in HBM",
+                "baseline_config": args.config, "baseline_config_is": cfg["baseline"],
                 "key_bits": KEY_BITS, "batch_per_gpu": B if args.scaling == "weak" else None,
                 "batch_total": int(total_per_step), "scheme": "DJN", "parallelism": f"shard{world}",
             },
             "roofline": {
                 "bound": "valu_int",
-                "kernel": "k_dec_a_padic (CRT-decrypt stage A: (ct mod s^2)^(s-1) for both primes)",
+                "kernel": f"k_dec_a_padic<{padic_nl(max(key.p.bit_length(), key.q.bit_length()))}> (CRT-decrypt stage A: (ct mod s^2)^(s-1) for both primes)",
                 "achieved": (executed / 1e12) if executed else None,
                 "peak": PEAK_MAC32_PER_S / 1e12,
+                "peak_sustained": PEAK_SUSTAINED_MAC32_PER_S / 1e12,
+                "frac_of_sustained": (executed / PEAK_SUSTAINED_MAC32_PER_S) if executed else None,
+                "peak_note": "peak = 18 ms burst, constant operands (profiles/r01/ubench_valu_mi355x.jsonl); peak_sustained = 3 s of "
+                             "back-to-back launches on data-dependent operands at the clock power management settles at (2.29 GHz, "
+                             "1290 W of 1400 W): profiles/r04/ubench_valu_sustained.jsonl + _power.txt.  One wave per SIMD (this "
+                             "kernel's occupancy: LDS-bound) issues the same instruction stream at 26.7 T MAC/s",
                 "unit": "T MAC/s (29x29-bit multiply-accumulates actually executed, v_mad_u64_u32)",
                 "frac": (executed / PEAK_MAC32_PER_S) if executed else None,
+                "executed_macs_per_element": macs_exec, "canonical_mac32_per_element": CANON_MAC_DEC,
                 "canonical_T_MAC32_s": (canonical / 1e12) if canonical else None,
                 "canonical_frac": (canonical / PEAK_MAC32_PER_S) if canonical else None,
                 "note": "frac = executed MACs / measured v_mad_u64_u32 peak (kernel quality).  canonical_* price the kernel at "
@@ -614,7 +723,7 @@ def main() -> None:
                 "kernel_ms": kern,
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic,
-                "traffic_unit": "HBM bytes per k_dec_a_padic launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, scaled from batch 2^20)",
+                "traffic_unit": "HBM bytes per k_dec_a_padic launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, scaled from the profile's batch)",
                 "hbm": {
                     "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                     "achieved_decrypt": (BYTES_DEC * B / t_deca / 1e9) if t_deca > 0 else None,
@@ -631,6 +740,7 @@ def main() -> None:
             "api_level": api,
             "other_ops": other,
             "small_batch": small,
+            "reference_bench": ref_bench,
             "parity_checked": True,
         }
         print(json.dumps(line), flush=True)

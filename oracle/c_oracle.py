@@ -10,6 +10,7 @@ import ctypes as C
 import os
 import subprocess
 from pathlib import Path
+from typing import Optional
 
 import numpy as np
 
@@ -262,3 +263,90 @@ class COracleKey:
                                               _p(ct), _p(m), C.byref(self._im_p), C.byref(self._im_q), threads)
         assert rc == 0
         return m.view(np.uint32)
+
+
+class CApi:
+    """The reference's API-level compositions (src/ipcl_python/ipcl_python.py) driven on the C port's batch primitives:
+    what the reference's Python layer does around its native calls, with this file's kernels in the place of
+    ipcl / IPP-Crypto.  Used by bench.py's `reference_bench` CPU leg (bench/bench_ipcl_python.py:22-78) and checked
+    against the Python-int oracle in tests/test_oracle.py.  Ciphertexts are [N][2 k/32] uint32 rows, exponents lists."""
+
+    def __init__(self, key: orc.OracleKey, threads: int = 0):
+        self.key, self.ck, self.threads = key, COracleKey(key), threads
+        self.ifma = ifma_available()
+        self.n_words = (key.bits + 31) // 32
+
+    def _encode(self, values):
+        """fixedpoint.py:54-96 per element (the reference's own per-element Python loop, ipcl_python.py:135-141)."""
+        encs, expos = [], []
+        for v in values:
+            e, x = orc.fp_encode(v, self.key.n, self.key.max_int)
+            encs.append(e), expos.append(x)
+        return encs, expos
+
+    def _pow(self, ct32: np.ndarray, es) -> np.ndarray:
+        if self.ifma:
+            return ifma_modexp(self.key.nsq, ct32, [int(e) for e in es], threads=self.threads).view(np.uint32)
+        nsq = self.key.nsq
+        return orc.ints_to_limbs([pow(c, int(e), nsq) for c, e in zip(orc.limbs_to_ints(ct32), es)], 2 * self.n_words)
+
+    def encrypt(self, values, r32: Optional[np.ndarray] = None):
+        """ipcl_python.py:108-147 (DJN)."""
+        encs, expos = self._encode(values)
+        m32 = orc.ints_to_limbs(encs, self.n_words)
+        if r32 is None:
+            rw = (self.key.randbits + 31) // 32
+            r32 = np.frombuffer(os.urandom(4 * rw * len(encs)), dtype=np.uint32).reshape(len(encs), rw).copy()
+            if self.key.randbits % 32:
+                r32[:, -1] &= (1 << (self.key.randbits % 32)) - 1
+        enc = self.ck.ifma_encrypt_djn if self.ifma else self.ck.encrypt_djn
+        return np.ascontiguousarray(enc(m32, r32, threads=self.threads)), expos
+
+    def raw_encrypt(self, values):
+        """ipcl_python.py:103-106: 1 + m n (no obfuscator)."""
+        encs, expos = self._encode(values)
+        n = self.key.n
+        return orc.ints_to_limbs([1 + m * n for m in encs], 2 * self.n_words), expos
+
+    def decrypt(self, ct32: np.ndarray, expos):
+        """ipcl_python.py:219-245."""
+        dec = self.ck.ifma_decrypt_crt if self.ifma else self.ck.decrypt_crt
+        ms = orc.limbs_to_ints(dec(ct32, threads=self.threads))
+        return [orc.fp_decode(m, e, self.key.n, self.key.max_int) for m, e in zip(ms, expos)]
+
+    def _align(self, a32, ea, b32, eb):
+        """ipcl_python.py:570-741: the lower-exponent side is raised by ct^(2^delta)."""
+        if b32.shape[0] == 1 and a32.shape[0] > 1:
+            b32, eb = np.repeat(b32, a32.shape[0], axis=0), list(eb) * a32.shape[0]
+        ea_, eb_ = np.asarray(ea), np.asarray(eb)
+        a32, b32 = a32.copy(), b32.copy()
+        lo_b, lo_a = np.nonzero(ea_ > eb_)[0], np.nonzero(ea_ < eb_)[0]
+        if len(lo_b):
+            b32[lo_b] = self._pow(b32[lo_b], [1 << int(d) for d in (ea_ - eb_)[lo_b]])
+        if len(lo_a):
+            a32[lo_a] = self._pow(a32[lo_a], [1 << int(d) for d in (eb_ - ea_)[lo_a]])
+        return a32, b32, [int(v) for v in np.maximum(ea_, eb_)]
+
+    def add_ctct(self, a32, ea, b32, eb):
+        """__raw_add on two ciphertext operands (ipcl_python.py:490-526)."""
+        a, b, e = self._align(a32, ea, b32, eb)
+        return modmul(self.key.nsq, a, b, threads=self.threads).view(np.uint32), e
+
+    def add_ctpt(self, a32, ea, values):
+        """ct + plaintext array: raw-encrypt, then add (ipcl_python.py:495-504)."""
+        b32, eb = self.raw_encrypt(values)
+        return self.add_ctct(a32, ea, b32, eb)
+
+    def mul_ctpt(self, a32, ea, values):
+        """ipcl_python.py:412-488: ct^mantissa, negative multipliers through the inverted ciphertext."""
+        encs, expos = self._encode(values)
+        n, nsq = self.key.n, self.key.nsq
+        cond = n - self.key.max_int
+        es, base = [], a32.copy()
+        for i, pt in enumerate(encs):
+            if pt >= cond:
+                base[i] = orc.ints_to_limbs([pow(orc.limbs_to_ints(a32[i:i + 1])[0], -1, nsq)], 2 * self.n_words)[0]
+                es.append(n - pt)
+            else:
+                es.append(pt)
+        return self._pow(base, es), [a + b for a, b in zip(ea, expos)]

@@ -139,11 +139,13 @@ def test_config3_4_every_rank_shard_at_full_size(bits, total_n):
         idx = np.linspace(0, N - 1, 24).astype(np.int64)
         got = engine.to_host_words(ct[torch.from_numpy(idx).to(pub.device)])
         assert np.array_equal(got, c_enc(res[idx], r_l[idx])), rank
-        if rank in (0, world - 1):
-            i = int(idx[-1])
-            c = engine.words_to_ints(got[-1:])[0]
-            assert c == orc.encrypt(key, engine.words_to_ints(res[i:i + 1])[0], orc.limbs_to_ints(r_l[i:i + 1])[0])
-            assert orc.decrypt_crt(key, c) == engine.words_to_ints(res[i:i + 1])[0]
+        # the Python-int oracle itself (not the IFMA port) on 8 elements of EVERY shard, CRT decryption on two of them
+        for k, j in enumerate(np.linspace(0, len(idx) - 1, 8).astype(np.int64)):
+            i = int(idx[j])
+            c = engine.words_to_ints(got[j:j + 1])[0]
+            assert c == orc.encrypt(key, engine.words_to_ints(res[i:i + 1])[0], orc.limbs_to_ints(r_l[i:i + 1])[0]), (rank, i)
+            if k in (0, 7):
+                assert orc.decrypt_crt(key, c) == engine.words_to_ints(res[i:i + 1])[0]
         total_residues += colsum(res)
         shard_products.append(engine.words_to_ints(engine.to_host_words(pub.ct_prod(ct, 1)))[0])
         if rank == 0:
@@ -159,3 +161,48 @@ def test_config3_4_every_rank_shard_at_full_size(bits, total_n):
     for c in shard_products:
         prod = prod * c % key.nsq
     assert orc.decrypt_crt(key, prod) == total_residues % key.n
+
+
+def test_config2_api_level_full_size_negative_multipliers_and_alignment():
+    """BASELINE configs[2] at its full size THROUGH THE PUBLIC API with SURVEY §8d's inputs: 2^20 floats, multipliers
+    default_rng(2003).uniform(-10, 10) (about half negative: the ciphertext-inversion path of ipcl_python.py:426-437),
+    a plaintext addend and a ciphertext addend from default_rng(3003) (exponents differ per element: the alignment of
+    ipcl_python.py:570-741), the reference's own composition (E(x) * y + z) (tests/ipcl_python_test.py:40-54).
+    Oracle bits on 256 elements spread over the batch, every element decrypted to the reference's 7 decimal places."""
+    from pailliercryptolib_python_amd import PaillierPrivateKey, PaillierPublicKey
+    from pailliercryptolib_python_amd.bindings import ipclPublicKey
+
+    key = key2048()
+    pk = PaillierPublicKey(ipclPublicKey(key.n, 2048, True, hs=key.hs, randbits=key.randbits, device=DEV))
+    sk = PaillierPrivateKey(pk, key.p, key.q)
+    N = 1 << 20
+    x = np.random.default_rng(1002).uniform(-1000, 1000, N)
+    y = np.random.default_rng(2003).uniform(-10, 10, N)
+    z = np.random.default_rng(3003).uniform(-1000, 1000, N)
+    assert 0.45 < (y < 0).mean() < 0.55
+    rx, rz = orc.synth_r_limbs(4002, N, key.randbits), orc.synth_r_limbs(4003, N, key.randbits)
+    ex = pk.encrypt(x, r=rx)
+    ez = pk.encrypt(z, r=rz)
+    prod = ex * y                                   # negative multipliers: batch inversion + ct^(n - pt)
+    res = prod + z                                  # plaintext addend: raw-encrypt + alignment + product
+    both = prod + ez                                # ciphertext addend: alignment + product
+    diff = ex - ez                                  # a - b = a + b * (-1.0): every element through the inversion
+    idx = np.unique(np.concatenate([np.linspace(0, N - 1, 250).astype(np.int64), np.nonzero(y < 0)[0][:3], np.nonzero(y > 0)[0][:3]]))
+    assert len(idx) >= 250
+
+    def sample(enc):
+        t = torch.from_numpy(idx).to(enc.words.device)
+        return engine.words_to_ints(engine.to_host_words(enc.words[t])), [enc.exponent(int(i)) for i in idx]
+
+    ox = orc.api_encrypt(key, [float(v) for v in x[idx]], orc.limbs_to_ints(rx[idx]))
+    oz = orc.api_encrypt(key, [float(v) for v in z[idx]], orc.limbs_to_ints(rz[idx]))
+    assert sample(ex) == (ox[0], ox[1])
+    op = orc.api_mul_plain(key, *ox, [float(v) for v in y[idx]])
+    assert sample(prod) == (op[0], op[1])
+    assert sample(res) == tuple(orc.api_add_plain(key, *op, [float(v) for v in z[idx]]))
+    assert sample(both) == tuple(orc.api_add_ct(key, *op, *oz))
+    assert sample(diff) == tuple(orc.api_sub_ct(key, *ox, *oz))
+    # every element, to the reference's assertAlmostEqual precision (7 decimal places)
+    for enc, want in ((res, x * y + z), (both, x * y + z), (diff, x - z), (prod, x * y)):
+        got = sk.decrypt_to_numpy(enc)
+        assert got.shape == (N,) and float(np.abs(got - want).max()) < 5e-8

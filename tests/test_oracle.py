@@ -209,3 +209,37 @@ def test_ifma_mb8_kernels_match_cpython_pow():
         assert orc.limbs_to_ints(ct) == [orc.encrypt(key, a, b) for a, b in zip(m, orc.limbs_to_ints(r32))]
         assert np.array_equal(ct, ck.encrypt_djn(m32, r32))
         assert np.array_equal(ck.ifma_decrypt_crt(ct), m32)
+
+
+def test_capi_compositions_on_the_c_port_match_the_python_oracle():
+    """oracle/c_oracle.CApi (bench.py's reference_bench CPU leg: ipcl_python.py's compositions on the C port's batch
+    primitives) against the Python-int restatement, with the reference benchmark's own inputs
+    (bench/bench_ipcl_python.py:26,36,46-47,58-59,70-71) plus negative multipliers and a broadcast addend."""
+    key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567, bits=2048)
+    api = co.CApi(key)
+    nb = 16
+    x = (np.arange(nb) + 11) * 5111.2834
+    y = (32768 - np.arange(nb)) * 1.3872
+    r_l = orc.synth_r_limbs(77, nb, key.randbits)
+    rs = orc.limbs_to_ints(r_l)
+    ct, ex = api.encrypt(x, r_l)
+    want_ct, want_ex = orc.api_encrypt(key, list(x), rs)
+    assert orc.limbs_to_ints(ct) == want_ct and ex == want_ex
+    assert api.decrypt(ct, ex) == orc.api_decrypt(key, want_ct, want_ex) == [float(v) for v in x]
+    cy, ey = api.encrypt(y, r_l)
+    wy, wey = orc.api_encrypt(key, list(y), rs)
+    s, es = api.add_ctct(ct, ex, cy, ey)
+    ws, wes = orc.api_add_ct(key, want_ct, want_ex, wy, wey)
+    assert orc.limbs_to_ints(s) == ws and es == wes
+    s1, es1 = api.add_ctct(ct, ex, cy[:1], ey[:1])                     # size-1 broadcast
+    ws1, wes1 = orc.api_add_ct(key, want_ct, want_ex, wy[:1], wey[:1])
+    assert orc.limbs_to_ints(s1) == ws1 and es1 == wes1
+    for mult in (y, -y, x * 1e-3):
+        m_, em = api.mul_ctpt(ct, ex, mult)
+        wm, wem = orc.api_mul_plain(key, want_ct, want_ex, list(mult))
+        assert orc.limbs_to_ints(m_) == wm and em == wem
+    m_, em = api.mul_ctpt(ct, ex, x)
+    a_, ea = api.add_ctpt(m_, em, y)                                   # BM_Add_CTPT: (ct * x) + y
+    wm, wem = orc.api_mul_plain(key, want_ct, want_ex, list(x))
+    wa, wea = orc.api_add_plain(key, wm, wem, list(y))
+    assert orc.limbs_to_ints(a_) == wa and ea == wea

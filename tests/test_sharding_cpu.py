@@ -40,6 +40,43 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
+def _worker_plan(rank, world, port, n_total, q):
+    """One rank of the bench's strong-scaling arrangement on CPU tensors: the library's partition (pai_shard_plan), this
+    rank's block, the final gather, and the round trip back to the blocks."""
+    from pailliercryptolib_python_amd import engine
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = (torch.arange(n_total * 6, dtype=torch.int64).reshape(n_total, 6) * 2654435761 % (1 << 31)).to(torch.int32)
+    plan = engine.shard_plan(n_total, world)
+    begin, count = plan[rank]
+    out = sharding.gather_rows(full[begin:begin + count].contiguous(), n_total)
+    ok = bool(torch.equal(out, full)) and sum(c for _, c in plan) == n_total
+    ok = ok and all(torch.equal(out[b:b + c], full[b:b + c]) for b, c in plan)      # every rank's block is where the plan says
+    q.put((rank, ok, count))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [1003, 5, 64])
+def test_shard_plan_and_gather_round_trip_world8_gloo(n_total):
+    """World size 8 (BASELINE configs[3]/[4]) with a ragged tail (1003 = 7 x 126 + 121), with trailing ranks that own
+    nothing (5 elements on 8 ranks) and with an exact split."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() + n_total) % 1000
+    procs = [ctx.Process(target=_worker_plan, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[0] for r in res] == list(range(world)) and all(r[1] for r in res)
+    per = -(-n_total // world)
+    assert [r[2] for r in res] == [max(0, min(per, n_total - g * per)) for g in range(world)]
+
+
 @pytest.mark.parametrize("n_total", [10, 11, 1])
 def test_gather_rows_world2_gloo(n_total):
     ctx = mp.get_context("spawn")
