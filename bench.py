@@ -54,6 +54,9 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# the CPU-baseline library is OpenMP: idle workers must sleep, not spin (a spinning pool eats the cgroup CPU quota of
+# the single-thread small-batch timings that follow a parallel region); read by libgomp when it is first loaded
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 DJN_X = 0x1234567
 # v_mad_u64_u32 rate of the chip, 8 waves/SIMD: PEAK = an 18 ms burst on constant operands (profiles/r01/ubench_valu_mi355x.jsonl);
@@ -516,12 +519,14 @@ def main() -> None:
         # the reference's own benchmark sizes (bench/bench_ipcl_python.py:24-25,34-35,45-46,56-57,67-68: 16 and 64 elements),
         # same port, one thread and all threads, beside the GPU latencies of small_batch
         if co.ifma_available():
-            def cpu_wall(f, reps=3):
+            def cpu_wall(f, reps=5):
                 f()
-                t1_ = time.perf_counter()
+                ts_ = []
                 for _ in range(reps):
+                    t1_ = time.perf_counter()
                     f()
-                return 1e3 * (time.perf_counter() - t1_) / reps
+                    ts_.append(time.perf_counter() - t1_)
+                return 1e3 * sorted(ts_)[len(ts_) // 2]            # median of 5 (one descheduled run does not move it)
 
             e53_h = [int(v) | 1 << 52 for v in np.random.default_rng(5).integers(0, 1 << 52, 64)]
             cpu_small = {"kind": kind, "unit": "ms per batch", "threads_all": threads}

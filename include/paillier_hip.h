@@ -17,8 +17,9 @@
  *    ordered by the stream, operations issued on DIFFERENT streams are chained with an event (the later call makes
  *    its stream wait for the earlier one), so any mix of threads and streams on one handle is safe, and handles
  *    of the same key material on different devices are independent.  Only pai_ct_invert (it reports
- *    non-invertible inputs) and pai_modexp_fixed (it stages a host exponent) return after their stream work has
- *    completed; everything else, pai_decrypt included, is asynchronous;
+ *    non-invertible inputs; pai_ct_invert_async + pai_pubkey_status is the asynchronous form), pai_pubkey_status,
+ *    pai_pubkey_trim and pai_ct_pow2 without a hint return after their stream work has completed; everything else,
+ *    pai_decrypt and pai_modexp_fixed (its host exponent is copied to pinned staging) included, is asynchronous;
  *  - a call never changes the calling thread's current HIP device (it is restored on return);
  *  - there is NO CPU fallback: without a usable gfx950 device key creation fails with
  *    PAI_E_NODEVICE.
@@ -142,6 +143,9 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
  * d_out[i] = d_ct[i]^-1 mod n^2 (batched: simultaneous inversion as a product tree + one extended GCD per top-level
  * product).  Synchronous; fails with PAI_E_INVALID if some ciphertext shares a factor with n.  d_out may alias d_ct. */
 int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream);
+/* The same work without the synchronisation: returns as soon as the kernels are queued on `stream`; a non-invertible input
+ * sets bit 0 of the handle's sticky status word (pai_pubkey_status below) instead of failing the call. */
+int pai_ct_invert_async(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream);
 
 /* __raw_add with its exponent alignment fused (ipcl_python.py:490-526 + :570-741): delta_i = exponent(a_i) - exponent(b_i)
  * (base-2 fixed-point exponents, int32 on the device); the operand with the LOWER exponent is raised first:
@@ -198,6 +202,13 @@ int pai_ct_pow2(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, in
  * read-back, the call is asynchronous for every batch size.  max_delta must be >= every delta_i (0: nothing to do). */
 int pai_ct_pow2_hint(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N, int max_delta,
                      void* stream);
+/* Sticky status word of a handle's ASYNCHRONOUS calls, read with a synchronisation of `stream` (and cleared when
+ * clear != 0): bit 0 — pai_ct_invert_async met a ciphertext that is not invertible modulo n^2 (its output rows are then
+ * undefined); bit 1 — a pai_ct_pow2_hint call was given a max_delta below a shift of its batch on the digit-engine path
+ * (batches >= PAI_POW2_DIGIT_MIN on keys up to 2048 bits; the raised ciphertexts of that call are then wrong).  The Python
+ * layer checks it before anything leaves the device (decryption, getTexts, pickling). */
+int pai_pubkey_status(const pai_pubkey* pk, int* status_out, int clear, void* stream);
+
 
 /* ---- data formats either side of the path --------------------------------------------------------------
  * Fixed-point codec of bindings/fixedpoint.py:54-115 for float64 arrays (the hot Python loops of
@@ -209,6 +220,14 @@ int pai_ct_pow2_hint(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delt
 int pai_fp_encode_f64(const pai_pubkey* pk, const double* d_x, size_t N, uint32_t* d_m, int32_t* d_expo, void* stream);
 /* the same for int64 arrays: exponent 0, residue = x mod n (fixedpoint.py:72-74,89-96) */
 int pai_fp_encode_i64(const pai_pubkey* pk, const int64_t* d_x, size_t N, uint32_t* d_m, int32_t* d_expo, void* stream);
+/* Encoders with a target exponent per element (d_target[N], or one value when target_bcast), for the plaintext operand
+ * of ct + plaintext (ipcl_python.py:495-504 raw-encrypts it, :570-741 then raise the lower-exponent side by
+ * ct^(2^delta)): for a RAW encryption (1 + m n)^(2^d) = 1 + (m 2^d mod n) n, so an element whose own exponent e is below
+ * its target t is encoded at t directly (mantissa shifted left by t - e; same ciphertext bits, same exponent, no
+ * squarings) whenever |mantissa| 2^(t-e) < 2^(bits(n) - 2); other elements keep e (d_expo tells).  is_f64: d_x is
+ * double[N], else int64[N]. */
+int pai_fp_encode_at(const pai_pubkey* pk, const void* d_x, int is_f64, size_t N, const int32_t* d_target, int target_bcast,
+                     uint32_t* d_m, int32_t* d_expo, void* stream);
 int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64_t* d_mant, int32_t* d_flag, void* stream);
 
 /* Obfuscator randomness, replacing upstream ipcl's per-element getRandomBN inside

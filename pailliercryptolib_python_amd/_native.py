@@ -60,6 +60,8 @@ PROTOTYPES = {
     "pai_ct_add": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp, voidp]),
     "pai_ct_mul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_int, C.c_int, C.c_size_t, voidp, voidp]),
     "pai_ct_invert": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
+    "pai_ct_invert_async": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
+    "pai_pubkey_status": (C.c_int, [voidp, C.POINTER(C.c_int), C.c_int, voidp]),
     "pai_ct_add_aligned": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_add_aligned_dom": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_ct_mont_mul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp, voidp]),
@@ -75,6 +77,7 @@ PROTOTYPES = {
     "pai_ct_pow2_hint": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, C.c_int, voidp]),
     "pai_fp_encode_f64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_fp_encode_i64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
+    "pai_fp_encode_at": (C.c_int, [voidp, voidp, C.c_int, C.c_size_t, voidp, C.c_int, voidp, voidp, voidp]),
     "pai_fp_decode_i64": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_draw_r": (C.c_int, [voidp, voidp, voidp, C.c_uint32, C.c_size_t, voidp, voidp]),
     "pai_modulus_create": (C.c_int, [voidp, C.c_int, C.c_int, C.POINTER(voidp)]),

@@ -594,6 +594,7 @@ class ipclCipherText(_Container):
         # Montgomery product (tags ka, kb -> ka + kb - 1); whoever needs the wire form (getTexts, pickling, decryption,
         # ct * pt, every `_t` / `words` access) gets it through one more product, done once and cached in place.
         self._dom = 0
+        self._lock = threading.Lock()                 # (_dev, _dom) change together: upload, device move, retag
         W = 2 * ((pubkey._bits + 31) // 32)
         if isinstance(data, torch.Tensor):
             if data.shape[1] != W:
@@ -619,25 +620,32 @@ class ipclCipherText(_Container):
     def _raw(self):
         """(limb matrix on the home device, domain tag): rows hold x R^tag mod n^2.  Host-built containers (pickles, lists
         of BigNumbers) are uploaded — and the key's device handle created — only when an operation first needs them."""
-        if self._dev is None:
-            self._dev = engine.to_device_words(self._host, self._pk.handle.device)
-            self._host = None
-        elif self._dev.device != self._pk.handle.device:
-            self._dev = self._dev.to(self._pk.handle.device)
-        return self._dev, self._dom
+        with self._lock:
+            if self._dev is None:
+                self._dev = engine.to_device_words(self._host, self._pk.handle.device)
+                self._host = None
+            elif self._dev.device != self._pk.handle.device:
+                self._dev = self._dev.to(self._pk.handle.device)
+            return self._dev, self._dom
 
     @property
     def _t(self) -> torch.Tensor:
-        """The limb matrix on the home device in the wire form (canonical residues of the ciphertexts themselves)."""
-        t, k = self._raw()
-        if k != 0:
-            self._dev, self._dom = self._pk.handle.ct_retag(t, k, 0), 0
-        return self._dev
+        """The limb matrix on the home device in the wire form (canonical residues of the ciphertexts themselves).  The
+        retag (one product, cached in place) happens under the container's lock: a second thread can never pair the
+        retagged rows with the old tag."""
+        self._raw()
+        with self._lock:
+            if self._dom != 0:
+                self._dev = self._pk.handle.ct_retag(self._dev, self._dom, 0)
+                self._dom = 0
+            return self._dev
 
     def getSize(self) -> int:
         return int(self._host.shape[0]) if self._dev is None else int(self._dev.shape[0])
 
     def getTexts(self) -> List[ipclBigNumber]:
+        if self._dev is not None:
+            self._pk.handle.check_status()               # nothing computed by a failed asynchronous call leaves the device
         words = self._host if self._dev is None else engine.to_host_words(self._t)
         return [ipclBigNumber(v) for v in engine.words_to_ints(words)]
 

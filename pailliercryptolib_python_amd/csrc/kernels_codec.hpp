@@ -79,6 +79,62 @@ k_fp_encode_i64(const int64_t* __restrict__ x, const uint32_t* __restrict__ n_wo
     }
 }
 
+// The two encoders with a per-element TARGET exponent (ct + plaintext, ipcl_python.py:495-504 + 570-741): the reference
+// raw-encrypts the plaintext at its own exponent e and then raises that ciphertext to 2^(t - e) when the other operand's
+// exponent t is larger.  For a raw encryption this is arithmetic on the plaintext: (1 + m n)^(2^d) = 1 + (m 2^d mod n) n
+// (mod n^2), so encoding the plaintext at exponent t directly — mantissa shifted left by d — yields the SAME ciphertext
+// bits and exponent with no squaring at all.  Done here when the shifted magnitude stays below n (|mant| 2^d < 2^(nbits-2));
+// otherwise the element keeps its own exponent and the ciphertext path raises it as before.  A zero mantissa takes any
+// larger target (1^anything = 1).  IS_F64: x holds doubles, else int64.
+template <bool IS_F64>
+__global__ void __launch_bounds__(256)
+k_fp_encode_at(const void* __restrict__ x_, const uint32_t* __restrict__ n_words_ptr, int nw, int nbits,
+               const int32_t* __restrict__ target, int t_bcast, uint32_t* __restrict__ out, int32_t* __restrict__ expo, size_t N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint64_t mant;
+    bool neg;
+    int e0, mbits;
+    if constexpr (IS_F64) {
+        const double v = reinterpret_cast<const double*>(x_)[i];
+        const uint64_t bits = (uint64_t)__double_as_longlong(v);
+        const bool tiny = fabs(v) < 1e-200;
+        mant = tiny ? 0ull : ((bits & 0xFFFFFFFFFFFFFull) | (1ull << 52));
+        neg = !tiny && (bits >> 63);
+        e0 = tiny ? 0 : (1075 - (int)((bits >> 52) & 0x7FF));
+        mbits = 53;
+    } else {
+        int64_t v = reinterpret_cast<const int64_t*>(x_)[i];
+        if (v == INT64_MIN) v = 0;                          // see k_fp_encode_i64
+        neg = v < 0;
+        mant = neg ? (0ull - (uint64_t)v) : (uint64_t)v;
+        e0 = 0;
+        mbits = 64;
+    }
+    int shift = 0;
+    const int t = target[t_bcast ? 0 : i];
+    if (t > e0) {
+        if (mant == 0) e0 = t;
+        else if (mbits + (t - e0) <= nbits - 2) { shift = t - e0; e0 = t; }
+    }
+    expo[i] = e0;
+    const int ws = shift >> 5, bs = shift & 31;
+    const uint64_t lo = mant << bs;
+    const uint32_t hi = bs ? (uint32_t)(mant >> (64 - bs)) : 0u;
+    uint32_t* row = out + i * (size_t)nw;
+    uint32_t borrow = 0;
+    for (int k = 0; k < nw; ++k) {
+        const uint32_t vk = k == ws ? (uint32_t)lo : (k == ws + 1 ? (uint32_t)(lo >> 32) : (k == ws + 2 ? hi : 0u));
+        if (!neg) {
+            row[k] = vk;
+        } else {
+            const uint64_t d = (uint64_t)n_words_ptr[k] - vk - borrow;
+            row[k] = (uint32_t)d;
+            borrow = (uint32_t)(d >> 63);
+        }
+    }
+}
+
 // flag 0: mantissa in (-2^63, 2^63) returned; flag 1: anything else (|mantissa| >= 2^63, overflow zone, corrupt
 // residue >= n) — the host then runs the exact big-integer path, which also raises the reference's exceptions.
 __global__ void __launch_bounds__(256)
@@ -149,7 +205,8 @@ k_draw_r(ChaChaKey K, uint32_t* __restrict__ out, size_t total_words, int r_word
 // ---- exponent alignment through the digit engine: delta_i -> the exponent 2^max(delta_i, 0) as two words -----------
 // (pai_ct_pow2 for large shifts: ct^(2^delta) is ct * pt with a one-bit exponent).  *dmax receives max(delta_i).
 __global__ void __launch_bounds__(256)
-k_pow2_expo(const int32_t* __restrict__ delta, int bcast, size_t n, uint32_t* __restrict__ e_out, int* __restrict__ dmax) {
+k_pow2_expo(const int32_t* __restrict__ delta, int bcast, size_t n, uint32_t* __restrict__ e_out, int* __restrict__ dmax,
+            int hint, int* __restrict__ status) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int d = 0;
     if (i < n) {
@@ -165,7 +222,12 @@ k_pow2_expo(const int32_t* __restrict__ delta, int bcast, size_t n, uint32_t* __
         const int o = __shfl_xor(d, off, 64);
         d = o > d ? o : d;
     }
-    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(dmax, d);
+    if ((threadIdx.x & 63) == 0 && d > 0) {
+        atomicMax(dmax, d);
+        // a caller's hint (pai_ct_pow2_hint) below a shift of the batch would truncate 2^delta on this path: remember it
+        // in the handle's sticky status word (bit 1, pai_pubkey_status) instead of returning wrong ciphertexts silently
+        if (hint >= 0 && d > hint) atomicOr(status, 2);
+    }
 }
 
 }  // namespace pai

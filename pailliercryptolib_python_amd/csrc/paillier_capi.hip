@@ -55,6 +55,10 @@ int guarded(F&& f) {
     }
 }
 
+__global__ void k_status_or(int* status, const int* flag, int bit) {
+    if (*flag) atomicOr(status, bit);
+}
+
 void require(bool ok, const char* msg) {
     if (!ok) throw PaiError(PAI_E_INVALID, msg);
 }
@@ -165,6 +169,14 @@ struct DevBuf {
         bytes = 0;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// a DevBuf that frees itself when its scope ends, exceptions included (temporaries of the table builders)
+struct ScopedDevBuf : DevBuf {
+    ScopedDevBuf() = default;
+    ScopedDevBuf(const ScopedDevBuf&) = delete;
+    ScopedDevBuf& operator=(const ScopedDevBuf&) = delete;
+    ~ScopedDevBuf() { release(); }
 };
 
 // NLMAX-padded radix-29 constant on the device
@@ -341,11 +353,45 @@ const GeoOps* geo_latency_for_bits(int bits) {
 }  // namespace pai
 
 // ------------------------------------------------------------------------------------------------
+// Pinned host staging for small host operands of asynchronous calls (pai_modexp_fixed's exponent): a ring of slots, each
+// reusable once the copy that read it has executed (event); the caller's pageable buffer is free on return.
+struct PinnedRing {
+    static constexpr int SLOTS = 4;
+    void* p[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    size_t bytes[SLOTS] = {0, 0, 0, 0};
+    hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int next = 0;
+    // copies `n` bytes of h_src to d_dst on stream s through the next slot
+    void h2d(void* d_dst, const void* h_src, size_t n, hipStream_t s) {
+        const int k = next;
+        next = (next + 1) % SLOTS;
+        if (!ev[k]) HIP_CHECK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        else HIP_CHECK(hipEventSynchronize(ev[k]));                 // the slot's previous copy has run (normally long ago)
+        if (bytes[k] < n) {
+            if (p[k]) (void)hipHostFree(p[k]);
+            p[k] = nullptr;
+            bytes[k] = 0;
+            HIP_CHECK(hipHostMalloc(&p[k], n, hipHostMallocDefault));
+            bytes[k] = n;
+        }
+        std::memcpy(p[k], h_src, n);
+        HIP_CHECK(hipMemcpyAsync(d_dst, p[k], n, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(ev[k], s));
+    }
+    void release() {
+        for (int k = 0; k < SLOTS; ++k) {
+            if (ev[k]) { (void)hipEventSynchronize(ev[k]); (void)hipEventDestroy(ev[k]); ev[k] = nullptr; }
+            if (p[k]) { (void)hipHostFree(p[k]); p[k] = nullptr; bytes[k] = 0; }
+        }
+    }
+};
+
 struct pai_modulus {
     int device = 0;
     DeviceInfo dev;
     ModSetup ms;
     DevBuf table, expo;
+    PinnedRing pinned;
     ScratchOrder order;
     std::mutex mu;
 };
@@ -391,6 +437,9 @@ struct pai_pubkey {
     uint32_t* d_nsq_words = nullptr;   // n^2 as packed words (extended-GCD modulus)
     mutable DevBuf table, tmp;    // standard-scheme scratch
     mutable DevBuf inv_prod, inv_inv, inv_fail;
+    // sticky device status word of the asynchronous calls (pai_pubkey_status): bit 0 = pai_ct_invert_async met a
+    // ciphertext that is not a unit, bit 1 = a pai_ct_pow2_hint hint was smaller than a shift of its batch
+    mutable DevBuf status;
     mutable DevBuf prod_a, prod_b;     // ping-pong levels of pai_ct_prod
     // Product trees run on single Montgomery products (k_modmul MODMUL_MONT); level k of a tree holds true values
     // times R^(1 - 2^k).  tree_c[k] = R^(1 - 2^k) mod n^2 brings a node without a partner to its level's form,
@@ -628,6 +677,7 @@ void pai_modulus_destroy(pai_modulus* m) {
     m->ms.release();
     m->table.release();
     m->expo.release();
+    m->pinned.release();
     m->order.release();
     delete m;
     if (prev_ >= 0) (void)hipSetDevice(prev_);
@@ -656,14 +706,13 @@ int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e
         hipStream_t s = (hipStream_t)stream;
         m->expo.ensure((size_t)e_words * 4);
         m->order.begin(s);
-        HIP_CHECK(hipMemcpyAsync(m->expo.p, h_e, (size_t)e_words * 4, hipMemcpyHostToDevice, s));
+        m->pinned.h2d(m->expo.p, h_e, (size_t)e_words * 4, s);         // h_e is free when this call returns
         const int grid = grid_for(g, N, m->dev.ncu);
         m->table.ensure(g->table_words((size_t)grid) * 4);
         g->modexp_fixed(s, grid, m->ms.d_ctx, d_base, m->ms.w32, m->expo.as<uint32_t>(), e_words, ebits > 0 ? ebits : 1,
                         d_out, m->ms.w32, (int)N, m->table.as<uint32_t>(), 0);
         HIP_CHECK(hipGetLastError());
         m->order.end(s);
-        HIP_CHECK(hipStreamSynchronize(s));     // h_e is a pageable host buffer owned by the caller
     });
 }
 // window width of the per-element-exponent kernels: table build 2^w - 2 products, then w squarings + 1 product per window
@@ -832,7 +881,7 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
     std::vector<uint32_t> bases(2 * (size_t)nl, 0), one(2 * (size_t)nl, 0);
     pair_of(Rm, one.data());
     pair_of(hbn::mulmod(pk->hs, Rm, pk->nsq), bases.data());        // B_0; the other window bases are squared on the device
-    DevBuf d_bases, d_one, d_half;
+    ScopedDevBuf d_bases, d_one, d_half;
     d_bases.ensure(bases.size() * 4);
     d_one.ensure(one.size() * 4);
     HIP_CHECK(hipMemcpy(d_bases.p, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
@@ -849,7 +898,7 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
     const int g1 = std::max(1, (J1 + epb - 1) / epb);
     // window bases from one chain of squarings on the integer-per-wavefront geometry (k_sq_chain), as for the digit engine
     FbBases fbb;
-    DevBuf d_plain, d_hs_plain;
+    ScopedDevBuf d_plain, d_hs_plain;
     if (pk->d_pair_kdig && ensure_lat_ctx(pk) && !fb_chain_disabled()) {
         std::vector<uint32_t> hw((size_t)pk->ct_words, 0);
         std::memcpy(hw.data(), pk->hs.data(), pk->hs.size() * 4);
@@ -915,9 +964,23 @@ static bool ensure_lat_ctx(const pai_pubkey* pk) {
 // Fixed-base tables of the DJN obfuscator hs^r, built by the FIRST call that obfuscates (pai_encrypt with
 // randomness / pai_obfuscate), under pk->mu: a handle that only adds, multiplies or decrypts — every unpickled
 // ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
+static void build_fb_tables_body(pai_pubkey* pk);
 void build_fb_tables(const pai_pubkey* cpk) {
     pai_pubkey* pk = const_cast<pai_pubkey*>(cpk);
     if (pk->fb_ready || !pk->djn) return;
+    try {
+        build_fb_tables_body(pk);
+    } catch (...) {
+        // a failed build (out of memory under pressure, a HIP error between the table allocation and fb_ready) must not
+        // leave a multi-GB table behind: the next obfuscating call would allocate over the dangling pointer
+        if (pk->d_fb_dig) { (void)hipFree(pk->d_fb_dig); pk->d_fb_dig = nullptr; }
+        if (pk->d_pair_fb) { (void)hipFree(pk->d_pair_fb); pk->d_pair_fb = nullptr; }
+        if (pk->d_fb) { (void)hipFree(pk->d_fb); pk->d_fb = nullptr; }
+        pk->fb_ready = false;
+        throw;
+    }
+}
+static void build_fb_tables_body(pai_pubkey* pk) {
     const int nl = pk->msq.nl;
     const int randbits = pk->randbits;
     // Fixed-base window width of the lane-group table (built only when the digit engine does not serve this key
@@ -947,7 +1010,7 @@ void build_fb_tables(const pai_pubkey* cpk) {
         const int pnl = pk->penc_nl;
         const Limbs Rm = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * pnl), pk->nsq);
         uint32_t* d_one = pk->d_one_dig;
-        DevBuf d_hs, d_half;
+        ScopedDevBuf d_hs, d_half;
         {
             const std::vector<uint32_t> h = pubkey_digits_of(pk, hbn::mulmod(pk->hs, Rm, pk->nsq));
             d_hs.ensure(h.size() * 4);
@@ -981,7 +1044,7 @@ void build_fb_tables(const pai_pubkey* cpk) {
         // product) instead of the same chain walked by every lane of the table kernel at 50 us per product
         const int h1 = dwb <= 12 ? dwb : dwb / 2, J1 = dwb <= 12 ? DJ : 2 * DJ;
         FbBases fbb;
-        DevBuf d_bases, d_hs_plain;
+        ScopedDevBuf d_bases, d_hs_plain;
         if (pk->d_ct_kdig && ensure_lat_ctx(pk) && !fb_chain_disabled()) {
             const std::vector<uint32_t> hw = [&] { std::vector<uint32_t> v((size_t)pk->ct_words, 0); std::memcpy(v.data(), pk->hs.data(), pk->hs.size() * 4); return v; }();
             d_hs_plain.ensure(hw.size() * 4);
@@ -1183,6 +1246,7 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->inv_prod.release();
     pk->inv_inv.release();
     pk->inv_fail.release();
+    pk->status.release();
     pk->table.release();
     pk->tmp.release();
     delete pk;
@@ -1396,6 +1460,24 @@ int pai_fp_encode_i64(const pai_pubkey* pk, const int64_t* d_x, size_t N, uint32
     });
 }
 
+int pai_fp_encode_at(const pai_pubkey* pk, const void* d_x, int is_f64, size_t N, const int32_t* d_target, int target_bcast,
+                     uint32_t* d_m, int32_t* d_expo, void* stream) {
+    return guarded([&] {
+        require(pk && d_x && d_m && d_expo && d_target, "NULL argument");
+        require(hbn::bitlen(pk->n) > 66, "device encode needs a modulus of more than 66 bits");
+        if (N == 0) return;
+        DeviceScope scope_(pk->device);
+        const int nbits = hbn::bitlen(pk->n);
+        if (is_f64)
+            hipLaunchKernelGGL(k_fp_encode_at<true>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, pk->d_nexp,
+                               pk->n_words, nbits, d_target, target_bcast, d_m, d_expo, N);
+        else
+            hipLaunchKernelGGL(k_fp_encode_at<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, pk->d_nexp,
+                               pk->n_words, nbits, d_target, target_bcast, d_m, d_expo, N);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 int pai_fp_decode_i64(const pai_pubkey* pk, const uint32_t* d_m, size_t N, int64_t* d_mant, int32_t* d_flag, void* stream) {
     return guarded([&] {
         require(pk && d_m && d_mant && d_flag, "NULL argument");
@@ -1598,6 +1680,15 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
     });
 }
 
+static int* status_word(const pai_pubkey* pk, hipStream_t s) {      // under pk->mu
+    if (!pk->status.p) {
+        pk->status.ensure(4);
+        HIP_CHECK(hipMemsetAsync(pk->status.p, 0, 4, s));
+        HIP_CHECK(hipStreamSynchronize(s));                          // once per handle: other streams may use it next
+    }
+    return pk->status.as<int>();
+}
+
 static int ct_pow2_impl(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delta, int delta_bcast, size_t N, int dmax_hint,
                         void* stream);
 
@@ -1634,7 +1725,7 @@ static int ct_pow2_impl(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_d
             pk->order.begin(s);
             HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int), s));
             hipLaunchKernelGGL(k_pow2_expo, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_delta, delta_bcast, N,
-                               pk->pow2_expo.as<uint32_t>(), d_max);
+                               pk->pow2_expo.as<uint32_t>(), d_max, dmax_hint, status_word(pk, s));
             HIP_CHECK(hipGetLastError());
             int dmax = dmax_hint;
             if (dmax_hint < 0) {                                          // no hint: read the largest shift back (synchronises)
@@ -1870,7 +1961,29 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
     });
 }
 
+static int ct_invert_impl(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream, bool sync);
 int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream) {
+    return ct_invert_impl(pk, d_ct, N, d_out, stream, true);
+}
+int pai_ct_invert_async(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream) {
+    return ct_invert_impl(pk, d_ct, N, d_out, stream, false);
+}
+int pai_pubkey_status(const pai_pubkey* pk, int* status_out, int clear, void* stream) {
+    return guarded([&] {
+        require(pk && status_out, "NULL argument");
+        std::lock_guard<std::mutex> lk(pk->mu);
+        DeviceScope scope_(pk->device);
+        hipStream_t s = (hipStream_t)stream;
+        int* w = status_word(pk, s);
+        int v = 0;
+        HIP_CHECK(hipMemcpyAsync(&v, w, 4, hipMemcpyDeviceToHost, s));
+        if (clear) HIP_CHECK(hipMemsetAsync(w, 0, 4, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        *status_out = v;
+    });
+}
+
+static int ct_invert_impl(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream, bool sync) {
     return guarded([&] {
         require(pk && d_ct && d_out, "NULL argument");
         if (N == 0) return;
@@ -1937,6 +2050,13 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
             if (lo < h) tree_mul(pk, s, pinv + lo * W, tree_c(k), 1, dst + lo * W, 1);
         }
         t.stop();
+        if (!sync) {
+            // asynchronous form: a non-unit is remembered in the handle's sticky status word (pai_pubkey_status)
+            hipLaunchKernelGGL(k_status_or, dim3(1), dim3(1), 0, s, status_word(pk, s), pk->inv_fail.as<int>(), 1);
+            HIP_CHECK(hipGetLastError());
+            order_.done();
+            return;
+        }
         int fail = 0;
         HIP_CHECK(hipMemcpyAsync(&fail, pk->inv_fail.p, 4, hipMemcpyDeviceToHost, s));
         order_.done();

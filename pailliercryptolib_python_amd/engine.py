@@ -171,6 +171,7 @@ class PublicKeyHandle:
         the device bytes released.  For processes that hold many keys on one device."""
         v = C.c_size_t(0)
         _native.check(self.lib.pai_pubkey_trim(self.h, C.byref(v)))
+        self.__dict__.pop("_dom_consts", None)          # the cached R^k rows go too
         return int(v.value)
 
     # ---- lazy Montgomery domain (include/paillier_hip.h: pai_ct_mont_mul).  A buffer with tag k holds x R^k mod n^2. ----
@@ -186,13 +187,15 @@ class PublicKeyHandle:
     def dom_const(self, k: int) -> torch.Tensor:
         """R^k mod n^2 as one packed device row (k any integer), cached per handle."""
         cache = self.__dict__.setdefault("_dom_consts", {})
-        t = cache.get(k)
+        t = cache.pop(k, None)
         if t is None:
             nsq = self.n * self.n
             r = pow(2, self.mont_bits, nsq)
             v = pow(r, k, nsq) if k >= 0 else pow(pow(r, -1, nsq), -k, nsq)
             t = to_device_words(int_to_words(v, self.ct_words)[None, :], self.device)
-            cache[k] = t
+        cache[k] = t                                   # most recently used last; a small LRU (tags are bounded: paillier.DOM_MAX)
+        while len(cache) > 32:
+            cache.pop(next(iter(cache)))
         return t
 
     def ct_mont_mul(self, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -271,11 +274,31 @@ class PublicKeyHandle:
                                                _ptr(sign), _ptr(out), _stream(self.device)))
         return out
 
-    def ct_invert(self, ct: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def ct_invert(self, ct: torch.Tensor, out: Optional[torch.Tensor] = None, sync: bool = True) -> torch.Tensor:
+        """ct^-1 mod n^2.  sync=False: pai_ct_invert_async — the call returns with the kernels queued; a non-invertible input
+        is remembered in the handle's sticky status word and raised by the next check_status() (the API layer calls it
+        before anything leaves the device)."""
         self._chk(ct, self.ct_words, "ct")
         out = self.empty_ct(ct.shape[0]) if out is None else out
-        _native.check(self.lib.pai_ct_invert(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.device)))
+        if sync:
+            _native.check(self.lib.pai_ct_invert(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.device)))
+        else:
+            _native.check(self.lib.pai_ct_invert_async(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.device)))
+            self._status_dirty = True
         return out
+
+    def check_status(self, force: bool = False) -> None:
+        """Reads (and clears) the sticky status word of this handle's asynchronous calls if one of them ran since the last
+        check; raises what the synchronous forms raise.  Synchronises the current stream."""
+        if not (force or self.__dict__.get("_status_dirty")):
+            return
+        self._status_dirty = False
+        v = C.c_int(0)
+        _native.check(self.lib.pai_pubkey_status(self.h, C.byref(v), 1, _stream(self.device)))
+        if v.value & 1:
+            raise _native.NativeError(_native.PAI_E_INVALID, "ct_invert: a ciphertext is not invertible modulo n^2")
+        if v.value & 2:
+            raise _native.NativeError(_native.PAI_E_INVALID, "ct_pow2_hint: max_delta was smaller than a shift of its batch")
 
     def ct_pow2_(self, ct: torch.Tensor, delta, max_delta: Optional[int] = None) -> torch.Tensor:
         """ct_i <- ct_i^(2^delta_i) in place for delta_i > 0.  delta: int32 device tensor, or a host numpy array (then the
@@ -313,6 +336,21 @@ class PublicKeyHandle:
         m = self.empty_pt(x.shape[0])
         expo = torch.empty((x.shape[0],), dtype=torch.int32, device=self.device)
         _native.check(self.lib.pai_fp_encode_i64(self.h, _ptr(x), x.shape[0], _ptr(m), _ptr(expo), _stream(self.device)))
+        return m, expo
+
+    def fp_encode_at(self, x: torch.Tensor, target: torch.Tensor):
+        """float64[N] or int64[N] -> (residues, exponents) with per-element target exponents (int32[N] or [1]): an element
+        whose own exponent is below its target is encoded AT the target (pai_fp_encode_at; the plaintext side of
+        ct + plaintext needs no ciphertext squarings then)."""
+        if x.dtype not in (torch.float64, torch.int64) or x.dim() != 1 or not x.is_contiguous() or x.device != self.device:
+            raise ValueError("x: expected contiguous float64 / int64 [N] on %s" % self.device)
+        if target.dtype != torch.int32 or target.dim() != 1 or target.shape[0] not in (1, x.shape[0]) or target.device != self.device:
+            raise ValueError("target: expected int32 [N] or [1] on %s" % self.device)
+        m = self.empty_pt(x.shape[0])
+        expo = torch.empty((x.shape[0],), dtype=torch.int32, device=self.device)
+        _native.check(self.lib.pai_fp_encode_at(self.h, _ptr(x), 1 if x.dtype == torch.float64 else 0, x.shape[0], _ptr(target.contiguous()),
+                                                1 if target.shape[0] == 1 and x.shape[0] != 1 else 0, _ptr(m), _ptr(expo),
+                                                _stream(self.device)))
         return m, expo
 
     def fp_decode_i64(self, m: torch.Tensor):

@@ -190,6 +190,30 @@ def encode_array(values, n: int, max_int: int, n_words: int) -> Tuple[np.ndarray
     return out, expo
 
 
+def align_encoded(residues: np.ndarray, exponents: np.ndarray, target: np.ndarray, n: int, max_int: int):
+    """Host counterpart of pai_fp_encode_at for the element-by-element codec path: an encoding whose exponent e is below
+    its target t becomes (mantissa * 2^(t - e)) mod n at exponent t whenever |mantissa| 2^(t-e) < 2^(bits(n) - 2) —
+    what raising its RAW encryption to 2^(t - e) yields (ipcl_python.py:570-741), computed on the plaintext."""
+    residues = np.ascontiguousarray(residues, dtype="<u4").copy()
+    expo = np.asarray(exponents, dtype=np.int32).copy()
+    tgt = np.broadcast_to(np.asarray(target, dtype=np.int64).reshape(-1), expo.shape)
+    step = 4 * residues.shape[1]
+    nbits = n.bit_length()
+    for i in np.nonzero(tgt > expo)[0].tolist():
+        enc = int.from_bytes(residues[i].tobytes(), "little")
+        if enc == 0:
+            expo[i] = int(tgt[i])
+            continue
+        mant = enc if enc <= max_int else enc - n
+        d = int(tgt[i]) - int(expo[i])
+        if enc > max_int and enc < n - max_int:
+            continue                                          # overflow zone: leave it to the ciphertext path
+        if abs(mant).bit_length() + d <= nbits - 2:
+            residues[i] = np.frombuffer(((mant << d) % n).to_bytes(step, "little"), dtype="<u4")
+            expo[i] = int(tgt[i])
+    return residues, expo
+
+
 def decode_array(residues: np.ndarray, exponents: Sequence[int], n: int, max_int: int) -> List:
     """(residues uint32[N][n_words], exponents) -> list of decoded values, element types as the
     reference returns them (int when exponent <= 0, float otherwise; fixedpoint.py:115)."""

@@ -99,9 +99,13 @@ class PaillierPublicKey:
         return self.encrypt(plaintext, apply_obfuscator=False)
 
     def encrypt(self, values: Union[np.ndarray, list, int, float], apply_obfuscator: bool = True, *,
-                r: Optional[Union[torch.Tensor, np.ndarray]] = None) -> "PaillierEncryptedNumber":
+                r: Optional[Union[torch.Tensor, np.ndarray]] = None, _align_to=None) -> "PaillierEncryptedNumber":
         """ipcl_python.py:108-147.  Scalars, lists and 1-D arrays of ints/floats; anything else is a
-        ValueError exactly as there (2-D arrays fail the per-element type check)."""
+        ValueError exactly as there (2-D arrays fail the per-element type check).
+        _align_to (private; raw encryptions only — the plaintext operand of ct + plaintext): target exponents, one per
+        element or a single one.  An element whose own exponent is lower is encoded AT its target: for a raw encryption
+        ct^(2^d) = E_raw(m 2^d mod n), so the bits and exponents are those the reference's alignment
+        (ipcl_python.py:570-741) produces, without the squarings."""
         if np.isscalar(values):
             values = [values]
         if isinstance(values, np.ndarray):
@@ -116,6 +120,11 @@ class PaillierPublicKey:
         h = pub.handle
         if isinstance(r, np.ndarray):
             r = engine.to_device_words(r, h.device)
+        tgt = None
+        if _align_to is not None and not apply_obfuscator:
+            tgt = np.ascontiguousarray(np.asarray(_align_to, dtype=np.int32).reshape(-1))
+            if tgt.shape[0] not in (1, len(values)):
+                tgt = None
         is_f64 = _fp.is_float_batch(values) and self.n.bit_length() > 66
         is_i64 = (isinstance(values, np.ndarray) and values.dtype in (np.int16, np.int32, np.int64) and values.ndim == 1
                   and values.shape[0] > 0 and self.n.bit_length() > 66)
@@ -134,6 +143,10 @@ class PaillierPublicKey:
                 if count == 0:
                     return hg.empty_ct(0), np.zeros(0, dtype=np.int32)
                 xs = torch.from_numpy(x[begin:begin + count]).to(dev)
+                if tgt is not None:
+                    tg = tgt if tgt.shape[0] == 1 else tgt[begin:begin + count]
+                    m, expo_d = hg.fp_encode_at(xs, torch.from_numpy(tg).to(dev))
+                    return hg.raw_encrypt(m), expo_d.cpu().numpy()
                 m, expo_d = hg.fp_encode_f64(xs) if is_f64 else hg.fp_encode_i64(xs)
                 if not apply_obfuscator:
                     ct_g = hg.raw_encrypt(m)
@@ -145,7 +158,11 @@ class PaillierPublicKey:
             ct = engine.gather_shards([p[0] for p in parts], h.device)
             expos = np.concatenate([p[1] for p in parts])
             return PaillierEncryptedNumber(self, ipclCipherText(pub, ct), exponents=expos, length=len(values))
-        if is_f64:
+        if (is_f64 or is_i64) and tgt is not None:
+            x = _fp.checked_float64(values) if is_f64 else np.ascontiguousarray(values, dtype=np.int64)
+            m, expo_d = h.fp_encode_at(torch.from_numpy(x).to(h.device), torch.from_numpy(tgt).to(h.device))
+            expos = expo_d.cpu().numpy()
+        elif is_f64:
             # float arrays: 8 B per element cross PCIe and the codec runs on the device (pai_fp_encode_f64)
             x = _fp.checked_float64(values)
             m, expo_d = h.fp_encode_f64(torch.from_numpy(x).to(h.device))
@@ -156,6 +173,8 @@ class PaillierPublicKey:
             expos = np.zeros(values.shape[0], dtype=np.int32)
         else:
             residues, expos = _fp.encode_array(values, self.n, self.max_int, h.n_words)
+            if tgt is not None:
+                residues, expos = _fp.align_encoded(residues, expos, tgt, self.n, self.max_int)
             m = engine.to_device_words(residues, h.device)
         ct = pub.encrypt_words(m, apply_obfuscator, r)
         return PaillierEncryptedNumber(self, ipclCipherText(self.pubkey, ct), exponents=expos, length=len(values))
@@ -196,6 +215,7 @@ class PaillierPrivateKey:
         return repr(self.prikey)
 
     def _decrypt_words(self, enc: "PaillierEncryptedNumber") -> np.ndarray:
+        enc.public_key.pubkey.handle.check_status()      # asynchronous inversions report here (engine.PublicKeyHandle.check_status)
         return engine.to_host_words(self.prikey.decrypt_words(enc.words))
 
     def _decrypt_mantissas(self, enc: "PaillierEncryptedNumber"):
@@ -207,6 +227,7 @@ class PaillierPrivateKey:
         # devices; the codec only depends on n, which the two share)
         pub = self.prikey._pk
         home = pub.handle.device
+        enc.public_key.pubkey.handle.check_status()      # asynchronous inversions report here
         words = enc.words if enc.words.device == home else enc.words.to(home)
         devs = pub.fanout_devices(len(enc)) if self.__n.bit_length() > 66 else None
         if devs is not None:
@@ -262,6 +283,8 @@ class PaillierPrivateKey:
 
 # batches from this size on are sorted by |exponent difference| before a fused aligned addition (PAI_ALIGN_SORT_MIN)
 ALIGN_SORT_MIN = 1 << 15
+# a lazily tagged sum (rows x R^k, bindings.ipclCipherText) is brought back to the wire form once |k| passes this bound
+DOM_MAX = 12
 
 
 def _add_aligned(h: engine.PublicKeyHandle, ta: torch.Tensor, tb: torch.Tensor, delta: np.ndarray, dom: int = 0) -> torch.Tensor:
@@ -400,7 +423,7 @@ class PaillierEncryptedNumber:
             ye = np.broadcast_to(ye, xe.shape)
         m = np.maximum(xe, ye)
         E = np.maximum(xe, ye + FixedPointNumber.FLOAT_MANTISSA_BITS - 1)
-        b_inv = h.ct_invert(other.words)
+        b_inv = h.ct_invert(other.words, sync=False)
         t = _add_aligned(h, self.words, b_inv, (xe - ye).astype(np.int32))
         k = (E - m).astype(np.int32)
         if (k > 0).any():
@@ -441,11 +464,11 @@ class PaillierEncryptedNumber:
         bcast = len(pts) == 1 and N > 1
         if neg.any():
             if bcast or neg.all():
-                base = h.ct_invert(ct)
+                base = h.ct_invert(ct, sync=False)
             else:
                 idx = torch.from_numpy(np.nonzero(neg)[0]).to(h.device)
                 base = ct.clone()
-                base[idx] = h.ct_invert(ct[idx].contiguous())
+                base[idx] = h.ct_invert(ct[idx].contiguous(), sync=False)
         else:
             base = ct
         mags = [n - p if s else p for p, s in zip(pts, neg)]
@@ -460,11 +483,11 @@ class PaillierEncryptedNumber:
         neg = mant < 0
         if neg.any():
             if neg.all():
-                base = h.ct_invert(ct)
+                base = h.ct_invert(ct, sync=False)
             else:
                 idx = torch.from_numpy(np.nonzero(neg)[0]).to(h.device)
                 base = ct.clone()
-                base[idx] = h.ct_invert(ct[idx].contiguous())
+                base[idx] = h.ct_invert(ct[idx].contiguous(), sync=False)
         else:
             base = ct
         mag = np.abs(mant).astype(np.uint64)
@@ -504,9 +527,11 @@ class PaillierEncryptedNumber:
         if isinstance(other, (np.ndarray, list)):
             if self.__length != len(other):
                 raise ValueError("PaillierEncryptedNumber.__raw_add: array(list) size mismatch with PaillierEncryptedNumber")
-            other = self.public_key.encrypt(other, apply_obfuscator=False)
+            # the plaintext side is aligned in the plaintext domain (PaillierPublicKey.encrypt: _align_to)
+            other = self.public_key.encrypt(other, apply_obfuscator=False, _align_to=self._expo)
         elif np.isscalar(other) and isinstance(other, (int, float, np.integer, np.floating)):
-            other = self.public_key.encrypt(other, apply_obfuscator=False)
+            other = self.public_key.encrypt(other, apply_obfuscator=False,
+                                            _align_to=[int(self._expo.min())] if self.__length else None)
         elif isinstance(other, PaillierEncryptedNumber):
             if self.public_key != other.public_key:
                 raise ValueError("PaillierEncryptedNumber.__raw_add: PublicKey mismatch")
@@ -518,14 +543,18 @@ class PaillierEncryptedNumber:
         h = self._h()
         xe = np.asarray(self._expo, dtype=np.int64)
         ye = np.asarray(other._expo, dtype=np.int64)
-        if other.words.shape[0] == 1 and self.words.shape[0] > 1:
+        # lazy Montgomery domain (bindings.ipclCipherText._raw): operands hold x R^k; the sum is ONE product and its tag
+        # remembers the stray R^-1 — whoever needs the wire form pays the second product once, sums of sums never do.
+        # (_raw() first: `.words` would canonicalise the operand — one product and a new buffer — just to read a shape.)
+        (ta, ka), (tb, kb) = self.__ipclCipherText._raw(), other.ciphertext()._raw()
+        if tb.shape[0] == 1 and ta.shape[0] > 1:
             ye = np.broadcast_to(ye, xe.shape)
         delta = (xe - ye).astype(np.int32)
-        # lazy Montgomery domain (bindings.ipclCipherText._raw): operands hold x R^k; the sum is ONE product and its tag
-        # remembers the stray R^-1 — whoever needs the wire form pays the second product once, chains of sums never do
-        (ta, ka), (tb, kb) = self.__ipclCipherText._raw(), other.ciphertext()._raw()
         if not delta.any():
-            return self._wrap(h.ct_mont_mul(ta, tb), np.maximum(xe, ye).astype(np.int32), self.__length, dom=ka + kb - 1)
+            res, dom = h.ct_mont_mul(ta, tb), ka + kb - 1
+            if abs(dom) > DOM_MAX:                       # long-lived accumulators: the tag (and the R^k constants it needs) stay bounded
+                res, dom = h.ct_retag(res, dom, 0), 0
+            return self._wrap(res, np.maximum(xe, ye).astype(np.int32), self.__length, dom=dom)
         if kb != ka:
             tb = h.ct_retag(tb, kb, ka)
         res = _add_aligned(h, ta, tb, delta, dom=ka)
@@ -698,10 +727,10 @@ class PaillierEncryptedNumber:
                 # one column: every base is used with one sign only — swap the inverted ciphertexts in (half the tables)
                 rows = torch.nonzero(neg[:, 0].repeat(R)).reshape(-1)
                 bases = bases.clone()
-                bases[rows] = h.ct_invert(bases[rows].contiguous())
+                bases[rows] = h.ct_invert(bases[rows].contiguous(), sync=False)
             else:
                 sign = neg.to(torch.uint8).contiguous()
-                inv = h.ct_invert(bases)
+                inv = h.ct_invert(bases, sync=False)
         try:
             out = h.ct_multiexp(bases, inv, R, K, M, e_t, ebits, sign)
         except _native.NativeError as exc:

@@ -641,3 +641,75 @@ def test_large_mixed_exponent_sums_are_sorted_by_shift_and_bit_identical(fixed, 
     assert sw == want[0] and [got["sorted"][1][i] for i in idx] == want[1]
     monkeypatch.delenv("PAI_ALIGN_SORT_MIN")
     assert np.allclose(sk.decrypt_to_numpy(a + b), x + y, rtol=0, atol=1e-6 * np.abs(x + y).max())
+
+
+def test_sums_of_sums_stay_lazy_and_tags_stay_bounded(fixed):
+    """(a+b)+(c+d) and x + acc keep their operands tagged (one product per addition: no operand is canonicalised just to
+    read its shape), a long accumulator's tag is renormalised at paillier.DOM_MAX, the handle's R^k cache stays small
+    and trim() drops it — bits always those of the reference's composition."""
+    from pailliercryptolib_python_amd import paillier as P
+
+    pk, sk, okey = fixed
+    N = 7
+    ints = [list(range(i, i + N)) for i in (1, 50, 700, 9000)]
+    rs = [orc.synth_r_limbs(970 + i, N, okey.randbits) for i in range(4)]
+    e = [pk.encrypt(v, r=r) for v, r in zip(ints, rs)]
+    o = [orc.api_encrypt(okey, v, orc.limbs_to_ints(r)) for v, r in zip(ints, rs)]
+    ab, cd = e[0] + e[1], e[2] + e[3]
+    tot = ab + cd
+    assert ab.ciphertext()._raw()[1] == -1 and cd.ciphertext()._raw()[1] == -1         # still tagged after being operands
+    assert tot.ciphertext()._raw()[1] == -3
+    wab, wcd = orc.api_add_ct(okey, *o[0], *o[1]), orc.api_add_ct(okey, *o[2], *o[3])
+    assert ct_ints(tot) == orc.api_add_ct(okey, *wab, *wcd)[0]
+    right = e[0] + ab                                                                   # tagged RIGHT operand
+    assert ab.ciphertext()._raw()[1] == -1 and right.ciphertext()._raw()[1] == -2
+    assert ct_ints(right) == orc.api_add_ct(okey, *o[0], *wab)[0]
+    acc, want = e[0], o[0]
+    tags = []
+    for k in range(2 * P.DOM_MAX + 3):
+        acc = acc + e[1 + k % 3]
+        want = orc.api_add_ct(okey, *want, *o[1 + k % 3])
+        tags.append(acc.ciphertext()._raw()[1])
+    assert min(tags) >= -P.DOM_MAX and 0 in tags[P.DOM_MAX:]                            # renormalised on the way
+    assert ct_ints(acc) == want[0]
+    h = pk.pubkey.handle
+    assert len(h.__dict__.get("_dom_consts", {})) <= 32
+    h.trim()
+    assert "_dom_consts" not in h.__dict__
+    assert ct_ints(e[0] + e[1]) == wab[0]
+
+
+def test_plaintext_addends_are_aligned_in_the_plaintext_domain(fixed, monkeypatch):
+    """ct + plaintext: the plaintext is encoded AT the ciphertext's exponent when its own is lower (pai_fp_encode_at /
+    fixedpoint.align_encoded: (1 + m n)^(2^d) = 1 + (m 2^d mod n) n), so no ciphertext squaring runs for it — and the
+    bits and exponents are exactly those of the reference's raw-encrypt-then-raise composition (oracle), for float
+    arrays, int arrays, Python lists, scalars (broadcast) and the reference benchmark's BM_Add_CTPT shape."""
+    pk, sk, okey = fixed
+    h = pk.pubkey.handle
+    calls = []
+    real = type(h).ct_add_aligned
+    monkeypatch.setattr(type(h), "ct_add_aligned", lambda self, *a, **k: calls.append(1) or real(self, *a, **k))
+    N = 24
+    ar = np.arange(N)
+    x, y = (ar + 11) * 5111.2834, (32768 - ar) * 1.3872
+    rx = orc.synth_r_limbs(31, N, okey.randbits)
+    ex = pk.encrypt(x, r=rx)
+    ox = orc.api_encrypt(okey, list(x), orc.limbs_to_ints(rx))
+    exx, oxx = ex * x, orc.api_mul_plain(okey, *ox, list(x))                             # exponents ~70: far above y's ~37
+    calls.clear()
+    got = exx + y
+    want = orc.api_add_plain(okey, *oxx, list(y))
+    assert (ct_ints(got), got.exponent()) == (want[0], want[1])
+    assert calls == []                                                                  # one plain product, no aligned-addition kernel
+    for other in (np.arange(N, dtype=np.int64) - 5, [float(v) for v in y], [int(v) for v in range(N)], 3.75, -2, 0.0,
+                  np.float64(1e-3), y * 2.0 ** 40, -y * 2.0 ** -30):
+        got = exx + other
+        want = orc.api_add_plain(okey, *oxx, other if np.isscalar(other) else list(other))
+        assert (ct_ints(got), got.exponent()) == (want[0], want[1]), repr(other)[:40]
+        got = other + ex                                                                 # __radd__, mixed directions
+        want = orc.api_add_plain(okey, *ox, other if np.isscalar(other) else list(other))
+        assert (ct_ints(got), got.exponent()) == (want[0], want[1]), repr(other)[:40]
+    d = exx - y
+    wd = orc.api_sub_plain(okey, *oxx, y)
+    assert (ct_ints(d), d.exponent()) == (wd[0], wd[1])
+    assert np.allclose(sk.decrypt_to_numpy(exx + y), x * x + y, rtol=1e-12)

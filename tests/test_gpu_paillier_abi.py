@@ -718,3 +718,48 @@ def test_pubkey_trim_releases_the_tables_and_the_next_call_rebuilds_them(k2048):
     _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))       # rebuilds
     assert np.array_equal(ct.get(), first)
     _native.check(nk.lib.pai_pubkey_trim(nk.pk, None))
+
+
+def test_async_invert_and_sticky_status():
+    """pai_ct_invert_async queues the same work without a synchronisation; a non-unit sets bit 0 of the handle's sticky
+    status word (pai_pubkey_status), which the API layer reads before anything leaves the device; pai_ct_pow2_hint with
+    a hint below a shift of its batch sets bit 1 instead of returning truncated powers silently."""
+    import ctypes as C
+
+    import torch
+
+    from pailliercryptolib_python_amd import _native, engine
+
+    key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1234567, bits=2048)
+    pub = engine.PublicKeyHandle(key.n, 2048, key.hs, key.randbits, device="cuda:0")
+    N = 300
+    rng = np.random.default_rng(5)
+    vals = [int.from_bytes(rng.bytes(500), "little") % key.nsq | 1 for _ in range(N)]
+    ct = engine.to_device_words(engine.ints_to_words(vals, pub.ct_words), pub.device)
+    got = pub.ct_invert(ct, sync=False)
+    pub.check_status()                                              # units only: nothing to report
+    assert engine.words_to_ints(engine.to_host_words(got)) == [pow(v, -1, key.nsq) for v in vals]
+    bad = list(vals)
+    bad[17] = key.p * 12345                                         # shares a factor with n
+    ctb = engine.to_device_words(engine.ints_to_words(bad, pub.ct_words), pub.device)
+    pub.ct_invert(ctb, sync=False)                                  # returns; the failure is remembered
+    with pytest.raises(_native.NativeError, match="not invertible"):
+        pub.check_status()
+    pub.check_status(force=True)                                    # cleared by the read
+    with pytest.raises(_native.NativeError, match="not invertible"):
+        pub.ct_invert(ctb)                                          # the synchronous form still fails at the call
+    # an under-estimated pow2 hint on the digit-engine path (batch >= PAI_POW2_DIGIT_MIN)
+    M = 1 << 14
+    big = ct[:1].expand(M, -1).contiguous()
+    d = torch.full((M,), 9, dtype=torch.int32, device=pub.device)
+    d[5] = 20
+    _native.check(pub.lib.pai_ct_pow2_hint(pub.h, big.data_ptr(), d.data_ptr(), 0, M, 12, None))
+    st = C.c_int(0)
+    _native.check(pub.lib.pai_pubkey_status(pub.h, C.byref(st), 1, None))
+    assert st.value & 2
+    big = ct[:1].expand(M, -1).contiguous()
+    _native.check(pub.lib.pai_ct_pow2_hint(pub.h, big.data_ptr(), d.data_ptr(), 0, M, 20, None))
+    _native.check(pub.lib.pai_pubkey_status(pub.h, C.byref(st), 1, None))
+    assert st.value == 0
+    rows = engine.words_to_ints(engine.to_host_words(big[[0, 5]]))
+    assert rows == [pow(vals[0], 1 << 9, key.nsq), pow(vals[0], 1 << 20, key.nsq)]
