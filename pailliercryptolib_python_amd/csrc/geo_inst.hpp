@@ -12,6 +12,12 @@
 #ifndef PAI_TILE_NMLDS
 #define PAI_TILE_NMLDS false
 #endif
+#ifndef PAI_MODMUL_W
+#define PAI_MODMUL_W true
+#endif
+#ifndef PAI_MODMUL_W_SPLIT8
+#define PAI_MODMUL_W_SPLIT8 true
+#endif
 
 namespace pai {
 
@@ -25,11 +31,25 @@ struct GeoInst {
     static void set_lds(const void* fn, int bytes) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
+    // wave-region form (kernels_modexp.hpp: k_modmul_w) for the lane-group geometries with canonical contexts; the
+    // single-lane and minus-one geometries keep the staged form
+    // 144-limb moduli (n^2 of 2048-bit keys) run it on EIGHT lanes of 18 limbs: ~110 VGPRs and 4.6 KB of LDS per wave, so
+    // four waves per SIMD cover each other's memory phases (the packed rows and the Montgomery constants do not depend on
+    // the geometry: same bits)
+    static constexpr bool SPLIT8 = PAI_MODMUL_W_SPLIT8 && G::T == 4 && G::NLL == 36;
+    using GW = typename std::conditional<SPLIT8, Geo<18, 8, 6, false>, Geo<G::NLL, G::T, G::U, true>>::type;
+    static constexpr bool MODMUL_W = PAI_MODMUL_W && G::T >= 2 && G::T <= 8 && !G::M1 && (G::NLL % 4 == 0);
     static void modmul(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, uint32_t* out,
                        int n, int w32, int b_bcast, int mode) {
-        constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
-        set_lds((const void*)k_modmul<GM>, bytes);
-        hipLaunchKernelGGL(k_modmul<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
+        if constexpr (MODMUL_W) {
+            constexpr int bytes = ModmulW<GW>::LDS_BYTES;
+            set_lds((const void*)k_modmul_w<GW>, bytes);
+            hipLaunchKernelGGL(k_modmul_w<GW>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
+        } else {
+            constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
+            set_lds((const void*)k_modmul<GM>, bytes);
+            hipLaunchKernelGGL(k_modmul<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
+        }
     }
     static void modexp_fixed(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32,
                              const uint32_t* expo, int ewords, int ebits, uint32_t* out, int out_w32, int n,

@@ -134,9 +134,8 @@ PAI_DEV void clear_stage(uint32_t* stage) {
 // chunk l + 64 it of the tile — straight-line code: every load is issued (index clamped, never branched around)
 // before the first LDS write, one HBM round trip per tile.  bcast: every staged row is a copy of row 0 of src.
 template <class G>
-PAI_DEV void load_tile(uint32_t* stage, const uint32_t* __restrict__ src, int rows, int W32, bool bcast = false) {
+PAI_DEV void load_tile_at(uint32_t* dst, const uint32_t* __restrict__ src, int rows, int W32, bool bcast = false) {
     using WT = WaveTile<G>;
-    uint32_t* dst = WT::slice(stage);
     const int lane = WT::lane();
     wave_lds_fence();
     if (!bcast && (W32 & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
@@ -166,11 +165,27 @@ PAI_DEV void load_tile(uint32_t* stage, const uint32_t* __restrict__ src, int ro
     wave_lds_fence();
 }
 
+template <class G>
+PAI_DEV void load_tile(uint32_t* stage, const uint32_t* __restrict__ src, int rows, int W32, bool bcast = false) {
+    load_tile_at<G>(WaveTile<G>::slice(stage), src, rows, W32, bcast);
+}
+// zeroes the pad words behind the W32 data words of every row of a wave's region (regions that are time-shared with
+// limb-form operands lose the zeros clear_stage wrote)
+template <class G>
+PAI_DEV void clear_row_pads(uint32_t* region, int W32) {
+    using WT = WaveTile<G>;
+    const int pad = G::SW - W32;
+    for (int i = WT::lane(); i < WT::EPW * pad; i += 64) {
+        const int e = i / pad, k = i - e * pad;
+        region[e * G::SW + W32 + k] = 0u;
+    }
+}
+
 // this lane's limb slice of its element's staged row
 template <class G>
-PAI_DEV void unpack_row(uint32_t (&x)[G::NLL], const uint32_t* stage) {
+PAI_DEV void unpack_row_at(uint32_t (&x)[G::NLL], const uint32_t* row) {
     const int start = RB * G::NLL * G::gl();
-    const uint32_t* p = stage + G::elem() * G::SW + (start >> 5);
+    const uint32_t* p = row + (start >> 5);
     const uint32_t s = (uint32_t)start & 31u;
     uint32_t w[G::NWIN + 1];
 #pragma unroll
@@ -183,6 +198,11 @@ PAI_DEV void unpack_row(uint32_t (&x)[G::NLL], const uint32_t* stage) {
         const int bit = RB * j, k = bit >> 5, sh = bit & 31;
         x[j] = (sh + RB <= 32 ? (w[k] >> sh) : __builtin_amdgcn_alignbit(w[k + 1], w[k], (uint32_t)sh)) & RMASK;
     }
+}
+
+template <class G>
+PAI_DEV void unpack_row(uint32_t (&x)[G::NLL], const uint32_t* stage) {
+    unpack_row_at<G>(x, stage + G::elem() * G::SW);
 }
 
 // limb slices (canonical 29-bit limbs) -> packed u32 words of one element, staged through LDS
@@ -211,7 +231,7 @@ PAI_DEV void store_elem(const uint32_t (&x)[G::NLL], uint32_t* __restrict__ row,
 // handed over by the previous lane (DPP / bpermute), and the lane writes the words that start inside its window.
 // Bits above 32*W32 must be zero.  The caller synchronises, then store_tile writes the rows out coalesced.
 template <class G>
-PAI_DEV void pack_row(const uint32_t (&x)[G::NLL], uint32_t* stage) {
+PAI_DEV void pack_row_at(const uint32_t (&x)[G::NLL], uint32_t* rowbase) {
     constexpr int NW = G::NWIN;                              // words a window can overlap, both partial ends included
     constexpr int WBITS = RB * G::NLL;
     static_assert(WBITS % 32 >= 2 && NW - 2 == WBITS / 32, "window geometry");
@@ -232,7 +252,7 @@ PAI_DEV void pack_row(const uint32_t (&x)[G::NLL], uint32_t* stage) {
 #pragma unroll
     for (int i = NW - 1; i >= 1; --i) w[i] = (uint32_t)((((uint64_t)w[i] << 32) | w[i - 1]) >> (32u - s));
     w[0] <<= s;
-    uint32_t* row = stage + G::elem() * G::SW + k0;
+    uint32_t* row = rowbase + k0;
     wave_lds_fence();
     if constexpr (G::T > 1) {
         // This lane owns the words that START inside its window: own = k0(t + 1) - k0(t) of them (NW - 2 or NW - 1).
@@ -250,11 +270,15 @@ PAI_DEV void pack_row(const uint32_t (&x)[G::NLL], uint32_t* stage) {
     }
 }
 
+template <class G>
+PAI_DEV void pack_row(const uint32_t (&x)[G::NLL], uint32_t* stage) {
+    pack_row_at<G>(x, stage + G::elem() * G::SW);
+}
+
 // this wave's staged rows -> `rows` consecutive packed rows at dst, coalesced full-width stores
 template <class G>
-PAI_DEV void store_tile(const uint32_t* stage, uint32_t* __restrict__ dst, int rows, int W32) {
+PAI_DEV void store_tile_at(const uint32_t* src, uint32_t* __restrict__ dst, int rows, int W32) {
     using WT = WaveTile<G>;
-    const uint32_t* src = WT::slice(const_cast<uint32_t*>(stage));
     const int lane = WT::lane();
     wave_lds_fence();
     if ((W32 & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
@@ -283,6 +307,11 @@ PAI_DEV void store_tile(const uint32_t* stage, uint32_t* __restrict__ dst, int r
         }
     }
     wave_lds_fence();
+}
+
+template <class G>
+PAI_DEV void store_tile(const uint32_t* stage, uint32_t* __restrict__ dst, int rows, int W32) {
+    store_tile_at<G>(WaveTile<G>::slice(const_cast<uint32_t*>(stage)), dst, rows, W32);
 }
 
 // publish this lane's slice as the element's multiplier operand b in LDS

@@ -128,6 +128,104 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_modmul on WAVE REGIONS (round 4): the same products with one private LDS region per wave that is time-shared between
+// the packed rows of a tile (load_tile_at / pack_row_at / store_tile_at) and the limb-form multiplier operand
+// ([limb][element-of-the-wave], stride EPW) — 9.2 KB per wave at 36 x 4 instead of 8.4 KB staging + 9.2 KB operand
+// buffer — with the modulus slice re-read from LDS (NmLds): 40 KB of LDS per workgroup and <= 168 VGPRs, i.e. THREE (or
+// four) waves per SIMD instead of two at 254 VGPRs + scratch.  A wave still runs load -> product -> store serially; the
+// memory phases of one wave are now covered by the products of two or three others, and the products issue at the
+// multi-wave rate (4.4-4.5 cycles per v_mad_u64_u32 instead of 4.8 at two waves: profiles/r04/ubench_valu_sustained.jsonl).
+#ifndef PAI_MODMUL_W_WAVES
+#define PAI_MODMUL_W_WAVES 3
+#endif
+template <class G>
+struct ModmulW {
+    using WT = WaveTile<G>;
+    static constexpr int WPB = BLOCK_THREADS / 64;
+    static constexpr int REG = (G::NL * WT::EPW > WT::EPW * G::SW) ? G::NL * WT::EPW : WT::EPW * G::SW;   // words per wave region
+    static constexpr int LDS_WORDS = (2 + WPB) * G::NL + WPB * REG;     // modulus, R^2, one broadcast operand per wave, the regions
+    static constexpr int LDS_BYTES = LDS_WORDS * 4;
+};
+
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_MODMUL_W_WAVES)
+k_modmul_w(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
+           int n, int w32, int b_bcast, int mode) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using WT = WaveTile<G>;
+    using MW = ModmulW<G>;
+    uint32_t* nm_lds = lds;
+    uint32_t* r2_lds = lds + G::NL;
+    uint32_t* bc_lds = lds + 2 * G::NL + WT::wave() * G::NL;             // this wave's broadcast operand (limb form, stride 1)
+    uint32_t* reg = lds + (2 + MW::WPB) * G::NL + WT::wave() * MW::REG;  // this wave's region
+    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) { nm_lds[i] = ctx->n[i]; r2_lds[i] = ctx->r2[i]; }
+    __syncthreads();
+    typename G::NM nm;
+    if constexpr (G::NMLDS) nm.p = nm_lds + G::NLL * G::gl();
+    else load_const_slice<G>(nm.v, ctx->n);
+    const uint32_t n0inv = ctx->n0inv;
+    const int el = WT::lane() / G::T;                                    // element of this lane group within the wave
+    uint32_t* myrow = reg + el * G::SW;                                  // its packed row while the region holds a tile
+    const uint32_t* b_col = reg + el;                                    // its column while the region holds limbs
+    const int wtiles = (n + WT::EPW - 1) / WT::EPW;
+    if (b_bcast) {                                                       // the shared operand, once per wave
+        uint32_t bb[G::NLL];
+        clear_row_pads<G>(reg, w32);
+        load_tile_at<G>(reg, b, 1, w32, true);
+        unpack_row_at<G>(bb, myrow);
+        if (mode == MODMUL_FULL) {                                       // b R: a broadcast addend then costs ONE product per element
+            uint32_t t[G::NLL];
+            mont_mul<G::NLL, G::U, G::T>(t, bb, r2_lds, 1, nm, n0inv);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) bb[j] = t[j];
+        }
+        wave_lds_fence();
+        if (el == 0) {
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) bc_lds[G::NLL * G::gl() + j] = bb[j];
+        }
+        wave_lds_fence();
+    }
+    const int npass = (mode == MODMUL_FULL && !b_bcast) ? 2 : 1;
+    const int per_wave = (wtiles + (int)gridDim.x * MW::WPB - 1) / ((int)gridDim.x * MW::WPB);
+    const int wt_begin = ((int)blockIdx.x * MW::WPB + WT::wave()) * per_wave;
+    const int wt_end = min(wtiles, wt_begin + per_wave);
+    for (int wt = wt_begin; wt < wt_end; ++wt) {
+        const int row0 = wt * WT::EPW;
+        const int rows = min(WT::EPW, n - row0);
+        uint32_t x[G::NLL];
+        __builtin_amdgcn_s_setprio(2);
+        clear_row_pads<G>(reg, w32);
+        load_tile_at<G>(reg, a + (size_t)row0 * w32, rows, w32);
+        unpack_row_at<G>(x, myrow);
+        if (!b_bcast) {
+            uint32_t y[G::NLL];
+            load_tile_at<G>(reg, b + (size_t)row0 * w32, rows, w32);     // (fences inside: every lane has read its window of a)
+            unpack_row_at<G>(y, myrow);
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) reg[(G::NLL * G::gl() + j) * WT::EPW + el] = y[j];   // limb form over the packed rows
+            wave_lds_fence();
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll 1
+        for (int pass = 0; pass < npass; ++pass) {
+            uint32_t r[G::NLL];
+            const uint32_t* bp = pass == 0 ? (b_bcast ? bc_lds : b_col) : r2_lds;
+            mont_mul<G::NLL, G::U, G::T>(r, x, bp, (pass == 0 && !b_bcast) ? WT::EPW : 1, nm, n0inv);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
+        }
+        cond_sub<G::NLL, G::T>(x, nm);
+        __builtin_amdgcn_s_setprio(2);
+        wave_lds_fence();
+        pack_row_at<G>(x, myrow);
+        store_tile_at<G>(reg, out + (size_t)row0 * w32, rows, w32);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fixed-window (W bits) exponentiation with a wave-uniform exponent.  The 2^W-entry table of each
 // resident element lives in a global scratch area laid out [entry][limb][slot] so that a wave reads
 // one entry with coalesced 128/256-byte rows; slot = blockIdx.x*EPB + element.

@@ -53,3 +53,25 @@ def test_missing_library_is_an_import_error(native, monkeypatch, tmp_path):
     monkeypatch.setattr(native, "LIB_PATH", tmp_path / "libpaillier_hip.so")
     with pytest.raises(ImportError, match="no CPU fallback"):
         native.load()
+
+
+def test_host_side_under_asan_ubsan():
+    """sanitizer pass over the native host code (key generation, host big integers, shard plans, failure
+    paths).  Builds the ASan + UBSan variant of csrc/paillier_capi.hip (host pass only, ~15 s) and runs the host-only
+    entry points on it in a child process with the sanitizer runtime preloaded.  PAI_SKIP_ASAN=1 skips it."""
+    import glob
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("PAI_SKIP_ASAN") == "1":
+        pytest.skip("PAI_SKIP_ASAN=1")
+    if not glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"):
+        pytest.skip("no clang ASan runtime in this image")
+    from pailliercryptolib_python_amd import build
+
+    build.build_native()
+    res = subprocess.run(["bash", str(ROOT / "tools" / "asan_host_build.sh")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    res = subprocess.run([sys.executable, str(ROOT / "tools" / "asan_host_run.py")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "asan host run: ok" in res.stdout, (res.stdout + res.stderr)[-3000:]
