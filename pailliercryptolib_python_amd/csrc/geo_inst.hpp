@@ -1,5 +1,7 @@
 // Instantiates every kernel for one geometry and fills its GeoOps table.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include "geo_ops.hpp"
 #include "kernels_modexp.hpp"
 
@@ -13,7 +15,7 @@
 #define PAI_TILE_NMLDS false
 #endif
 #ifndef PAI_MODMUL_W
-#define PAI_MODMUL_W true
+#define PAI_MODMUL_W false     // measured (profiles/r04/ctadd_ab_*.jsonl): 2.14-2.35 ms per 2^20 against 1.98 ms of the staged 36 x 4 kernel
 #endif
 #ifndef PAI_MODMUL_W_SPLIT8
 #define PAI_MODMUL_W_SPLIT8 true
@@ -31,6 +33,17 @@ struct GeoInst {
     static void set_lds(const void* fn, int bytes) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
+    // PAI_DEBUG_OCC=1: print the resident workgroups per CU the runtime computes for a kernel (dev probe)
+    static void report_occupancy(const char* name, const void* fn, int bytes) {
+        static const bool on = [] { const char* e = std::getenv("PAI_DEBUG_OCC"); return e && e[0] == '1'; }();
+        if (!on) return;
+        int nb = -1;
+        hipFuncAttributes fa;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK_THREADS, (size_t)bytes);
+        (void)hipFuncGetAttributes(&fa, fn);
+        fprintf(stderr, "PAI_OCC %s<%dx%d>: blocks/CU=%d lds=%d B regs=%d scratch=%zu B\n", name, G::NLL, G::T, nb, bytes, fa.numRegs,
+                (size_t)fa.localSizeBytes);
+    }
     // wave-region form (kernels_modexp.hpp: k_modmul_w) for the lane-group geometries with canonical contexts; the
     // single-lane and minus-one geometries keep the staged form
     // 144-limb moduli (n^2 of 2048-bit keys) run it on EIGHT lanes of 18 limbs: ~110 VGPRs and 4.6 KB of LDS per wave, so
@@ -44,10 +57,12 @@ struct GeoInst {
         if constexpr (MODMUL_W) {
             constexpr int bytes = ModmulW<GW>::LDS_BYTES;
             set_lds((const void*)k_modmul_w<GW>, bytes);
+            report_occupancy("k_modmul_w", (const void*)k_modmul_w<GW>, bytes);
             hipLaunchKernelGGL(k_modmul_w<GW>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
         } else {
             constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
             set_lds((const void*)k_modmul<GM>, bytes);
+            report_occupancy("k_modmul", (const void*)k_modmul<GM>, bytes);
             hipLaunchKernelGGL(k_modmul<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
         }
     }

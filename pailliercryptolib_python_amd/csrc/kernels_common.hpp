@@ -169,6 +169,39 @@ template <class G>
 PAI_DEV void load_tile(uint32_t* stage, const uint32_t* __restrict__ src, int rows, int W32, bool bcast = false) {
     load_tile_at<G>(WaveTile<G>::slice(stage), src, rows, W32, bcast);
 }
+// The two halves of load_tile for aligned rows (W32 % 4 == 0, 16-byte aligned source): tile_fetch issues the tile's global
+// loads into registers and returns at once, tile_commit writes them to the wave's staging slice — so the loads of SEVERAL
+// tiles can be in flight together (one memory latency per set of operands instead of one per operand).
+template <class G>
+PAI_DEV void tile_fetch(uint4 (&v)[WaveTile<G>::IT4], const uint32_t* __restrict__ src, int rows, int W32) {
+    using WT = WaveTile<G>;
+    const int lane = WT::lane();
+    const int total = rows * (W32 >> 2);
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+    for (int it = 0; it < WT::IT4; ++it) {
+        const int c = lane + it * 64;
+        v[it] = s4[c < total ? c : total - 1];
+    }
+}
+template <class G>
+PAI_DEV void tile_commit(uint32_t* stage, const uint4 (&v)[WaveTile<G>::IT4], int rows, int W32) {
+    using WT = WaveTile<G>;
+    uint4* d4 = reinterpret_cast<uint4*>(WT::slice(stage));
+    const int lane = WT::lane();
+    const int wv = W32 >> 2;
+    const int total = rows * wv;
+    const uint32_t inv = (65536u + (uint32_t)wv - 1u) / (uint32_t)wv;
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < WT::IT4; ++it) {
+        const int c = lane + it * 64;
+        const int e = (int)(((uint32_t)c * inv) >> 16), k = c - e * wv;
+        if (c < total) d4[e * WT::SV + k] = v[it];
+    }
+    wave_lds_fence();
+}
+
 // zeroes the pad words behind the W32 data words of every row of a wave's region (regions that are time-shared with
 // limb-form operands lose the zeros clear_stage wrote)
 template <class G>

@@ -42,6 +42,17 @@ namespace pai {
 #define PHASE_REPORT(name) do { } while (0)
 #endif
 
+#ifndef PAI_MODMUL_LOAD2
+#define PAI_MODMUL_LOAD2 0
+#endif
+#ifndef PAI_MODMUL_PRIO
+#define PAI_MODMUL_PRIO 1
+#endif
+#if PAI_MODMUL_PRIO
+#define PAI_MODMUL_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define PAI_MODMUL_SETPRIO(p) do { } while (0)
+#endif
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
@@ -91,19 +102,37 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
         // The tile I/O phases are short on VALU work and long on memory latency: they run at raised priority so that
         // the multiply stream of the other wave on this SIMD does not starve their address arithmetic (VALU
         // arbitration is priority, then age); the products run at base priority.
-        __builtin_amdgcn_s_setprio(2);
-        if (!b_bcast) {
-            load_tile<G>(stage, b + (size_t)row0 * w32, rows, w32);
+        PAI_MODMUL_SETPRIO(2);
+#if PAI_MODMUL_LOAD2
+        const bool fast = (w32 & 3) == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+        if (!b_bcast && fast) {
+            // both operands' global loads in flight together: one memory latency per tile instead of two
+            uint4 va[WT::IT4], vb[WT::IT4];
+            tile_fetch<G>(vb, b + (size_t)row0 * w32, rows, w32);
+            tile_fetch<G>(va, a + (size_t)row0 * w32, rows, w32);
+            tile_commit<G>(stage, vb, rows, w32);
             PHASE_MARK(2);
             unpack_row<G>(x, stage);
             stage_b<G>(x, lds);
             PHASE_MARK(3);
+            tile_commit<G>(stage, va, rows, w32);
+            PHASE_MARK(0);
+        } else
+#endif
+        {
+            if (!b_bcast) {
+                load_tile<G>(stage, b + (size_t)row0 * w32, rows, w32);
+                PHASE_MARK(2);
+                unpack_row<G>(x, stage);
+                stage_b<G>(x, lds);
+                PHASE_MARK(3);
+            }
+            load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
+            PHASE_MARK(0);
         }
-        load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
-        PHASE_MARK(0);
         unpack_row<G>(x, stage);
         PHASE_MARK(1);
-        __builtin_amdgcn_s_setprio(0);
+        PAI_MODMUL_SETPRIO(0);
 #pragma unroll 1
         for (int pass = 0; pass < npass; ++pass) {
             uint32_t r[G::NLL];
@@ -114,7 +143,7 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
             PHASE_MARK(4 + pass);
         }
         cond_sub<G::NLL, G::T>(x, nm);
-        __builtin_amdgcn_s_setprio(2);
+        PAI_MODMUL_SETPRIO(2);
         PHASE_MARK(6);
         pack_row<G>(x, stage);
         PHASE_MARK(7);
@@ -123,7 +152,7 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
 #endif
         PHASE_MARK(8);
     }
-    __builtin_amdgcn_s_setprio(0);
+    PAI_MODMUL_SETPRIO(0);
     PHASE_REPORT("k_modmul");
 }
 

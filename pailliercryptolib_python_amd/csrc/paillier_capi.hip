@@ -448,6 +448,7 @@ struct pai_pubkey {
     uint32_t* d_tree_c = nullptr;
     uint32_t* d_tree_fix = nullptr;
     mutable bool fb_ready = false;     // fixed-base tables are built by the first obfuscating call (build_fb_tables)
+    mutable size_t fb_bytes = 0;       // device bytes of the built tables (the per-device table cache accounts with it)
     // latency path of ct * pt (small batches): n^2 on a wide-group geometry, built by the first small call
     mutable bool lat_ready = false, lat_usable = false;
     mutable ModSetup lat_msq;
@@ -964,12 +965,76 @@ static bool ensure_lat_ctx(const pai_pubkey* pk) {
 // Fixed-base tables of the DJN obfuscator hs^r, built by the FIRST call that obfuscates (pai_encrypt with
 // randomness / pai_obfuscate), under pk->mu: a handle that only adds, multiplies or decrypts — every unpickled
 // ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
+// ---- per-device cache of the DJN fixed-base tables (round 4) ---------------------------------------------------
+// Every DJN key builds a multi-GB table on its first obfuscating call.  A process that holds many keys (federated
+// learning: one key per party or per round) used to need pai_pubkey_trim by hand; now the handles with built tables of a
+// device form an LRU list under a byte budget — PAI_FB_CACHE_MB, default half of the device memory — and a build that
+// would pass the budget first returns the tables of the least recently used handles (which rebuild on their next
+// obfuscating call, bit-identical).  Lock order: own pk->mu, then the registry, then try_lock of a victim (a busy victim
+// is skipped, never waited for).
+struct FbRegistry {
+    std::mutex mu;
+    std::vector<pai_pubkey*> lru;      // most recently used last
+};
+static FbRegistry g_fb;
+static size_t fb_cache_budget(size_t mem_total) {
+    if (const char* env = std::getenv("PAI_FB_CACHE_MB")) { double v = std::atof(env); if (v >= 1.0) return (size_t)(v * 1048576.0); }
+    return mem_total / 2;
+}
+static void fb_free_tables(pai_pubkey* pk) {          // caller holds pk->mu and has synchronised the device
+    if (pk->d_fb) { (void)hipFree(pk->d_fb); pk->d_fb = nullptr; }
+    if (pk->d_fb_dig) { (void)hipFree(pk->d_fb_dig); pk->d_fb_dig = nullptr; }
+    if (pk->d_pair_fb) { (void)hipFree(pk->d_pair_fb); pk->d_pair_fb = nullptr; }
+    pk->fb_ready = false;
+    pk->fb_bytes = 0;
+}
+static void fb_unregister(pai_pubkey* pk) {
+    std::lock_guard<std::mutex> g(g_fb.mu);
+    g_fb.lru.erase(std::remove(g_fb.lru.begin(), g_fb.lru.end(), pk), g_fb.lru.end());
+}
+static void fb_touch(pai_pubkey* pk) {                // caller holds pk->mu
+    std::lock_guard<std::mutex> g(g_fb.mu);
+    auto it = std::find(g_fb.lru.begin(), g_fb.lru.end(), pk);
+    if (it != g_fb.lru.end() && it + 1 != g_fb.lru.end()) std::rotate(it, it + 1, g_fb.lru.end());
+}
+// makes room for `need` more table bytes on pk's device; returns the bytes it freed
+static size_t fb_make_room(pai_pubkey* pk, size_t need, size_t mem_total) {
+    const size_t budget = fb_cache_budget(mem_total);
+    size_t freed = 0;
+    std::lock_guard<std::mutex> g(g_fb.mu);
+    size_t used = 0;
+    for (pai_pubkey* o : g_fb.lru) if (o->device == pk->device) used += o->fb_bytes;
+    for (size_t i = 0; i < g_fb.lru.size() && used + need > budget;) {
+        pai_pubkey* v = g_fb.lru[i];
+        if (v == pk || v->device != pk->device || !v->mu.try_lock()) { ++i; continue; }
+        (void)hipDeviceSynchronize();                  // nothing in flight may still read the victim's tables
+        used -= std::min(used, v->fb_bytes);
+        freed += v->fb_bytes;
+        fb_free_tables(v);
+        v->mu.unlock();
+        g_fb.lru.erase(g_fb.lru.begin() + (long)i);
+    }
+    return freed;
+}
+
 static void build_fb_tables_body(pai_pubkey* pk);
 void build_fb_tables(const pai_pubkey* cpk) {
     pai_pubkey* pk = const_cast<pai_pubkey*>(cpk);
-    if (pk->fb_ready || !pk->djn) return;
+    if (!pk->djn) return;
+    if (pk->fb_ready) { fb_touch(pk); return; }
+    size_t mem_free_b = 0, mem_total_b = 0;
+    HIP_CHECK(hipMemGetInfo(&mem_free_b, &mem_total_b));
+    // the largest table the sizing rules below produce is 1/32 of the device memory (PAI_FB_TABLE_MB may ask for more)
+    size_t need = mem_total_b / 32;
+    if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) need = (size_t)(v * 1048576.0); }
+    fb_make_room(pk, need, mem_total_b);
     try {
         build_fb_tables_body(pk);
+        size_t mem_free_a = 0;
+        HIP_CHECK(hipMemGetInfo(&mem_free_a, &mem_total_b));
+        pk->fb_bytes = mem_free_b > mem_free_a ? mem_free_b - mem_free_a : 0;   // (after any eviction: a lower bound then; the tables dominate)
+        std::lock_guard<std::mutex> g(g_fb.mu);
+        g_fb.lru.push_back(pk);
     } catch (...) {
         // a failed build (out of memory under pressure, a HIP error between the table allocation and fb_ready) must not
         // leave a multi-GB table behind: the next obfuscating call would allocate over the dangling pointer
@@ -1206,6 +1271,7 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
 
 void pai_pubkey_destroy(pai_pubkey* pk) {
     if (!pk) return;
+    fb_unregister(pk);
     int prev_ = -1;
     (void)hipGetDevice(&prev_);
     (void)hipSetDevice(pk->device);
@@ -1262,10 +1328,8 @@ int pai_pubkey_trim(pai_pubkey* pk, size_t* freed_bytes) {
         size_t before = 0, after = 0, total = 0;
         HIP_CHECK(hipMemGetInfo(&before, &total));
         // the DJN fixed-base tables (rebuilt by the next obfuscating call) ...
-        if (pk->d_fb) { (void)hipFree(pk->d_fb); pk->d_fb = nullptr; }
-        if (pk->d_fb_dig) { (void)hipFree(pk->d_fb_dig); pk->d_fb_dig = nullptr; }
-        if (pk->d_pair_fb) { (void)hipFree(pk->d_pair_fb); pk->d_pair_fb = nullptr; }
-        pk->fb_ready = false;
+        fb_unregister(pk);
+        fb_free_tables(pk);
         if (pk->d_lat_fb) { (void)hipFree(pk->d_lat_fb); pk->d_lat_fb = nullptr; }
         if (pk->d_lat_nR) { (void)hipFree(pk->d_lat_nR); pk->d_lat_nR = nullptr; }
         pk->lat_fb_ready = false;

@@ -763,3 +763,41 @@ def test_async_invert_and_sticky_status():
     assert st.value == 0
     rows = engine.words_to_ints(engine.to_host_words(big[[0, 5]]))
     assert rows == [pow(vals[0], 1 << 9, key.nsq), pow(vals[0], 1 << 20, key.nsq)]
+
+
+def test_fixed_base_table_cache_evicts_least_recently_used(monkeypatch):
+    """Per-device LRU of the DJN fixed-base tables under a byte budget (PAI_FB_CACHE_MB): with room for one table, a
+    second key's first obfuscating call returns the first key's table; the first key rebuilds on its next call and
+    produces the same ciphertext bits; device memory in use stays bounded; trim()/destroy keep the list consistent."""
+    import torch
+
+    from pailliercryptolib_python_amd import engine
+
+    monkeypatch.setenv("PAI_FB_TABLE_MB", "256")
+    monkeypatch.setenv("PAI_FB_CACHE_MB", "400")
+    fx = json.loads((Path(__file__).parent / "golden" / "fixture_keys.json").read_text())
+    keys = [orc.make_key(int(fx["1024"]["p"], 16), int(fx["1024"]["q"], 16), djn_x=x, bits=1024) for x in (3, 5, 7)]
+    pubs = [engine.PublicKeyHandle(k.n, 1024, k.hs, k.randbits, device="cuda:0") for k in keys]
+    N = 5000                                                        # beyond the small-batch path: the big tables are used
+    m = engine.to_device_words(ints_to_limbs([12345 + i for i in range(N)], pubs[0].n_words), pubs[0].device)
+    r_l = orc.synth_r_limbs(5, N, keys[0].randbits)
+    r = engine.to_device_words(r_l, pubs[0].device)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    first = [None, None, None]
+    for rnd in range(2):
+        for i, pub in enumerate(pubs):
+            ct = pub.encrypt(m, r)
+            torch.cuda.synchronize()
+            if first[i] is None:
+                first[i] = ct.clone()
+                want = orc.encrypt(keys[i], 12345, orc.limbs_to_ints(r_l[:1])[0])
+                assert engine.words_to_ints(engine.to_host_words(ct[:1]))[0] == want
+            else:
+                assert torch.equal(ct, first[i])                    # rebuilt table, same bits
+            used = free0 - torch.cuda.mem_get_info()[0]
+            assert used < 700 * (1 << 20), f"tables of evicted keys are still resident: {used >> 20} MiB"
+    assert pubs[0].trim() >= 0
+    ct = pubs[0].encrypt(m, r)
+    assert torch.equal(ct, first[0])
+    del pubs
