@@ -86,6 +86,7 @@ constexpr int PADIC_TBL_ENTRIES = 1 << (PADIC_SLIDE_BITS - 1);    // odd powers
 int padic_nl_for_prime_bits(int bits);
 size_t padic_table_words(int nl, size_t blocks);
 size_t padic_scratch_words(int nl, size_t blocks);
+int padic_blocks_per_cu(int nl);           // resident workgroups per CU of the stage-A kernel for this limb count
 bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
                         uint32_t* u_out, int n, uint32_t* table);
 

@@ -105,9 +105,11 @@ PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const u
 // vs 391 ms; 56 limbs (squaring as product, LDS-qualified accesses) 142 vs 151 ms
 #define PADIC_SGPR_MODULUS(NL) 1
 #endif
-constexpr int PADIC_LDS_M = 0, PADIC_WBUF = 2;
+// MODE PADIC_REGM (round 4): LDS holds only the digit pair; the squaring keeps its quotient digits in registers
+//                   (Padic::sqr_regm), the product parks them in a strided global scratch column: two workgroups per CU.
+constexpr int PADIC_LDS_M = 0, PADIC_REGM = 1, PADIC_WBUF = 2;
 template <int NL, int U, int WB, int MODE>
-__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+__global__ void __launch_bounds__(BLOCK_THREADS, MODE == PADIC_REGM ? 2 : 1)
 k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n,
               uint4* __restrict__ table) {
     using E = Padic<NL, U, (NL >= PADIC_XLDS_FROM)>;
@@ -144,7 +146,9 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const typename E::MBuf M = MODE != PADIC_LDS_M ? typename E::MBuf{P.wscratch + slot, nslots} : typename E::MBuf{B + E::NC * 64, 64};
     const typename E::MBuf Wb{P.wscratch + (size_t)E::NC * nslots + slot, nslots};      // MODE 2 only
     auto SQR = [&]() {
-        if constexpr (MODE == PADIC_WBUF && NL > PADIC_SQR_MUL_ABOVE) {
+        if constexpr (MODE == PADIC_REGM) {
+            E::sqr_regm(A, B, nm, pm1, n0inv);
+        } else if constexpr (MODE == PADIC_WBUF && NL > PADIC_SQR_MUL_ABOVE) {
             // Wide digits: the fully unrolled limb-class symmetric squaring (sqr_wbuf) is 62 KB of code at 72 limbs
             // (beyond the instruction cache), and at 56 limbs it made the compiler lose the LDS address space of the
             // whole kernel (flat loads); round 1 therefore squared as a product (mul_wbuf(x, x), 5 NL^2).

@@ -431,7 +431,7 @@ PAI_DEV void mont_mul_m1(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uin
 // of the group's last lane) and is never stored.
 // (a, b) in registers (lane slices), (c, d) as LDS rows c_ptr / d_ptr [limb * stride], M - 1 as LDS limbs (uniform).
 // Inputs lazy (< 2M + eps), outputs lazy; R / M >= 2^20 required.
-constexpr int PAIR_NORM_MAX = 16;              // three 2^58 products per row and column: 16 rows stay below 2^64
+constexpr int PAIR_NORM_MAX = 18;              // three 2^58 products per row and column: 18 rows (54 x 2^58 + the normalised rest < 2^29 + 2^35) stay below 2^64
 
 // sqr (wave-uniform): the rows at c_ptr / d_ptr are (a, b) themselves — a d + b c is then 2 a d, one multiply-accumulate
 // per limb pair less (4 NL^2 instead of 5 NL^2); both forms share this one body.

@@ -802,6 +802,42 @@ struct Padic {
         else sqr_sym_wbuf(A, B, M, Wb, nm, pm1, n0inv);
     }
 
+    // (A, B) <- (A, B)^2 with the quotient digits of the first half in REGISTERS: both halves of the squaring are fully
+    // unrolled anyway (mm1_sqr_blocks / mm2_sqr), so m[] is indexed statically and never needs a buffer.  With the
+    // product's quotient digits parked in a global scratch column (mul() on a strided MBuf) the LDS then holds only the
+    // digit pair itself: 2 x NL limbs per lane, 72 KB per workgroup at 36 limbs — TWO workgroups per CU (round 4,
+    // kernels_padic.hpp MODE PADIC_REGM).  Unlike sqr_lean the first result digit w stays in registers too.
+    PAI_DEV static void sqr_regm(uint4* A, uint4* B, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
+                                 uint32_t n0inv) {
+        uint32_t m[NL], w[NL], v[NL];
+        {
+            uint64_t acc[NW];
+            zero(acc);
+            int none = 0;
+            mm1_unrolled<0, true>(acc, m, A, none, nm, n0inv);
+            finish(acc, w);
+        }
+        {
+            uint64_t acc[NW];
+            init_from_m(acc, m);
+            uint32_t dummy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dummy[u] = 0;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                uint32_t xv[U], q[U];
+                digits(B, blk, xv);
+                block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);   // HI = 0: every limb doubled
+                if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
+            }
+            finish(acc, v);
+        }
+        wave_lds_fence();
+        store_digit(A, w);
+        store_digit(B, v);
+        wave_lds_fence();
+    }
+
     // (A, B) <- (A, B)^2
     PAI_DEV static void sqr(uint4* A, uint4* B, MBuf M, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
                             uint32_t n0inv) {

@@ -16,9 +16,18 @@ int padic_nl_for_prime_bits(int bits) {
     return 0;
 }
 size_t padic_table_words(int nl, size_t blocks) { return (size_t)(PADIC_TBL_ENTRIES + 1) * 2 * nl * blocks * BLOCK_THREADS; }
-size_t padic_scratch_words(int nl, size_t blocks) { return nl <= 36 ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS; }
+#ifndef PADIC_DEC36_MODE
+#define PADIC_DEC36_MODE PADIC_LDS_M      // PADIC_REGM: digit pair only in LDS, two workgroups per CU (A/B: tools/variant_dec.sh)
+#endif
+int padic_blocks_per_cu(int nl) { return (nl <= 36 && PADIC_DEC36_MODE == PADIC_REGM) ? 2 : 1; }
+size_t padic_scratch_words(int nl, size_t blocks) {
+    return (nl <= 36 && PADIC_DEC36_MODE != PADIC_REGM) ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS;
+}
 #ifndef PADIC_U72
 #define PADIC_U72 8
+#endif
+#ifndef PADIC_U36
+#define PADIC_U36 12     // row-block size of the 36-limb decrypt kernel (A/B r04: 4-row blocks, profiles/r04/README.md)
 #endif
 template <int NL, int U, int MODE>
 static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table) {
@@ -30,8 +39,8 @@ static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, cons
 bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
                         uint32_t* u_out, int n, uint32_t* table) {
     switch (nl) {
-        case 24: launch_padic<24, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
-        case 36: launch_padic<36, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
+        case 24: launch_padic<24, 12, PADIC_DEC36_MODE>(s, gridx, P, ct, u_out, n, table); return true;
+        case 36: launch_padic<36, PADIC_U36, PADIC_DEC36_MODE>(s, gridx, P, ct, u_out, n, table); return true;
         case 56: launch_padic<56, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
         case 72: launch_padic<72, PADIC_U72, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
         default: return false;

@@ -1386,6 +1386,12 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
             }
         }
         if (pk->lat_usable && !pk->lat_fb_ready) {
+            // window width of the small-batch table: every window is one sequential product (~11 us at 2048-bit keys) of
+            // the call's latency; 12 bits = 86 windows x 4096 entries (0.2 GB at 2048-bit keys; 10 bits: 103 windows, 60 MB;
+            // 14 bits: 74 windows, 0.7 GB).  PAI_LAT_FB_WBITS pins it (4..16).
+            int lw = 12;
+            if (const char* env = std::getenv("PAI_LAT_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 16) lw = v; }
+            pk->lat_fb_wbits = lw;
             pk->lat_fb_windows = (pk->randbits + pk->lat_fb_wbits - 1) / pk->lat_fb_wbits;
             pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
             pk->d_lat_fb = build_lane_group_fb(pk, pk->lat_msq, pk->lat_fb_wbits, pk->lat_fb_windows);
@@ -2387,7 +2393,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         int gridx = grid_for(ga, N, dev.ncu, 1);          // x2 primes => 2 workgroups per CU
         if (sk->padic_nl) {
             const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
-            const size_t per_prime = (size_t)dev.ncu / 2;                                         // x2 primes => one workgroup per CU
+            const size_t per_prime = (size_t)dev.ncu * (size_t)padic_blocks_per_cu(sk->padic_nl) / 2;   // x2 primes => one (or two) workgroups per CU
             gridx = (int)std::max<size_t>(1, std::min<size_t>(tiles, per_prime));
             sk->table.ensure(padic_table_words(sk->padic_nl, (size_t)gridx * 2) * 4);
             if (const size_t sw = padic_scratch_words(sk->padic_nl, (size_t)gridx * 2)) sk->wscratch.ensure(sw * 4);

@@ -801,3 +801,19 @@ def test_fixed_base_table_cache_evicts_least_recently_used(monkeypatch):
     ct = pubs[0].encrypt(m, r)
     assert torch.equal(ct, first[0])
     del pubs
+
+
+@pytest.mark.parametrize("wbits", [5, 10, 14])
+def test_small_batch_table_widths_give_the_same_bits(wbits, monkeypatch):
+    """PAI_LAT_FB_WBITS: the window width of the small-batch DJN table (default 12 bits) only trades memory for latency."""
+    monkeypatch.setenv("PAI_LAT_FB_WBITS", str(wbits))
+    monkeypatch.setenv("PAI_LATENCY_MAX", "100000")
+    nk = NativeKey(bench_key())
+    key = nk.key
+    N = 21
+    m = plaintexts(key, N, 77 + wbits)
+    r = orc.synth_r_limbs(500 + wbits, N, key.randbits)
+    want = [orc.encrypt(key, x, rr) for x, rr in zip(m, orc.limbs_to_ints(r))]
+    dm, dr, ct = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r), DevArray(shape=(N, nk.cw))
+    _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+    assert limbs_to_ints(ct.get()) == want
