@@ -71,7 +71,7 @@ def test_bench_single_gpu_config_lines_carry_roofline_and_cpu_baseline():
     """`python bench.py --config cfg5` (and cfg4) on one GPU: a line with roofline + cpu_baseline for the 4096 / 3072-bit
     configurations (small batch here; the driver runs the full sizes)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PAI_BENCH_BACKEND")}
-    for config, bits, nl in (("cfg5", 4096, 72), ("cfg4", 3072, 56)):
+    for config, bits, nl, prof_batch in (("cfg5", 4096, 72, 1 << 18), ("cfg4", 3072, 56, 1 << 20)):
         cmd = [sys.executable, str(ROOT / "bench.py"), "--config", config, "--batch", "4096", "--steps", "1", "--warmup", "1",
                "--no-extras", "--cpu-seconds", "2"]
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
@@ -80,7 +80,7 @@ def test_bench_single_gpu_config_lines_carry_roofline_and_cpu_baseline():
         assert line["config"]["key_bits"] == bits and f"{bits}-bit key" in line["metric"] and line["parity_checked"] is True
         rf, cpu = line["roofline"], line["cpu_baseline"]
         assert f"k_dec_a_padic<{nl}>" in rf["kernel"] and 0 < rf["frac"] < 1.2 and rf["peak_sustained"] < rf["peak"]
-        assert rf["traffic"] is not None and rf["traffic_source"]["profile_batch"] == 65536
+        assert rf["traffic"] is not None and rf["traffic_source"]["profile_batch"] == prof_batch
         assert cpu["value"] > 0 and cpu["cores"] >= 1 and "port" in cpu["kind"]
 
 
