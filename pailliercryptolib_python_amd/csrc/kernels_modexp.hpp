@@ -48,6 +48,9 @@ namespace pai {
 #ifndef PAI_MODMUL_PRIO
 #define PAI_MODMUL_PRIO 1
 #endif
+#ifndef PAI_MODMUL_STAGGER
+#define PAI_MODMUL_STAGGER 0      // s_sleep(127) units (~3.4 us each) the odd-slot wave of a SIMD waits before its first tile
+#endif
 #if PAI_MODMUL_PRIO
 #define PAI_MODMUL_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
 #else
@@ -94,6 +97,17 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
     const int per_wave = (wtiles + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
     const int wt_begin = ((int)blockIdx.x * WPB + WT::wave()) * per_wave;
     const int wt_end = min(wtiles, wt_begin + per_wave);
+#if PAI_MODMUL_STAGGER
+    // Every wave alternates a memory phase (tile loads / stores) with a product phase, all tiles cost the same, and all
+    // waves start together: left alone the whole chip runs in LOCKSTEP — two waves of a SIMD wait on memory at the same
+    // time (SIMD idle, HBM hit by every wave at once), then share the multiplier.  The wave in the odd hardware slot of
+    // its SIMD therefore starts half a product late: the pair settles in anti-phase, one wave's memory phase under the
+    // other's products.
+    if (per_wave > 1 && (__builtin_amdgcn_s_getreg(6148) & 1)) {            // HW_REG_HW_ID[3:0] = wave slot on the SIMD
+#pragma unroll 1
+        for (int k = 0; k < PAI_MODMUL_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     for (int wt = wt_begin; wt < wt_end; ++wt) {
         const int row0 = wt * WT::EPW;
         const int rows = min(WT::EPW, n - row0);
