@@ -20,6 +20,10 @@
 #pragma once
 #include "mont_dev.hpp"
 
+#ifndef PADIC_FENCE_CHUNKS
+#define PADIC_FENCE_CHUNKS 0       // 1: the chunk-streaming (scheduler-fenced) rank update also below 48 limbs (register-lean builds)
+#endif
+
 namespace pai {
 
 // XLDS: digit-buffer accesses through LDS-qualified pointers instead of leaving it to address-space inference.  One
@@ -155,7 +159,7 @@ struct Padic {
             }
         }
         // remaining chunks: a pure rank-(2U or 3U) update
-        if constexpr (NL <= 48) {
+        if constexpr (NL <= 48 && !PADIC_FENCE_CHUNKS) {
 #pragma unroll
             for (int c = UC; c < NC; ++c) {
                 uint32_t xa[4] = {0, 0, 0, 0}, ya[4] = {0, 0, 0, 0};
