@@ -113,9 +113,10 @@ k_fp_encode_at(const void* __restrict__ x_, const uint32_t* __restrict__ n_words
     }
     int shift = 0;
     const int t = target[t_bcast ? 0 : i];
-    if (t > e0) {
+    const long long dist = (long long)t - (long long)e0;      // (64-bit: any int32 pair)
+    if (dist > 0) {
         if (mant == 0) e0 = t;
-        else if (mbits + (t - e0) <= nbits - 2) { shift = t - e0; e0 = t; }
+        else if ((long long)mbits + dist <= (long long)nbits - 2) { shift = (int)dist; e0 = t; }
     }
     expo[i] = e0;
     const int ws = shift >> 5, bs = shift & 31;

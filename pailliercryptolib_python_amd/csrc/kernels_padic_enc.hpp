@@ -39,6 +39,9 @@ namespace pai {
 #ifndef PAI_FUSED_CTMUL
 #define PAI_FUSED_CTMUL true
 #endif
+#ifndef PAI_CTMUL_SQR_SYM
+#define PAI_CTMUL_SQR_SYM false
+#endif
 #ifndef PAI_FUSED_POW
 #define PAI_FUSED_POW(NL) ((NL) > 36)      // 36 limbs (1024-bit keys): r^n 25.1 ms unfused vs 29.0 fused per 65536
 #endif
@@ -435,7 +438,11 @@ k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_
 #pragma unroll 1
         for (int wi = nwin - 2; wi >= 0; --wi) {
 #pragma unroll 1
-            for (int sq = 0; sq < W; ++sq) E::template sqr_rolled_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);      // 4 NL^2 instead of the product rule's 5
+            for (int sq = 0; sq < W; ++sq) {
+                // 4 NL^2 instead of the product rule's 5; PAI_CTMUL_SQR_SYM: limb-class symmetric first half, 3.5 NL^2 (A/B r04)
+                if constexpr (PAI_CTMUL_SQR_SYM) E::template sqr_sym_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);
+                else E::template sqr_rolled_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);
+            }
             const int d = (int)window(wi);
             if (__any(d != 0)) E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_table(d, 0), from_table(d, 1), nm, nm1, n0inv);
         }
