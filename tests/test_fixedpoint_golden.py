@@ -114,3 +114,35 @@ def test_nonfinite_inputs_raise_like_the_reference():
         fp.encode_float64_array(np.array([1.0, float("nan")]), N_KEY, 64)
     with pytest.raises(OverflowError):
         fp.encode_float64_array(np.array([float("inf")]), N_KEY, 64)
+
+
+def test_align_encoded_equals_raising_the_raw_encryption():
+    """fixedpoint.align_encoded (host counterpart of pai_fp_encode_at): encoding a plaintext AT a larger target exponent
+    equals raising its raw encryption to 2^(target - exponent) — (1 + m n)^(2^d) = 1 + (m 2^d mod n) n — for positive,
+    negative, zero, integer and huge-shift cases; elements whose shifted magnitude would not stay below n keep their
+    exponent (the ciphertext path raises those)."""
+    import numpy as np
+
+    from oracle import paillier_oracle as orc
+    from pailliercryptolib_python_amd import fixedpoint as fp
+
+    key = orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=3, bits=2048)
+    n, nsq = key.n, key.nsq
+    vals = [1.5, -2.25, 0.0, 3, -7, 1e10, -1e-5, 2.0 ** 60, -(2.0 ** -40), 123456789, 5e-324]
+    res, ex = fp.encode_array(vals, n, key.max_int, 64)
+    for tg in (np.array([60] * len(vals)), np.array([60, 60, 5, 10, 3, 10, 100, -8, 200, 1, 7]), np.array([1990]), np.array([5000])):
+        r2, e2 = fp.align_encoded(res, ex, tg, n, key.max_int)
+        t = np.broadcast_to(tg, ex.shape)
+        for i in range(len(vals)):
+            enc = int.from_bytes(res[i].tobytes(), "little")
+            enc2 = int.from_bytes(r2[i].tobytes(), "little")
+            d = int(e2[i]) - int(ex[i])
+            assert d >= 0 and int(e2[i]) in (int(ex[i]), int(t[i]))
+            assert pow(orc.raw_encrypt(enc, n), 1 << d, nsq) == orc.raw_encrypt(enc2, n), (i, int(t[i]))
+            if enc == 0 and t[i] > ex[i]:
+                assert e2[i] == t[i]                                  # zero takes any larger target
+            if 0 < d < 900:                                           # a moved element still decodes to the same value
+                assert orc.fp_decode(enc2, int(e2[i]), n, key.max_int) == orc.fp_decode(enc, int(ex[i]), n, key.max_int)
+    # a shift that would pass n is refused (exponent kept)
+    r3, e3 = fp.align_encoded(res[:1], ex[:1], np.array([int(ex[0]) + 2040]), n, key.max_int)
+    assert e3[0] == ex[0] and np.array_equal(r3[0], res[0])

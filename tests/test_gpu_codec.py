@@ -138,3 +138,34 @@ def test_api_float_arrays_use_the_device_codec_and_keep_reference_semantics():
     # two encryptions of the same values draw different randomness
     a, b = pk.encrypt(x[:4]), pk.encrypt(x[:4])
     assert a.ciphertextBN(0) != b.ciphertextBN(0)
+
+
+def test_device_encode_at_a_target_exponent_equals_the_host_alignment(nk):
+    """pai_fp_encode_at against fixedpoint.align_encoded (itself pinned on CPU to raising the raw encryption by 2^d):
+    float64 and int64 inputs, per-element and broadcast targets, targets below / at / far above the own exponent, shifts
+    that stop just short of n and shifts that are refused, zero mantissas, INT32 extremes as targets."""
+    from pailliercryptolib_python_amd import fixedpoint as fp
+
+    key = nk.key
+    n, max_int = key.n, key.n // 3 - 1
+    rng = np.random.default_rng(21)
+    xf = np.concatenate([np.array(EDGE), rng.uniform(-1e3, 1e3, 2000), np.ldexp(rng.uniform(-1, 1, 1000), rng.integers(-300, 300, 1000))])
+    xi = np.concatenate([np.array([0, 1, -1, 2**63 - 1, -(2**63), 2**53, -(2**53) - 1], dtype=np.int64),
+                         rng.integers(-(2**63), 2**63 - 1, 1000, dtype=np.int64), rng.integers(-1000, 1000, 500, dtype=np.int64)])
+    nbits = n.bit_length()
+    for x, is_f64 in ((xf, 1), (xi, 0)):
+        N = x.shape[0]
+        res0, ex0 = fp.encode_array(x if is_f64 else [int(v) for v in x], n, max_int, nk.nw)
+        if not is_f64:
+            res0, ex0 = np.array(res0), np.zeros(N, dtype=np.int32)
+        tg_sets = [rng.integers(-50, 120, N).astype(np.int32), np.array([60], dtype=np.int32), np.array([-2000], dtype=np.int32),
+                   (np.asarray(ex0, dtype=np.int64) + rng.integers(nbits - 70, nbits - 50, N)).astype(np.int32),   # around the limit
+                   np.array([2**31 - 1], dtype=np.int32), np.array([-(2**31)], dtype=np.int32)]
+        for tg in tg_sets:
+            dx, dt = DevArray(x), DevArray(tg)
+            dm, de = DevArray(shape=(N, nk.nw)), DevArray(shape=(N,), dtype=np.int32)
+            _native.check(nk.lib.pai_fp_encode_at(nk.pk, dx.ptr, is_f64, N, dt.ptr, 1 if tg.shape[0] == 1 else 0, dm.ptr, de.ptr, None))
+            want_r, want_e = fp.align_encoded(res0, ex0, tg, n, max_int)
+            got_e = de.get()
+            assert got_e.tolist() == want_e.tolist(), (is_f64, tg[:3])
+            assert np.array_equal(dm.get(), want_r), (is_f64, tg[:3])
