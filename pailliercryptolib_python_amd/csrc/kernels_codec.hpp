@@ -109,7 +109,7 @@ k_fp_encode_at(const void* __restrict__ x_, const uint32_t* __restrict__ n_words
         neg = v < 0;
         mant = neg ? (0ull - (uint64_t)v) : (uint64_t)v;
         e0 = 0;
-        mbits = 64;
+        mbits = mant ? 64 - __clzll((long long)mant) : 0;        // the magnitude's own bit length (as fixedpoint.align_encoded)
     }
     int shift = 0;
     const int t = target[t_bcast ? 0 : i];

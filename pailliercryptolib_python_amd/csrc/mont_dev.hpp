@@ -39,6 +39,9 @@ constexpr uint32_t RMASK = (1u << RB) - 1u;
 constexpr int NORM_ROWS = 24;                   // rows between carry normalisations (must stay < 30)
 
 #define PAI_DEV __device__ __forceinline__
+#ifndef PAI_BCAST8_SWIZZLE
+#define PAI_BCAST8_SWIZZLE 0       // 1: quotient-digit broadcast in groups of 8 lanes through ds_swizzle_b32 (A/B r04)
+#endif
 
 // Per-modulus constants in device memory (all limbs radix 2^29, zero-padded to NLMAX).
 constexpr int NLMAX = 288;                      // 8192-bit moduli (+2 bits) => 283 limbs, padded
@@ -67,6 +70,12 @@ template <int T> PAI_DEV uint32_t bcast0(uint32_t v) {
     else if constexpr (T == 2) return dpp_mov<0xA0>(v);          // quad_perm [0,0,2,2]
     else if constexpr (T == 4) return dpp_mov<0x00>(v);          // quad_perm [0,0,0,0]
     else if constexpr (T == 8) {
+#if PAI_BCAST8_SWIZZLE
+        // ONE LDS-crossbar instruction (ds_swizzle_b32, bit mode: source lane = lane & 0b11000 inside each half wave; no
+        // memory access, no VALU issue slot) instead of two DPP moves and a select: the 8-lane row blocks are bound by
+        // VALU issue, and the swizzle's latency hides behind the other wave of the SIMD
+        return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x18);
+#endif
         // two DPP moves instead of ds_bpermute: lane 0 / 4 of each quad pair, then the upper quad fetches from 4 lanes below
         // (groups of 8 are aligned halves of a 16-lane DPP row)
         const uint32_t q = dpp_mov<0x00>(v);
