@@ -113,6 +113,12 @@ bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams&
 struct MexpPadicParams;
 bool launch_mexp_table_padic(int nl, hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* ct, const uint32_t* ct_inv, int nlanes);
 bool launch_mexp_padic(int nl, hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* e, const uint8_t* sign, uint32_t* out, int nlanes);
+// g-factoring of a finished digit-form table (kernels_padic_enc.hpp): passes 1 and 2 over `count` entries in chunks of K
+bool padic_enc_gform_supported();
+bool launch_fb_g_prefix_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* table, size_t count, int K,
+                              uint32_t* pref, uint32_t* tot, int tw, uint32_t* mscratch);
+bool launch_fb_g_finish_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, uint32_t* table, size_t count, int K,
+                              const uint32_t* pref, const uint32_t* inv, int tw, uint32_t* mscratch);
 bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r,
                           const uint32_t* ct_in, uint32_t* ct_out, int n, int mode);
 

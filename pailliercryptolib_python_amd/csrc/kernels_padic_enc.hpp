@@ -56,7 +56,11 @@ struct EncPadicParams {
     int nd;
     int fb_windows, fb_wbits;
     int pt_words, ct_words, r_words;
+    int fb_gform;                // g-factored table (round 4): entry = (a, t) with x R == a (1 + t n) (mod n^2), see k_fb_g_*
 };
+
+// the g-factored product needs the fused product rule in both encryption kernels
+constexpr bool PAI_ENC_GFORM_OK = PAI_FUSED_ENCRYPT && PAI_FUSED_OBFUSCATE;
 
 // ---- table construction: one lane per window j ------------------------------------------------------
 template <int NL, int U>
@@ -194,6 +198,186 @@ k_fb_expand_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1g, const 
     }
 }
 
+// ---- g-factoring of a finished fixed-base table (round 4) ---------------------------------------------------------------
+// A table entry is the Montgomery digit pair (a, d) of x = hs^(digit 2^(w j)):  a + d n == x R (mod n^2).  With g = 1 + n,
+// a (1 + t n) == a + a t n, so x R == a g^t for t = d a^-1 mod n: every entry factors into an element WITHOUT a second
+// digit and a power of g, and g^t g^t' = g^(t + t').  The encryption kernels then multiply by (a, 0) — 4 NL^2 limb
+// products instead of 5 — and add the exponents t (kernels above).  The conversion needs a^-1 mod n for every entry:
+// Montgomery's simultaneous inversion over chunks of K consecutive entries, one chunk per lane —
+//   pass 1 (k_fb_g_prefix): prefix products P_i = a_0 ... a_i in Montgomery form (R = 2^(29 NL), modulo n) into `pref`,
+//           the chunk total as a packed canonical residue into `tot`;
+//   the totals are inverted by the wave-parallel extended GCD (inv_eea.hip: launch_inv_eea);
+//   pass 2 (k_fb_g_finish): back sweep a_i^-1 = (a_0 ... a_i)^-1 P_(i-1), t_i = d_i a_i^-1 written over d_i.
+// Six single-digit Montgomery products per entry (2 + 4).  X0 / X1 are the two LDS digit buffers of the lane; the quotient
+// digits of mm1_mul are not needed and go to the lane's scratch column.
+template <class E>
+PAI_DEV void gf_load_digit(uint4* X, const uint4* __restrict__ src) {
+    wave_lds_fence();
+#pragma unroll 1
+    for (int c = 0; c < E::NC; ++c) E::st(X, c, src[c]);
+    wave_lds_fence();
+}
+template <class E, int NL>
+PAI_DEV void gf_put_digit(uint4* X, const uint32_t (&w)[NL]) {
+    wave_lds_fence();
+    E::store_digit(X, w);
+    wave_lds_fence();
+}
+
+template <int NL, int U>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_fb_g_prefix(const MontCtx* __restrict__ nctx, const uint4* __restrict__ table, size_t count, int K,
+              uint4* __restrict__ pref, uint32_t* __restrict__ tot, int tw, uint4* __restrict__ mscratch) {
+    using E = Padic<NL, U>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = nctx->n[i]; ldsn[NL + i] = nctx->r2[i]; }
+    __syncthreads();
+    const uint32_t* nm = ldsn;
+    const uint32_t* r2 = ldsn + NL;
+    const uint32_t n0inv = nctx->n0inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* X0 = reinterpret_cast<uint4*>(lds + wave * 2 * E::DIGIT_WORDS) + lane;
+    const size_t nslots = (size_t)gridDim.x * BLOCK_THREADS;
+    const size_t slot = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const typename E::MBuf M{mscratch + slot, nslots};
+    auto r2dig = [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(r2, blk, xv); };
+    auto one = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = 0;
+        if (blk == 0) xv[0] = 1;
+    };
+    const size_t nchunks = count / (size_t)K;                           // the host makes K divide count
+    const size_t tiles = (nchunks + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t ch = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = ch < nchunks;
+        const size_t cs = live ? ch : nchunks - 1;
+        uint32_t w[NL];
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+            const size_t g = cs * (size_t)K + i;
+            gf_load_digit<E>(X0, table + g * 2 * E::NC);                 // a_i
+            E::mm1_mul(w, M, X0, r2dig, nm, n0inv);                       // a_i R
+            if (i > 0) {
+                gf_put_digit<E, NL>(X0, w);
+                const uint4* prev = pref + (g - 1) * E::NC;
+                auto pdig = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                    for (int c = 0; c < E::UC; ++c) {
+                        const uint4 t = prev[E::UC * blk + c];
+                        xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                    }
+                };
+                E::mm1_mul(w, M, X0, pdig, nm, n0inv);                    // P_i = P_(i-1) a_i  (Montgomery form)
+            }
+            if (live) {
+                uint4* dst = pref + g * E::NC;
+#pragma unroll
+                for (int c = 0; c < E::NC; ++c) dst[c] = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+            }
+            __threadfence_block();
+        }
+        // chunk total, plain and canonical, as packed words
+        gf_put_digit<E, NL>(X0, w);
+        E::mm1_mul(w, M, X0, one, nm, n0inv);
+        E::cond_sub(w, nm);
+        E::cond_sub(w, nm);
+        if (live) {
+            uint32_t* orow = tot + ch * (size_t)tw;
+            constexpr int MAXW = (RB * NL + 31) / 32;
+#pragma unroll
+            for (int k = 0; k < MAXW; ++k) {
+                const int j0 = (32 * k) / RB, s0 = 32 * k - RB * j0;
+                uint64_t t = (uint64_t)w[j0] >> s0;
+                if (j0 + 1 < NL) t |= (uint64_t)w[j0 + 1] << (RB - s0);
+                if (j0 + 2 < NL) t |= (uint64_t)w[j0 + 2] << (2 * RB - s0);
+                if (k < tw) orow[k] = (uint32_t)t;
+            }
+            for (int k = MAXW; k < tw; ++k) orow[k] = 0;
+        }
+    }
+}
+
+template <int NL, int U>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_fb_g_finish(const MontCtx* __restrict__ nctx, uint4* __restrict__ table, size_t count, int K,
+              const uint4* __restrict__ pref, const uint32_t* __restrict__ inv, int tw, uint4* __restrict__ mscratch) {
+    using E = Padic<NL, U>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
+    for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = nctx->n[i]; ldsn[NL + i] = nctx->r2[i]; }
+    __syncthreads();
+    const uint32_t* nm = ldsn;
+    const uint32_t* r2 = ldsn + NL;
+    const uint32_t n0inv = nctx->n0inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* X0 = reinterpret_cast<uint4*>(lds + wave * 2 * E::DIGIT_WORDS) + lane;      // the running inverse (Montgomery form)
+    uint4* X1 = X0 + E::NC * 64;                                                       // a_i^-1 R for the t product
+    const size_t nslots = (size_t)gridDim.x * BLOCK_THREADS;
+    const size_t slot = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const typename E::MBuf M{mscratch + slot, nslots};
+    auto r2dig = [&](int blk, uint32_t (&xv)[U]) { E::digits_uniform(r2, blk, xv); };
+    const size_t nchunks = count / (size_t)K;
+    const size_t tiles = (nchunks + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t ch = tile * BLOCK_THREADS + threadIdx.x;
+        const bool live = ch < nchunks;
+        const size_t cs = live ? ch : nchunks - 1;
+        uint32_t w[NL];
+        {   // the chunk's inverse total enters Montgomery form: X0 = (a_0 ... a_(K-1))^-1 R
+            const uint32_t* irow = inv + cs * (size_t)tw;
+            wave_lds_fence();
+#pragma unroll 1
+            for (int c = 0; c < E::NC; ++c)
+                E::st(X0, c, make_uint4(row_limb(irow, tw, 4 * c), row_limb(irow, tw, 4 * c + 1), row_limb(irow, tw, 4 * c + 2),
+                                        row_limb(irow, tw, 4 * c + 3)));
+            wave_lds_fence();
+            E::mm1_mul(w, M, X0, r2dig, nm, n0inv);
+            gf_put_digit<E, NL>(X0, w);
+        }
+#pragma unroll 1
+        for (int i = K - 1; i >= 0; --i) {
+            const size_t g = cs * (size_t)K + i;
+            uint4* ent = table + g * 2 * E::NC;
+            auto from = [&](const uint4* p) {
+                return [p](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                    for (int c = 0; c < E::UC; ++c) {
+                        const uint4 t = p[E::UC * blk + c];
+                        xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                    }
+                };
+            };
+            // u = a_i^-1 R: the running inverse times P_(i-1) (i = 0: the running inverse itself)
+            if (i > 0) {
+                E::mm1_mul(w, M, X0, from(pref + (g - 1) * E::NC), nm, n0inv);
+                gf_put_digit<E, NL>(X1, w);
+            } else {
+                wave_lds_fence();
+#pragma unroll 1
+                for (int c = 0; c < E::NC; ++c) E::st(X1, c, E::ld(X0, c));
+                wave_lds_fence();
+            }
+            // t_i = d_i a_i^-1 (plain), canonical, over d_i
+            E::mm1_mul(w, M, X1, from(ent + E::NC), nm, n0inv);
+            E::cond_sub(w, nm);
+            E::cond_sub(w, nm);
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < E::NC; ++c) ent[E::NC + c] = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+            }
+            // running inverse <- running inverse * a_i (plain a_i drops the R: re-enter Montgomery form)
+            if (i > 0) {
+                E::mm1_mul(w, M, X0, from(ent), nm, n0inv);
+                gf_put_digit<E, NL>(X0, w);
+                E::mm1_mul(w, M, X0, r2dig, nm, n0inv);
+                gf_put_digit<E, NL>(X0, w);
+            }
+        }
+    }
+}
+
 // ---- (lo in LDS digit A, hi in LDS digit B) as one 2 NL-limb integer: conditional subtraction of n^2 ----
 template <class E>
 PAI_DEV void cond_sub_2nl(uint4* A, uint4* B, const uint32_t* __restrict__ nsq) {
@@ -236,7 +420,7 @@ PAI_DEV uint32_t lds_limb(const uint4* A, const uint4* B, int J) {
 
 // OBF = true is the apply_obfuscator instantiation (mode 2 only): kept out of the encryption kernel, whose register
 // allocation suffers from the extra digit-form conversion (k_encrypt 67 -> 78 ms per 2^20 when both shared one kernel)
-template <int NL, int U, bool OBF>
+template <int NL, int U, bool OBF, bool GFORM>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
                 const uint32_t* __restrict__ ct_in, uint32_t* __restrict__ ct_out, int n, int mode) {
@@ -284,6 +468,15 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
             const uint32_t* rrow = r + (size_t)es * P.r_words;
             // mode 2 (apply_obfuscator): start from the existing ciphertext in digit form instead of the first entry
             if constexpr (OBF) padic_to_digit_form<E>(A, B, M, ct_in + (size_t)es * P.ct_words, P.ct_words, P.kdig, P.nd, nm, nm1, n0inv);
+            // g-factored tables: the entries are (a, t) with x = (a, 0) g^t, g = 1 + n: the product takes the 4 NL^2 rule for a
+            // right operand without a second digit and the exponents t are summed lazily in registers (limbs < 2^29, at
+            // most 7 additions between carry passes); g^(m + sum t) joins in the final product with the plain pair (1, s)
+            uint32_t tsum[GFORM ? NL : 1];
+            if constexpr (GFORM) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) tsum[j] = 0;
+            }
+            int since_norm = 0;
 #pragma unroll 1
             for (int jw = 0; jw < P.fb_windows; ++jw) {
                 const int bit = jw * P.fb_wbits, k = bit >> 5;
@@ -291,6 +484,41 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
                 if (k + 1 < P.r_words) bits2 |= (uint64_t)rrow[k + 1] << 32;
                 const uint32_t d = (uint32_t)(bits2 >> (bit & 31)) & ((1u << P.fb_wbits) - 1u);
                 const uint4* ent = P.fb_table + (((size_t)jw << P.fb_wbits) + d) * 2 * E::NC;
+                if constexpr (GFORM) {
+                    {
+#pragma unroll
+                        for (int c = 0; c < E::NC; ++c) {
+                            const uint4 t = ent[E::NC + c];
+                            tsum[4 * c] += t.x; tsum[4 * c + 1] += t.y; tsum[4 * c + 2] += t.z; tsum[4 * c + 3] += t.w;
+                        }
+                        if (++since_norm == 6) {               // limbs < 7 * 2^29 + carry: no 32-bit wrap
+                            since_norm = 0;
+                            uint32_t cy = 0;
+#pragma unroll
+                            for (int j = 0; j < NL; ++j) {
+                                const uint32_t tj = tsum[j] + cy;       // (tsum[j] < 7 * 2^29, cy < 8)
+                                cy = tj >> RB;
+                                tsum[j] = tj & RMASK;
+                            }                                           // (the sum stays far below 2^(29 NL): cy == 0 at the top)
+                        }
+                        if (jw == 0 && !OBF) {
+                            wave_lds_fence();
+#pragma unroll 1
+                            for (int c = 0; c < E::NC; ++c) { E::st(A, c, ent[c]); E::st(B, c, make_uint4(0u, 0u, 0u, 0u)); }
+                            wave_lds_fence();
+                        } else {
+                            auto from_a = [&](int blk, uint32_t (&xv)[U]) {
+#pragma unroll
+                                for (int c = 0; c < E::UC; ++c) {
+                                    const uint4 t = ent[E::UC * blk + c];
+                                    xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                                }
+                            };
+                            E::mul_fused_c0(A, B, from_a, nm, nm1, n0inv);
+                        }
+                        continue;
+                    }
+                }
                 if (jw == 0 && !OBF) {
                     wave_lds_fence();
 #pragma unroll 1
@@ -313,9 +541,36 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
             {
                 // mode 2 leaves Montgomery form with the plain pair (1, 0)
                 const uint32_t* mrow = OBF ? nullptr : m + (size_t)es * P.pt_words;
-                auto mdig = [&](int blk, uint32_t (&xv)[U]) {
+                constexpr bool gf = GFORM;
+                if constexpr (GFORM) {
+                    {
+                        // s = m + sum t (lazy: < 2^7 n, well inside the digit), parked in this lane's Wb column for the row-block reads
+                        uint32_t cy = 0;
 #pragma unroll
-                    for (int u = 0; u < U; ++u) xv[u] = OBF ? 0u : row_limb(mrow, P.pt_words, U * blk + u);
+                        for (int c = 0; c < E::NC; ++c) {
+                            uint32_t sl[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int j = 4 * c + k;
+                                const uint64_t tj = (uint64_t)tsum[j] + (OBF ? 0u : row_limb(mrow, P.pt_words, j)) + cy;
+                                cy = (uint32_t)(tj >> RB);
+                                sl[k] = (uint32_t)tj & RMASK;
+                            }
+                            Wb.p[(size_t)c * Wb.stride] = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+                        }
+                    }
+                }
+                auto mdig = [&](int blk, uint32_t (&xv)[U]) {
+                    if constexpr (gf) {
+#pragma unroll
+                        for (int c = 0; c < E::UC; ++c) {
+                            const uint4 t = Wb.p[(size_t)(E::UC * blk + c) * Wb.stride];
+                            xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) xv[u] = OBF ? 0u : row_limb(mrow, P.pt_words, U * blk + u);
+                    }
                 };
                 E::mm1_mul(w, M, A, one, nm, n0inv);
                 E::mm2_mul(v, M, A, B, mdig, one, nm, nm1, n0inv);

@@ -730,6 +730,37 @@ struct Padic {
         finish_pair(acc1, acc2, A, B);
         wave_lds_fence();
     }
+    // (A, B) <- (A, B) * (C, 0): the product rule with a right operand whose SECOND digit is zero — w = (a c + m p) / R,
+    // v = (b c - m + R p + m' p) / R: 4 NL^2 limb products instead of 5.  The fixed-base tables store such operands
+    // (g-factored entries, kernels_padic_enc.hpp): x = (c, 0) * (1 + p)^t with the exponents t summed on the side.
+    template <class CSrc>
+    PAI_DEV static void mul_fused_c0(uint4* A, uint4* B, CSrc&& csrc, const uint32_t* __restrict__ nm,
+                                     const uint32_t* __restrict__ pm1, uint32_t n0inv) {
+        uint64_t acc1[NW], acc2[NW];
+        zero(acc1);
+        zero(acc2);
+        acc2[0] = 1;                          // (R - 1 - m) + 1
+        uint32_t dummy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dummy[u] = 0;
+        uint32_t cn[U];
+        csrc(0, cn);
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            uint32_t cv[U], q1[U], q2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cv[u] = cn[u];
+            csrc(blk + 1 < NB ? blk + 1 : blk, cn);
+            block<true, 0, NL, false, false>(acc1, A, cv, A, dummy, nm, n0inv, nm, blk, q1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc2[u] += (uint64_t)(RMASK - q1[u]);
+            block<false, 0, NL, true, true>(acc2, A, dummy, B, cv, nm, n0inv, pm1, blk, q2);
+            if (blk != NB - 1 && ((blk + 1) * U) % P1 == 0) { normalize(acc1); normalize(acc2); }   // two products per row and column each
+        }
+        wave_lds_fence();
+        finish_pair(acc1, acc2, A, B);
+        wave_lds_fence();
+    }
     // squaring: first half a * a (every limb pair twice), second half 2 a b with doubled multiplier digits — 4 NL^2
     PAI_DEV static void sqr_fused(uint4* A, uint4* B, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
                                   uint32_t n0inv) {

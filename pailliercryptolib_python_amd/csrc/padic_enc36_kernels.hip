@@ -13,6 +13,10 @@ void enc36_encrypt(hipStream_t s, int grid, const EncPadicParams& P, const uint3
 void enc36_ctmul(hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e, uint32_t* out, int n) {
     L36::ctmul(s, grid, P, ct, e, out, n);
 }
+void enc36_g_prefix(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* table, size_t count, int K, uint32_t* pref, uint32_t* tot,
+                    int tw, uint32_t* mscratch) { L36::g_prefix(s, grid, nctx, table, count, K, pref, tot, tw, mscratch); }
+void enc36_g_finish(hipStream_t s, int grid, const MontCtx* nctx, uint32_t* table, size_t count, int K, const uint32_t* pref,
+                    const uint32_t* inv, int tw, uint32_t* mscratch) { L36::g_finish(s, grid, nctx, table, count, K, pref, inv, tw, mscratch); }
 void enc36_pow(hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n) { L36::pow(s, grid, P, base, out, n); }
 
 void enc36_mexp_table(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* ct, const uint32_t* ct_inv, int nlanes) {

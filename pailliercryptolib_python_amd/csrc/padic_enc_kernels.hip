@@ -43,6 +43,21 @@ bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams&
     else return false;
     return true;
 }
+bool padic_enc_gform_supported() { return PAI_ENC_GFORM_OK; }
+bool launch_fb_g_prefix_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* table, size_t count, int K,
+                              uint32_t* pref, uint32_t* tot, int tw, uint32_t* mscratch) {
+    if (nl == 72) L72E::g_prefix(s, grid, nctx, table, count, K, pref, tot, tw, mscratch);
+    else if (nl == 36) enc36_g_prefix(s, grid, nctx, table, count, K, pref, tot, tw, mscratch);
+    else return false;
+    return true;
+}
+bool launch_fb_g_finish_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, uint32_t* table, size_t count, int K,
+                              const uint32_t* pref, const uint32_t* inv, int tw, uint32_t* mscratch) {
+    if (nl == 72) L72E::g_finish(s, grid, nctx, table, count, K, pref, inv, tw, mscratch);
+    else if (nl == 36) enc36_g_finish(s, grid, nctx, table, count, K, pref, inv, tw, mscratch);
+    else return false;
+    return true;
+}
 size_t ctmul_padic_table_words(int nl, int wbits, size_t blocks) { return ((size_t)1 << wbits) * 2 * nl * blocks * BLOCK_THREADS; }
 bool launch_ctmul_padic(int nl, hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e,
                         uint32_t* out, int n) {

@@ -24,13 +24,32 @@ struct EncLaunch {
     }
     static void encrypt(hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r, const uint32_t* ct_in,
                         uint32_t* ct_out, int n, int mode) {
+        // one instantiation per (apply_obfuscator?, g-factored table?): the table format is fixed when the table is built
+        auto go = [&](auto kernel) {
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, P, m, r, ct_in, ct_out, n, mode);
+        };
+        const bool gf = PAI_ENC_GFORM_OK && P.fb_gform != 0;
         if (mode == 2) {
-            (void)hipFuncSetAttribute((const void*)k_encrypt_padic<NL, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
-            hipLaunchKernelGGL((k_encrypt_padic<NL, U, true>), dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, P, m, r, ct_in, ct_out, n, mode);
+            if (gf) go(k_encrypt_padic<NL, U, true, PAI_ENC_GFORM_OK>);
+            else go(k_encrypt_padic<NL, U, true, false>);
         } else {
-            (void)hipFuncSetAttribute((const void*)k_encrypt_padic<NL, U, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
-            hipLaunchKernelGGL((k_encrypt_padic<NL, U, false>), dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, P, m, r, ct_in, ct_out, n, mode);
+            if (gf) go(k_encrypt_padic<NL, U, false, PAI_ENC_GFORM_OK>);
+            else go(k_encrypt_padic<NL, U, false, false>);
         }
+    }
+    // g-factoring passes over a finished table (kernels_padic_enc.hpp: k_fb_g_prefix / k_fb_g_finish)
+    static void g_prefix(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* table, size_t count, int K, uint32_t* pref,
+                         uint32_t* tot, int tw, uint32_t* mscratch) {
+        (void)hipFuncSetAttribute((const void*)k_fb_g_prefix<NL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
+        hipLaunchKernelGGL((k_fb_g_prefix<NL, U>), dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, nctx, reinterpret_cast<const uint4*>(table),
+                           count, K, reinterpret_cast<uint4*>(pref), tot, tw, reinterpret_cast<uint4*>(mscratch));
+    }
+    static void g_finish(hipStream_t s, int grid, const MontCtx* nctx, uint32_t* table, size_t count, int K, const uint32_t* pref,
+                         const uint32_t* inv, int tw, uint32_t* mscratch) {
+        (void)hipFuncSetAttribute((const void*)k_fb_g_finish<NL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
+        hipLaunchKernelGGL((k_fb_g_finish<NL, U>), dim3(grid), dim3(BLOCK_THREADS), BYTES2, s, nctx, reinterpret_cast<uint4*>(table), count,
+                           K, reinterpret_cast<const uint4*>(pref), inv, tw, reinterpret_cast<uint4*>(mscratch));
     }
     static void ctmul(hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e, uint32_t* out, int n) {
         (void)hipFuncSetAttribute((const void*)k_ctmul_padic<NL, U>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES2);
@@ -58,6 +77,10 @@ void enc36_fb_expand(hipStream_t s, int grid, const MontCtx* nctx, const uint32_
 void enc36_encrypt(hipStream_t s, int grid, const EncPadicParams& P, const uint32_t* m, const uint32_t* r, const uint32_t* ct_in,
                    uint32_t* ct_out, int n, int mode);
 void enc36_ctmul(hipStream_t s, int grid, const CtMulPadicParams& P, const uint32_t* ct, const uint32_t* e, uint32_t* out, int n);
+void enc36_g_prefix(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* table, size_t count, int K, uint32_t* pref, uint32_t* tot,
+                    int tw, uint32_t* mscratch);
+void enc36_g_finish(hipStream_t s, int grid, const MontCtx* nctx, uint32_t* table, size_t count, int K, const uint32_t* pref,
+                    const uint32_t* inv, int tw, uint32_t* mscratch);
 void enc36_pow(hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n);
 void enc36_mexp_table(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* ct, const uint32_t* ct_inv, int nlanes);
 void enc36_mexp(hipStream_t s, int grid, const MexpPadicParams& P, const uint32_t* e, const uint8_t* sign, uint32_t* out, int nlanes);

@@ -408,6 +408,7 @@ struct pai_pubkey {
     uint32_t* d_nexp = nullptr;   // n as packed words (exponent of the standard obfuscator)
     int fb_windows = 0, fb_wbits = 8;
     int fbd_windows = 0, fbd_wbits = 8;   // window geometry of the digit-form table (may be wider: see pai_pubkey_create)
+    bool fb_gform = false;                // the digit-form table holds g-factored entries (a, t): kernels_padic_enc.hpp
     // digit engine with base n (raw / DJN encryption): modulus n, n - 1, n^2 limbs, digit-form table, scratch
     int penc_nl = 0;
     ModSetup nmod;
@@ -965,6 +966,52 @@ static bool ensure_lat_ctx(const pai_pubkey* pk) {
 // Fixed-base tables of the DJN obfuscator hs^r, built by the FIRST call that obfuscates (pai_encrypt with
 // randomness / pai_obfuscate), under pk->mu: a handle that only adds, multiplies or decrypts — every unpickled
 // ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
+// g-factoring of the finished digit-form table (kernels_padic_enc.hpp: k_fb_g_prefix / k_fb_g_finish + the wave-parallel
+// extended GCD on the chunk totals): entries (a, d) become (a, t = d a^-1 mod n), after which every table product of an
+// encryption is the 4 NL^2 rule.  Slabs bound the scratch (one digit per entry).  PAI_FB_GFORM=0 keeps the plain table;
+// any failure (a non-unit would mean a broken key) leaves the table as it was built.
+static void gfactor_digit_table(pai_pubkey* pk, size_t NE, int dwb) {
+    if (const char* env = std::getenv("PAI_FB_GFORM")) { if (env[0] == '0') return; }
+    if (!padic_enc_gform_supported()) return;
+    const int pnl = pk->penc_nl;
+    const int K = (int)std::min<size_t>(64, (size_t)1 << dwb);           // divides the entries of a window, hence NE
+    const int tw = pk->n_words;
+    if ((tw + 63) / 64 > 4) return;                                      // inv_eea instantiations: up to 256 words
+    const size_t slab_max = (size_t)1 << 22;                             // entries per slab: 1.2 GB of prefix scratch at 72 limbs
+    const size_t slab = std::min(NE, slab_max) / K * K;
+    ScopedDevBuf d_pref, d_tot, d_inv, d_fail;
+    d_pref.ensure(slab * (size_t)pnl * 4);
+    d_tot.ensure(slab / K * (size_t)tw * 4);
+    d_inv.ensure(slab / K * (size_t)tw * 4);
+    d_fail.ensure(4);
+    HIP_CHECK(hipMemset(d_fail.p, 0, 4));
+    const int grid = pk->dev.ncu;                                         // the scratch column is sized for this grid
+    const size_t ent_words = 2 * (size_t)pnl;
+    // pass 1 and the inversions of every slab first (pass 2 overwrites the second digits: no partial conversion on failure)
+    // -> with one slab of scratch the passes must alternate; a failure after some slabs were converted is handled by
+    //    rebuilding (fb_ready stays false and the caller's catch frees the table)
+    for (size_t e0 = 0; e0 < NE; e0 += slab) {
+        const size_t cnt = std::min(slab, NE - e0);
+        uint32_t* tbl = pk->d_fb_dig + e0 * ent_words;
+        if (!launch_fb_g_prefix_padic(pnl, nullptr, grid, pk->nmod.d_ctx, tbl, cnt, K, d_pref.as<uint32_t>(), d_tot.as<uint32_t>(), tw,
+                                      pk->d_mscratch))
+            throw PaiError(PAI_E_INTERNAL, "no g-factoring kernel for this limb count");
+        HIP_CHECK(hipGetLastError());
+        if (!launch_inv_eea(nullptr, tw, pk->d_nexp, d_tot.as<uint32_t>(), d_inv.as<uint32_t>(), (int)(cnt / K), 2 * 32 * tw + 64,
+                            d_fail.as<int>()))
+            throw PaiError(PAI_E_INTERNAL, "no extended-GCD instantiation for this key size");
+        HIP_CHECK(hipGetLastError());
+        int fail = 0;
+        HIP_CHECK(hipMemcpy(&fail, d_fail.p, 4, hipMemcpyDeviceToHost));
+        if (fail) throw PaiError(PAI_E_INTERNAL, "fixed-base table entry without an inverse modulo n");
+        launch_fb_g_finish_padic(pnl, nullptr, grid, pk->nmod.d_ctx, tbl, cnt, K, d_pref.as<uint32_t>(), d_inv.as<uint32_t>(), tw,
+                                 pk->d_mscratch);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    pk->fb_gform = true;
+}
+
 // ---- per-device cache of the DJN fixed-base tables (round 4) ---------------------------------------------------
 // Every DJN key builds a multi-GB table on its first obfuscating call.  A process that holds many keys (federated
 // learning: one key per party or per round) used to need pai_pubkey_trim by hand; now the handles with built tables of a
@@ -1143,6 +1190,8 @@ static void build_fb_tables_body(pai_pubkey* pk) {
         if (!ok) throw PaiError(PAI_E_INTERNAL, "no digit-engine table kernel for this limb count");
         HIP_CHECK(e1);
         HIP_CHECK(e2);
+        pk->fb_gform = false;
+        gfactor_digit_table(pk, (size_t)DJ << dwb, dwb);
     }
     pk->fb_ready = true;
 }
@@ -1432,6 +1481,7 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         Q.nd = pk->ct_nd;
         Q.fb_windows = pk->fbd_windows;
         Q.fb_wbits = pk->fbd_wbits;
+        Q.fb_gform = pk->fb_gform ? 1 : 0;
         Q.pt_words = pk->n_words;
         Q.ct_words = pk->ct_words;
         Q.r_words = pk->r_words;
