@@ -131,6 +131,10 @@ bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, 
                           const uint32_t* one_pair, uint32_t* S, int nwin, int h, const FbBases& fb);
 bool launch_pair_fb_expand(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
                            uint32_t* T, int J, int h);
+bool launch_pair_g_prefix(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* table, size_t count, int K,
+                          uint32_t* pref, uint32_t* tot, int tw);
+bool launch_pair_g_finish(int nl, hipStream_t s, int grid, const MontCtx* nctx, uint32_t* table, size_t count, int K,
+                          const uint32_t* pref, const uint32_t* inv, int tw);
 bool launch_pair_fixed_base(int nl, hipStream_t s, int grid, const PairParams& P, const uint32_t* m, const uint32_t* r,
                             uint32_t* wv_out, int n, int with_m);
 bool launch_pair_ctmul(int nl, hipStream_t s, int grid, const PairCtMulParams& P, const uint32_t* ct, const uint32_t* e,

@@ -31,6 +31,7 @@ struct PairParams {
     int fb_windows, fb_wbits;
     int pt_words, r_words;
     int out_words;               // packed words per output digit row (>= ceil(29 NL / 32))
+    int fb_gform;                // g-factored table: entry = (a, t), x R == a (1 + n)^t (k_pair_g_prefix / k_pair_g_finish)
 };
 
 // LDS: [c rows][d rows] ([limb][element] operand buffers, G::LDS_WORDS each), then the NL limbs of n - 1
@@ -47,6 +48,9 @@ struct PairLds {
     static constexpr int BYTES = (2 * G::LDS_WORDS + 2 * G::NL) * 4;
     static constexpr int BYTES_FB = BYTES + (STREAM ? 2 * G::LDS_WORDS * 4 : 0);      // k_pair_fixed_base: + the second buffer pair
     static constexpr int BYTES_CT = BYTES + 2 * G::LDS_WORDS * 4;                     // k_pair_ctmul: always two buffer pairs
+    // g-factored tables on the non-streaming geometries: the lane slices of the exponent sum live in LDS (64-bit columns)
+    static constexpr int BYTES_FBG = BYTES_FB + (STREAM ? 0 : G::NLL * 8 * BLOCK_THREADS);
+    PAI_DEV static uint64_t* tsum(uint32_t* lds) { return reinterpret_cast<uint64_t*>(lds + BYTES_FB / 4) + threadIdx.x; }
     PAI_DEV static uint32_t* c2(uint32_t* lds) { return lds + 2 * G::LDS_WORDS + 2 * G::NL; }
     PAI_DEV static uint32_t* d2(uint32_t* lds) { return lds + 3 * G::LDS_WORDS + 2 * G::NL; }
     PAI_DEV static uint32_t* mod(uint32_t* lds) { return lds + 2 * G::LDS_WORDS + G::NL; }   // modulus copy (NMLDS geometries)
@@ -120,6 +124,33 @@ PAI_DEV void pair_store(const uint32_t (&a)[G::NLL], const uint32_t (&b)[G::NLL]
             a2[c] = make_uint2(a[2 * c], a[2 * c + 1]);
             b2[c] = make_uint2(b[2 * c], b[2 * c + 1]);
         }
+    }
+}
+// this lane's slice of ONE raw digit [NL]
+template <class G>
+PAI_DEV void digit_load(uint32_t (&a)[G::NLL], const uint32_t* __restrict__ dig) {
+    const uint32_t* pa = dig + G::NLL * G::gl();
+    if constexpr (G::NLL % 4 == 0) {
+        const uint4* a4 = reinterpret_cast<const uint4*>(pa);
+#pragma unroll
+        for (int c = 0; c < G::NLL / 4; ++c) { const uint4 va = a4[c]; a[4 * c] = va.x; a[4 * c + 1] = va.y; a[4 * c + 2] = va.z; a[4 * c + 3] = va.w; }
+    } else {
+        const uint2* a2 = reinterpret_cast<const uint2*>(pa);
+#pragma unroll
+        for (int c = 0; c < G::NLL / 2; ++c) { const uint2 va = a2[c]; a[2 * c] = va.x; a[2 * c + 1] = va.y; }
+    }
+}
+template <class G>
+PAI_DEV void digit_store(const uint32_t (&a)[G::NLL], uint32_t* __restrict__ dig) {
+    uint32_t* pa = dig + G::NLL * G::gl();
+    if constexpr (G::NLL % 4 == 0) {
+        uint4* a4 = reinterpret_cast<uint4*>(pa);
+#pragma unroll
+        for (int c = 0; c < G::NLL / 4; ++c) a4[c] = make_uint4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+    } else {
+        uint2* a2 = reinterpret_cast<uint2*>(pa);
+#pragma unroll
+        for (int c = 0; c < G::NLL / 2; ++c) a2[c] = make_uint2(a[2 * c], a[2 * c + 1]);
     }
 }
 // (a, b) <- (a, b) (x) (c, d) with (c, d) in registers: staged as LDS rows, then the fused product
@@ -228,11 +259,121 @@ k_pair_fb_expand(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ 
     }
 }
 
+// ---- g-factoring of a finished pair table (round 4; the lane-group counterpart of k_fb_g_prefix / k_fb_g_finish) -----------
+// entry (a, d) -> (a, t = d a^-1 mod n) by Montgomery's simultaneous inversion over chunks of K consecutive entries, one chunk
+// per lane GROUP; products are single Montgomery products modulo n (mont_mul, R = 2^(29 NL)) with the right operand staged
+// as an LDS column.  pass 1: prefix products P_i = a_0 ... a_i R into `pref` ([entry][NL] raw limbs), the chunk total as a
+// packed canonical residue into `tot`; the totals are inverted by launch_inv_eea; pass 2: the back sweep.
+template <class G>
+PAI_DEV void pair_g_setup(uint32_t* lds, const MontCtx* __restrict__ ctx, uint32_t*& r2_lds) {
+    r2_lds = lds + G::LDS_WORDS + G::NL;                            // behind the operand buffer and a modulus copy
+    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) r2_lds[i] = ctx->r2[i];
+    __syncthreads();
+}
+template <class G>
+struct PairGLds { static constexpr int BYTES = (G::LDS_WORDS + 2 * G::NL) * 4; };
+
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
+k_pair_g_prefix(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ table, size_t count, int K,
+                uint32_t* __restrict__ pref, uint32_t* __restrict__ tot, int tw) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typename G::NM nm;
+    load_modulus<G>(nm, nctx, lds);
+    uint32_t* r2_lds;
+    pair_g_setup<G>(lds, nctx, r2_lds);
+    const uint32_t n0inv = nctx->n0inv;
+    const uint32_t* col = lds + G::elem();
+    const size_t nchunks = count / (size_t)K;
+    const size_t tiles = (nchunks + G::EPB - 1) / G::EPB;
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t ch = tile * G::EPB + G::elem();
+        const bool live = ch < nchunks;
+        const size_t cs = live ? ch : nchunks - 1;
+        uint32_t P[G::NLL], x[G::NLL], t[G::NLL];
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+            const size_t g = cs * (size_t)K + i;
+            digit_load<G>(x, table + g * 2 * G::NL);
+            mont_mul<G::NLL, G::U, G::T>(t, x, r2_lds, 1, nm, n0inv);                 // a_i R
+            if (i > 0) {
+                stage_b<G>(P, lds);
+                mont_mul<G::NLL, G::U, G::T>(x, t, col, G::EPB, nm, n0inv);           // P_i = P_(i-1) a_i
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) P[j] = x[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) P[j] = t[j];
+            }
+            if (live) digit_store<G>(P, pref + g * G::NL);
+        }
+        set_plain_one<G>(x);
+        stage_b<G>(x, lds);
+        mont_mul<G::NLL, G::U, G::T>(t, P, col, G::EPB, nm, n0inv);                   // the chunk total, plain
+        cond_sub<G::NLL, G::T>(t, nm);
+        cond_sub<G::NLL, G::T>(t, nm);
+        // every group runs store_elem (it stages through LDS with wave-level fences); dead groups write their clamped chunk's
+        // own total again: the same value
+        store_elem<G>(t, tot + cs * (size_t)tw, tw, lds);
+    }
+}
+
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
+k_pair_g_finish(const MontCtx* __restrict__ nctx, uint32_t* __restrict__ table, size_t count, int K,
+                const uint32_t* __restrict__ pref, const uint32_t* __restrict__ inv, int tw) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typename G::NM nm;
+    load_modulus<G>(nm, nctx, lds);
+    uint32_t* r2_lds;
+    pair_g_setup<G>(lds, nctx, r2_lds);
+    const uint32_t n0inv = nctx->n0inv;
+    const uint32_t* col = lds + G::elem();
+    const size_t nchunks = count / (size_t)K;
+    const size_t tiles = (nchunks + G::EPB - 1) / G::EPB;
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t ch = tile * G::EPB + G::elem();
+        const bool live = ch < nchunks;
+        const size_t cs = live ? ch : nchunks - 1;
+        uint32_t I[G::NLL], x[G::NLL], u[G::NLL], t[G::NLL];
+        load_elem<G>(x, inv + cs * (size_t)tw, tw);
+        mont_mul<G::NLL, G::U, G::T>(I, x, r2_lds, 1, nm, n0inv);                     // (a_0 ... a_(K-1))^-1 R
+#pragma unroll 1
+        for (int i = K - 1; i >= 0; --i) {
+            const size_t g = cs * (size_t)K + i;
+            uint32_t* ent = table + g * 2 * G::NL;
+            if (i > 0) {
+                digit_load<G>(x, pref + (g - 1) * G::NL);
+                stage_b<G>(x, lds);
+                mont_mul<G::NLL, G::U, G::T>(u, I, col, G::EPB, nm, n0inv);           // a_i^-1 R
+            } else {
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) u[j] = I[j];
+            }
+            digit_load<G>(x, ent + G::NL);                                            // d_i
+            stage_b<G>(x, lds);
+            mont_mul<G::NLL, G::U, G::T>(t, u, col, G::EPB, nm, n0inv);               // t_i = d_i a_i^-1 (plain)
+            cond_sub<G::NLL, G::T>(t, nm);
+            cond_sub<G::NLL, G::T>(t, nm);
+            if (live) digit_store<G>(t, ent + G::NL);
+            if (i > 0) {
+                digit_load<G>(x, ent);                                                // a_i (plain: drops the R ...)
+                stage_b<G>(x, lds);
+                mont_mul<G::NLL, G::U, G::T>(t, I, col, G::EPB, nm, n0inv);
+                mont_mul<G::NLL, G::U, G::T>(I, t, r2_lds, 1, nm, n0inv);             // ... re-entered here
+            }
+        }
+    }
+}
+
 // ---- hs^r (and the plaintext factor) ------------------------------------------------------------------------------
 // with_m != 0: (w, v) = plain pair of hs^r (1 + m n): the last factor is the PLAIN pair (1, m), which also takes the
 // product out of Montgomery form; with_m == 0: plain pair of hs^r (last factor (1, 0)).
 // wv_out: [n][2][out_words] packed rows, w first.
-template <class G>
+// GFORM: the table holds g-factored entries (a, t) — x R == a (1 + n)^t, built by k_pair_g_prefix / k_pair_g_finish —: the
+// table products take the rule for a right operand without a second digit (pair_mul c0: 4 NL^2), the exponents t are summed
+// in lane-sliced 64-bit columns, and g^(m + sum t) joins through the final plain pair (1, s).
+template <class G, bool GFORM>
 __global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
 k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
                   uint32_t* __restrict__ wv_out, int n, int with_m) {
@@ -255,7 +396,20 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
             return P.fb_table + (((size_t)jw << P.fb_wbits) + d) * 2 * G::NL;
         };
         uint32_t a[G::NLL], b[G::NLL], c[G::NLL], d[G::NLL];
+        // lane slice of sum t (128 windows x 2^29 stay below 2^37): registers on the streaming geometries (8 lanes x 18 limbs),
+        // LDS columns on the others (4 lanes x 28 limbs: 56 more registers made the row loop shuffle through AGPRs)
+        constexpr bool TREG = GFORM && PairLds<G>::STREAM;
+        uint64_t tacc[TREG ? G::NLL : 1];
+        uint64_t* tl = PairLds<G>::tsum(lds);
         pair_load<G>(a, b, entry(0));
+        if constexpr (GFORM) {
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) {                     // entry 0: (a, 0) and its exponent
+                if constexpr (TREG) tacc[j] = b[j];
+                else tl[j * BLOCK_THREADS] = b[j];
+                b[j] = 0;
+            }
+        }
         if constexpr (PairLds<G>::STREAM) {
             constexpr int CH = (G::NLL % 4 == 0) ? 4 : 2, NCH = G::NLL / CH;
             // buffer pair k lives at lds + k * PAIR_OFF (c rows, then d rows): plain offsets from the shared base — a runtime
@@ -264,7 +418,12 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
             if (P.fb_windows > 1) {
                 pair_load<G>(c, d, entry(1));
                 stage_b<G>(c, lds + PAIR_OFF);
-                stage_b<G>(d, lds + PAIR_OFF + G::LDS_WORDS);
+                if constexpr (GFORM) {
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) tacc[j] += d[j];
+                } else {
+                    stage_b<G>(d, lds + PAIR_OFF + G::LDS_WORDS);
+                }
             }
             const int col = (G::NLL * G::gl()) * G::EPB + G::elem();
 #pragma unroll 1
@@ -273,15 +432,45 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
                 // the next window's entry streams into the other buffer pair while this product runs (the last window
                 // re-reads its own entry: harmless, keeps the loop body uniform)
                 const uint32_t* ent = entry(jw + 1 < P.fb_windows ? jw + 1 : jw);
-                RowStream<CH, NCH, NCH> pf;
-                pf.src0 = ent + G::NLL * G::gl();
-                pf.src1 = ent + G::NL + G::NLL * G::gl();
-                pf.dst0 = lds + nxt + col;
-                pf.dst1 = lds + nxt + G::LDS_WORDS + col;
-                pf.stride = G::EPB;
-                pair_mul<G::NLL, G::U, G::T>(a, b, lds + cur + G::elem(), lds + cur + G::LDS_WORDS + G::elem(), G::EPB,
-                                             PairLds<G>::nm1(lds), nm, n0inv, &pf);
+                if constexpr (GFORM) {
+                    RowStream<CH, NCH, 0> pf;                      // only the first digit goes to LDS
+                    pf.src0 = ent + G::NLL * G::gl();
+                    pf.src1 = pf.src0;
+                    pf.dst0 = lds + nxt + col;
+                    pf.dst1 = pf.dst0;
+                    pf.stride = G::EPB;
+                    const bool more = jw + 1 < P.fb_windows;
+                    uint32_t tn[G::NLL];                           // the next entry's exponent slice travels during the product
+                    digit_load<G>(tn, ent + G::NL);                // (measured: 37.4 ms against 38.5 ms with the load after it)
+                    pair_mul<G::NLL, G::U, G::T>(a, b, lds + cur + G::elem(), lds + cur + G::elem(), G::EPB,
+                                                 PairLds<G>::nm1(lds), nm, n0inv, &pf, false, true);
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) tacc[j] += more ? tn[j] : 0u;
+                } else {
+                    RowStream<CH, NCH, NCH> pf;
+                    pf.src0 = ent + G::NLL * G::gl();
+                    pf.src1 = ent + G::NL + G::NLL * G::gl();
+                    pf.dst0 = lds + nxt + col;
+                    pf.dst1 = lds + nxt + G::LDS_WORDS + col;
+                    pf.stride = G::EPB;
+                    pair_mul<G::NLL, G::U, G::T>(a, b, lds + cur + G::elem(), lds + cur + G::LDS_WORDS + G::elem(), G::EPB,
+                                                 PairLds<G>::nm1(lds), nm, n0inv, &pf);
+                }
                 wave_lds_fence();
+            }
+        } else if constexpr (GFORM) {
+            // g-factored entries: only the first digit is prefetched across the product; the exponent slice of the window just
+            // multiplied is fetched after it (half the prefetch registers)
+            if (P.fb_windows > 1) digit_load<G>(c, entry(1));
+#pragma unroll 1
+            for (int jw = 1; jw < P.fb_windows; ++jw) {
+                stage_b<G>(c, PairLds<G>::c(lds));
+                if (jw + 1 < P.fb_windows) digit_load<G>(c, entry(jw + 1));
+                pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::c(lds) + G::elem(), G::EPB,
+                                             PairLds<G>::nm1(lds), nm, n0inv, (NoStream*)nullptr, false, true);
+                digit_load<G>(d, entry(jw) + G::NL);
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) tl[j * BLOCK_THREADS] += d[j];
             }
         } else {
         if (P.fb_windows > 1) pair_load<G>(c, d, entry(1));
@@ -306,6 +495,17 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
         else {
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) d[j] = 0;
+        }
+        if constexpr (GFORM) {
+            // s = m + sum t (< 2^8 n, inside the digit): carry-propagated across the group's lanes
+            using RW = Rows<G::NLL, G::U, G::T>;
+            uint64_t sw[RW::NW];
+#pragma unroll
+            for (int j = 0; j < RW::NW; ++j) {
+                if constexpr (TREG) sw[j] = j < G::NLL ? tacc[j] + d[j] : 0ull;
+                else sw[j] = j < G::NLL ? tl[j * BLOCK_THREADS] + d[j] : 0ull;
+            }
+            RW::finish(sw, d);
         }
         pair_times<G>(a, b, c, d, lds, nm, n0inv);
         if (live) {

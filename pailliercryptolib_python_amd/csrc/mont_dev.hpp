@@ -445,8 +445,10 @@ constexpr int PAIR_NORM_MAX = 18;              // three 2^58 products per row an
 // sqr (wave-uniform): the rows at c_ptr / d_ptr are (a, b) themselves — a d + b c is then 2 a d, one multiply-accumulate
 // per limb pair less (4 NL^2 instead of 5 NL^2); both forms share this one body.
 template <int NLL, int U, int T, class NM, class PF = NoStream>
+// c0 (wave-uniform): the right operand has no second digit (g-factored table entries, kernels_pair.hpp): a d drops out,
+// 4 NL^2 as well, and d_ptr is not read.
 PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_ptr, const uint32_t* d_ptr, int stride,
-                      const uint32_t* mm1, const NM& nm, uint32_t n0inv, PF* pf = nullptr, bool sqr = false) {
+                      const uint32_t* mm1, const NM& nm, uint32_t n0inv, PF* pf = nullptr, bool sqr = false, bool c0 = false) {
     static_assert(NLL % U == 0 && U <= PAIR_NORM_MAX, "row-block size");
     using RW = Rows<NLL, U, T>;
     constexpr int NW = RW::NW;
@@ -465,7 +467,7 @@ PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             cv[u] = c_ptr[(blk * U + u) * stride];
-            dv[u] = d_ptr[(blk * U + u) * stride];
+            dv[u] = c0 ? 0u : d_ptr[(blk * U + u) * stride];
             dv[u] = sqr ? dv[u] << 1 : dv[u];
             const uint32_t f = mm1[blk * U + u];
             acc2[NLL + u] += top ? (uint64_t)f : 0ull;           // (M - 1) R: column NL + row
@@ -480,8 +482,10 @@ PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_
             acc1[u + 1] += acc1[u] >> RB;
             low1[u] = (uint32_t)acc1[u] & RMASK;
             acc2[u] += lane0 ? (uint64_t)(RMASK - q1) : 0ull;
+            if (!c0) {
 #pragma unroll
-            for (int j = 0; j < NLL; ++j) acc2[j + u] += (uint64_t)a[j] * dv[u];
+                for (int j = 0; j < NLL; ++j) acc2[j + u] += (uint64_t)a[j] * dv[u];
+            }
             if (!sqr) {
 #pragma unroll
                 for (int j = 0; j < NLL; ++j) acc2[j + u] += (uint64_t)b[j] * cv[u];

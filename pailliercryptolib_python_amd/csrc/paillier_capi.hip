@@ -1012,6 +1012,43 @@ static void gfactor_digit_table(pai_pubkey* pk, size_t NE, int dwb) {
     pk->fb_gform = true;
 }
 
+// the same for the lane-group pair table of keys above 2048 bits (kernels_pair.hpp: k_pair_g_prefix / k_pair_g_finish)
+static void gfactor_pair_table(pai_pubkey* pk, size_t NE, int wb) {
+    if (const char* env = std::getenv("PAI_FB_GFORM")) { if (env[0] == '0') return; }
+    const int nl = pk->pair_nl;
+    const int K = (int)std::min<size_t>(64, (size_t)1 << wb);
+    const int tw = pk->n_words;
+    if ((tw + 63) / 64 > 4) return;
+    const size_t slab = std::min(NE, (size_t)1 << 21) / K * K;            // 2^21 entries: 1.2 GB of prefix scratch at 144 limbs
+    ScopedDevBuf d_pref, d_tot, d_inv, d_fail;
+    d_pref.ensure(slab * (size_t)nl * 4);
+    d_tot.ensure(slab / K * (size_t)tw * 4);
+    d_inv.ensure(slab / K * (size_t)tw * 4);
+    d_fail.ensure(4);
+    HIP_CHECK(hipMemset(d_fail.p, 0, 4));
+    const int epb = pair_epb(nl);
+    const size_t ent_words = 2 * (size_t)nl;
+    for (size_t e0 = 0; e0 < NE; e0 += slab) {
+        const size_t cnt = std::min(slab, NE - e0);
+        uint32_t* tbl = pk->d_pair_fb + e0 * ent_words;
+        const int grid = (int)std::max<size_t>(1, std::min<size_t>((cnt / K + epb - 1) / epb, (size_t)pk->dev.ncu * 2));
+        if (!launch_pair_g_prefix(nl, nullptr, grid, pk->npair.d_ctx, tbl, cnt, K, d_pref.as<uint32_t>(), d_tot.as<uint32_t>(), tw))
+            throw PaiError(PAI_E_INTERNAL, "no g-factoring kernel for this limb count");
+        HIP_CHECK(hipGetLastError());
+        if (!launch_inv_eea(nullptr, tw, pk->d_nexp, d_tot.as<uint32_t>(), d_inv.as<uint32_t>(), (int)(cnt / K), 2 * 32 * tw + 64,
+                            d_fail.as<int>()))
+            throw PaiError(PAI_E_INTERNAL, "no extended-GCD instantiation for this key size");
+        HIP_CHECK(hipGetLastError());
+        int fail = 0;
+        HIP_CHECK(hipMemcpy(&fail, d_fail.p, 4, hipMemcpyDeviceToHost));
+        if (fail) throw PaiError(PAI_E_INTERNAL, "fixed-base table entry without an inverse modulo n");
+        launch_pair_g_finish(nl, nullptr, grid, pk->npair.d_ctx, tbl, cnt, K, d_pref.as<uint32_t>(), d_inv.as<uint32_t>(), tw);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    pk->fb_gform = true;
+}
+
 // ---- per-device cache of the DJN fixed-base tables (round 4) ---------------------------------------------------
 // Every DJN key builds a multi-GB table on its first obfuscating call.  A process that holds many keys (federated
 // learning: one key per party or per round) used to need pai_pubkey_trim by hand; now the handles with built tables of a
@@ -1115,6 +1152,8 @@ static void build_fb_tables_body(pai_pubkey* pk) {
     pk->fb_windows = J;
     if (pk->pair_nl) {
         build_pair_fb(pk, wb, J);
+        pk->fb_gform = false;
+        gfactor_pair_table(pk, (size_t)J << wb, wb);
     } else if (!pk->penc_nl) {
         pk->d_fb = build_lane_group_fb(pk, pk->msq, wb, J);
     } else {
@@ -1503,6 +1542,7 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
         Q.pt_words = pk->n_words;
         Q.r_words = pk->r_words;
         Q.out_words = pk->pair_out_words;
+        Q.fb_gform = pk->fb_gform ? 1 : 0;
         pk->pair_wv.ensure(N * 2 * (size_t)pk->pair_out_words * 4);
         const int epb = pair_epb(pk->pair_nl);
         const size_t tiles = (N + epb - 1) / epb;

@@ -23,8 +23,22 @@ struct PairLaunch {
     }
     static void fixed_base(hipStream_t s, int grid, const PairParams& P, const uint32_t* m, const uint32_t* r, uint32_t* wv_out,
                            int n, int with_m) {
-        (void)hipFuncSetAttribute((const void*)k_pair_fixed_base<G>, hipFuncAttributeMaxDynamicSharedMemorySize, PairLds<G>::BYTES_FB);
-        hipLaunchKernelGGL(k_pair_fixed_base<G>, dim3(grid), dim3(BLOCK_THREADS), PairLds<G>::BYTES_FB, s, P, m, r, wv_out, n, with_m);
+        auto go = [&](auto kernel, int bytes) {
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK_THREADS), bytes, s, P, m, r, wv_out, n, with_m);
+        };
+        if (P.fb_gform) go(k_pair_fixed_base<G, true>, PairLds<G>::BYTES_FBG);
+        else go(k_pair_fixed_base<G, false>, PairLds<G>::BYTES_FB);
+    }
+    static void g_prefix(hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* table, size_t count, int K, uint32_t* pref,
+                         uint32_t* tot, int tw) {
+        (void)hipFuncSetAttribute((const void*)k_pair_g_prefix<G>, hipFuncAttributeMaxDynamicSharedMemorySize, PairGLds<G>::BYTES);
+        hipLaunchKernelGGL(k_pair_g_prefix<G>, dim3(grid), dim3(BLOCK_THREADS), PairGLds<G>::BYTES, s, nctx, table, count, K, pref, tot, tw);
+    }
+    static void g_finish(hipStream_t s, int grid, const MontCtx* nctx, uint32_t* table, size_t count, int K, const uint32_t* pref,
+                         const uint32_t* inv, int tw) {
+        (void)hipFuncSetAttribute((const void*)k_pair_g_finish<G>, hipFuncAttributeMaxDynamicSharedMemorySize, PairGLds<G>::BYTES);
+        hipLaunchKernelGGL(k_pair_g_finish<G>, dim3(grid), dim3(BLOCK_THREADS), PairGLds<G>::BYTES, s, nctx, table, count, K, pref, inv, tw);
     }
     static void ctmul(hipStream_t s, int grid, const PairCtMulParams& P, const uint32_t* ct, const uint32_t* e, uint32_t* wv_out, int n) {
         (void)hipFuncSetAttribute((const void*)k_pair_ctmul<G>, hipFuncAttributeMaxDynamicSharedMemorySize, PairLds<G>::BYTES_CT);
@@ -42,6 +56,10 @@ using G144 = PAIR_G144;
 static_assert(G112::NL == 112 && G144::NL == 144, "pair geometries");
 using P112 = PairLaunch<G112>;
 using P144 = PairLaunch<G144>;
+// the table-conversion kernels run single Montgomery products (mont_mul: row blocks must divide its 24-row normalisation
+// interval); the table layout does not depend on the row-block size
+using P112C = PairLaunch<Geo<G112::NLL, G112::T, 4, false>>;
+using P144C = PairLaunch<Geo<G144::NLL, G144::T, 6, false>>;
 
 int pair_nl_for_n_bits(int bits) {
     if (bits <= 2048) return 0;                    // the one-element-per-lane digit engine serves those
@@ -68,6 +86,21 @@ bool launch_pair_fixed_base(int nl, hipStream_t s, int grid, const PairParams& P
                             uint32_t* wv_out, int n, int with_m) {
     if (nl == 112) P112::fixed_base(s, grid, P, m, r, wv_out, n, with_m);
     else if (nl == 144) P144::fixed_base(s, grid, P, m, r, wv_out, n, with_m);
+    else return false;
+    return true;
+}
+
+bool launch_pair_g_prefix(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* table, size_t count, int K,
+                          uint32_t* pref, uint32_t* tot, int tw) {
+    if (nl == 112) P112C::g_prefix(s, grid, nctx, table, count, K, pref, tot, tw);
+    else if (nl == 144) P144C::g_prefix(s, grid, nctx, table, count, K, pref, tot, tw);
+    else return false;
+    return true;
+}
+bool launch_pair_g_finish(int nl, hipStream_t s, int grid, const MontCtx* nctx, uint32_t* table, size_t count, int K,
+                          const uint32_t* pref, const uint32_t* inv, int tw) {
+    if (nl == 112) P112C::g_finish(s, grid, nctx, table, count, K, pref, inv, tw);
+    else if (nl == 144) P144C::g_finish(s, grid, nctx, table, count, K, pref, inv, tw);
     else return false;
     return true;
 }
