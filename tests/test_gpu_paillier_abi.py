@@ -817,3 +817,40 @@ def test_small_batch_table_widths_give_the_same_bits(wbits, monkeypatch):
     dm, dr, ct = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r), DevArray(shape=(N, nk.cw))
     _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
     assert limbs_to_ints(ct.get()) == want
+
+
+@pytest.mark.parametrize("bits,env", [(1024, {}), (2048, {"PAI_FB_DIGIT_WBITS": "4"}), (2048, {"PAI_FB_DIGIT_WBITS": "12"}), (2048, {}),
+                                      (3072, {"PAI_FB_WBITS": "6"}), (3072, {}), (4096, {"PAI_FB_WBITS": "5"}), (4096, {})])
+def test_g_factored_tables_give_the_bits_of_the_plain_tables(bits, env, monkeypatch):
+    """Round 4: the fixed-base tables hold g-factored entries (a, t) — x R == a (1 + n)^t — so that a table product is
+    the 4 NL^2 rule and the exponents are summed on the side (kernels_padic_enc.hpp / kernels_pair.hpp; conversion by
+    simultaneous inversion: k_fb_g_prefix / k_fb_g_finish, k_pair_g_*).  Same ciphertext bits as the plain table
+    (PAI_FB_GFORM=0) and as the oracle, for encryption and apply_obfuscator, over table widths that make the inversion
+    chunks 16 / 32 / 64 entries long, r = 0 and r = all ones included."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("PAI_LATENCY_MAX", "0")                      # the big tables for every batch size
+    key = (bench_key() if bits == 2048 else seeded_key(bits))
+    N = 70 if bits <= 2048 else 20
+    m = plaintexts(key, N, bits + 17)
+    r = orc.synth_r_limbs(bits + 5, N, key.randbits)
+    r[0] = 0
+    r[1] = 0xFFFFFFFF
+    r[1, -1] &= np.uint32((1 << (key.randbits - 32 * (r.shape[1] - 1))) - 1) if key.randbits % 32 else np.uint32(0xFFFFFFFF)
+    got = {}
+    for g in ("1", "0"):
+        monkeypatch.setenv("PAI_FB_GFORM", g)
+        nk = NativeKey(key)
+        dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
+        ct = DevArray(shape=(N, nk.cw))
+        _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+        enc = ct.get().copy()
+        _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
+        got[g] = (enc, ct.get().copy())
+        del nk
+    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+    rs = orc.limbs_to_ints(r)
+    nchk = N if bits <= 2048 else 6
+    want = [orc.encrypt(key, x, rr) for x, rr in zip(m[:nchk], rs[:nchk])]
+    assert limbs_to_ints(got["1"][0][:nchk]) == want
+    assert limbs_to_ints(got["1"][1][:nchk]) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, rs[:nchk])]
