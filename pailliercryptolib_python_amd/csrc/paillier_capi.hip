@@ -980,10 +980,15 @@ static void gfactor_digit_table(pai_pubkey* pk, size_t NE, int dwb) {
     const size_t slab_max = (size_t)1 << 22;                             // entries per slab: 1.2 GB of prefix scratch at 72 limbs
     const size_t slab = std::min(NE, slab_max) / K * K;
     ScopedDevBuf d_pref, d_tot, d_inv, d_fail;
-    d_pref.ensure(slab * (size_t)pnl * 4);
-    d_tot.ensure(slab / K * (size_t)tw * 4);
-    d_inv.ensure(slab / K * (size_t)tw * 4);
-    d_fail.ensure(4);
+    try {                                                                // no room for the scratch: keep the plain table (nothing was touched yet)
+        d_pref.ensure(slab * (size_t)pnl * 4);
+        d_tot.ensure(slab / K * (size_t)tw * 4);
+        d_inv.ensure(slab / K * (size_t)tw * 4);
+        d_fail.ensure(4);
+    } catch (const PaiError&) {
+        (void)hipGetLastError();
+        return;
+    }
     HIP_CHECK(hipMemset(d_fail.p, 0, 4));
     const int grid = pk->dev.ncu;                                         // the scratch column is sized for this grid
     const size_t ent_words = 2 * (size_t)pnl;
@@ -1021,10 +1026,15 @@ static void gfactor_pair_table(pai_pubkey* pk, size_t NE, int wb) {
     if ((tw + 63) / 64 > 4) return;
     const size_t slab = std::min(NE, (size_t)1 << 21) / K * K;            // 2^21 entries: 1.2 GB of prefix scratch at 144 limbs
     ScopedDevBuf d_pref, d_tot, d_inv, d_fail;
-    d_pref.ensure(slab * (size_t)nl * 4);
-    d_tot.ensure(slab / K * (size_t)tw * 4);
-    d_inv.ensure(slab / K * (size_t)tw * 4);
-    d_fail.ensure(4);
+    try {
+        d_pref.ensure(slab * (size_t)nl * 4);
+        d_tot.ensure(slab / K * (size_t)tw * 4);
+        d_inv.ensure(slab / K * (size_t)tw * 4);
+        d_fail.ensure(4);
+    } catch (const PaiError&) {
+        (void)hipGetLastError();
+        return;
+    }
     HIP_CHECK(hipMemset(d_fail.p, 0, 4));
     const int epb = pair_epb(nl);
     const size_t ent_words = 2 * (size_t)nl;
