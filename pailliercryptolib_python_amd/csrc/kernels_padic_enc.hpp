@@ -203,7 +203,8 @@ k_fb_expand_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1g, const 
 // a (1 + t n) == a + a t n, so x R == a g^t for t = d a^-1 mod n: every entry factors into an element WITHOUT a second
 // digit and a power of g, and g^t g^t' = g^(t + t').  The encryption kernels then multiply by (a, 0) — 4 NL^2 limb
 // products instead of 5 — and add the exponents t (kernels above).  The conversion needs a^-1 mod n for every entry:
-// Montgomery's simultaneous inversion over chunks of K consecutive entries, one chunk per lane —
+// Montgomery's simultaneous inversion over chunks of K entries, one chunk per lane (chunk c = entries c, c + nchunks,
+// c + 2 nchunks, ...: any grouping serves the trick, and this one makes the lanes of a wave walk consecutive entries) —
 //   pass 1 (k_fb_g_prefix): prefix products P_i = a_0 ... a_i in Montgomery form (R = 2^(29 NL), modulo n) into `pref`,
 //           the chunk total as a packed canonical residue into `tot`;
 //   the totals are inverted by the wave-parallel extended GCD (inv_eea.hip: launch_inv_eea);
@@ -256,12 +257,12 @@ k_fb_g_prefix(const MontCtx* __restrict__ nctx, const uint4* __restrict__ table,
         uint32_t w[NL];
 #pragma unroll 1
         for (int i = 0; i < K; ++i) {
-            const size_t g = cs * (size_t)K + i;
+            const size_t g = (size_t)i * nchunks + cs;      // interleaved chunks: at step i the lanes of a wave touch consecutive entries
             gf_load_digit<E>(X0, table + g * 2 * E::NC);                 // a_i
             E::mm1_mul(w, M, X0, r2dig, nm, n0inv);                       // a_i R
             if (i > 0) {
                 gf_put_digit<E, NL>(X0, w);
-                const uint4* prev = pref + (g - 1) * E::NC;
+                const uint4* prev = pref + (g - nchunks) * E::NC;
                 auto pdig = [&](int blk, uint32_t (&xv)[U]) {
 #pragma unroll
                     for (int c = 0; c < E::UC; ++c) {
@@ -338,7 +339,7 @@ k_fb_g_finish(const MontCtx* __restrict__ nctx, uint4* __restrict__ table, size_
         }
 #pragma unroll 1
         for (int i = K - 1; i >= 0; --i) {
-            const size_t g = cs * (size_t)K + i;
+            const size_t g = (size_t)i * nchunks + cs;      // interleaved chunks: at step i the lanes of a wave touch consecutive entries
             uint4* ent = table + g * 2 * E::NC;
             auto from = [&](const uint4* p) {
                 return [p](int blk, uint32_t (&xv)[U]) {
@@ -351,7 +352,7 @@ k_fb_g_finish(const MontCtx* __restrict__ nctx, uint4* __restrict__ table, size_
             };
             // u = a_i^-1 R: the running inverse times P_(i-1) (i = 0: the running inverse itself)
             if (i > 0) {
-                E::mm1_mul(w, M, X0, from(pref + (g - 1) * E::NC), nm, n0inv);
+                E::mm1_mul(w, M, X0, from(pref + (g - nchunks) * E::NC), nm, n0inv);
                 gf_put_digit<E, NL>(X1, w);
             } else {
                 wave_lds_fence();

@@ -293,7 +293,7 @@ k_pair_g_prefix(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ t
         uint32_t P[G::NLL], x[G::NLL], t[G::NLL];
 #pragma unroll 1
         for (int i = 0; i < K; ++i) {
-            const size_t g = cs * (size_t)K + i;
+            const size_t g = (size_t)i * nchunks + cs;      // interleaved chunks: at step i the lanes of a wave touch consecutive entries
             digit_load<G>(x, table + g * 2 * G::NL);
             mont_mul<G::NLL, G::U, G::T>(t, x, r2_lds, 1, nm, n0inv);                 // a_i R
             if (i > 0) {
@@ -340,10 +340,10 @@ k_pair_g_finish(const MontCtx* __restrict__ nctx, uint32_t* __restrict__ table, 
         mont_mul<G::NLL, G::U, G::T>(I, x, r2_lds, 1, nm, n0inv);                     // (a_0 ... a_(K-1))^-1 R
 #pragma unroll 1
         for (int i = K - 1; i >= 0; --i) {
-            const size_t g = cs * (size_t)K + i;
+            const size_t g = (size_t)i * nchunks + cs;      // interleaved chunks: at step i the lanes of a wave touch consecutive entries
             uint32_t* ent = table + g * 2 * G::NL;
             if (i > 0) {
-                digit_load<G>(x, pref + (g - 1) * G::NL);
+                digit_load<G>(x, pref + (g - nchunks) * G::NL);
                 stage_b<G>(x, lds);
                 mont_mul<G::NLL, G::U, G::T>(u, I, col, G::EPB, nm, n0inv);           // a_i^-1 R
             } else {

@@ -976,7 +976,11 @@ static void gfactor_digit_table(pai_pubkey* pk, size_t NE, int dwb) {
     const int pnl = pk->penc_nl;
     // chunk length: divides the entries of a window, hence NE; one extended GCD per K entries.  64 measured best (first 2^20
     // encryption of a 2048-bit key 0.203 s; 256-entry chunks: 0.295 s)
-    const int K = (int)std::min<size_t>(64, (size_t)1 << dwb);
+    int K = (int)std::min<size_t>(64, (size_t)1 << dwb);
+    if (const char* env = std::getenv("PAI_FB_GFORM_K")) {               // experiments: a power of two up to the window's entry count
+        const int v = std::atoi(env);
+        if (v >= 2 && (v & (v - 1)) == 0 && (size_t)v <= ((size_t)1 << dwb)) K = v;
+    }
     const int tw = pk->n_words;
     if ((tw + 63) / 64 > 4) return;                                      // inv_eea instantiations: up to 256 words
     const size_t slab_max = (size_t)1 << 22;                             // entries per slab: 1.2 GB of prefix scratch at 72 limbs
