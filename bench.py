@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: Paillier encrypt+decrypt ops/sec, 2048-bit key, batch = 1 M.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scaling strong|weak] [--no-cpu-baseline] [--no-extras]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config headline|cfg2|cfg4|cfg5] [--key-bits B] [--batch B]
+                    [--scaling strong|weak] [--no-cpu-baseline] [--no-extras] [--no-reference-bench]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` with N > 1 and no torchrun environment launches the N ranks itself (one process per GPU under
@@ -37,6 +38,13 @@ The JSON line also carries
                  float64 array (codec, CSPRNG-keyed randomness and PCIe included): SURVEY.md §8d(i).
   other_ops    — BASELINE configs[2]: ct+ct add, ct x pt mul (and ct^-1, sum) on the same resident batch, each
                  checked against the oracle; small_batch — latency at the reference's own batch sizes 16 / 64.
+  reference_bench — the reference's own benchmark suite (bench/bench_ipcl_python.py:13-78: KeyGen, Encrypt, Decrypt,
+                 Add_CTCT, Add_CTPT, Mul_CTPT at 16 / 64 with its inputs and key) through the PUBLIC API, microseconds per
+                 call, with the same composition on the CPU port beside it and a bit-for-bit parity check of every
+                 deterministic row (2048-bit configurations only).
+--config selects the BASELINE.json configuration: headline (2048-bit, 2^20: the metric), cfg2 (2048-bit, 65 536),
+cfg4 (3072-bit, 2^20), cfg5 (4096-bit, 2^18): key size, batch, executed / canonical MAC counts, dominant kernel and the
+PMC file for roofline.traffic follow the key size; the parity check and cpu_baseline are the same.
 """
 from __future__ import annotations
 
