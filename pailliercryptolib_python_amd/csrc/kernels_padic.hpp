@@ -100,6 +100,9 @@ PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const u
 #define PADIC_FUSED_72 true
 #endif
 #define PADIC_FUSED(NL) ((NL) == 56 ? PADIC_FUSED_56 : ((NL) == 72 ? PADIC_FUSED_72 : false))
+#ifndef PADIC_REGM_MUL_WBUF
+#define PADIC_REGM_MUL_WBUF 0       // PADIC_REGM: products through mul_wbuf (quotient digits AND first result digit in global scratch)
+#endif
 #ifndef PADIC_SGPR_MODULUS
 // measured per 65 536 decryptions with the modulus in SGPRs vs read from LDS: 36 limbs 488 vs 508 ms (x16), 72 limbs 364
 // vs 391 ms; 56 limbs (squaring as product, LDS-qualified accesses) 142 vs 151 ms
@@ -165,6 +168,7 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     };
     auto MUL = [&](auto&& csrc, auto&& dsrc) {
         if constexpr (MODE == PADIC_WBUF) E::template mul_w<PADIC_FUSED(NL)>(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);
+        else if constexpr (MODE == PADIC_REGM && PADIC_REGM_MUL_WBUF) E::mul_wbuf(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);   // w parked too: no 36-register result digit across the second half
         else E::mul(A, B, M, csrc, dsrc, nm, pm1, n0inv);
     };
     // table entry e: digit d (0 = first, 1 = second), chunk c
