@@ -205,11 +205,13 @@ k_fb_expand_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1g, const 
 // products instead of 5 — and add the exponents t (kernels above).  The conversion needs a^-1 mod n for every entry:
 // Montgomery's simultaneous inversion over chunks of K entries, one chunk per lane (chunk c = entries c, c + nchunks,
 // c + 2 nchunks, ...: any grouping serves the trick, and this one makes the lanes of a wave walk consecutive entries) —
-//   pass 1 (k_fb_g_prefix): prefix products P_i = a_0 ... a_i in Montgomery form (R = 2^(29 NL), modulo n) into `pref`,
-//           the chunk total as a packed canonical residue into `tot`;
+//   pass 1 (k_fb_g_prefix): prefix products P_i = a_0 ... a_i R^-i (one Montgomery product per entry, R = 2^(29 NL), modulo n)
+//           into `pref`, the chunk total as a packed canonical residue into `tot`;
 //   the totals are inverted by the wave-parallel extended GCD (inv_eea.hip: launch_inv_eea);
-//   pass 2 (k_fb_g_finish): back sweep a_i^-1 = (a_0 ... a_i)^-1 P_(i-1), t_i = d_i a_i^-1 written over d_i.
-// Six single-digit Montgomery products per entry (2 + 4).  X0 / X1 are the two LDS digit buffers of the lane; the quotient
+//   pass 2 (k_fb_g_finish): back sweep with the running inverse (a_0 ... a_i)^-1 R^(i+1): a_i^-1 R = running * P_(i-1) R^-1,
+//           t_i = d_i a_i^-1 written over d_i, running <- running * a_i R^-1.
+// Four single-digit Montgomery products per entry (1 + 3): the powers of R of the prefix products and of the running
+// inverse cancel step by step.  X0 / X1 are the two LDS digit buffers of the lane; the quotient
 // digits of mm1_mul are not needed and go to the lane's scratch column.
 template <class E>
 PAI_DEV void gf_load_digit(uint4* X, const uint4* __restrict__ src) {
@@ -259,9 +261,11 @@ k_fb_g_prefix(const MontCtx* __restrict__ nctx, const uint4* __restrict__ table,
         for (int i = 0; i < K; ++i) {
             const size_t g = (size_t)i * nchunks + cs;      // interleaved chunks: at step i the lanes of a wave touch consecutive entries
             gf_load_digit<E>(X0, table + g * 2 * E::NC);                 // a_i
-            E::mm1_mul(w, M, X0, r2dig, nm, n0inv);                       // a_i R
+            if (i == 0) {
+#pragma unroll
+                for (int c = 0; c < E::NC; ++c) { const uint4 t = E::ld(X0, c); w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w; }
+            }
             if (i > 0) {
-                gf_put_digit<E, NL>(X0, w);
                 const uint4* prev = pref + (g - nchunks) * E::NC;
                 auto pdig = [&](int blk, uint32_t (&xv)[U]) {
 #pragma unroll
@@ -270,7 +274,7 @@ k_fb_g_prefix(const MontCtx* __restrict__ nctx, const uint4* __restrict__ table,
                         xv[4 * c] = t.x; xv[4 * c + 1] = t.y; xv[4 * c + 2] = t.z; xv[4 * c + 3] = t.w;
                     }
                 };
-                E::mm1_mul(w, M, X0, pdig, nm, n0inv);                    // P_i = P_(i-1) a_i  (Montgomery form)
+                E::mm1_mul(w, M, X0, pdig, nm, n0inv);                    // P_i = P_(i-1) a_i R^-1 = a_0 ... a_i R^-i
             }
             if (live) {
                 uint4* dst = pref + g * E::NC;
@@ -279,9 +283,7 @@ k_fb_g_prefix(const MontCtx* __restrict__ nctx, const uint4* __restrict__ table,
             }
             __threadfence_block();
         }
-        // chunk total, plain and canonical, as packed words
-        gf_put_digit<E, NL>(X0, w);
-        E::mm1_mul(w, M, X0, one, nm, n0inv);
+        // the chunk total a_0 ... a_(K-1) R^-(K-1) as a canonical residue, packed words (its inverse carries R^(K-1))
         E::cond_sub(w, nm);
         E::cond_sub(w, nm);
         if (live) {
@@ -326,7 +328,7 @@ k_fb_g_finish(const MontCtx* __restrict__ nctx, uint4* __restrict__ table, size_
         const bool live = ch < nchunks;
         const size_t cs = live ? ch : nchunks - 1;
         uint32_t w[NL];
-        {   // the chunk's inverse total enters Montgomery form: X0 = (a_0 ... a_(K-1))^-1 R
+        {   // the inverse of the chunk total is (a_0 ... a_(K-1))^-1 R^(K-1); one more R: X0 = (a_0 ... a_(K-1))^-1 R^K
             const uint32_t* irow = inv + cs * (size_t)tw;
             wave_lds_fence();
 #pragma unroll 1
@@ -350,7 +352,8 @@ k_fb_g_finish(const MontCtx* __restrict__ nctx, uint4* __restrict__ table, size_
                     }
                 };
             };
-            // u = a_i^-1 R: the running inverse times P_(i-1) (i = 0: the running inverse itself)
+            // u = a_i^-1 R: the running inverse (a_0 ... a_i)^-1 R^(i+1) times P_(i-1) = a_0 ... a_(i-1) R^-(i-1), times R^-1
+            // (i = 0: the running inverse itself)
             if (i > 0) {
                 E::mm1_mul(w, M, X0, from(pref + (g - nchunks) * E::NC), nm, n0inv);
                 gf_put_digit<E, NL>(X1, w);
@@ -368,11 +371,10 @@ k_fb_g_finish(const MontCtx* __restrict__ nctx, uint4* __restrict__ table, size_
 #pragma unroll
                 for (int c = 0; c < E::NC; ++c) ent[E::NC + c] = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
             }
-            // running inverse <- running inverse * a_i (plain a_i drops the R: re-enter Montgomery form)
+            // running inverse <- running inverse * a_i R^-1: (a_0 ... a_(i-1))^-1 R^i, one power of R less per step, as the
+            // prefix products lose one per step
             if (i > 0) {
                 E::mm1_mul(w, M, X0, from(ent), nm, n0inv);
-                gf_put_digit<E, NL>(X0, w);
-                E::mm1_mul(w, M, X0, r2dig, nm, n0inv);
                 gf_put_digit<E, NL>(X0, w);
             }
         }

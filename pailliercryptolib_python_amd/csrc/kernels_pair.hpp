@@ -294,22 +294,20 @@ k_pair_g_prefix(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ t
 #pragma unroll 1
         for (int i = 0; i < K; ++i) {
             const size_t g = (size_t)i * nchunks + cs;      // interleaved chunks: at step i the lanes of a wave touch consecutive entries
-            digit_load<G>(x, table + g * 2 * G::NL);
-            mont_mul<G::NLL, G::U, G::T>(t, x, r2_lds, 1, nm, n0inv);                 // a_i R
+            digit_load<G>(x, table + g * 2 * G::NL);                                  // a_i
             if (i > 0) {
                 stage_b<G>(P, lds);
-                mont_mul<G::NLL, G::U, G::T>(x, t, col, G::EPB, nm, n0inv);           // P_i = P_(i-1) a_i
-#pragma unroll
-                for (int j = 0; j < G::NLL; ++j) P[j] = x[j];
-            } else {
+                mont_mul<G::NLL, G::U, G::T>(t, x, col, G::EPB, nm, n0inv);           // P_i = P_(i-1) a_i R^-1 = a_0 ... a_i R^-i
 #pragma unroll
                 for (int j = 0; j < G::NLL; ++j) P[j] = t[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) P[j] = x[j];
             }
             if (live) digit_store<G>(P, pref + g * G::NL);
         }
-        set_plain_one<G>(x);
-        stage_b<G>(x, lds);
-        mont_mul<G::NLL, G::U, G::T>(t, P, col, G::EPB, nm, n0inv);                   // the chunk total, plain
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) t[j] = P[j];                                 // the chunk total a_0 ... a_(K-1) R^-(K-1), canonical
         cond_sub<G::NLL, G::T>(t, nm);
         cond_sub<G::NLL, G::T>(t, nm);
         // every group runs store_elem (it stages through LDS with wave-level fences); dead groups write their clamped chunk's
@@ -337,7 +335,7 @@ k_pair_g_finish(const MontCtx* __restrict__ nctx, uint32_t* __restrict__ table, 
         const size_t cs = live ? ch : nchunks - 1;
         uint32_t I[G::NLL], x[G::NLL], u[G::NLL], t[G::NLL];
         load_elem<G>(x, inv + cs * (size_t)tw, tw);
-        mont_mul<G::NLL, G::U, G::T>(I, x, r2_lds, 1, nm, n0inv);                     // (a_0 ... a_(K-1))^-1 R
+        mont_mul<G::NLL, G::U, G::T>(I, x, r2_lds, 1, nm, n0inv);                     // (a_0 ... a_(K-1))^-1 R^(K-1) * R
 #pragma unroll 1
         for (int i = K - 1; i >= 0; --i) {
             const size_t g = (size_t)i * nchunks + cs;      // interleaved chunks: at step i the lanes of a wave touch consecutive entries
@@ -357,10 +355,11 @@ k_pair_g_finish(const MontCtx* __restrict__ nctx, uint32_t* __restrict__ table, 
             cond_sub<G::NLL, G::T>(t, nm);
             if (live) digit_store<G>(t, ent + G::NL);
             if (i > 0) {
-                digit_load<G>(x, ent);                                                // a_i (plain: drops the R ...)
+                digit_load<G>(x, ent);                                                // a_i
                 stage_b<G>(x, lds);
-                mont_mul<G::NLL, G::U, G::T>(t, I, col, G::EPB, nm, n0inv);
-                mont_mul<G::NLL, G::U, G::T>(I, t, r2_lds, 1, nm, n0inv);             // ... re-entered here
+                mont_mul<G::NLL, G::U, G::T>(t, I, col, G::EPB, nm, n0inv);           // running inverse: one power of R less per step
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) I[j] = t[j];
             }
         }
     }
