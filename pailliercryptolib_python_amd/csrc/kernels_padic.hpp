@@ -110,9 +110,11 @@ PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const u
 #endif
 // MODE PADIC_REGM (round 4): LDS holds only the digit pair; the squaring keeps its quotient digits in registers
 //                   (Padic::sqr_regm), the product parks them in a strided global scratch column: two workgroups per CU.
-constexpr int PADIC_LDS_M = 0, PADIC_REGM = 1, PADIC_WBUF = 2;
+// MODE PADIC_COMBA (round 4): as PADIC_REGM, but runs of squarings stay in registers (Padic::sqr_comba): the digit pair
+//                   is loaded from LDS before a run and stored after it; the products run the PADIC_REGM forms.
+constexpr int PADIC_LDS_M = 0, PADIC_REGM = 1, PADIC_WBUF = 2, PADIC_COMBA = 3;
 template <int NL, int U, int WB, int MODE>
-__global__ void __launch_bounds__(BLOCK_THREADS, MODE == PADIC_REGM ? 2 : 1)
+__global__ void __launch_bounds__(BLOCK_THREADS, (MODE == PADIC_REGM || MODE == PADIC_COMBA) ? 2 : 1)
 k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n,
               uint4* __restrict__ table) {
     using E = Padic<NL, U, (NL >= PADIC_XLDS_FROM)>;
@@ -148,8 +150,9 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     // M: quotient digits of the first half of the product rule: an LDS digit buffer, or (PADIC_WBUF) a strided global column
     const typename E::MBuf M = MODE != PADIC_LDS_M ? typename E::MBuf{P.wscratch + slot, nslots} : typename E::MBuf{B + E::NC * 64, 64};
     const typename E::MBuf Wb{P.wscratch + (size_t)E::NC * nslots + slot, nslots};      // MODE 2 only
+    constexpr bool TWO_WG = MODE == PADIC_REGM || MODE == PADIC_COMBA;
     auto SQR = [&]() {
-        if constexpr (MODE == PADIC_REGM) {
+        if constexpr (MODE == PADIC_REGM || MODE == PADIC_COMBA) {
             E::sqr_regm(A, B, nm, pm1, n0inv);
         } else if constexpr (MODE == PADIC_WBUF && NL > PADIC_SQR_MUL_ABOVE) {
             // Wide digits: the fully unrolled limb-class symmetric squaring (sqr_wbuf) is 62 KB of code at 72 limbs
@@ -168,8 +171,25 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     };
     auto MUL = [&](auto&& csrc, auto&& dsrc) {
         if constexpr (MODE == PADIC_WBUF) E::template mul_w<PADIC_FUSED(NL)>(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);
-        else if constexpr (MODE == PADIC_REGM && PADIC_REGM_MUL_WBUF) E::mul_wbuf(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);   // w parked too: no 36-register result digit across the second half
+        else if constexpr (TWO_WG && PADIC_REGM_MUL_WBUF) E::mul_wbuf(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);   // w parked too: no 36-register result digit across the second half
         else E::mul(A, B, M, csrc, dsrc, nm, pm1, n0inv);
+    };
+    auto SQRN = [&](int nsq) __attribute__((always_inline)) {
+        if constexpr (MODE == PADIC_COMBA) {
+            uint32_t a[NL], b[NL];
+            wave_lds_fence();
+            E::load_digit(A, a);
+            E::load_digit(B, b);
+#pragma unroll 1
+            for (int s = 0; s < nsq; ++s) E::sqr_comba(a, b, nm, n0inv);
+            wave_lds_fence();
+            E::store_digit(A, a);
+            E::store_digit(B, b);
+            wave_lds_fence();
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < nsq; ++s) SQR();
+        }
     };
     // table entry e: digit d (0 = first, 1 = second), chunk c
     auto tbl = [&](int e, int d, int c) -> uint4& { return table[(((size_t)e * 2 + d) * E::NC + c) * nslots + slot]; };
@@ -194,7 +214,7 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
                 }
             };
         };
-        SQR();
+        SQRN(1);
 #pragma unroll 1
         for (int c = 0; c < E::NC; ++c) { tbl(NT, 0, c) = E::ld(A, c); tbl(NT, 1, c) = E::ld(B, c); }
         wave_lds_fence();
@@ -219,8 +239,7 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
         for (int k = 1; k < nops; ++k) {
             const int op = (int)ops[k];
             const int nsq = op & 0xFF, idx = op >> 8;
-#pragma unroll 1
-            for (int s = 0; s < nsq; ++s) SQR();
+            SQRN(nsq);
             if (idx != 0xFF) {
                 MUL(from_table(idx, 0), from_table(idx, 1));
             }

@@ -873,6 +873,68 @@ struct Padic {
         wave_lds_fence();
     }
 
+    // (a, b) <- (a, b)^2 entirely in registers, product scanning (Comba): column k of  a^2 + m p  and of
+    // 2 a b - m + R p + m' p  is summed in two lazy 64-bit accumulators (s: the doubled limb pairs, once; d: carry, square /
+    // constant terms, quotient products), the quotient digit falls out of the column's low word, and the column is folded as
+    //     sum = d + 2 (s mod 2^29),   d' = sum >> 29,   s' = s >> 29   (the doubled carry stays with the doubled accumulator)
+    // (s <= NL 2^58 + 2^36, d <= (NL + 1) 2^58 + 2^36: nothing wraps for NL <= 62).  No accumulator window, no LDS or scratch
+    // traffic, ~5 NL + 30 live registers; the modulus limbs are the SGPR array of the caller (p - 1 differs from p in limb
+    // 0 only, p being odd).  Bounds as in the row-wise forms: a, b < 2p + eps in, same out.
+    PAI_DEV static void sqr_comba(uint32_t (&a)[NL], uint32_t (&b)[NL], const uint32_t* __restrict__ nm, uint32_t n0inv) {
+        uint32_t m[NL], w[NL], m2[NL], v[NL];
+        uint64_t carry = 0, s = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * NL - 1; ++k) {
+            const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+            uint64_t d = carry;
+#pragma unroll
+            for (int i = lo; 2 * i < k; ++i) s += (uint64_t)a[i] * a[k - i];
+            if (k % 2 == 0) d += (uint64_t)a[k / 2] * a[k / 2];
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (i != k) d += (uint64_t)m[i] * nm[k - i];
+            uint64_t sum = d + ((uint64_t)((uint32_t)s & RMASK) << 1);
+            if (k < NL) {
+                m[k] = ((uint32_t)sum * n0inv) & RMASK;
+                sum += (uint64_t)m[k] * nm[0];
+            } else {
+                w[k - NL] = (uint32_t)sum & RMASK;
+            }
+            carry = sum >> RB;
+            s >>= RB;                      // the doubled part's carry stays in the doubled accumulator
+        }
+        w[NL - 1] = (uint32_t)carry + ((uint32_t)s << 1);
+        carry = 0;
+        s = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * NL - 1; ++k) {
+            const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+            // (R - 1 - m) + 1 in the low columns, p - 1 in the high ones
+            uint64_t d = carry + (k < NL ? (uint64_t)((RMASK - m[k]) + (k == 0 ? 1u : 0u)) : (uint64_t)(nm[k - NL] - (k == NL ? 1u : 0u)));
+#pragma unroll
+            for (int i = lo; i <= hi; ++i) s += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (i != k) d += (uint64_t)m2[i] * nm[k - i];
+            uint64_t sum = d + ((uint64_t)((uint32_t)s & RMASK) << 1);
+            if (k < NL) {
+                m2[k] = ((uint32_t)sum * n0inv) & RMASK;
+                sum += (uint64_t)m2[k] * nm[0];
+            } else {
+                v[k - NL] = (uint32_t)sum & RMASK;
+            }
+            carry = sum >> RB;
+            s >>= RB;
+        }
+        v[NL - 1] = (uint32_t)carry + ((uint32_t)s << 1) + nm[NL - 1];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { a[j] = w[j]; b[j] = v[j]; }
+    }
+    PAI_DEV static void load_digit(const uint4* x, uint32_t (&r)[NL]) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const uint4 t = ld(x, c); r[4 * c] = t.x; r[4 * c + 1] = t.y; r[4 * c + 2] = t.z; r[4 * c + 3] = t.w; }
+    }
+
     // (A, B) <- (A, B)^2
     PAI_DEV static void sqr(uint4* A, uint4* B, MBuf M, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
                             uint32_t n0inv) {

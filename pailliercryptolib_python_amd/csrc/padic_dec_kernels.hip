@@ -19,9 +19,9 @@ size_t padic_table_words(int nl, size_t blocks) { return (size_t)(PADIC_TBL_ENTR
 #ifndef PADIC_DEC36_MODE
 #define PADIC_DEC36_MODE PADIC_LDS_M      // PADIC_REGM: digit pair only in LDS, two workgroups per CU (A/B: tools/variant_dec.sh)
 #endif
-int padic_blocks_per_cu(int nl) { return (nl <= 36 && PADIC_DEC36_MODE == PADIC_REGM) ? 2 : 1; }
+int padic_blocks_per_cu(int nl) { return (nl <= 36 && PADIC_DEC36_MODE != PADIC_LDS_M) ? 2 : 1; }
 size_t padic_scratch_words(int nl, size_t blocks) {
-    return (nl <= 36 && PADIC_DEC36_MODE != PADIC_REGM) ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS;
+    return (nl <= 36 && PADIC_DEC36_MODE == PADIC_LDS_M) ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS;
 }
 #ifndef PADIC_U72
 #define PADIC_U72 8

@@ -975,7 +975,7 @@ static void gfactor_digit_table(pai_pubkey* pk, size_t NE, int dwb) {
     if (!padic_enc_gform_supported()) return;
     const int pnl = pk->penc_nl;
     // chunk length: divides the entries of a window, hence NE; one extended GCD per K entries.  64 measured best (first 2^20
-    // encryption of a 2048-bit key 0.203 s; 256-entry chunks: 0.295 s)
+    // encryption of a 2048-bit key 0.188 s; 256-entry chunks measured slower)
     int K = (int)std::min<size_t>(64, (size_t)1 << dwb);
     if (const char* env = std::getenv("PAI_FB_GFORM_K")) {               // experiments: a power of two up to the window's entry count
         const int v = std::atoi(env);
