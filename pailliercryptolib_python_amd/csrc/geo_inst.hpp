@@ -98,6 +98,14 @@ struct GeoInst {
                       uint32_t* table) {
         // the wide-group (latency) geometries run stage A on minus-one contexts (mont_dev.hpp: Rows::block_m1)
         using GD = Geo<G::NLL, G::T, G::U, G::NMLDS, (G::T >= 16)>;
+        if constexpr (GD::M1) {
+            if (P.rl) {         // gridx counts workgroups of EPB / 2 integers here
+                constexpr int bytes = ((RL_RING + 1) * GD::LDS_WORDS + 16) * 4;
+                set_lds((const void*)k_dec_a_rl<GD>, bytes);
+                hipLaunchKernelGGL((k_dec_a_rl<GD>), dim3(gridx, 2), dim3(BLOCK_THREADS), bytes, s, P, ct, u_out, n);
+                return;
+            }
+        }
         set_lds((const void*)k_dec_a<GD, MODEXP_WINDOW>, GD::LDS_BYTES);
         hipLaunchKernelGGL((k_dec_a<GD, MODEXP_WINDOW>), dim3(gridx, 2), dim3(BLOCK_THREADS), GD::LDS_BYTES, s, P, ct,
                            u_out, n, table);

@@ -236,6 +236,7 @@ struct DecAParams {
     const uint16_t* ops[2];      // minus-one geometries: sliding-window schedule of s - 1 (squarings | table index << 8,
     int nops[2];                 // index 0xFF = no multiplication), table of the odd powers base^(2i+1), i < tbl_entries;
     int tbl_entries;             // slot tbl_entries keeps base^2.  NULL: fixed W-bit windows
+    int rl = 0;                  // minus-one geometries, smallest batches: k_dec_a_rl (squarings and products on separate waves)
 };
 
 template <class G, int W>
@@ -370,6 +371,139 @@ k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_
             }
         }
         if (live) store_elem<G>(x, u_out + ((size_t)which * n + ei) * P.u_words, P.u_words, lds);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decrypt stage A for the smallest batches (minus-one geometries): RIGHT-TO-LEFT exponentiation with the squarings and the
+// products on SEPARATE waves.  Left to right, every product of the window method sits on the critical path between two
+// squarings (~1 030 squarings + ~180 products at 1024-bit primes, each ~3 us when an integer is spread over a wavefront).
+// Right to left, the chain s_i = base^(2^i) does not depend on the accumulator: wave A (waves 0 and 1 of the workgroup)
+// runs the e_bits - 1 squarings back to back, publishing every s_i in a ring of LDS operand buffers — the staging a squaring
+// does anyway —, and wave B (waves 2 and 3, on the other SIMDs of the CU) multiplies the s_i at the set bits of s - 1 into
+// the accumulator straight from the ring, half a product per squaring on average: the critical path is the squarings plus
+// one product.  Hand-over through two LDS words per wave pair (head: slots published by A; tail: first slot B still needs),
+// release / acquire at workgroup scope; a wait that does not end traps instead of hanging the device.
+#ifndef PAI_RL_RING
+#define PAI_RL_RING 16
+#endif
+#ifndef PAI_RL_DEBUG_NOB
+#define PAI_RL_DEBUG_NOB 0          // timing probe only: wave B skips its products (wrong results)
+#endif
+constexpr int RL_RING = PAI_RL_RING;
+PAI_DEV void rl_publish(uint32_t* flag, uint32_t v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// waits until *flag >= need; returns the value seen (the flag is wave-uniform: the loop branches on a scalar)
+#ifndef PAI_RL_SLEEP_B
+#define PAI_RL_SLEEP_B 8            // s_sleep units (64 cycles) between wave B's polls of `head`: a polling wave costs the squaring wave
+#endif                              // of its CU scalar issue slots and LDS cycles (3.48 vs 3.37 ms with B polling all the time)
+template <int SLEEP = 1>
+PAI_DEV uint32_t rl_wait(uint32_t* flag, uint32_t need) {
+    int spins = 0;
+    uint32_t v;
+    while ((v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) < need) {
+        __builtin_amdgcn_s_sleep(SLEEP);
+        if (++spins > (1 << 22)) __builtin_trap();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return v;
+}
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_dec_a_rl(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out /*[2][n][u_words]*/, int n) {
+    static_assert(G::M1 && G::EPB >= 2 && BLOCK_THREADS == 256, "minus-one geometries, two wave pairs per workgroup");
+    constexpr int HALF = G::EPB / 2;                                   // integers per workgroup: waves 0, 1 square, waves 2, 3 multiply
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     // staging buffer, RL_RING operand buffers, flags
+    uint32_t* stage = lds;
+    uint32_t* ring = lds + G::LDS_WORDS;
+    uint32_t* flags = lds + (RL_RING + 1) * G::LDS_WORDS;
+    const int which = blockIdx.y;
+    const MontCtx* ctx = P.sq[which];
+    const uint32_t* expo = P.expo[which];
+    const int ebits = P.ebits[which];
+    const int t = G::gl();
+    const int wave = (int)threadIdx.x >> 6;
+    const bool is_a = wave < 2;
+    const int col = G::elem() - (is_a ? 0 : HALF);                     // the pair's column in the ring buffers
+    uint32_t* head = flags + 2 * (wave & 1);
+    uint32_t* tail = head + 1;
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t nblk = ctx->rows / G::U;
+    const int nrows = (int)ctx->rows;
+    auto bit_of = [&](int i) -> uint32_t { return (expo[i >> 5] >> (i & 31)) & 1u; };
+    auto next_set = [&](int i) -> int {                                // first set bit at or above i (ebits if none)
+        while (i < ebits && !bit_of(i)) ++i;
+        return i;
+    };
+    const int tiles = (n + HALF - 1) / HALF;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+        __syncthreads();
+        const int ei = tile * HALF + col;
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        if (is_a) {
+            const uint32_t* row = ct + (size_t)es * P.ct_words;
+            uint32_t x[G::NLL];
+            {
+                uint32_t hi[G::NLL], c[G::NLL];
+                load_elem_off<G>(hi, row, P.ct_words, nrows);
+                load_const_slice<G>(c, P.r3[which]);
+                mm_times<G>(hi, c, stage, nm, nblk);                   // hi * R^2
+                load_elem_off<G>(x, row, P.ct_words, 0);
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) x[j] = (G::NLL * t + j < nrows) ? x[j] : 0u;
+                load_const_slice<G>(c, ctx->r2);
+                mm_times<G>(x, c, stage, nm, nblk);                    // lo * R
+                add_limbs<G>(x, hi);
+            }
+            uint32_t tail_seen = 0;                                     // B only moves it forward: re-read when the cached value is too old
+#pragma unroll 1
+            for (int i = 0; i < ebits; ++i) {
+                if (i >= RL_RING && tail_seen < (uint32_t)(i - RL_RING + 1)) tail_seen = rl_wait(tail, (uint32_t)(i - RL_RING + 1));
+                uint32_t* slot = ring + (i % RL_RING) * G::LDS_WORDS;
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) slot[(G::NLL * t + j) * G::EPB + col] = x[j];
+                rl_publish(head, (uint32_t)(i + 1));
+                if (i + 1 < ebits) {
+                    uint32_t r[G::NLL];
+                    mont_mul_m1<G::NLL, G::U, G::T>(r, x, slot + col, G::EPB, nm, (int)nblk);
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
+                }
+            }
+        } else {
+            uint32_t acc[G::NLL];
+            int i = next_set(0);
+            rl_publish(tail, (uint32_t)i);
+            bool first = true;
+#pragma unroll 1
+            while (i < ebits) {
+                rl_wait<PAI_RL_SLEEP_B>(head, (uint32_t)(i + 1));
+                const uint32_t* slot = ring + (i % RL_RING) * G::LDS_WORDS;
+                if (first) {
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) acc[j] = slot[(G::NLL * t + j) * G::EPB + col];
+                    first = false;
+                } else if (!PAI_RL_DEBUG_NOB) {
+                    uint32_t r[G::NLL];
+                    mont_mul_m1<G::NLL, G::U, G::T>(r, acc, slot + col, G::EPB, nm, (int)nblk);
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) acc[j] = r[j];
+                }
+                i = next_set(i + 1);
+                rl_publish(tail, (uint32_t)i);
+            }
+            uint32_t one[G::NLL];
+            set_plain_one<G>(one);
+            mm_times<G>(acc, one, stage, nm, nblk);
+            m1_reduce_to_true_modulus<G>(acc, stage, P.fin[which]);
+            if (live) store_elem<G>(acc, u_out + ((size_t)which * n + ei) * P.u_words, P.u_words, stage);
+        }
+        __syncthreads();
     }
 }
 

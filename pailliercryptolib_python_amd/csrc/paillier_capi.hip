@@ -722,6 +722,10 @@ static bool lat_dense_disabled() {                  // PAI_LAT_DENSE=0: small-ba
     const char* env = std::getenv("PAI_LAT_DENSE");
     return env && env[0] == '0';
 }
+static bool lat_rl_disabled() {                     // PAI_LAT_RL=0: small-batch stage A left to right on one wave per integer
+    const char* env = std::getenv("PAI_LAT_RL");
+    return env && env[0] == '0';
+}
 static bool fb_chain_disabled() {                   // PAI_DISABLE_FB_CHAIN=1: window bases by the table kernel's own squaring chain
     const char* env = std::getenv("PAI_DISABLE_FB_CHAIN");
     return env && env[0] == '1';
@@ -2450,7 +2454,11 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 const GeoOps* ga = SQ[0].geo;
                 const GeoOps* gb = L.pr[0].geo;
                 const int u_words = std::max(L.sq_true[0].w32, L.sq_true[1].w32);
-                const int gridx = (int)((N + ga->epb - 1) / ga->epb);
+                // right-to-left stage A on wave pairs (kernels_paillier.hpp: k_dec_a_rl) while two waves per (element, prime)
+                // leave at most one wave per SIMD: 4 N <= 4 x CUs
+                const bool rl = !dense && N <= (size_t)dev.ncu && !lat_rl_disabled();
+                const int epb_a = rl ? ga->epb / 2 : ga->epb;
+                const int gridx = (int)((N + epb_a - 1) / epb_a);
                 L.table.ensure(ga->table_words((size_t)gridx * 2) * 4 / 32 * (PADIC_TBL_ENTRIES + 2));    // odd powers + base^2
                 sk->ubuf.ensure(2 * N * (size_t)u_words * 4);
                 sk->order.begin(s);
@@ -2473,6 +2481,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 A.ct_words = pk->ct_words;
                 A.u_words = u_words;
                 A.tbl_entries = PADIC_TBL_ENTRIES;
+                A.rl = rl ? 1 : 0;
                 B.pinvqR = L.d_pinvqR;
                 B.u_words = u_words;
                 B.pt_words = pk->n_words;

@@ -496,11 +496,14 @@ def test_decrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
         # short randomness keeps the oracle's CPython pow cheap; decryption does not care how a ciphertext was obfuscated
         ct = [orc.encrypt(key, x, int.from_bytes(rng.bytes(16), "little")) for x in m]
         dct = DevArray(ints_to_limbs(ct, nk.cw))
-        for switch in ("0", "100000"):
+        # PAI_LAT_RL: up to one integer per CU the latency path runs right to left on wave pairs (k_dec_a_rl: squarings on
+        # one wave, products on another); 0 keeps the left-to-right window kernel
+        for switch, rl in (("0", "1"), ("100000", "1"), ("100000", "0")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
+            monkeypatch.setenv("PAI_LAT_RL", rl)
             out = DevArray(shape=(N, nk.nw))
             _native.check(nk.lib.pai_decrypt(nk.sk, dct.ptr, N, out.ptr, None))
-            assert limbs_to_ints(out.get()) == m, (bits, N, switch)
+            assert limbs_to_ints(out.get()) == m, (bits, N, switch, rl)
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 4096])
