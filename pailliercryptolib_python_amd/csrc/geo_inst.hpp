@@ -82,6 +82,13 @@ struct GeoInst {
     }
     static void encrypt(hipStream_t s, int grid, EncParams P, const uint32_t* m, const uint32_t* r,
                         const uint32_t* ct_in, uint32_t* ct_out, int n, int mode) {
+        if constexpr (G::T >= 16 && G::T <= 64) {
+            if (mode >= 5) {       // modes 5 / 6: modes 1 / 2 with the fixed-base chain shared by the four waves (grid counts 64 / T integers)
+                set_lds((const void*)k_encrypt_tree<G>, G::LDS_BYTES);
+                hipLaunchKernelGGL(k_encrypt_tree<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, m, r, ct_in, ct_out, n, mode - 4);
+                return;
+            }
+        }
         set_lds((const void*)k_encrypt<G>, G::LDS_BYTES);
         hipLaunchKernelGGL(k_encrypt<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, m, r, ct_in, ct_out, n, mode);
     }

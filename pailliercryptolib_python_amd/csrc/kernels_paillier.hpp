@@ -129,6 +129,103 @@ k_encrypt(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// DJN encryption / obfuscation for the smallest batches (wide-group geometries, modes 1 and 2 of k_encrypt): the
+// fixed-base product  c0 * prod_j T[j][r_j]  is a chain of fb_windows sequential products on one wave in k_encrypt — every one
+// of them latency.  Here the four waves of a workgroup share the integers of ONE wave (64 / T of them): wave w multiplies the
+// windows j == w (mod 4) (the next entry's three limbs are fetched under the current product), wave 3 starts its chain
+// from c0 = 1 + m n (or the ciphertext to obfuscate), and the four partial products meet through LDS in two levels:
+// fb_windows / 4 + 2 products on the critical path instead of fb_windows + 2.  Waves 0-2 hold Montgomery forms (x R), wave 3
+// a plain value, so the last product leaves the plain ciphertext: same bits as k_encrypt.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, PAI_LG_WAVES(G))
+k_encrypt_tree(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
+               const uint32_t* __restrict__ ct_in, uint32_t* __restrict__ ct_out, int n, int mode) {
+    static_assert(G::T >= 16 && G::T <= 64 && BLOCK_THREADS == 256, "one to four integers per wave, four waves");
+    constexpr int EPW = 64 / G::T;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typename G::NM nm;
+    load_modulus<G>(nm, P.nsq, lds);
+    const uint32_t n0inv = P.nsq->n0inv;
+    const int t = G::gl();
+    const int wave = (int)threadIdx.x >> 6;
+    const int e = G::elem() - wave * EPW;
+    const int tiles = (n + EPW - 1) / EPW;
+    auto digit = [&](const uint32_t* rrow, int jw) -> uint32_t {
+        const int bit = jw * P.fb_wbits, k = bit >> 5;
+        uint64_t bits2 = rrow[k];
+        if (k + 1 < P.r_words) bits2 |= (uint64_t)rrow[k + 1] << 32;
+        return (uint32_t)(bits2 >> (bit & 31)) & ((1u << P.fb_wbits) - 1u);
+    };
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int ei = tile * EPW + e;
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        const uint32_t* rrow = r + (size_t)es * P.r_words;
+        uint32_t x[G::NLL];
+        bool have = false;
+        // first entry of this wave's chain in flight while wave 3 prepares c0
+        uint32_t y[G::NLL];
+        int jw = wave;
+        if (jw < P.fb_windows) {
+            const uint32_t* ent = P.fb_table + ((((size_t)jw << P.fb_wbits) + digit(rrow, jw)) * G::NL) + G::NLL * t;
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) y[j] = ent[j];
+        }
+        if (wave == 3) {
+            if (mode == 1) {
+                uint32_t nr[G::NLL], one[G::NLL];
+                load_elem<G>(x, m + (size_t)es * P.pt_words, P.pt_words);
+                load_const_slice<G>(nr, P.nR);
+                mm_times<G>(x, nr, lds, nm, n0inv);                  // 1 + m n = m * (n R) * R^-1 + 1
+                set_plain_one<G>(one);
+                add_limbs<G>(x, one);
+            } else {
+                load_elem<G>(x, ct_in + (size_t)es * P.ct_words, P.ct_words);
+            }
+            have = true;
+        }
+#pragma unroll 1
+        for (; jw < P.fb_windows; jw += 4) {
+            uint32_t cur[G::NLL];
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) cur[j] = y[j];
+            if (jw + 4 < P.fb_windows) {
+                const uint32_t* ent = P.fb_table + ((((size_t)(jw + 4) << P.fb_wbits) + digit(rrow, jw + 4)) * G::NL) + G::NLL * t;
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) y[j] = ent[j];
+            }
+            if (!have) {
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) x[j] = cur[j];
+                have = true;
+            } else {
+                mm_times<G>(x, cur, lds, nm, n0inv);
+            }
+        }
+        if (!have) load_const_slice<G>(x, P.nsq->one);               // fewer windows than waves: the Montgomery form of 1
+        // level 1: waves 0 and 2 take in the partial products of waves 1 and 3
+        stage_b<G>(x, lds);
+        __syncthreads();
+        if (wave == 0 || wave == 2) {
+            uint32_t p[G::NLL];
+            mont_mul<G::NLL, G::U, G::T>(p, x, lds + G::elem() + EPW, G::EPB, nm, n0inv);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) x[j] = p[j];
+        }
+        __syncthreads();
+        if (wave == 2) stage_b<G>(x, lds);
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t p[G::NLL];
+            mont_mul<G::NLL, G::U, G::T>(p, x, lds + G::elem() + 2 * EPW, G::EPB, nm, n0inv);
+            cond_sub<G::NLL, G::T>(p, nm);
+            if (live) store_elem<G>(p, ct_out + (size_t)ei * P.ct_words, P.ct_words, lds);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Last step of the digit-pair obfuscator (kernels_pair.hpp): the plain pair (w, v) of x = hs^r (1 + m n) [or hs^r]
 // arrives as two packed rows of `wv_words` words per element; ct = w + v n (mul_ct = 0) or ct_in (w + v n) mod n^2.
 // A kernel of its own: as extra modes of k_encrypt it cost that kernel's fixed-base loop 50 % (36x8: 61 -> 94 ms per 65536).

@@ -726,6 +726,11 @@ static bool lat_rl_disabled() {                     // PAI_LAT_RL=0: small-batch
     const char* env = std::getenv("PAI_LAT_RL");
     return env && env[0] == '0';
 }
+static size_t lat_enc_tree_max(size_t ncu) {        // PAI_LAT_ENC_TREE: largest batch of the wave-shared small-batch encryption (0 disables)
+    if (const char* env = std::getenv("PAI_LAT_ENC_TREE")) return (size_t)std::strtoull(env, nullptr, 10);
+    (void)ncu;
+    return (size_t)1 << 30;                         // measured ahead over the whole latency range (2048-bit keys: 0.29 vs 0.98 ms up to 256
+}                                                   // elements, 0.54 vs 1.01 at 1024, 1.63 vs 1.91 at 4096; profiles/r04/lat_enc_tree.jsonl)
 static bool fb_chain_disabled() {                   // PAI_DISABLE_FB_CHAIN=1: window bases by the table kernel's own squaring chain
     const char* env = std::getenv("PAI_DISABLE_FB_CHAIN");
     return env && env[0] == '1';
@@ -1518,7 +1523,11 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
             PL.r_words = pk->r_words;
             pk->order.begin(s);
             ScopedKernelTimer t(from_plain ? "k_encrypt(djn)" : "k_encrypt(obfuscate)", s);
-            gl->encrypt(s, (int)((N + gl->epb - 1) / gl->epb), PL, d_m, d_r, d_ct_in, d_ct_out, (int)N, from_plain ? 1 : 2);
+            // the four waves of a workgroup share one wave's integers (k_encrypt_tree: a quarter of the windows each, two
+            // levels of combining products); PAI_LAT_ENC_TREE=0 keeps one chain per integer
+            const bool tree = gl->t >= 16 && gl->t <= 64 && N <= lat_enc_tree_max((size_t)pk->dev.ncu);
+            const int per_wg = tree ? 64 / gl->t : gl->epb;
+            gl->encrypt(s, (int)((N + per_wg - 1) / per_wg), PL, d_m, d_r, d_ct_in, d_ct_out, (int)N, (from_plain ? 1 : 2) + (tree ? 4 : 0));
             t.stop();
             HIP_CHECK(hipGetLastError());
             pk->order.end(s);

@@ -537,13 +537,15 @@ def test_djn_encrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
         r[1, -1] &= np.uint32((1 << (key.randbits - 32 * (r.shape[1] - 1))) - 1) if key.randbits % 32 else np.uint32(0xFFFFFFFF)
         want = [orc.encrypt(key, x, rr) for x, rr in zip(m, orc.limbs_to_ints(r))]
         dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
-        for switch in ("0", "100000"):
+        # PAI_LAT_ENC_TREE: the four waves of a workgroup share one wave's integers (k_encrypt_tree); 0 = one chain per integer
+        for switch, tree in (("0", "100000"), ("100000", "100000"), ("100000", "0")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
+            monkeypatch.setenv("PAI_LAT_ENC_TREE", tree)
             ct = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
-            assert limbs_to_ints(ct.get()) == want, (bits, N, switch)
+            assert limbs_to_ints(ct.get()) == want, (bits, N, switch, tree)
             _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
-            assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, orc.limbs_to_ints(r))]
+            assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, orc.limbs_to_ints(r))], (bits, N, switch, tree)
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
