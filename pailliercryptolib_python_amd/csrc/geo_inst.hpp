@@ -130,6 +130,13 @@ struct GeoInst {
         if constexpr (G::T >= 16) {
             if (fin != nullptr) {        // wide-group geometries with a minus-one context (c) and the true modulus' context (fin)
                 using GM1 = Geo<G::NLL, G::T, G::U, false, true>;
+                if (wbits == 0) {    // right to left on wave pairs, no table (grid counts workgroups of EPB / 2 integers)
+                    constexpr int bytes = ((RL_RING + 1) * GM1::LDS_WORDS + 16) * 4;
+                    set_lds((const void*)k_modexp_rl<GM1>, bytes);
+                    hipLaunchKernelGGL(k_modexp_rl<GM1>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, base, base_w32, expo, ew, ebits_max,
+                                       exp_bcast, out, out_w32, n, fin);
+                    return;
+                }
                 set_lds((const void*)k_modexp_var_win<GM1>, VarWinCfg<GM1>::LDS_BYTES);
                 hipLaunchKernelGGL(k_modexp_var_win<GM1>, dim3(grid), dim3(BLOCK_THREADS), VarWinCfg<GM1>::LDS_BYTES, s, c, base, base_w32,
                                    expo, ew, ebits_max, exp_bcast, out, out_w32, n, table, wbits, fin);

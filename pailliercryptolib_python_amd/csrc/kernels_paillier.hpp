@@ -605,6 +605,91 @@ k_dec_a_rl(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// base_i ^ e_i mod M for the smallest batches, right to left on wave pairs as k_dec_a_rl (small-batch ct * pt): wave A
+// squares ebits_max - 1 times, wave B multiplies base^(2^i) into the accumulators whose exponent has bit i (one product
+// for the whole wave wherever some integer of it needs one, kept per integer), starting from the Montgomery form of 1.
+// No table of powers: ~ebits_max + 8 sequential products instead of ~1.5 ebits_max + 2^w.  ctx: minus-one context of M k,
+// fin: M's own context (as k_modexp_var_win on these geometries).
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_modexp_rl(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, int base_w32, const uint32_t* __restrict__ expo,
+            int ew, int ebits_max, int exp_bcast, uint32_t* __restrict__ out, int out_w32, int n, const MontCtx* __restrict__ fin) {
+    static_assert(G::M1 && G::EPB >= 2 && BLOCK_THREADS == 256, "minus-one geometries, two wave pairs per workgroup");
+    constexpr int HALF = G::EPB / 2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* stage = lds;
+    uint32_t* ring = lds + G::LDS_WORDS;
+    uint32_t* flags = lds + (RL_RING + 1) * G::LDS_WORDS;
+    const int t = G::gl();
+    const int wave = (int)threadIdx.x >> 6;
+    const bool is_a = wave < 2;
+    const int col = G::elem() - (is_a ? 0 : HALF);
+    uint32_t* head = flags + 2 * (wave & 1);
+    uint32_t* tail = head + 1;
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t nblk = ctx->rows / G::U;
+    const int tiles = (n + HALF - 1) / HALF;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+        __syncthreads();
+        const int ei = tile * HALF + col;
+        const bool live = ei < n;
+        const int es = live ? ei : n - 1;
+        if (is_a) {
+            uint32_t x[G::NLL], c[G::NLL];
+            load_elem<G>(x, base + (size_t)es * base_w32, base_w32);
+            load_const_slice<G>(c, ctx->r2);
+            mm_times<G>(x, c, stage, nm, nblk);
+            uint32_t tail_seen = 0;
+#pragma unroll 1
+            for (int i = 0; i < ebits_max; ++i) {
+                if (i >= RL_RING && tail_seen < (uint32_t)(i - RL_RING + 1)) tail_seen = rl_wait(tail, (uint32_t)(i - RL_RING + 1));
+                uint32_t* slot = ring + (i % RL_RING) * G::LDS_WORDS;
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) slot[(G::NLL * t + j) * G::EPB + col] = x[j];
+                rl_publish(head, (uint32_t)(i + 1));
+                if (i + 1 < ebits_max) {
+                    uint32_t r[G::NLL];
+                    mont_mul_m1<G::NLL, G::U, G::T>(r, x, slot + col, G::EPB, nm, (int)nblk);
+#pragma unroll
+                    for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
+                }
+            }
+        } else {
+            const uint32_t* erow = expo + (size_t)(exp_bcast ? 0 : es) * ew;
+            auto my_bit = [&](int i) -> bool { return (i >> 5) < ew && ((erow[i >> 5] >> (i & 31)) & 1u) != 0u; };
+            auto next_any = [&](int i) -> int {                    // first bit position at or above i some integer of this wave has set
+                while (i < ebits_max && !__any(my_bit(i) ? 1 : 0)) ++i;
+                return i;
+            };
+            uint32_t acc[G::NLL];
+            load_const_slice<G>(acc, ctx->one);
+            int i = next_any(0);
+            rl_publish(tail, (uint32_t)i);
+#pragma unroll 1
+            while (i < ebits_max) {
+                rl_wait<PAI_RL_SLEEP_B>(head, (uint32_t)(i + 1));
+                const uint32_t* slot = ring + (i % RL_RING) * G::LDS_WORDS;
+                uint32_t r[G::NLL];
+                mont_mul_m1<G::NLL, G::U, G::T>(r, acc, slot + col, G::EPB, nm, (int)nblk);
+                const bool mine = my_bit(i);
+#pragma unroll
+                for (int j = 0; j < G::NLL; ++j) acc[j] = mine ? r[j] : acc[j];
+                i = next_any(i + 1);
+                rl_publish(tail, (uint32_t)i);
+            }
+            uint32_t one[G::NLL];
+            set_plain_one<G>(one);
+            mm_times<G>(acc, one, stage, nm, nblk);
+            m1_reduce_to_true_modulus<G>(acc, stage, fin);
+            if (live) store_elem<G>(acc, out + (size_t)ei * out_w32, out_w32, stage);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Decrypt stage B in the geometry of the primes themselves.
 struct DecBParams {
     const MontCtx* pr[2];        // moduli p, q

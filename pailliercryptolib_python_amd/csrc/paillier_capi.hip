@@ -731,6 +731,10 @@ static size_t lat_enc_tree_max(size_t ncu) {        // PAI_LAT_ENC_TREE: largest
     (void)ncu;
     return (size_t)1 << 30;                         // measured ahead over the whole latency range (2048-bit keys: 0.29 vs 0.98 ms up to 256
 }                                                   // elements, 0.54 vs 1.01 at 1024, 1.63 vs 1.91 at 4096; profiles/r04/lat_enc_tree.jsonl)
+static size_t lat_mul_rl_max(size_t ncu) {          // PAI_LAT_MUL_RL: largest batch of the wave-pair small-batch ct * pt (0 disables)
+    if (const char* env = std::getenv("PAI_LAT_MUL_RL")) return (size_t)std::strtoull(env, nullptr, 10);
+    return 2 * ncu;
+}
 static bool fb_chain_disabled() {                   // PAI_DISABLE_FB_CHAIN=1: window bases by the table kernel's own squaring chain
     const char* env = std::getenv("PAI_DISABLE_FB_CHAIN");
     return env && env[0] == '1';
@@ -1786,9 +1790,13 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
             std::lock_guard<std::mutex> lk(pk->mu);
             if (ensure_lat_ctx(pk)) {
                 const GeoOps* g = pk->lat_msq.geo;
-                const int grid = (int)((N + g->epb - 1) / g->epb);
-                const int wbits = var_window_bits(ebits_max);
-                pk->lat_table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
+                // right to left on wave pairs (k_modexp_rl: squarings on one wave, products on another, no table) for the
+                // smallest batches; needs the minus-one context
+                const bool rl = pk->lat_m1_ok && g->epb >= 2 && N <= lat_mul_rl_max((size_t)pk->dev.ncu);
+                const int per_wg = rl ? g->epb / 2 : g->epb;
+                const int grid = (int)((N + per_wg - 1) / per_wg);
+                const int wbits = rl ? 0 : var_window_bits(ebits_max);
+                if (!rl) pk->lat_table.ensure(((size_t)1 << wbits) * g->nl * (size_t)grid * g->epb * 4);
                 pk->order.begin(s);
                 ScopedKernelTimer t("k_ctmul", s);
                 g->modexp_var_win(s, grid, pk->lat_m1_ok ? pk->lat_msq_m1.d_ctx : pk->lat_msq.d_ctx, d_ct, pk->ct_words, d_e, e_words,

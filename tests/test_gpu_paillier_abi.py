@@ -517,11 +517,19 @@ def test_ct_mul_latency_and_throughput_paths_agree(bits, monkeypatch):
         e[0] = 0
         ew = (ebits + 31) // 32
         dc, de = DevArray(ints_to_limbs(c, nk.cw)), DevArray(ints_to_limbs(e, ew))
-        for switch in ("0", "100000"):
+        # PAI_LAT_MUL_RL: the smallest batches run right to left on wave pairs (k_modexp_rl, no table); 0 = windowed kernel
+        want = [pow(a, b, key.nsq) for a, b in zip(c, e)]
+        for switch, rl in (("0", "100000"), ("100000", "100000"), ("100000", "0")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
+            monkeypatch.setenv("PAI_LAT_MUL_RL", rl)
             out = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
-            assert limbs_to_ints(out.get()) == [pow(a, b, key.nsq) for a, b in zip(c, e)], (bits, N, ebits, switch)
+            assert limbs_to_ints(out.get()) == want, (bits, N, ebits, switch, rl)
+        # one broadcast exponent
+        monkeypatch.setenv("PAI_LAT_MUL_RL", "100000")
+        out = DevArray(shape=(N, nk.cw))
+        _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, C.c_void_p(de.ptr.value + 4 * ew), ew, ebits, 1, N, out.ptr, None))
+        assert limbs_to_ints(out.get()) == [pow(a, e[1], key.nsq) for a in c], (bits, N, ebits, "bcast")
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
