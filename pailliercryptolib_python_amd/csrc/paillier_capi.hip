@@ -722,9 +722,9 @@ static bool lat_dense_disabled() {                  // PAI_LAT_DENSE=0: small-ba
     const char* env = std::getenv("PAI_LAT_DENSE");
     return env && env[0] == '0';
 }
-static bool lat_rl_disabled() {                     // PAI_LAT_RL=0: small-batch stage A left to right on one wave per integer
-    const char* env = std::getenv("PAI_LAT_RL");
-    return env && env[0] == '0';
+static size_t lat_rl_max(size_t ncu) {              // PAI_LAT_RL: largest batch of the wave-pair small-batch decryption (0 disables)
+    if (const char* env = std::getenv("PAI_LAT_RL")) return (size_t)std::strtoull(env, nullptr, 10);
+    return ncu;
 }
 static size_t lat_enc_tree_max(size_t ncu) {        // PAI_LAT_ENC_TREE: largest batch of the wave-shared small-batch encryption (0 disables)
     if (const char* env = std::getenv("PAI_LAT_ENC_TREE")) return (size_t)std::strtoull(env, nullptr, 10);
@@ -2473,7 +2473,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 const int u_words = std::max(L.sq_true[0].w32, L.sq_true[1].w32);
                 // right-to-left stage A on wave pairs (kernels_paillier.hpp: k_dec_a_rl) while two waves per (element, prime)
                 // leave at most one wave per SIMD: 4 N <= 4 x CUs
-                const bool rl = !dense && N <= (size_t)dev.ncu && !lat_rl_disabled();
+                const bool rl = N <= lat_rl_max((size_t)dev.ncu);
                 const int epb_a = rl ? ga->epb / 2 : ga->epb;
                 const int gridx = (int)((N + epb_a - 1) / epb_a);
                 L.table.ensure(ga->table_words((size_t)gridx * 2) * 4 / 32 * (PADIC_TBL_ENTRIES + 2));    // odd powers + base^2

@@ -498,7 +498,7 @@ def test_decrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
         dct = DevArray(ints_to_limbs(ct, nk.cw))
         # PAI_LAT_RL: up to one integer per CU the latency path runs right to left on wave pairs (k_dec_a_rl: squarings on
         # one wave, products on another); 0 keeps the left-to-right window kernel
-        for switch, rl in (("0", "1"), ("100000", "1"), ("100000", "0")):
+        for switch, rl in (("0", "100000"), ("100000", "100000"), ("100000", "0")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
             monkeypatch.setenv("PAI_LAT_RL", rl)
             out = DevArray(shape=(N, nk.nw))
