@@ -2476,7 +2476,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 const bool rl = N <= lat_rl_max((size_t)dev.ncu);
                 const int epb_a = rl ? ga->epb / 2 : ga->epb;
                 const int gridx = (int)((N + epb_a - 1) / epb_a);
-                L.table.ensure(ga->table_words((size_t)gridx * 2) * 4 / 32 * (PADIC_TBL_ENTRIES + 2));    // odd powers + base^2
+                if (!rl) L.table.ensure(ga->table_words((size_t)gridx * 2) * 4 / 32 * (PADIC_TBL_ENTRIES + 2));    // odd powers + base^2
                 sk->ubuf.ensure(2 * N * (size_t)u_words * 4);
                 sk->order.begin(s);
                 DecAParams A;
