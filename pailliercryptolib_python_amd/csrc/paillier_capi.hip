@@ -206,7 +206,8 @@ struct ModSetup {
     int bits = 0, w32 = 0;
     int nl = 0;       // radix-29 limbs of the Montgomery representation (R = 2^(29 nl))
     // nl_override != 0: constants for the wide engine's limb count instead of the lane-group geometry's
-    void init(const Limbs& mod_, int nl_override = 0, const GeoOps* force_geo = nullptr) {
+    // r2_override: the constant MODMUL_FULL multiplies by instead of R^2 (small-batch tagged products: pai_ct_mont_mul)
+    void init(const Limbs& mod_, int nl_override = 0, const GeoOps* force_geo = nullptr, const Limbs* r2_override = nullptr) {
         M = mod_;
         require(hbn::is_odd(M), "modulus must be odd");
         bits = hbn::bitlen(M);
@@ -225,7 +226,7 @@ struct ModSetup {
             std::memcpy(dst, r.data(), (size_t)nl * 4);
         };
         put(h.n, M);
-        put(h.r2, R2);
+        put(h.r2, r2_override ? *r2_override : R2);
         put(h.one, R);
         h.n0inv = hbn::neg_inv32(M[0]) & ((1u << hbn::RB) - 1u);
         h.nl = (uint32_t)nl;
@@ -455,6 +456,10 @@ struct pai_pubkey {
     mutable ModSetup lat_msq;
     mutable ModSetup lat_msq_m1;       // minus-one context of n^2 for the small-batch ct * pt
     mutable bool lat_m1_tried = false, lat_m1_ok = false;
+    // small-batch ct + ct: n^2 on the latency geometry; the "tag" context multiplies by R_lat^2 / R instead of R_lat^2, so that
+    // MODMUL_FULL there returns a b R^-1 in terms of the throughput geometry's R (the lazy domain tags of the containers)
+    mutable ModSetup lat_msq_tag;
+    mutable bool lat_tag_tried = false, lat_tag_ok = false;
     mutable DevBuf lat_table;
     // latency path of DJN encryption: n R and a 10-bit fixed-base table in the wide-group geometry (81 MB at 2048-bit keys)
     mutable bool lat_fb_ready = false;
@@ -976,6 +981,35 @@ static bool ensure_lat_ctx(const pai_pubkey* pk) {
     return pk->lat_usable;
 }
 
+// Small batches of ct + ct (one or two Montgomery products per element, all of them latency): n^2 spread over a wavefront per
+// ciphertext instead of four lanes.  Returns the context to use on the latency geometry, or nullptr (throughput geometry).
+// tagged: the product must come out as a b R^-1 with the THROUGHPUT geometry's R (pai_ct_mont_mul): MODMUL_FULL with the
+// constant R_lat^2 / R = 2^(29 (2 nl_lat - nl)) in place of R_lat^2.
+static size_t lat_add_max() {                       // PAI_LAT_ADD_MAX: largest ct + ct batch on the latency geometry (0 disables)
+    if (const char* env = std::getenv("PAI_LAT_ADD_MAX")) return (size_t)std::strtoull(env, nullptr, 10);
+    return (size_t)1024;
+}
+// Measured at 2048-bit keys (profiles/r04/lat_add_probe.jsonl): wire-form a b 30 against 60 us up to 1024 elements (39 / 65 at
+// 2048, level at 4096), the tagged single product 29 against 35 us up to 1024 (level at 2048), aligned additions with shifts
+// up to 13: 0.18 against 0.44 ms up to 1024, 0.31 / 0.45 at 4096 — hence the scale factors 2 / 1 / 4 on PAI_LAT_ADD_MAX.
+static const ModSetup* lat_add_ctx(const pai_pubkey* pk, size_t N, bool tagged, int scale = 1) {
+    if (N > (size_t)scale * lat_add_max()) return nullptr;
+    std::lock_guard<std::mutex> lk(pk->mu);
+    if (!ensure_lat_ctx(pk)) return nullptr;
+    if (!tagged) return &pk->lat_msq;
+    if (!pk->lat_tag_tried) {
+        pk->lat_tag_tried = true;
+        const int nl_lat = pk->lat_msq.nl, nl_thr = pk->msq.nl;
+        if (2 * nl_lat >= nl_thr) {
+            const Limbs c = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * (2 * nl_lat - nl_thr)), pk->nsq);
+            pk->lat_msq_tag.init(pk->nsq, 0, pk->lat_msq.geo, &c);
+            pk->lat_tag_ok = true;
+        }
+    }
+    return pk->lat_tag_ok ? &pk->lat_msq_tag : nullptr;
+}
+
+
 // Fixed-base tables of the DJN obfuscator hs^r, built by the FIRST call that obfuscates (pai_encrypt with
 // randomness / pai_obfuscate), under pk->mu: a handle that only adds, multiplies or decrypts — every unpickled
 // ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
@@ -1422,6 +1456,7 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->prod_b.release();
     pk->lat_msq.release();
     pk->lat_msq_m1.release();
+    pk->lat_msq_tag.release();
     pk->lat_table.release();
     if (pk->d_lat_nR) (void)hipFree(pk->d_lat_nR);
     if (pk->d_lat_fb) (void)hipFree(pk->d_lat_fb);
@@ -1737,10 +1772,12 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
         require(pk && d_a && d_b && d_out, "NULL argument");
         if (N == 0) return;
         DeviceScope scope_(pk->device);
-        const GeoOps* g = pk->msq.geo;
         g_last_times.clear();
+        const ModSetup* L = lat_add_ctx(pk, N, false, 2);
+        const GeoOps* g = L ? L->geo : pk->msq.geo;
         ScopedKernelTimer t("k_modmul", (hipStream_t)stream);
-        g->modmul((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
+        g->modmul((hipStream_t)stream, L ? (int)((N + g->epb - 1) / g->epb) : grid_for(g, N, pk->dev.ncu), L ? L->d_ctx : pk->msq.d_ctx,
+                  d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
                   MODMUL_FULL);
         t.stop();
         HIP_CHECK(hipGetLastError());
@@ -1948,10 +1985,14 @@ static void add_aligned_common(const pai_pubkey* pk, const uint32_t* d_a, const 
     require(pk && d_a && d_b && d_delta && d_out, "NULL argument");
     if (N == 0) return;
     DeviceScope scope_(pk->device);
-    const GeoOps* g = pk->msq.geo;
+    // wire-form operands (no entry constant): small batches on the latency geometry — the kernel enters and leaves the
+    // Montgomery domain itself, so the geometry's R does not show in the result
+    const ModSetup* L = d_entry == nullptr ? lat_add_ctx(pk, N, false, 4) : nullptr;
+    const GeoOps* g = L ? L->geo : pk->msq.geo;
     g_last_times.clear();
     ScopedKernelTimer t("k_add_aligned", (hipStream_t)stream);
-    g->add_aligned((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, b_bcast, d_delta, d_out, (int)N,
+    g->add_aligned((hipStream_t)stream, L ? (int)((N + g->epb - 1) / g->epb) : grid_for(g, N, pk->dev.ncu), L ? L->d_ctx : pk->msq.d_ctx,
+                   d_a, d_b, b_bcast, d_delta, d_out, (int)N,
                    pk->ct_words, d_entry);
     t.stop();
     HIP_CHECK(hipGetLastError());
@@ -1976,8 +2017,17 @@ int pai_ct_mont_mul(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d
         require(pk && d_a && d_b && d_out, "NULL argument");
         if (N == 0) return;
         DeviceScope scope_(pk->device);
-        const GeoOps* g = pk->msq.geo;
         g_last_times.clear();
+        if (const ModSetup* L = lat_add_ctx(pk, N, true)) {
+            const GeoOps* gl = L->geo;
+            ScopedKernelTimer t("k_modmul", (hipStream_t)stream);
+            gl->modmul((hipStream_t)stream, (int)((N + gl->epb - 1) / gl->epb), L->d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
+                       MODMUL_FULL);
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+        const GeoOps* g = pk->msq.geo;
         ScopedKernelTimer t("k_modmul", (hipStream_t)stream);
         g->modmul((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
                   MODMUL_MONT);

@@ -330,9 +330,11 @@ def test_ct_invert_other_key_sizes():
 
 # ---- round 2: tile I/O kernels, single-product trees, reductions in the library -------------------------------
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
-def test_ct_add_tile_edges_and_broadcast(bits):
+@pytest.mark.parametrize("lat_add", ["0", "4096"])
+def test_ct_add_tile_edges_and_broadcast(bits, lat_add, monkeypatch):
     """k_modmul with coalesced tile I/O: ragged last tile, one-element batches, broadcast addend (one Montgomery
     product per element), in-place output — against a*b mod n^2."""
+    monkeypatch.setenv("PAI_LAT_ADD_MAX", lat_add)      # small batches: n^2 on the latency geometry (an integer per wavefront) or not
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     key = nk.key
     rng = np.random.default_rng(bits + 1)
@@ -557,10 +559,13 @@ def test_djn_encrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
-def test_ct_add_aligned_matches_the_two_step_definition(bits):
+@pytest.mark.parametrize("lat_add", ["0", "4096"])
+def test_ct_add_aligned_matches_the_two_step_definition(bits, lat_add, monkeypatch):
     """pai_ct_add_aligned: the lower-exponent side is raised by ^(2^|delta|), then the ciphertexts are multiplied
     (ipcl_python.py:570-741 + :490-526) — one kernel, against CPython pow, with zero / positive / negative deltas
-    mixed inside wave tiles, a broadcast right operand and in-place output."""
+    mixed inside wave tiles, a broadcast right operand and in-place output; on the throughput geometry and (small
+    batches, PAI_LAT_ADD_MAX) on the latency geometry."""
+    monkeypatch.setenv("PAI_LAT_ADD_MAX", lat_add)
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     key, M = nk.key, nk.key.nsq
     rng = np.random.default_rng(bits + 7)
@@ -658,11 +663,14 @@ def test_ct_multiexp_matches_the_product_of_powers(bits, R, K, M, lanes, wbits, 
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
-def test_lazy_montgomery_domain_exports(bits):
+@pytest.mark.parametrize("lat_add", ["0", "4096"])
+def test_lazy_montgomery_domain_exports(bits, lat_add, monkeypatch):
     """pai_ct_mont_mul / pai_pubkey_mont_bits / pai_ct_add_aligned_dom (include/paillier_hip.h, 'lazy Montgomery domain'):
     the single product a b R^-1 against CPython ints, the tag algebra (ka, kb -> ka + kb - 1; retag by a broadcast
     constant), a chain of three single-product additions brought back to the wire form with one more product = the bits of
-    three pai_ct_add calls, and the aligned addition on operands stored as x R^k for k in {-2, -1, 1, 3}."""
+    three pai_ct_add calls, and the aligned addition on operands stored as x R^k for k in {-2, -1, 1, 3}.  Small batches
+    run the single product on the latency geometry with a constant that keeps R the throughput geometry's (PAI_LAT_ADD_MAX)."""
+    monkeypatch.setenv("PAI_LAT_ADD_MAX", lat_add)
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     M = nk.key.nsq
     rb = C.c_int(0)
