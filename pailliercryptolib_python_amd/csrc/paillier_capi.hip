@@ -1974,6 +1974,13 @@ static int ct_pow2_impl(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_d
             if (dmax == 0) return;
         }
         ScopedKernelTimer t("k_pow2", (hipStream_t)stream);
+        if (const ModSetup* L = lat_add_ctx(pk, N, false, 4)) {           // small batches: an integer per wavefront (as the aligned additions)
+            const GeoOps* gl = L->geo;
+            gl->pow2((hipStream_t)stream, (int)((N + gl->epb - 1) / gl->epb), L->d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words);
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         g->pow2((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words);
         t.stop();
         HIP_CHECK(hipGetLastError());

@@ -378,9 +378,11 @@ def test_ct_prod_matches_plain_products(bits, members, groups):
     assert nk.lib.pai_ct_prod(nk.pk, da.ptr, count, groups + count + 1, out.ptr, None) == _native.PAI_E_INVALID
 
 
-def test_pow2_tile_skips_and_mixed_deltas(k2048):
+@pytest.mark.parametrize("lat_add", ["0", "4096"])
+def test_pow2_tile_skips_and_mixed_deltas(k2048, lat_add, monkeypatch):
     """k_pow2 on tile I/O: tiles whose deltas are all <= 0 are skipped by the workgroup, untouched rows inside a live
-    tile are written back unchanged."""
+    tile are written back unchanged; on the throughput and (small batches, PAI_LAT_ADD_MAX) on the latency geometry."""
+    monkeypatch.setenv("PAI_LAT_ADD_MAX", lat_add)
     key, N = k2048.key, 64 * 5 + 9
     rng = np.random.default_rng(4242)
     a = rand_below(rng, key.nsq, N)
