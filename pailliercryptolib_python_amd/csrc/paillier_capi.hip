@@ -1545,7 +1545,7 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
             if (const char* env = std::getenv("PAI_LAT_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 16) lw = v; }
             pk->lat_fb_wbits = lw;
             pk->lat_fb_windows = (pk->randbits + pk->lat_fb_wbits - 1) / pk->lat_fb_wbits;
-            pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
+            if (!pk->d_lat_nR) pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
             pk->d_lat_fb = build_lane_group_fb(pk, pk->lat_msq, pk->lat_fb_wbits, pk->lat_fb_windows);
             pk->lat_fb_ready = true;
         }
@@ -1572,6 +1572,26 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
             pk->order.end(s);
             return;
         }
+    }
+    if (d_r == nullptr && from_plain && N <= 2 * lat_add_max() && ensure_lat_ctx(pk)) {
+        // small raw encryptions (the plaintext side of ct + pt): 1 + m n as ONE product with n^2 spread over a wavefront
+        // (k_encrypt mode 0 on the latency geometry): 25 against 60 us of kernel time
+        if (!pk->d_lat_nR) pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
+        const GeoOps* gl = pk->lat_msq.geo;
+        EncParams PL;
+        PL.nsq = pk->lat_msq.d_ctx;
+        PL.nR = pk->d_lat_nR;
+        PL.fb_table = nullptr;
+        PL.fb_windows = 0;
+        PL.fb_wbits = 0;
+        PL.pt_words = pk->n_words;
+        PL.ct_words = pk->ct_words;
+        PL.r_words = pk->r_words;
+        ScopedKernelTimer t("k_encrypt(raw)", s);
+        gl->encrypt(s, (int)((N + gl->epb - 1) / gl->epb), PL, d_m, nullptr, nullptr, d_ct_out, (int)N, 0);
+        t.stop();
+        HIP_CHECK(hipGetLastError());
+        return;
     }
     if (d_r && pk->djn) build_fb_tables(pk);
     EncParams P = pk->enc_params();

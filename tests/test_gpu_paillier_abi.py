@@ -67,7 +67,9 @@ def plaintexts(key, N, seed):
     return m
 
 
-def test_raw_encrypt_and_decrypt_2048(k2048):
+@pytest.mark.parametrize("lat_add", ["0", "4096"])
+def test_raw_encrypt_and_decrypt_2048(k2048, lat_add, monkeypatch):
+    monkeypatch.setenv("PAI_LAT_ADD_MAX", lat_add)       # small raw encryptions: one product on the latency geometry, or the digit engine
     key, N = k2048.key, 300
     m = plaintexts(key, N, 1)
     dm = DevArray(ints_to_limbs(m, k2048.nw))
