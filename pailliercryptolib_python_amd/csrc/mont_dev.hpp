@@ -198,10 +198,15 @@ struct Rows {
     // The wide-group (latency) geometries spend 80 % of their instructions outside the multiplier; this halves them.
     template <class NM>
     PAI_DEV static void block_m1(uint64_t (&acc)[NW], const uint32_t (&a)[NLL], const uint32_t (&bv)[U], const NM& npp) {
+#ifndef PAI_M1_DEBUG_HALF
+#define PAI_M1_DEBUG_HALF 0        // timing probes only (wrong results): 1 = without the a*b products, 2 = without the q*(M+1) products
+#endif
+        if constexpr (PAI_M1_DEBUG_HALF != 1) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int j = 0; j < NLL; ++j) acc[j + u] += (uint64_t)a[j] * bv[u];
+        }
         }
         uint32_t low[U], q[U];
         uint64_t c = 0;
@@ -221,8 +226,10 @@ struct Rows {
             acc[NLL + u] = 0;
             if constexpr (T > 1) acc[NLL - U + u] += (uint64_t)from_next<T>(low[u]);
         }
+        if constexpr (PAI_M1_DEBUG_HALF != 2) {
 #pragma unroll
         for (int u = 0; u < U; ++u) npp.template mac<NLL>(acc, u, q[u]);
+        }
     }
 
     // full carry propagation into canonical 29-bit limbs (across the T lanes of the group)
