@@ -83,6 +83,17 @@ struct GeoInst {
     static void encrypt(hipStream_t s, int grid, EncParams P, const uint32_t* m, const uint32_t* r,
                         const uint32_t* ct_in, uint32_t* ct_out, int n, int mode) {
         if constexpr (G::T >= 16 && G::T <= 64) {
+            using GM1 = Geo<G::NLL, G::T, G::U, false, true>;
+            if (mode == 7) {       // table conversion to a minus-one context's Montgomery form: m = table in, ct_out = table out, r = the constant
+                set_lds((const void*)k_fb_to_m1<GM1>, GM1::LDS_BYTES);
+                hipLaunchKernelGGL(k_fb_to_m1<GM1>, dim3(grid), dim3(BLOCK_THREADS), GM1::LDS_BYTES, s, P.nsq, m, ct_out, n, r);
+                return;
+            }
+            if (mode >= 5 && P.fin != nullptr) {     // the shared chain on a minus-one context
+                set_lds((const void*)k_encrypt_tree<GM1>, GM1::LDS_BYTES);
+                hipLaunchKernelGGL(k_encrypt_tree<GM1>, dim3(grid), dim3(BLOCK_THREADS), GM1::LDS_BYTES, s, P, m, r, ct_in, ct_out, n, mode - 4);
+                return;
+            }
             if (mode >= 5) {       // modes 5 / 6: modes 1 / 2 with the fixed-base chain shared by the four waves (grid counts 64 / T integers)
                 set_lds((const void*)k_encrypt_tree<G>, G::LDS_BYTES);
                 hipLaunchKernelGGL(k_encrypt_tree<G>, dim3(grid), dim3(BLOCK_THREADS), G::LDS_BYTES, s, P, m, r, ct_in, ct_out, n, mode - 4);

@@ -205,6 +205,8 @@ struct ModSetup {
     MontCtx* d_ctx = nullptr;
     int bits = 0, w32 = 0;
     int nl = 0;       // radix-29 limbs of the Montgomery representation (R = 2^(29 nl))
+    int m1_rows = 0;  // minus-one contexts: rows per product, R = 2^(29 m1_rows)
+    int rows() const { return m1_rows ? m1_rows : nl; }
     // nl_override != 0: constants for the wide engine's limb count instead of the lane-group geometry's
     // r2_override: the constant MODMUL_FULL multiplies by instead of R^2 (small-batch tagged products: pai_ct_mont_mul)
     void init(const Limbs& mod_, int nl_override = 0, const GeoOps* force_geo = nullptr, const Limbs* r2_override = nullptr) {
@@ -271,6 +273,7 @@ struct ModSetup {
         h.nl = (uint32_t)nl;
         h.bits = (uint32_t)bits;
         h.rows = (uint32_t)rows;
+        m1_rows = rows;
         HIP_CHECK(hipMalloc((void**)&d_ctx, sizeof(MontCtx)));
         HIP_CHECK(hipMemcpy(d_ctx, &h, sizeof(MontCtx), hipMemcpyHostToDevice));
     }
@@ -463,6 +466,8 @@ struct pai_pubkey {
     mutable DevBuf lat_table;
     // latency path of DJN encryption: n R and a 10-bit fixed-base table in the wide-group geometry (81 MB at 2048-bit keys)
     mutable bool lat_fb_ready = false;
+    mutable uint32_t* d_lat_fb_m1 = nullptr;          // the same table in the Montgomery form of lat_msq_m1 (k_encrypt_tree on a minus-one context)
+    mutable uint32_t* d_lat_nR_m1 = nullptr;
     mutable uint32_t* d_lat_nR = nullptr;
     mutable uint32_t* d_lat_fb = nullptr;
     mutable int lat_fb_windows = 0, lat_fb_wbits = 10;
@@ -739,6 +744,10 @@ static size_t lat_enc_tree_max(size_t ncu) {        // PAI_LAT_ENC_TREE: largest
 static size_t lat_mul_rl_max(size_t ncu) {          // PAI_LAT_MUL_RL: largest batch of the wave-pair small-batch ct * pt (0 disables)
     if (const char* env = std::getenv("PAI_LAT_MUL_RL")) return (size_t)std::strtoull(env, nullptr, 10);
     return 2 * ncu;
+}
+static bool lat_enc_m1_disabled() {                 // PAI_LAT_ENC_M1=0: the wave-shared small-batch encryption on the conventional context
+    const char* env = std::getenv("PAI_LAT_ENC_M1");
+    return env && env[0] == '0';
 }
 static bool fb_chain_disabled() {                   // PAI_DISABLE_FB_CHAIN=1: window bases by the table kernel's own squaring chain
     const char* env = std::getenv("PAI_DISABLE_FB_CHAIN");
@@ -1460,6 +1469,8 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->lat_table.release();
     if (pk->d_lat_nR) (void)hipFree(pk->d_lat_nR);
     if (pk->d_lat_fb) (void)hipFree(pk->d_lat_fb);
+    if (pk->d_lat_fb_m1) (void)hipFree(pk->d_lat_fb_m1);
+    if (pk->d_lat_nR_m1) (void)hipFree(pk->d_lat_nR_m1);
     pk->order.release();
     pk->inv_prod.release();
     pk->inv_inv.release();
@@ -1483,6 +1494,7 @@ int pai_pubkey_trim(pai_pubkey* pk, size_t* freed_bytes) {
         fb_unregister(pk);
         fb_free_tables(pk);
         if (pk->d_lat_fb) { (void)hipFree(pk->d_lat_fb); pk->d_lat_fb = nullptr; }
+        if (pk->d_lat_fb_m1) { (void)hipFree(pk->d_lat_fb_m1); pk->d_lat_fb_m1 = nullptr; }
         if (pk->d_lat_nR) { (void)hipFree(pk->d_lat_nR); pk->d_lat_nR = nullptr; }
         pk->lat_fb_ready = false;
         // ... and the grow-only scratch of the batch operations (re-grown on demand)
@@ -1537,24 +1549,65 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
                 pk->lat_usable = true;
             }
         }
-        if (pk->lat_usable && !pk->lat_fb_ready) {
-            // window width of the small-batch table: every window is one sequential product (~11 us at 2048-bit keys) of
-            // the call's latency; 12 bits = 86 windows x 4096 entries (0.2 GB at 2048-bit keys; 10 bits: 103 windows, 60 MB;
-            // 14 bits: 74 windows, 0.7 GB).  PAI_LAT_FB_WBITS pins it (4..16).
-            int lw = 12;
-            if (const char* env = std::getenv("PAI_LAT_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 16) lw = v; }
-            pk->lat_fb_wbits = lw;
-            pk->lat_fb_windows = (pk->randbits + pk->lat_fb_wbits - 1) / pk->lat_fb_wbits;
-            if (!pk->d_lat_nR) pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
-            pk->d_lat_fb = build_lane_group_fb(pk, pk->lat_msq, pk->lat_fb_wbits, pk->lat_fb_windows);
-            pk->lat_fb_ready = true;
-        }
         if (pk->lat_usable) {
             const GeoOps* gl = pk->lat_msq.geo;
+            if (!pk->lat_fb_ready) {
+                // window width of the small-batch table: every window is one sequential product (~11 us at 2048-bit keys, 6 us on
+                // a minus-one context) of the call's latency; 12 bits = 86 windows x 4096 entries (0.2 GB at 2048-bit keys; 10
+                // bits: 103 windows, 60 MB; 14 bits: 74 windows, 0.7 GB).  PAI_LAT_FB_WBITS pins it (4..16).
+                int lw = 12;
+                if (const char* env = std::getenv("PAI_LAT_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 16) lw = v; }
+                pk->lat_fb_wbits = lw;
+                pk->lat_fb_windows = (pk->randbits + pk->lat_fb_wbits - 1) / pk->lat_fb_wbits;
+                pk->lat_fb_ready = true;
+            }
+            // the four waves of a workgroup share one wave's integers (k_encrypt_tree: a quarter of the windows each, two
+            // levels of combining products); PAI_LAT_ENC_TREE=0 keeps one chain per integer
+            const bool tree = gl->t >= 16 && gl->t <= 64 && N <= lat_enc_tree_max((size_t)pk->dev.ncu);
+            // ... and on a minus-one context of n^2 where one fits (ensure_lat_ctx): the table is converted once into that
+            // context's Montgomery form and the conventional copy is dropped (rebuilt only if PAI_LAT_ENC_M1 / _TREE ask for it)
+            ensure_lat_ctx(pk);
+            const bool m1 = tree && pk->lat_m1_ok && !lat_enc_m1_disabled();
+            if ((m1 && !pk->d_lat_fb_m1) || (!m1 && !pk->d_lat_fb)) {
+                if (!pk->d_lat_fb) pk->d_lat_fb = build_lane_group_fb(pk, pk->lat_msq, pk->lat_fb_wbits, pk->lat_fb_windows);
+                if (m1) {
+                    const ModSetup& M1 = pk->lat_msq_m1;
+                    // c == R'^2 / R_c (mod n^2), R' = 2^(29 rows), R_c = 2^(29 nl): a power of two, negative exponents by halving
+                    const int e = hbn::RB * (2 * (int)M1.rows() - pk->lat_msq.nl);
+                    Limbs c;
+                    if (e >= 0) c = hbn::mod(hbn::shl(Limbs{1u}, e), pk->nsq);
+                    else {
+                        c = Limbs{1u};
+                        for (int i = 0; i < -e; ++i) { if (hbn::is_odd(c)) c = hbn::add(c, pk->nsq); c = hbn::shr(c, 1); }
+                    }
+                    uint32_t* d_c = upload_r29(c, M1.nl);
+                    const size_t NE = (size_t)pk->lat_fb_windows << pk->lat_fb_wbits;
+                    hipError_t e0 = hipMalloc((void**)&pk->d_lat_fb_m1, NE * (size_t)M1.nl * 4);
+                    if (e0 == hipSuccess) {
+                        EncParams PC;
+                        PC.nsq = M1.d_ctx;
+                        const int gconv = (int)std::max<size_t>(1, std::min<size_t>((NE + gl->epb - 1) / gl->epb, (size_t)pk->dev.ncu * 8));
+                        gl->encrypt(nullptr, gconv, PC, pk->d_lat_fb, d_c, nullptr, pk->d_lat_fb_m1, (int)NE, 7);
+                        e0 = hipGetLastError();
+                        const hipError_t e1 = hipDeviceSynchronize();
+                        if (e0 == hipSuccess) e0 = e1;
+                    }
+                    (void)hipFree(d_c);
+                    if (e0 != hipSuccess) {
+                        if (pk->d_lat_fb_m1) { (void)hipFree(pk->d_lat_fb_m1); pk->d_lat_fb_m1 = nullptr; }
+                        HIP_CHECK(e0);
+                    }
+                    (void)hipFree(pk->d_lat_fb);
+                    pk->d_lat_fb = nullptr;
+                    if (!pk->d_lat_nR_m1) pk->d_lat_nR_m1 = upload_r29(hbn::mulmod(pk->n, M1.R, M1.M), M1.nl);
+                }
+            }
+            if (!pk->d_lat_nR) pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
             EncParams PL;
-            PL.nsq = pk->lat_msq.d_ctx;
-            PL.nR = pk->d_lat_nR;
-            PL.fb_table = pk->d_lat_fb;
+            PL.nsq = m1 ? pk->lat_msq_m1.d_ctx : pk->lat_msq.d_ctx;
+            PL.nR = m1 ? pk->d_lat_nR_m1 : pk->d_lat_nR;
+            PL.fb_table = m1 ? pk->d_lat_fb_m1 : pk->d_lat_fb;
+            PL.fin = m1 ? pk->lat_msq.d_ctx : nullptr;
             PL.fb_windows = pk->lat_fb_windows;
             PL.fb_wbits = pk->lat_fb_wbits;
             PL.pt_words = pk->n_words;
@@ -1562,9 +1615,6 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
             PL.r_words = pk->r_words;
             pk->order.begin(s);
             ScopedKernelTimer t(from_plain ? "k_encrypt(djn)" : "k_encrypt(obfuscate)", s);
-            // the four waves of a workgroup share one wave's integers (k_encrypt_tree: a quarter of the windows each, two
-            // levels of combining products); PAI_LAT_ENC_TREE=0 keeps one chain per integer
-            const bool tree = gl->t >= 16 && gl->t <= 64 && N <= lat_enc_tree_max((size_t)pk->dev.ncu);
             const int per_wg = tree ? 64 / gl->t : gl->epb;
             gl->encrypt(s, (int)((N + per_wg - 1) / per_wg), PL, d_m, d_r, d_ct_in, d_ct_out, (int)N, (from_plain ? 1 : 2) + (tree ? 4 : 0));
             t.stop();

@@ -552,14 +552,16 @@ def test_djn_encrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
         want = [orc.encrypt(key, x, rr) for x, rr in zip(m, orc.limbs_to_ints(r))]
         dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
         # PAI_LAT_ENC_TREE: the four waves of a workgroup share one wave's integers (k_encrypt_tree); 0 = one chain per integer
-        for switch, tree in (("0", "100000"), ("100000", "100000"), ("100000", "0")):
+        # PAI_LAT_ENC_M1: the shared chain on a minus-one context of n^2 (table converted once) or on the conventional one
+        for switch, tree, m1 in (("0", "100000", "1"), ("100000", "100000", "1"), ("100000", "100000", "0"), ("100000", "0", "1")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
             monkeypatch.setenv("PAI_LAT_ENC_TREE", tree)
+            monkeypatch.setenv("PAI_LAT_ENC_M1", m1)
             ct = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
-            assert limbs_to_ints(ct.get()) == want, (bits, N, switch, tree)
+            assert limbs_to_ints(ct.get()) == want, (bits, N, switch, tree, m1)
             _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
-            assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, orc.limbs_to_ints(r))], (bits, N, switch, tree)
+            assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, orc.limbs_to_ints(r))], (bits, N, switch, tree, m1)
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
