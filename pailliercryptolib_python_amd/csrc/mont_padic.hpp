@@ -880,53 +880,89 @@ struct Padic {
     // (s <= NL 2^58 + 2^36, d <= (NL + 1) 2^58 + 2^36: nothing wraps for NL <= 62).  No accumulator window, no LDS or scratch
     // traffic, ~5 NL + 30 live registers; the modulus limbs are the SGPR array of the caller (p - 1 differs from p in limb
     // 0 only, p being odd).  Bounds as in the row-wise forms: a, b < 2p + eps in, same out.
+    // One pass of the product-scanning squaring.  SECOND = false: w = (a^2 + m p) / R with the quotient digits to mq;
+    // SECOND = true: v = (2 a b - min + R p + m' p) / R.  x = a, y = a (first) or b (second), dbl = 2 y.
+    // Column k: the first part (limb products, independent of the quotient digits) is accumulated ONE COLUMN AHEAD,
+    // statement by statement between the quotient products of column k - 1: two dependent chains per wave instead of one
+    // (a lone chain of v_mad_u64_u32 is latency-bound: the first version of this routine ran at 5.8 cycles per multiply with
+    // two waves per SIMD whatever its instruction count).
+    template <bool SECOND>
+    PAI_DEV static void comba_pass(uint32_t (&out)[NL], uint32_t (&mq)[NL], const uint32_t (&x)[NL], const uint32_t (&y)[NL],
+                                   const uint32_t (&dbl)[NL], const uint32_t (&min)[NL], const uint32_t* __restrict__ nm, uint32_t n0inv) {
+        constexpr int PW = SECOND ? 3 : 2;                                   // units per index of a full column
+        auto lo_of = [](int k) { return k < NL ? 0 : k - NL + 1; };
+        auto hi_of = [](int k) { return k < NL ? k : NL - 1; };
+        auto central = [](int k) { return k >= 0 && k < 2 * NL - 1 && PW * comba_terms(k) > 63; };
+        // first-part term t of column k (returns false past the end): outer columns add to `f` (doubled limbs), central ones to `s`
+        auto first_count = [&](int k) -> int {
+            if (k >= 2 * NL - 1) return 0;
+            if (SECOND) return hi_of(k) - lo_of(k) + 1;
+            return (k + 1) / 2 - lo_of(k) + (k % 2 == 0 ? 1 : 0);           // pairs i < k - i, then the square of an even column
+        };
+#ifndef PADIC_COMBA_CHAINS
+#define PADIC_COMBA_CHAINS 2         // dependent chains per wave: 2 (quotient products / next column's first part) or 4 (each split by parity)
+#endif
+        constexpr bool SPLIT = PADIC_COMBA_CHAINS == 4;
+        uint64_t carry = 0, s = 0, f = 0, fn = 0, sn = 0;
+        // column 0's first part
+        if (SECOND) f = (uint64_t)x[0] * dbl[0];
+        else f = (uint64_t)x[0] * x[0];
+#pragma unroll
+        for (int k = 0; k < 2 * NL - 1; ++k) {
+            const int lo = lo_of(k), hi = hi_of(k);
+            const bool cen = central(k), cen_n = central(k + 1);
+            uint64_t d = carry, d1 = 0, x1 = 0;                             // d1 / x1: the odd terms' chains (SPLIT)
+            if (SECOND) d += (k < NL ? (uint64_t)((RMASK - min[k]) + (k == 0 ? 1u : 0u)) : (uint64_t)(nm[k - NL] - (k == NL ? 1u : 0u)));
+            fn = 0;
+            sn = cen ? (s >> RB) : 0;                                       // (the doubled carry stays with the doubled accumulator)
+            const int nq = (hi - lo + 1) - (k < NL ? 1 : 0);                 // quotient products of this column
+            const int nf = first_count(k + 1);
+            const int lo_n = lo_of(k + 1);
+#pragma unroll
+            for (int t = 0; t < (nq > nf ? nq : nf); ++t) {
+                const bool odd = SPLIT && (t & 1);
+                if (t < nq) (odd ? d1 : d) += (uint64_t)mq[lo + t] * nm[k - lo - t];
+                if (t < nf) {
+                    const int kn = k + 1;
+                    const int i = lo_n + t;
+                    if (SECOND || 2 * i < kn) {
+                        const uint64_t pr = (uint64_t)x[i] * (cen_n ? y[kn - i] : dbl[kn - i]);
+                        if (odd) x1 += pr;
+                        else if (cen_n) sn += pr;
+                        else fn += pr;
+                    } else {
+                        fn += (uint64_t)x[kn / 2] * x[kn / 2];                   // the square of an even column (last term)
+                    }
+                }
+            }
+            if (SPLIT) {
+                asm volatile("" : "+v"(d1), "+v"(x1));                      // (keeps the optimiser from re-associating the four chains into two)
+                d += d1;
+                if (cen_n) sn += x1; else fn += x1;
+            }
+            uint64_t sum = d + f + (cen ? ((uint64_t)((uint32_t)s & RMASK) << 1) : 0);
+            if (k < NL) {
+                mq[k] = ((uint32_t)sum * n0inv) & RMASK;
+                sum += (uint64_t)mq[k] * nm[0];
+            } else {
+                out[k - NL] = (uint32_t)sum & RMASK;
+            }
+            carry = sum >> RB;
+            if (cen && !cen_n) { carry += sn << 1; sn = 0; }              // leaving the central band
+            f = fn;
+            s = sn;
+        }
+        out[NL - 1] = (uint32_t)carry + (SECOND ? nm[NL - 1] : 0u);
+    }
+    PAI_DEV static constexpr int comba_terms(int k) { return k < NL ? k + 1 : 2 * NL - 1 - k; }
     PAI_DEV static void sqr_comba(uint32_t (&a)[NL], uint32_t (&b)[NL], const uint32_t* __restrict__ nm, uint32_t n0inv) {
-        uint32_t m[NL], w[NL], m2[NL], v[NL];
-        uint64_t carry = 0, s = 0;
+        uint32_t m[NL], w[NL], m2[NL], v[NL], dbl[NL];
 #pragma unroll
-        for (int k = 0; k < 2 * NL - 1; ++k) {
-            const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
-            uint64_t d = carry;
+        for (int j = 0; j < NL; ++j) dbl[j] = a[j] << 1;
+        comba_pass<false>(w, m, a, a, dbl, m, nm, n0inv);
 #pragma unroll
-            for (int i = lo; 2 * i < k; ++i) s += (uint64_t)a[i] * a[k - i];
-            if (k % 2 == 0) d += (uint64_t)a[k / 2] * a[k / 2];
-#pragma unroll
-            for (int i = lo; i <= hi; ++i)
-                if (i != k) d += (uint64_t)m[i] * nm[k - i];
-            uint64_t sum = d + ((uint64_t)((uint32_t)s & RMASK) << 1);
-            if (k < NL) {
-                m[k] = ((uint32_t)sum * n0inv) & RMASK;
-                sum += (uint64_t)m[k] * nm[0];
-            } else {
-                w[k - NL] = (uint32_t)sum & RMASK;
-            }
-            carry = sum >> RB;
-            s >>= RB;                      // the doubled part's carry stays in the doubled accumulator
-        }
-        w[NL - 1] = (uint32_t)carry + ((uint32_t)s << 1);
-        carry = 0;
-        s = 0;
-#pragma unroll
-        for (int k = 0; k < 2 * NL - 1; ++k) {
-            const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
-            // (R - 1 - m) + 1 in the low columns, p - 1 in the high ones
-            uint64_t d = carry + (k < NL ? (uint64_t)((RMASK - m[k]) + (k == 0 ? 1u : 0u)) : (uint64_t)(nm[k - NL] - (k == NL ? 1u : 0u)));
-#pragma unroll
-            for (int i = lo; i <= hi; ++i) s += (uint64_t)a[i] * b[k - i];
-#pragma unroll
-            for (int i = lo; i <= hi; ++i)
-                if (i != k) d += (uint64_t)m2[i] * nm[k - i];
-            uint64_t sum = d + ((uint64_t)((uint32_t)s & RMASK) << 1);
-            if (k < NL) {
-                m2[k] = ((uint32_t)sum * n0inv) & RMASK;
-                sum += (uint64_t)m2[k] * nm[0];
-            } else {
-                v[k - NL] = (uint32_t)sum & RMASK;
-            }
-            carry = sum >> RB;
-            s >>= RB;
-        }
-        v[NL - 1] = (uint32_t)carry + ((uint32_t)s << 1) + nm[NL - 1];
+        for (int j = 0; j < NL; ++j) dbl[j] = b[j] << 1;
+        comba_pass<true>(v, m2, a, b, dbl, m, nm, n0inv);
 #pragma unroll
         for (int j = 0; j < NL; ++j) { a[j] = w[j]; b[j] = v[j]; }
     }
