@@ -42,6 +42,9 @@ The JSON line also carries
                  Add_CTCT, Add_CTPT, Mul_CTPT at 16 / 64 with its inputs and key) through the PUBLIC API, microseconds per
                  call, with the same composition on the CPU port beside it and a bit-for-bit parity check of every
                  deterministic row (2048-bit configurations only).
+  configs      — default single-GPU invocation only: BASELINE configs[1] (2048-bit, 65 536), configs[3] (3072-bit, 2^20) and
+                 configs[4] (4096-bit, 2^18) timed in the same run after the headline leg (--config-steps timed steps each),
+                 each with value, ms_per_step, the full-batch parity check, per-kernel times, roofline and a CPU sample.
 --config selects the BASELINE.json configuration: headline (2048-bit, 2^20: the metric), cfg2 (2048-bit, 65 536),
 cfg4 (3072-bit, 2^20), cfg5 (4096-bit, 2^18): key size, batch, executed / canonical MAC counts, dominant kernel and the
 PMC file for roofline.traffic follow the key size; the parity check and cpu_baseline are the same.
@@ -263,6 +266,11 @@ def reference_bench(key, okey, device) -> dict:
             raise SystemExit("bench.py: reference_bench ct * x is not deterministic")
         for name, (gpu_call, _) in cases.items():
             row = {"gpu_api_us": us(gpu_call, sync=True)}
+            if name.startswith("BM_Add"):
+                # an addition returns a lazily tagged ciphertext (one Montgomery product); the reference and the CPU leg return
+                # the fully reduced wire form, so the row compared with them pays the retag product inside the timed call
+                row["gpu_api_lazy_us"] = row["gpu_api_us"]
+                row["gpu_api_us"] = us(lambda: gpu_call().words, sync=True)
             for label, c in capis.items():
                 row[label] = us(lambda: cpu_f[name](c), sync=False)
             best_cpu = min(v for k_, v in row.items() if k_.startswith("cpu_"))
@@ -270,8 +278,8 @@ def reference_bench(key, okey, device) -> dict:
             out["rows"][f"{name}/{nb}"] = row
     out["parity_checked"] = "decrypt values; Add_CTCT / Add_CTPT / Mul_CTPT ciphertext bits and exponents (GPU API vs CPU port), 16 and 64"
     out["note"] = ("gpu_api_us: PaillierPublicKey / PaillierPrivateKey / PaillierEncryptedNumber calls, host ndarray in, each followed "
-                   "by torch.cuda.synchronize(); additions return lazily tagged ciphertexts (the wire form costs one more product at "
-                   "export).  cpu_*: c_oracle.CApi, Python glue of the reference's shape included")
+                   "by torch.cuda.synchronize(); BM_Add_* rows time the addition INCLUDING its export to the wire form (.words), the "
+                   "work the reference and the CPU leg do; gpu_api_lazy_us is the addition alone (lazily tagged result).  cpu_*: c_oracle.CApi, Python glue of the reference's shape included")
     return out
 
 
@@ -314,6 +322,9 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip api_level / other_ops / small_batch (profiling runs)")
     ap.add_argument("--no-reference-bench", action="store_true", help="skip the reproduction of bench/bench_ipcl_python.py")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs block (BASELINE configs[1], [3], [4] after the headline leg)")
+    ap.add_argument("--config-steps", type=int, default=2, help="timed steps of each configuration in the configs block")
+    ap.add_argument("--config-cpu-seconds", type=float, default=3.0, help="CPU sample duration of each configuration in the configs block")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     KEY_BITS = args.key_bits or cfg["key_bits"]
@@ -362,27 +373,40 @@ def main() -> None:
 
     from pailliercryptolib_python_amd import engine, fixedpoint, sharding
 
-    key = synthetic_key(KEY_BITS, DJN_X)
-    pub = engine.PublicKeyHandle(key.n, KEY_BITS, key.hs, key.randbits, device=device)
-    priv = engine.PrivateKeyHandle(pub, key.p, key.q)
     # the oracle enters only as the checker of what was timed and as the CPU baseline
     from oracle import paillier_oracle as orc
-    okey = orc.make_key(key.p, key.q, djn_x=DJN_X, bits=KEY_BITS)
-    assert okey.n == key.n and okey.hs == key.hs and okey.randbits == key.randbits
+
+    def make_ctx(bits: int) -> SimpleNamespace:
+        """Key material, device handles and the checker's key for one key size."""
+        key_ = synthetic_key(bits, DJN_X)
+        pub_ = engine.PublicKeyHandle(key_.n, bits, key_.hs, key_.randbits, device=device)
+        priv_ = engine.PrivateKeyHandle(pub_, key_.p, key_.q)
+        okey_ = orc.make_key(key_.p, key_.q, djn_x=DJN_X, bits=bits)
+        assert okey_.n == key_.n and okey_.hs == key_.hs and okey_.randbits == key_.randbits
+        return SimpleNamespace(bits=bits, key=key_, pub=pub_, priv=priv_, okey=okey_)
+
+    ctx0 = make_ctx(KEY_BITS)
+    key, pub, priv, okey = ctx0.key, ctx0.pub, ctx0.priv, ctx0.okey
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def run_leg(scaling: str):
+    def run_leg(scaling: str, ctx: Optional[SimpleNamespace] = None, batch: Optional[int] = None, steps: Optional[int] = None,
+                warmup: Optional[int] = None):
         """Inputs of this rank for one arrangement, W warm-up steps, K timed steps (barrier + synchronize on both sides,
         maximum over ranks), then the parity check of what was timed."""
+        ctx = ctx or ctx0
+        key, pub, priv, okey = ctx.key, ctx.pub, ctx.priv, ctx.okey
+        batch = args.batch if batch is None else batch
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         if scaling == "strong":
-            begin, B = engine.shard_plan(args.batch, world)[rank]        # this rank's contiguous block of the global batch
-            x = np.random.default_rng(1002).uniform(-1000.0, 1000.0, args.batch)[begin:begin + B]
-            total_per_step = float(args.batch)
+            begin, B = engine.shard_plan(batch, world)[rank]             # this rank's contiguous block of the global batch
+            x = np.random.default_rng(1002).uniform(-1000.0, 1000.0, batch)[begin:begin + B]
+            total_per_step = float(batch)
         else:
-            begin, B = 0, args.batch
+            begin, B = 0, batch
             x = np.random.default_rng(1002 + rank).uniform(-1000.0, 1000.0, B)
             total_per_step = float(B) * world
         res, expo = fixedpoint.encode_float64_array(x, key.n, pub.n_words)
@@ -399,12 +423,12 @@ def main() -> None:
                 pub.encrypt(m, r, out=ct)
                 priv.decrypt(ct, out=out)
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
         barrier()
@@ -432,7 +456,23 @@ def main() -> None:
         if not ok:
             raise SystemExit("bench.py: parity check failed (decrypt(encrypt(m)) != m or ciphertext bits differ from the oracle)")
         return SimpleNamespace(scaling=scaling, begin=begin, B=B, x=x, res=res, expo=expo, m=m, r=r, ct=ct, out=out,
-                               elapsed=elapsed, total_per_step=total_per_step)
+                               elapsed=elapsed, total_per_step=total_per_step, steps=steps, warmup=warmup)
+
+    def kernel_times(ctx: SimpleNamespace, leg_: SimpleNamespace, reps: int) -> dict:
+        """Per-kernel durations (ms) of one step, HIP events on the launch stream, mean of `reps` passes."""
+        engine.profile_enable(True)
+        acc_ = {}
+        for _ in range(reps):
+            if not leg_.B:
+                break
+            ctx.pub.encrypt(leg_.m, leg_.r, out=leg_.ct)
+            for k_, v in engine.profile_last().items():
+                acc_[k_] = acc_.get(k_, 0.0) + v
+            ctx.priv.decrypt(leg_.ct, out=leg_.out)
+            for k_, v in engine.profile_last().items():
+                acc_[k_] = acc_.get(k_, 0.0) + v
+        engine.profile_enable(False)
+        return {k_: v / reps for k_, v in acc_.items()}
 
     leg = run_leg(args.scaling)
     begin, B, x, res, expo, m, r, ct, out = leg.begin, leg.B, leg.x, leg.res, leg.expo, leg.m, leg.r, leg.ct, leg.out
@@ -453,20 +493,7 @@ def main() -> None:
         del full
 
     # ---- per-kernel durations with HIP events on the launch stream (every rank; rank 0 reports) ----
-    engine.profile_enable(True)
-    acc = {}
-    reps = max(1, min(args.steps, 3))
-    for _ in range(reps):
-        if not B:
-            break
-        pub.encrypt(m, r, out=ct)
-        for k_, v in engine.profile_last().items():
-            acc[k_] = acc.get(k_, 0.0) + v
-        priv.decrypt(ct, out=out)
-        for k_, v in engine.profile_last().items():
-            acc[k_] = acc.get(k_, 0.0) + v
-    engine.profile_enable(False)
-    kern = {k_: v / reps for k_, v in acc.items()}
+    kern = kernel_times(ctx0, leg, max(1, min(args.steps, 3)))
     per_rank_kern = [kern]
     if world > 1:
         per_rank_kern = [None] * world
@@ -485,13 +512,14 @@ def main() -> None:
     extras = single and not args.no_extras
 
     # ---- CPU baseline on the host cores (rank 0, N = 1 only) -------------------------------------
-    cpu = None
-    if single and not args.no_cpu_baseline:
+    def cpu_baseline_for(ctx: SimpleNamespace, leg_: SimpleNamespace, seconds: float, min_sample: int, with_small: bool):
+        """The same two operations on the host cores, on a bounded sample of the batch that was just timed (same key, same
+        randomness; ciphertext bits compared with the GPU's)."""
         import ctypes.util
 
         from oracle import c_oracle as co
 
-        ck = co.COracleKey(okey)
+        ck = co.COracleKey(ctx.okey)
         # SURVEY §8d step (1): the reference's own kernel library, if the box happens to have it
         mb_lib = ctypes.util.find_library("crypto_mb") or ctypes.util.find_library("ippcp")
         if co.ifma_available():
@@ -501,23 +529,25 @@ def main() -> None:
         else:
             enc, dec, how, kind = ck.encrypt_djn, ck.decrypt_crt, "plain-C CIOS port oracle/paillier_ref.c", "port"
         threads = co.max_threads()
-        cap = min(B, 8192 * max(1, threads // 2))
-        r_host = engine.to_host_words(r[:cap])
-        probe = 8 * threads
-        dec(enc(res[:probe], r_host[:probe]))                        # cold call: thread pool, page faults
+        res_, r_, ct_ = leg_.res, leg_.r, leg_.ct
+        cap = min(leg_.B, 8192 * max(1, threads // 2))
+        r_host = engine.to_host_words(r_[:cap])
+        probe = min(cap, 8 * threads)
+        dec(enc(res_[:probe], r_host[:probe]))                       # cold call: thread pool, page faults
         t1 = time.perf_counter()
-        dec(enc(res[:probe], r_host[:probe]))                        # warm probe sizes the sample
+        dec(enc(res_[:probe], r_host[:probe]))                       # warm probe sizes the sample
         t_probe = time.perf_counter() - t1
-        sample = int(min(cap, max(8192, probe * args.cpu_seconds / max(t_probe, 1e-4))))
+        sample = int(min(cap, max(min_sample, probe * seconds / max(t_probe, 1e-4))))
         sample -= sample % 8
         t1 = time.perf_counter()
-        c_ct = enc(res[:sample], r_host[:sample])
+        c_ct = enc(res_[:sample], r_host[:sample])
         t_enc_cpu = time.perf_counter() - t1
         c_m = dec(c_ct)
         t_cpu = time.perf_counter() - t1
-        assert np.array_equal(c_m, res[:sample]), "CPU baseline failed its own round trip"
-        assert np.array_equal(c_ct[:256], engine.to_host_words(ct[:256])), "CPU baseline and GPU ciphertexts differ"
-        cpu = {
+        assert np.array_equal(c_m, res_[:sample]), "CPU baseline failed its own round trip"
+        nchk_ = min(256, sample)
+        assert np.array_equal(c_ct[:nchk_], engine.to_host_words(ct_[:nchk_])), "CPU baseline and GPU ciphertexts differ"
+        cpu_ = {
             "value": sample / t_cpu, "unit": "encrypt+decrypt ops/s", "cores": threads, "kind": kind,
             "sample": f"{sample} elements of the same batch, same key and randomness; {how}, OpenMP over {threads} host "
                       f"threads, {t_cpu:.1f} s (encrypt {t_enc_cpu:.1f} s)",
@@ -527,7 +557,7 @@ def main() -> None:
         }
         # the reference's own benchmark sizes (bench/bench_ipcl_python.py:24-25,34-35,45-46,56-57,67-68: 16 and 64 elements),
         # same port, one thread and all threads, beside the GPU latencies of small_batch
-        if co.ifma_available():
+        if with_small and co.ifma_available():
             def cpu_wall(f, reps=5):
                 f()
                 ts_ = []
@@ -544,12 +574,17 @@ def main() -> None:
                 cpu_small[str(nb)] = {}
                 for label, th in (("1_thread", 1), ("all_threads", threads)):
                     cpu_small[str(nb)][label] = {
-                        "encrypt_ms": cpu_wall(lambda: enc(res[:nb], r_host[:nb], threads=th)),
+                        "encrypt_ms": cpu_wall(lambda: enc(res_[:nb], r_host[:nb], threads=th)),
                         "decrypt_ms": cpu_wall(lambda: dec(ct_s, threads=th)),
-                        "ct_add_ms": cpu_wall(lambda: co.modmul(key.nsq, ct_s, ct_s, threads=th)),
-                        "ct_mul_53bit_ms": cpu_wall(lambda: co.ifma_modexp(key.nsq, ct_s, e53_h[:nb], threads=th)),
+                        "ct_add_ms": cpu_wall(lambda: co.modmul(ctx.key.nsq, ct_s, ct_s, threads=th)),
+                        "ct_mul_53bit_ms": cpu_wall(lambda: co.ifma_modexp(ctx.key.nsq, ct_s, e53_h[:nb], threads=th)),
                     }
-            cpu["small_batch"] = cpu_small
+            cpu_["small_batch"] = cpu_small
+        return cpu_
+
+    cpu = None
+    if single and not args.no_cpu_baseline:
+        cpu = cpu_baseline_for(ctx0, leg, args.cpu_seconds, 8192, True)
 
     # ---- API level: host float64 -> encrypt -> decrypt -> host float64 (rank 0, N = 1) ----------
     api = None
@@ -601,7 +636,8 @@ def main() -> None:
         NLSQ = modmul_limbs(2 * KEY_BITS)                 # limbs of the lane-group geometry serving n^2
         ct_b = torch.roll(ct, 1, dims=0).contiguous()
         ct2 = pub.empty_ct(B)
-        e53 = torch.randint(0, 1 << 30, (B, 2), dtype=torch.int32, device=device)     # 53-bit multipliers (float mantissas)
+        # dense 53-bit multipliers (float mantissas): all 32 bits of the low word and the 20 below the top bit are random
+        e53 = torch.randint(-(1 << 31), 1 << 31, (B, 2), dtype=torch.int64, device=device).to(torch.int32)
         e53[:, 1] &= (1 << 21) - 1
         e53[:, 1] |= 1 << 20
         ca, cb = rows(ct), rows(ct_b)
@@ -682,15 +718,80 @@ def main() -> None:
     if extras and KEY_BITS == 2048 and not args.no_reference_bench:
         ref_bench = reference_bench(key, okey, device)
 
+    def roofline_for(ctx: SimpleNamespace, B_: int, kern_: dict) -> dict:
+        """The dominant kernel (k_dec_a_padic: both CRT half-size exponentiations) against the integer-VALU roof."""
+        k_ = ctx.key
+        canon_enc, canon_dec = CANON[ctx.bits][0], CANON[ctx.bits][1]
+        bytes_enc, bytes_dec, _ = alg_bytes(ctx.bits)
+        t_deca = kern_.get("k_dec_a", 0.0) * 1e-3
+        t_enc = kern_.get("k_encrypt(djn)", 0.0) * 1e-3
+        macs_exec = executed_macs_decrypt(k_.p, k_.q)
+        canonical = (canon_dec * B_ / t_deca) if t_deca > 0 else None
+        executed = (macs_exec * B_ / t_deca) if t_deca > 0 else None
+        traffic = pmc_traffic("k_dec_a_padic", B_, ctx.bits)
+        return {
+            "bound": "valu_int",
+            "kernel": f"k_dec_a_padic<{padic_nl(max(k_.p.bit_length(), k_.q.bit_length()))}> (CRT-decrypt stage A: (ct mod s^2)^(s-1) for both primes)",
+            "achieved": (executed / 1e12) if executed else None,
+            "peak": PEAK_MAC32_PER_S / 1e12,
+            "peak_sustained": PEAK_SUSTAINED_MAC32_PER_S / 1e12,
+            "frac_of_sustained": (executed / PEAK_SUSTAINED_MAC32_PER_S) if executed else None,
+            "peak_note": "peak = 18 ms burst, constant operands (profiles/r01/ubench_valu_mi355x.jsonl); peak_sustained = 3 s of "
+                         "back-to-back launches on data-dependent operands at the clock power management settles at (2.29 GHz, "
+                         "1290 W of 1400 W): profiles/r04/ubench_valu_sustained.jsonl + _power.txt.  One wave per SIMD (this "
+                         "kernel's occupancy: LDS-bound) issues the same instruction stream at 26.7 T MAC/s",
+            "unit": "T MAC/s (29x29-bit multiply-accumulates actually executed, v_mad_u64_u32)",
+            "frac": (executed / PEAK_MAC32_PER_S) if executed else None,
+            "executed_macs_per_element": macs_exec, "canonical_mac32_per_element": canon_dec,
+            "canonical_T_MAC32_s": (canonical / 1e12) if canonical else None,
+            "canonical_frac": (canonical / PEAK_MAC32_PER_S) if canonical else None,
+            "note": "frac = executed MACs / measured v_mad_u64_u32 peak (kernel quality).  canonical_* price the kernel at "
+                    "the CANONICAL algorithm's work (SURVEY §8d: CIOS mod s^2, 5-bit windows); the kernel runs a cheaper "
+                    "algorithm (arithmetic mod s on base-s digit pairs), so the canonical fraction can exceed 1",
+            "kernel_ms": kern_,
+            "traffic": traffic["bytes"] if traffic else None,
+            "traffic_source": traffic,
+            "traffic_unit": "HBM bytes per k_dec_a_padic launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, scaled from the profile's batch)",
+            "hbm": {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "achieved_decrypt": (bytes_dec * B_ / t_deca / 1e9) if t_deca > 0 else None,
+                "achieved_encrypt": (bytes_enc * B_ / t_enc / 1e9) if t_enc > 0 else None,
+            },
+        }
+
+    # ---- the other BASELINE.json configurations, driver-timed in the same run (rank 0, N = 1, default invocation) ----
+    # configs[1] (2048-bit, 65 536), configs[3] (3072-bit, 2^20), configs[4] (4096-bit, 2^18): the same step, the same
+    # barrier / synchronize bracket, the same full-batch parity check (decrypt(encrypt(m)) == m on every element, ciphertext
+    # bits against the oracle on samples), per-kernel HIP-event times, the same roofline object and a CPU sample each
+    configs_block = None
+    if single and args.config == "headline" and args.key_bits is None and args.batch == CONFIGS["headline"]["batch"] \
+            and not args.no_configs:
+        configs_block = {}
+        for name in ("cfg2", "cfg4", "cfg5"):
+            c_ = CONFIGS[name]
+            ctx_ = ctx0 if c_["key_bits"] == KEY_BITS else make_ctx(c_["key_bits"])
+            t_first = time.perf_counter()
+            leg_ = run_leg("strong", ctx_, c_["batch"], args.config_steps, 1)
+            t_first = time.perf_counter() - t_first
+            kern_ = kernel_times(ctx_, leg_, 1)
+            blk = {
+                "baseline_config_is": c_["baseline"], "key_bits": c_["key_bits"], "batch": c_["batch"],
+                "value": leg_.total_per_step * leg_.steps / leg_.elapsed, "unit": "ops/s",
+                "ms_per_step": 1e3 * leg_.elapsed / leg_.steps, "steps": leg_.steps, "warmup": leg_.warmup,
+                "wall_s_including_key_setup_table_build_and_parity_check": t_first,
+                "parity_checked": True, "roofline": roofline_for(ctx_, leg_.B, kern_),
+                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_for(ctx_, leg_, args.config_cpu_seconds, 512, False),
+            }
+            configs_block[name] = blk
+            del leg_
+            if ctx_ is not ctx0:
+                ctx_.pub.trim()
+                del ctx_
+            torch.cuda.empty_cache()
+
     if rank == 0:
         total_ops = total_per_step * args.steps
         value = total_ops / elapsed
-        t_deca = kern.get("k_dec_a", 0.0) * 1e-3
-        t_enc = kern.get("k_encrypt(djn)", 0.0) * 1e-3
-        canonical = (CANON_MAC_DEC * B / t_deca) if t_deca > 0 else None
-        executed = (executed_macs_decrypt(key.p, key.q) * B / t_deca) if t_deca > 0 else None
-        macs_exec = executed_macs_decrypt(key.p, key.q)
-        traffic = pmc_traffic("k_dec_a_padic", B, KEY_BITS)
         metric = BASELINE_METRIC if args.config == "headline" and KEY_BITS == 2048 else \
             f"Paillier encrypt+decrypt ops/sec, {KEY_BITS}-bit key, batch={args.batch}; {world} MI355X ({cfg['baseline']})"
         line = {
@@ -715,42 +816,14 @@ def main() -> None:
                 "key_bits": KEY_BITS, "batch_per_gpu": B if args.scaling == "weak" else None,
                 "batch_total": int(total_per_step), "scheme": "DJN", "parallelism": f"shard{world}",
             },
-            "roofline": {
-                "bound": "valu_int",
-                "kernel": f"k_dec_a_padic<{padic_nl(max(key.p.bit_length(), key.q.bit_length()))}> (CRT-decrypt stage A: (ct mod s^2)^(s-1) for both primes)",
-                "achieved": (executed / 1e12) if executed else None,
-                "peak": PEAK_MAC32_PER_S / 1e12,
-                "peak_sustained": PEAK_SUSTAINED_MAC32_PER_S / 1e12,
-                "frac_of_sustained": (executed / PEAK_SUSTAINED_MAC32_PER_S) if executed else None,
-                "peak_note": "peak = 18 ms burst, constant operands (profiles/r01/ubench_valu_mi355x.jsonl); peak_sustained = 3 s of "
-                             "back-to-back launches on data-dependent operands at the clock power management settles at (2.29 GHz, "
-                             "1290 W of 1400 W): profiles/r04/ubench_valu_sustained.jsonl + _power.txt.  One wave per SIMD (this "
-                             "kernel's occupancy: LDS-bound) issues the same instruction stream at 26.7 T MAC/s",
-                "unit": "T MAC/s (29x29-bit multiply-accumulates actually executed, v_mad_u64_u32)",
-                "frac": (executed / PEAK_MAC32_PER_S) if executed else None,
-                "executed_macs_per_element": macs_exec, "canonical_mac32_per_element": CANON_MAC_DEC,
-                "canonical_T_MAC32_s": (canonical / 1e12) if canonical else None,
-                "canonical_frac": (canonical / PEAK_MAC32_PER_S) if canonical else None,
-                "note": "frac = executed MACs / measured v_mad_u64_u32 peak (kernel quality).  canonical_* price the kernel at "
-                        "the CANONICAL algorithm's work (SURVEY §8d: CIOS mod s^2, 5-bit windows); the kernel runs a cheaper "
-                        "algorithm (arithmetic mod s on base-s digit pairs), so the canonical fraction can exceed 1",
-                "kernel_ms": kern,
-                "traffic": traffic["bytes"] if traffic else None,
-                "traffic_source": traffic,
-                "traffic_unit": "HBM bytes per k_dec_a_padic launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, scaled from the profile's batch)",
-                "hbm": {
-                    "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                    "achieved_decrypt": (BYTES_DEC * B / t_deca / 1e9) if t_deca > 0 else None,
-                    "achieved_encrypt": (BYTES_ENC * B / t_enc / 1e9) if t_enc > 0 else None,
-                },
-                "encrypt_canonical_T_MAC32_s": (CANON_MAC_ENC * B / t_enc / 1e12) if t_enc > 0 else None,
-            },
+            "roofline": roofline_for(ctx0, B, kern),
             "per_rank_kernel_ms": per_rank_kern if world > 1 else None,
             "gather_ms": gather_ms,
             "ranks_seen": ranks_seen,
             "collective_backend": (backend if world > 1 else None),
             ("weak_scaling" if args.scaling == "strong" else "strong_scaling"): other_leg,
             "cpu_baseline": cpu,
+            "configs": configs_block,
             "api_level": api,
             "other_ops": other,
             "small_batch": small,

@@ -146,6 +146,11 @@ int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t
 /* The same work without the synchronisation: returns as soon as the kernels are queued on `stream`; a non-invertible input
  * sets bit 0 of the handle's sticky status word (pai_pubkey_status below) instead of failing the call. */
 int pai_ct_invert_async(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream);
+/* The asynchronous form whose outcome travels with the RESULT instead of the handle: *d_flag (one device word the caller owns,
+ * zeroed by the caller) receives bit 0 when an input of THIS call is not invertible (the output rows are then undefined).  The
+ * Python layer keeps the word with the container built from d_out (and with everything computed from it) and reads it — one
+ * synchronisation — when that container is exported or decrypted, so the error is raised on the faulty object. */
+int pai_ct_invert_flag(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, int32_t* d_flag, void* stream);
 
 /* __raw_add with its exponent alignment fused (ipcl_python.py:490-526 + :570-741): delta_i = exponent(a_i) - exponent(b_i)
  * (base-2 fixed-point exponents, int32 on the device); the operand with the LOWER exponent is raised first:
@@ -205,8 +210,9 @@ int pai_ct_pow2_hint(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_delt
 /* Sticky status word of a handle's ASYNCHRONOUS calls, read with a synchronisation of `stream` (and cleared when
  * clear != 0): bit 0 — pai_ct_invert_async met a ciphertext that is not invertible modulo n^2 (its output rows are then
  * undefined); bit 1 — a pai_ct_pow2_hint call was given a max_delta below a shift of its batch on the digit-engine path
- * (batches >= PAI_POW2_DIGIT_MIN on keys up to 2048 bits; the raised ciphertexts of that call are then wrong).  The Python
- * layer checks it before anything leaves the device (decryption, getTexts, pickling). */
+ * (batches >= PAI_POW2_DIGIT_MIN on keys up to 2048 bits, hints the digit path serves; the raised ciphertexts of that call are
+ * then wrong — a hint outside that range runs the lane-group kernel, which is correct for any shift, and flags nothing).  The
+ * Python layer computes its hints from host arrays and uses pai_ct_invert_flag, so it never depends on this word. */
 int pai_pubkey_status(const pai_pubkey* pk, int* status_out, int clear, void* stream);
 
 

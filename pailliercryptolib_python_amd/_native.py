@@ -61,6 +61,7 @@ PROTOTYPES = {
     "pai_ct_mul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_int, C.c_int, C.c_size_t, voidp, voidp]),
     "pai_ct_invert": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_invert_async": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
+    "pai_ct_invert_flag": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_pubkey_status": (C.c_int, [voidp, C.POINTER(C.c_int), C.c_int, voidp]),
     "pai_ct_add_aligned": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_add_aligned_dom": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp, voidp]),
@@ -88,6 +89,10 @@ PROTOTYPES = {
 }
 
 _lib = None
+# host-side limits of the native key helpers (csrc/host_keygen.hpp: kg::MAXL 64-bit limbs): pai_keygen serves keys up to
+# KEYGEN_MAX_BITS, pai_host_modexp odd moduli up to HOST_MODEXP_MAX_WORDS 32-bit words; callers fall back to CPython ints above
+KEYGEN_MAX_BITS = 8192
+HOST_MODEXP_MAX_WORDS = 260
 
 
 def load() -> C.CDLL:

@@ -47,8 +47,38 @@ class ipclBigNumber:
             if int(data) < 0:
                 raise ValueError("ipclBigNumber: negative values are not supported")
             self._v = int(data)
+        elif isinstance(data, (list, tuple)):
+            # classes.cpp:386-393: a list of 32-bit words, little-endian
+            v = 0
+            for i, w in enumerate(data):
+                w = int(w)
+                if not 0 <= w < 1 << 32:
+                    raise TypeError("ipclBigNumber: list elements must be 32-bit unsigned words")
+                v |= w << (32 * i)
+            self._v = v
         else:
             raise TypeError(f"ipclBigNumber: cannot build from {type(data)}")
+
+    def DwordSize(self) -> int:
+        """classes.cpp:458: number of 32-bit words of the value (1 for zero, as BITSIZE_WORD of a one-word BigNumber)."""
+        return max(1, (self._v.bit_length() + 31) // 32)
+
+    def BitSize(self) -> int:
+        """classes.cpp:459: the bit size of the word array (32 * DwordSize)."""
+        return 32 * self.DwordSize()
+
+    def __getitem__(self, n: int) -> int:
+        """classes.cpp:422-432: the n-th 32-bit word, little-endian; IndexError (std::out_of_range) past the end."""
+        n = int(n)
+        length = self.DwordSize()
+        if not 0 <= n < length:
+            raise IndexError("Index is larger than size: %d" % length)
+        return (self._v >> (32 * n)) & 0xFFFFFFFF
+
+    def data(self):
+        """classes.cpp:460-471: (word count, [words])."""
+        length = self.DwordSize()
+        return (length, [(self._v >> (32 * i)) & 0xFFFFFFFF for i in range(length)])
 
     def to_bytes(self) -> bytes:
         """BN2bytes: little-endian, length = ceil(bits/32)*4 (0 encodes as 4 zero bytes upstream)."""
@@ -175,7 +205,9 @@ class ipclPublicKey:
                 # upstream DJN set-up: hs = (-x^2)^n mod n^2 for a random unit x
                 nsq = self._n * self._n
                 x = _random_unit(self._n)
-                hs = _native.host_modexp((-x * x) % nsq, self._n, nsq) if self._n & 1 else pow((-x * x) % nsq, self._n, nsq)
+                # pai_host_modexp serves odd moduli up to 260 words (n^2 of keys up to 4160 bits); beyond: CPython's pow
+                native_ok = self._n & 1 and nsq.bit_length() <= 32 * _native.HOST_MODEXP_MAX_WORDS
+                hs = _native.host_modexp((-x * x) % nsq, self._n, nsq) if native_ok else pow((-x * x) % nsq, self._n, nsq)
             self._hs = int(hs)
             self._randbits = int(randbits) if randbits is not None else self._bits // 2
         else:
@@ -391,7 +423,7 @@ class ipclPublicKey:
         if isinstance(x, ipclCipherText):
             ct = x._t.clone()
             h.obfuscate_(ct, self._draw_r(ct.shape[0]) if r is None else r)
-            return ipclCipherText(self, ct).getTexts()
+            return ipclCipherText(self, ct, taint=x._taint).getTexts()
         raise TypeError("apply_obfuscator: expected ipclBigNumber or ipclCipherText")
 
 
@@ -463,6 +495,7 @@ class ipclPrivateKey:
         """classes.cpp:127-133."""
         if ct.public_key._n != self._pk._n:
             raise RuntimeError("ipclPrivateKey.decrypt: public key mismatch")
+        ct._check()                                          # a failed asynchronous inversion is raised here, on its own result
         return ipclPlainText(self.decrypt_words(ct._t))
 
     def decrypt_tolist(self, ct: "ipclCipherText") -> list:
@@ -582,12 +615,27 @@ class ipclPlainText(_Container):
         self._ints = [int.from_bytes(b, "little") for b in t[1]]
 
 
+def merge_taint(*taints) -> tuple:
+    """Union (by identity) of the outcome words of several containers (ipclCipherText._taint)."""
+    out, seen = [], set()
+    for t in taints:
+        for f in t:
+            if id(f) not in seen:
+                seen.add(id(f))
+                out.append(f)
+    return tuple(out)
+
+
 class ipclCipherText(_Container):
     """bindings/ipcl_bindings_classes.cpp:268-378: ciphertext container bound to a public key."""
 
-    def __init__(self, pubkey: ipclPublicKey, data=None, *, dom: int = 0):
+    def __init__(self, pubkey: ipclPublicKey, data=None, *, dom: int = 0, taint: tuple = ()):
         self._pk = pubkey
         self._ints: List[int] = []
+        # Outcome words of the asynchronous inversions this container's rows were computed from (pai_ct_invert_flag: one int32
+        # device word per call, bit 0 = an input was not invertible).  They travel with every container derived from this one
+        # and are read — one synchronisation, then dropped — when rows leave the device: _check().
+        self._taint: tuple = tuple(taint)
         self._dev: Optional[torch.Tensor] = None      # limb matrix on the key's home device ...
         self._host: Optional[np.ndarray] = None       # ... or host words that have not been needed on a device yet
         # Lazy Montgomery domain (extension, DESIGN.md §2.5): the device rows hold x R^_dom mod n^2.  Additions are ONE
@@ -603,6 +651,7 @@ class ipclCipherText(_Container):
             self._dom = int(dom)
         elif isinstance(data, ipclCipherText):
             self._dev, self._host, self._dom = data._dev, data._host, data._dom
+            self._taint = merge_taint(self._taint, data._taint)
         elif isinstance(data, np.ndarray) and data.dtype == np.uint32 and data.ndim == 2:
             if data.shape[1] != W:
                 raise RuntimeError("ipclCipherText: width does not match the key")
@@ -640,12 +689,22 @@ class ipclCipherText(_Container):
                 self._dom = 0
             return self._dev
 
+    def _check(self) -> None:
+        """Raises if an asynchronous inversion behind these rows met a non-invertible ciphertext (the rows are then undefined):
+        nothing computed by a failed call leaves the device, and the error is raised on the object it belongs to, every time
+        that object is exported.  A clean outcome is final, so the words are dropped after the first look."""
+        if self._taint:
+            for f in self._taint:
+                if int(f.item()) & 1:
+                    raise _native.NativeError(_native.PAI_E_INVALID, "ct_invert: a ciphertext this result was computed from is "
+                                                                     "not invertible modulo n^2")
+            self._taint = ()
+
     def getSize(self) -> int:
         return int(self._host.shape[0]) if self._dev is None else int(self._dev.shape[0])
 
     def getTexts(self) -> List[ipclBigNumber]:
-        if self._dev is not None:
-            self._pk.handle.check_status()               # nothing computed by a failed asynchronous call leaves the device
+        self._check()
         words = self._host if self._dev is None else engine.to_host_words(self._t)
         return [ipclBigNumber(v) for v in engine.words_to_ints(words)]
 
@@ -655,7 +714,9 @@ class ipclCipherText(_Container):
 
     @property
     def words(self) -> torch.Tensor:
-        """Device tensor [N, ct_words] int32 (extension: direct access to the limb matrix)."""
+        """Device tensor [N, ct_words] int32 (extension: direct access to the limb matrix; the outcome of pending
+        asynchronous inversions is checked first — internal callers that stay on the device use `_t`)."""
+        self._check()
         return self._t
 
     def getCipherText(self):
@@ -665,14 +726,19 @@ class ipclCipherText(_Container):
         if isinstance(key, slice):
             a, b = _slice_bounds(key, len(self))
             t, dom = self._raw()
-            return ipclCipherText(self._pk, engine.rows_slice(t, a, b - a), dom=dom)
+            return ipclCipherText(self._pk, engine.rows_slice(t, a, b - a), dom=dom, taint=self._taint)
+        self._check()
         return ipclBigNumber(engine.to_host_words(self._row(int(key)))[0])
+
+    def getElementVec(self, i: int) -> List[int]:
+        self._check()
+        return super().getElementVec(i)
 
     def rotate(self, shift: int) -> "ipclCipherText":
         n = len(self)
         k = shift % n if n else 0
         t, dom = self._raw()
-        return ipclCipherText(self._pk, engine.rows_rotate(t, k), dom=dom)
+        return ipclCipherText(self._pk, engine.rows_rotate(t, k), dom=dom, taint=self._taint)
 
     def __add__(self, other):
         h = self._pk.handle
@@ -683,7 +749,8 @@ class ipclCipherText(_Container):
         if len(other) != len(self) and len(other) != 1:
             raise RuntimeError("Size mismatch")
         (ta, ka), (tb, kb) = self._raw(), other._raw()
-        return ipclCipherText(self._pk, h.ct_mont_mul(ta, tb), dom=ka + kb - 1)        # one product; the tag remembers the R^-1
+        return ipclCipherText(self._pk, h.ct_mont_mul(ta, tb), dom=ka + kb - 1,        # one product; the tag remembers the R^-1
+                              taint=merge_taint(self._taint, other._taint))
 
     def __mul__(self, other: ipclPlainText):
         if not isinstance(other, ipclPlainText):
@@ -695,7 +762,7 @@ class ipclCipherText(_Container):
         bits = max(1, max(v.bit_length() for v in vals))
         ew = (bits + 31) // 32
         e = engine.to_device_words(engine.ints_to_words(vals, ew), h.device)
-        return ipclCipherText(self._pk, self._pk.ct_mul_words(self._t, e, bits))
+        return ipclCipherText(self._pk, self._pk.ct_mul_words(self._t, e, bits), taint=self._taint)
 
     def __repr__(self):
         return "<ipclCipherText %s>" % str(id(self))[:10]
@@ -759,7 +826,7 @@ class ipclKeypair:
             raise RuntimeError("generate_keypair: n_length must be a multiple of 4 and at least 64")
         half = n_length // 2
         while True:
-            if n_length % 64 == 0 and n_length >= 128:
+            if n_length % 64 == 0 and 128 <= n_length <= _native.KEYGEN_MAX_BITS:
                 # native search (pai_keygen): sieve + Miller-Rabin on the host cores, both primes in parallel
                 p, q = _native.keygen(n_length, enable_DJN)
             else:

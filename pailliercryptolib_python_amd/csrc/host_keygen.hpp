@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <string.h>
 #include <stdexcept>
 #include <thread>
 #include <vector>
@@ -255,6 +256,8 @@ inline void random_prime(uint64_t* out, int bits, bool mod4_3, int rounds, Rng& 
             if (carry || bitlen(cand, L) != bits) break;    // ran over the top: new start
             if (miller_rabin(cand, L, 0, rng) && miller_rabin(cand, L, rounds, rng)) {
                 std::memcpy(out, cand, 8 * L);
+                explicit_bzero(cand, sizeof(cand));             // the prime and its search start leave this stack frame
+                explicit_bzero(c, sizeof(c));
                 return;
             }
         }
@@ -277,9 +280,11 @@ inline bool gcd_is_two(const uint64_t* a_, const uint64_t* b_, int L) {
         sub_n(b, b, a, L);
     }
     // gcd = a << shift
-    if (shift != 1) return false;
-    for (int i = 1; i < L; ++i) if (a[i]) return false;
-    return a[0] == 1;
+    bool two = shift == 1 && a[0] == 1;
+    for (int i = 1; i < L && two; ++i) if (a[i]) two = false;
+    explicit_bzero(a, sizeof(a));                               // copies of p - 1, q - 1
+    explicit_bzero(b, sizeof(b));
+    return two;
 }
 
 // Two primes for a key of n_bits bits (n_bits a multiple of 128): p != q, p q of exactly n_bits bits; DJN keys
@@ -303,7 +308,10 @@ inline void generate_primes(int n_bits, bool djn, const uint64_t* seed, uint64_t
             uint64_t pm1[MAXL], qm1[MAXL];
             std::memcpy(pm1, p, 8 * L); pm1[0] &= ~1ull;
             std::memcpy(qm1, q, 8 * L); qm1[0] &= ~1ull;
-            if (!gcd_is_two(pm1, qm1, L)) continue;
+            const bool ok = gcd_is_two(pm1, qm1, L);
+            explicit_bzero(pm1, sizeof(pm1));
+            explicit_bzero(qm1, sizeof(qm1));
+            if (!ok) continue;
         }
         return;
     }

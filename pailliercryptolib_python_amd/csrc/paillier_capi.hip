@@ -3,6 +3,7 @@
 #include "../../include/paillier_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -454,6 +455,7 @@ struct pai_pubkey {
     uint32_t* d_tree_fix = nullptr;
     mutable bool fb_ready = false;     // fixed-base tables are built by the first obfuscating call (build_fb_tables)
     mutable size_t fb_bytes = 0;       // device bytes of the built tables (the per-device table cache accounts with it)
+    mutable size_t fb_table_budget = 0;  // non-zero: this build takes the small operating point (build_fb_tables)
     // latency path of ct * pt (small batches): n^2 on a wide-group geometry, built by the first small call
     mutable bool lat_ready = false, lat_usable = false;
     mutable ModSetup lat_msq;
@@ -554,6 +556,8 @@ int pai_keygen(int key_bits, int djn, const uint64_t* h_seed, uint32_t* h_p, uin
         kg::generate_primes(key_bits, djn != 0, h_seed, p, q);
         std::memcpy(h_p, p, 4 * (size_t)words);
         std::memcpy(h_q, q, 4 * (size_t)words);
+        explicit_bzero(p, sizeof(p));                                 // the primes do not stay on this thread's stack
+        explicit_bzero(q, sizeof(q));
         (void)L;
     });
 }
@@ -864,6 +868,7 @@ uint32_t* build_lane_group_fb(const pai_pubkey* pk, const ModSetup& ms, int wb, 
     const size_t NE = (size_t)J * ENT;
     uint32_t* d_fb = nullptr;
     HIP_CHECK(hipMalloc((void**)&d_fb, NE * (size_t)nl * 4));
+    pk->fb_bytes += NE * (size_t)nl * 4;
     const GeoOps* g = ms.geo;
     uint32_t* level1 = d_fb;
     if (two_level) {
@@ -918,6 +923,7 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
     const size_t ent_words = 2 * (size_t)nl;
     const size_t NE = (size_t)J << wb, NE1 = (size_t)J1 << h;
     HIP_CHECK(hipMalloc((void**)&pk->d_pair_fb, NE * ent_words * 4));
+    pk->fb_bytes += NE * ent_words * 4;
     uint32_t* level1 = pk->d_pair_fb;
     if (two_level) {
         d_half.ensure(NE1 * ent_words * 4);
@@ -1173,6 +1179,26 @@ static size_t fb_make_room(pai_pubkey* pk, size_t need, size_t mem_total) {
     return freed;
 }
 
+// Table size of a key: the big tables (1/32 of the device memory: 8.6 GB at 2048-bit keys) are for the few keys a process
+// works with at a time.  A handle that finds PAI_FB_BIG_KEYS (default 8) built tables on its device already, or whose big
+// table would not fit the cache budget beside the resident ones, takes the small operating point instead
+// (PAI_FB_SMALL_TABLE_MB, default 256: 12-bit windows, 0.2 GB at 2048-bit keys, ~1.6 x the encryption time) — a server
+// holding a hundred parties' keys neither exhausts the device nor evicts and rebuilds a multi-GB table on every call.
+static size_t fb_small_table_bytes() {
+    if (const char* env = std::getenv("PAI_FB_SMALL_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) return (size_t)(v * 1048576.0); }
+    return (size_t)256 << 20;
+}
+static int fb_big_keys() {
+    if (const char* env = std::getenv("PAI_FB_BIG_KEYS")) { int v = std::atoi(env); if (v >= 0) return v; }
+    return 8;
+}
+static void fb_drop_tables(pai_pubkey* pk) {           // a failed build leaves nothing behind
+    if (pk->d_fb_dig) { (void)hipFree(pk->d_fb_dig); pk->d_fb_dig = nullptr; }
+    if (pk->d_pair_fb) { (void)hipFree(pk->d_pair_fb); pk->d_pair_fb = nullptr; }
+    if (pk->d_fb) { (void)hipFree(pk->d_fb); pk->d_fb = nullptr; }
+    pk->fb_ready = false;
+    pk->fb_bytes = 0;
+}
 static void build_fb_tables_body(pai_pubkey* pk);
 void build_fb_tables(const pai_pubkey* cpk) {
     pai_pubkey* pk = const_cast<pai_pubkey*>(cpk);
@@ -1182,23 +1208,40 @@ void build_fb_tables(const pai_pubkey* cpk) {
     HIP_CHECK(hipMemGetInfo(&mem_free_b, &mem_total_b));
     // the largest table the sizing rules below produce is 1/32 of the device memory (PAI_FB_TABLE_MB may ask for more)
     size_t need = mem_total_b / 32;
-    if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) need = (size_t)(v * 1048576.0); }
+    bool pinned = false;
+    if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) { need = (size_t)(v * 1048576.0); pinned = true; } }
+    pk->fb_table_budget = 0;
+    if (!pinned) {
+        size_t used = 0; int resident = 0;
+        {
+            std::lock_guard<std::mutex> g(g_fb.mu);
+            for (pai_pubkey* o : g_fb.lru) if (o->device == pk->device && o != pk) { used += o->fb_bytes; ++resident; }
+        }
+        if (resident >= fb_big_keys() || used + need > fb_cache_budget(mem_total_b)) {
+            need = std::min(need, fb_small_table_bytes());
+            pk->fb_table_budget = need;
+        }
+    }
     fb_make_room(pk, need, mem_total_b);
-    try {
-        build_fb_tables_body(pk);
-        size_t mem_free_a = 0;
-        HIP_CHECK(hipMemGetInfo(&mem_free_a, &mem_total_b));
-        pk->fb_bytes = mem_free_b > mem_free_a ? mem_free_b - mem_free_a : 0;   // (after any eviction: a lower bound then; the tables dominate)
-        std::lock_guard<std::mutex> g(g_fb.mu);
-        g_fb.lru.push_back(pk);
-    } catch (...) {
-        // a failed build (out of memory under pressure, a HIP error between the table allocation and fb_ready) must not
-        // leave a multi-GB table behind: the next obfuscating call would allocate over the dangling pointer
-        if (pk->d_fb_dig) { (void)hipFree(pk->d_fb_dig); pk->d_fb_dig = nullptr; }
-        if (pk->d_pair_fb) { (void)hipFree(pk->d_pair_fb); pk->d_pair_fb = nullptr; }
-        if (pk->d_fb) { (void)hipFree(pk->d_fb); pk->d_fb = nullptr; }
-        pk->fb_ready = false;
-        throw;
+    for (int attempt = 0;; ++attempt) {
+        try {
+            pk->fb_bytes = 0;                           // the builders add what they allocate for the tables
+            build_fb_tables_body(pk);
+            std::lock_guard<std::mutex> g(g_fb.mu);
+            g_fb.lru.push_back(pk);
+            return;
+        } catch (const PaiError& e) {
+            // a failed build (out of memory under pressure, a HIP error between the table allocation and fb_ready) must not
+            // leave a multi-GB table behind: the next obfuscating call would allocate over the dangling pointer
+            fb_drop_tables(pk);
+            (void)hipGetLastError();
+            // out of memory: return every other handle's tables on this device and try once more
+            if (attempt == 0 && e.code == PAI_E_HIP && fb_make_room(pk, (size_t)-1 / 2, mem_total_b) > 0) continue;
+            throw;
+        } catch (...) {
+            fb_drop_tables(pk);
+            throw;
+        }
     }
 }
 static void build_fb_tables_body(pai_pubkey* pk) {
@@ -1214,6 +1257,7 @@ static void build_fb_tables_body(pai_pubkey* pk) {
                                    : std::max(256.0 * 1048576.0, std::min((double)mem_total0 / 32.0, (double)mem_free0 / 4.0));
     if (!pk->penc_nl) {
         if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) lg_budget = v * 1048576.0; }
+        if (pk->fb_table_budget) lg_budget = (double)pk->fb_table_budget;      // the small operating point (build_fb_tables)
     }
     int wb = pk->penc_nl ? 12 : 16;
     while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > lg_budget) wb -= (wb > 8 ? 2 : 1);
@@ -1251,6 +1295,7 @@ static void build_fb_tables_body(pai_pubkey* pk) {
         HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
         double budget = std::min((double)mem_total / 32.0, (double)mem_free / 4.0);   // never more than a quarter of what is free
         if (const char* env = std::getenv("PAI_FB_TABLE_MB")) { double v = std::atof(env); if (v >= 1.0) budget = v * 1048576.0; }
+        if (pk->fb_table_budget) budget = (double)pk->fb_table_budget;         // the small operating point (build_fb_tables)
         int dwb = wb;
         for (int cand = 20; cand > 12; cand -= 2)
             if (table_bytes(cand) <= budget) { dwb = cand; break; }
@@ -1262,6 +1307,7 @@ static void build_fb_tables_body(pai_pubkey* pk) {
         pk->fbd_wbits = dwb;
         pk->fbd_windows = DJ;
         HIP_CHECK(hipMalloc((void**)&pk->d_fb_dig, ((size_t)DJ << dwb) * ent_bytes));
+        pk->fb_bytes += ((size_t)DJ << dwb) * ent_bytes;
         bool ok = true;
         // window bases hs^(2^(h j)): one chain of squarings on the integer-per-wavefront geometry (k_sq_chain, ~6 us per
         // product) instead of the same chain walked by every lane of the table kernel at 50 us per product
@@ -2028,8 +2074,11 @@ static int ct_pow2_impl(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_d
             int* d_max = reinterpret_cast<int*>(pk->pow2_expo.as<uint32_t>() + 2 * N);
             pk->order.begin(s);
             HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int), s));
+            // an under-estimated hint only matters where the digit path will run on it (it would truncate 2^delta): with a
+            // hint outside that range the lane-group kernel below serves any shift correctly and nothing is flagged
+            const bool hint_digit = dmax_hint >= POW2_DIGIT_MIN_SHIFT && dmax_hint <= 62;
             hipLaunchKernelGGL(k_pow2_expo, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_delta, delta_bcast, N,
-                               pk->pow2_expo.as<uint32_t>(), d_max, dmax_hint, status_word(pk, s));
+                               pk->pow2_expo.as<uint32_t>(), d_max, hint_digit ? dmax_hint : -1, hint_digit ? status_word(pk, s) : nullptr);
             HIP_CHECK(hipGetLastError());
             int dmax = dmax_hint;
             if (dmax_hint < 0) {                                          // no hint: read the largest shift back (synchronises)
@@ -2285,12 +2334,16 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
     });
 }
 
-static int ct_invert_impl(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream, bool sync);
+static int ct_invert_impl(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream, bool sync, int* d_flag);
 int pai_ct_invert(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream) {
-    return ct_invert_impl(pk, d_ct, N, d_out, stream, true);
+    return ct_invert_impl(pk, d_ct, N, d_out, stream, true, nullptr);
 }
 int pai_ct_invert_async(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream) {
-    return ct_invert_impl(pk, d_ct, N, d_out, stream, false);
+    return ct_invert_impl(pk, d_ct, N, d_out, stream, false, nullptr);
+}
+int pai_ct_invert_flag(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, int32_t* d_flag, void* stream) {
+    if (!d_flag) return guarded([&] { require(false, "NULL argument"); });
+    return ct_invert_impl(pk, d_ct, N, d_out, stream, false, d_flag);
 }
 int pai_pubkey_status(const pai_pubkey* pk, int* status_out, int clear, void* stream) {
     return guarded([&] {
@@ -2307,7 +2360,7 @@ int pai_pubkey_status(const pai_pubkey* pk, int* status_out, int clear, void* st
     });
 }
 
-static int ct_invert_impl(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream, bool sync) {
+static int ct_invert_impl(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uint32_t* d_out, void* stream, bool sync, int* d_flag) {
     return guarded([&] {
         require(pk && d_ct && d_out, "NULL argument");
         if (N == 0) return;
@@ -2375,8 +2428,9 @@ static int ct_invert_impl(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, 
         }
         t.stop();
         if (!sync) {
-            // asynchronous form: a non-unit is remembered in the handle's sticky status word (pai_pubkey_status)
-            hipLaunchKernelGGL(k_status_or, dim3(1), dim3(1), 0, s, status_word(pk, s), pk->inv_fail.as<int>(), 1);
+            // asynchronous forms: a non-unit is remembered in the caller's flag word (pai_ct_invert_flag: the outcome travels
+            // with the result) or in the handle's sticky status word (pai_ct_invert_async + pai_pubkey_status)
+            hipLaunchKernelGGL(k_status_or, dim3(1), dim3(1), 0, s, d_flag ? d_flag : status_word(pk, s), pk->inv_fail.as<int>(), 1);
             HIP_CHECK(hipGetLastError());
             order_.done();
             return;

@@ -274,18 +274,28 @@ class PublicKeyHandle:
                                                _ptr(sign), _ptr(out), _stream(self.device)))
         return out
 
-    def ct_invert(self, ct: torch.Tensor, out: Optional[torch.Tensor] = None, sync: bool = True) -> torch.Tensor:
-        """ct^-1 mod n^2.  sync=False: pai_ct_invert_async — the call returns with the kernels queued; a non-invertible input
-        is remembered in the handle's sticky status word and raised by the next check_status() (the API layer calls it
-        before anything leaves the device)."""
+    def ct_invert(self, ct: torch.Tensor, out: Optional[torch.Tensor] = None, sync: bool = True,
+                  flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ct^-1 mod n^2.  flag (an int32 device word, see new_flag()): pai_ct_invert_flag — the call returns with the kernels
+        queued and a non-invertible input sets bit 0 of THAT word; the API layer keeps it with the container built from the
+        result and reads it when the container is exported or decrypted (bindings.ipclCipherText._check).  sync=False without
+        a flag: pai_ct_invert_async — the outcome goes to the handle's sticky status word (check_status())."""
         self._chk(ct, self.ct_words, "ct")
         out = self.empty_ct(ct.shape[0]) if out is None else out
-        if sync:
+        if flag is not None:
+            if flag.dtype != torch.int32 or flag.numel() != 1 or flag.device != self.device:
+                raise ValueError("flag: expected one int32 word on %s" % self.device)
+            _native.check(self.lib.pai_ct_invert_flag(self.h, _ptr(ct), ct.shape[0], _ptr(out), _ptr(flag), _stream(self.device)))
+        elif sync:
             _native.check(self.lib.pai_ct_invert(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.device)))
         else:
             _native.check(self.lib.pai_ct_invert_async(self.h, _ptr(ct), ct.shape[0], _ptr(out), _stream(self.device)))
             self._status_dirty = True
         return out
+
+    def new_flag(self) -> torch.Tensor:
+        """A zeroed device word for pai_ct_invert_flag."""
+        return torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def check_status(self, force: bool = False) -> None:
         """Reads (and clears) the sticky status word of this handle's asynchronous calls if one of them ran since the last
@@ -304,7 +314,8 @@ class PublicKeyHandle:
         """ct_i <- ct_i^(2^delta_i) in place for delta_i > 0.  delta: int32 device tensor, or a host numpy array (then the
         largest shift is known here and the call never reads anything back: asynchronous for every batch size)."""
         self._chk(ct, self.ct_words, "ct")
-        if isinstance(delta, np.ndarray):
+        from_host = isinstance(delta, np.ndarray)
+        if from_host:
             delta = np.ascontiguousarray(delta, dtype=np.int32).reshape(-1)
             max_delta = int(delta.max()) if delta.size else 0
             delta = torch.from_numpy(delta).to(self.device)
@@ -316,6 +327,8 @@ class PublicKeyHandle:
         else:
             _native.check(self.lib.pai_ct_pow2_hint(self.h, _ptr(ct), _ptr(delta), bcast, ct.shape[0], int(max_delta),
                                                     _stream(self.device)))
+            if not from_host:
+                self._status_dirty = True               # a caller's own hint may be too small: check_status() reports it
         return ct
 
     # -- data formats either side of the path (device codec, obfuscator randomness) ----------------

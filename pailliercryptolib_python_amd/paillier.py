@@ -32,6 +32,7 @@ from .bindings import (
     ipclPlainText,
     ipclPrivateKey,
     ipclPublicKey,
+    merge_taint,
 )
 from .fixedpoint import FixedPointNumber
 
@@ -215,7 +216,7 @@ class PaillierPrivateKey:
         return repr(self.prikey)
 
     def _decrypt_words(self, enc: "PaillierEncryptedNumber") -> np.ndarray:
-        enc.public_key.pubkey.handle.check_status()      # asynchronous inversions report here (engine.PublicKeyHandle.check_status)
+        # `.words` checks the outcome of the asynchronous inversions behind THIS ciphertext (ipclCipherText._check)
         return engine.to_host_words(self.prikey.decrypt_words(enc.words))
 
     def _decrypt_mantissas(self, enc: "PaillierEncryptedNumber"):
@@ -227,8 +228,8 @@ class PaillierPrivateKey:
         # devices; the codec only depends on n, which the two share)
         pub = self.prikey._pk
         home = pub.handle.device
-        enc.public_key.pubkey.handle.check_status()      # asynchronous inversions report here
-        words = enc.words if enc.words.device == home else enc.words.to(home)
+        words = enc.words                                # asynchronous inversions behind this ciphertext report here (_check)
+        words = words if words.device == home else words.to(home)
         devs = pub.fanout_devices(len(enc)) if self.__n.bit_length() > 66 else None
         if devs is not None:
             ct_sh = engine.scatter_shards(words, devs)
@@ -327,11 +328,19 @@ class PaillierEncryptedNumber:
         """Device limb matrix [N, ct_words] (extension)."""
         return self.__ipclCipherText.words
 
+    @property
+    def _w(self) -> torch.Tensor:
+        """The wire-form limb matrix for operations that stay on the device: no look at pending inversion outcomes (they
+        travel on with the result: _wrap), hence no synchronisation."""
+        return self.__ipclCipherText._t
+
     def _h(self) -> engine.PublicKeyHandle:
         return self.public_key.pubkey.handle
 
-    def _wrap(self, ct: torch.Tensor, expo, length: Optional[int] = None, dom: int = 0) -> "PaillierEncryptedNumber":
-        return PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, ct, dom=dom), expo,
+    def _wrap(self, ct: torch.Tensor, expo, length: Optional[int] = None, dom: int = 0, others=(), flags=()) -> "PaillierEncryptedNumber":
+        """A result computed from self (and `others`): it inherits their pending inversion outcomes plus the new `flags`."""
+        taint = merge_taint(self.__ipclCipherText._taint, *[o.ciphertext()._taint for o in others], tuple(flags))
+        return PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, ct, dom=dom, taint=taint), expo,
                                        ct.shape[0] if length is None else length)
 
     def __repr__(self):
@@ -371,9 +380,9 @@ class PaillierEncryptedNumber:
     def apply_obfuscator(self, *, r: Optional[torch.Tensor] = None):
         """ipcl_python.py:342-346: re-randomise in place."""
         h = self._h()
-        ct = self.words.clone()
+        ct = self._w.clone()
         h.obfuscate_(ct, self.public_key.pubkey._draw_r(ct.shape[0]) if r is None else r)
-        self.__ipclCipherText = ipclCipherText(self.public_key.pubkey, ct)
+        self.__ipclCipherText = ipclCipherText(self.public_key.pubkey, ct, taint=self.__ipclCipherText._taint)
 
     def __getitem__(self, key: Union[int, slice]) -> "PaillierEncryptedNumber":
         """ipcl_python.py:348-360 (open-ended slices are accepted as an extension)."""
@@ -419,16 +428,17 @@ class PaillierEncryptedNumber:
         h = self._h()
         xe = np.asarray(self._expo, dtype=np.int64)
         ye = np.asarray(other._expo, dtype=np.int64)
-        if other.words.shape[0] == 1 and self.words.shape[0] > 1:
+        if other._w.shape[0] == 1 and self._w.shape[0] > 1:
             ye = np.broadcast_to(ye, xe.shape)
         m = np.maximum(xe, ye)
         E = np.maximum(xe, ye + FixedPointNumber.FLOAT_MANTISSA_BITS - 1)
-        b_inv = h.ct_invert(other.words, sync=False)
-        t = _add_aligned(h, self.words, b_inv, (xe - ye).astype(np.int32))
+        flag = h.new_flag()
+        b_inv = h.ct_invert(other._w, flag=flag)
+        t = _add_aligned(h, self._w, b_inv, (xe - ye).astype(np.int32))
         k = (E - m).astype(np.int32)
         if (k > 0).any():
             h.ct_pow2_(t, k)
-        return self._wrap(t, E.astype(np.int32), self.__length)
+        return self._wrap(t, E.astype(np.int32), self.__length, others=(other,), flags=(flag,))
 
     def __rsub__(self, other):
         """ipcl_python.py:391-397: (self * -1.0) + other; for a plaintext `other` the sum raw-encrypts it first (:495-504),
@@ -455,7 +465,7 @@ class PaillierEncryptedNumber:
         inv_other = 1.0 / other
         return self * inv_other
 
-    def _pow(self, ct: torch.Tensor, pts: List[int], neg: np.ndarray) -> torch.Tensor:
+    def _pow(self, ct: torch.Tensor, pts: List[int], neg: np.ndarray, flags: list) -> torch.Tensor:
         """ct_i^(pt_i) with the reference's sign rule: pt >= n - max_int means a negative multiplier, which is
         applied as (ct^-1)^(n - pt) (ipcl_python.py:426-437, 470-479)."""
         h = self._h()
@@ -463,12 +473,13 @@ class PaillierEncryptedNumber:
         N = ct.shape[0]
         bcast = len(pts) == 1 and N > 1
         if neg.any():
+            flags.append(h.new_flag())                   # the inversion's outcome travels with the result (_wrap)
             if bcast or neg.all():
-                base = h.ct_invert(ct, sync=False)
+                base = h.ct_invert(ct, flag=flags[-1])
             else:
                 idx = torch.from_numpy(np.nonzero(neg)[0]).to(h.device)
                 base = ct.clone()
-                base[idx] = h.ct_invert(ct[idx].contiguous(), sync=False)
+                base[idx] = h.ct_invert(ct[idx].contiguous(), flag=flags[-1])
         else:
             base = ct
         mags = [n - p if s else p for p, s in zip(pts, neg)]
@@ -477,17 +488,18 @@ class PaillierEncryptedNumber:
         e = engine.to_device_words(engine.ints_to_words(mags, ew), h.device)
         return self.public_key.pubkey.ct_mul_words(base, e, bits)
 
-    def _pow_small(self, ct: torch.Tensor, mant: np.ndarray) -> torch.Tensor:
+    def _pow_small(self, ct: torch.Tensor, mant: np.ndarray, flags: list) -> torch.Tensor:
         """The same for a batch of signed 64-bit multipliers (float mantissas): no per-element Python objects."""
         h = self._h()
         neg = mant < 0
         if neg.any():
+            flags.append(h.new_flag())
             if neg.all():
-                base = h.ct_invert(ct, sync=False)
+                base = h.ct_invert(ct, flag=flags[-1])
             else:
                 idx = torch.from_numpy(np.nonzero(neg)[0]).to(h.device)
                 base = ct.clone()
-                base[idx] = h.ct_invert(ct[idx].contiguous(), sync=False)
+                base[idx] = h.ct_invert(ct[idx].contiguous(), flag=flags[-1])
         else:
             base = ct
         mag = np.abs(mant).astype(np.uint64)
@@ -507,20 +519,22 @@ class PaillierEncryptedNumber:
             if not 0 <= pt < n:
                 raise ValueError(f"PaillierEncryptedNumber.__mul__: Scalar out ofbounds: {pt}")
             res_expo = self._expo + np.int32(pt_exponent)
-            res = self._pow(self.words, [pt], np.array([pt >= n - max_int]))
-            return self._wrap(res, res_expo, self.__length)
+            flags: list = []
+            res = self._pow(self._w, [pt], np.array([pt >= n - max_int]), flags)
+            return self._wrap(res, res_expo, self.__length, flags=flags)
         if len(other) != self.__length:
             raise ValueError("PaillierEncryptedNumber.__mul__: Multiply size mismatch")
         h = self._h()
+        flags = []
         if _fp.is_float_batch(other) and n.bit_length() > 66:
             mant, pexpo = _fp.float64_mantissas(_fp.checked_float64(other))
-            return self._wrap(self._pow_small(self.words, mant), self._expo + pexpo, self.__length)
+            return self._wrap(self._pow_small(self._w, mant, flags), self._expo + pexpo, self.__length, flags=flags)
         residues, pexpo = _fp.encode_array(other, n, max_int, h.n_words)
         pts = engine.words_to_ints(residues)
         neg = np.array([p >= n - max_int for p in pts])
         res_expo = self._expo + pexpo
-        res = self._pow(self.words, pts, neg)
-        return self._wrap(res, res_expo, self.__length)
+        res = self._pow(self._w, pts, neg, flags)
+        return self._wrap(res, res_expo, self.__length, flags=flags)
 
     def __raw_add(self, other):
         """ipcl_python.py:490-526."""
@@ -554,21 +568,21 @@ class PaillierEncryptedNumber:
             res, dom = h.ct_mont_mul(ta, tb), ka + kb - 1
             if abs(dom) > DOM_MAX:                       # long-lived accumulators: the tag (and the R^k constants it needs) stay bounded
                 res, dom = h.ct_retag(res, dom, 0), 0
-            return self._wrap(res, np.maximum(xe, ye).astype(np.int32), self.__length, dom=dom)
+            return self._wrap(res, np.maximum(xe, ye).astype(np.int32), self.__length, dom=dom, others=(other,))
         if kb != ka:
             tb = h.ct_retag(tb, kb, ka)
         res = _add_aligned(h, ta, tb, delta, dom=ka)
-        return self._wrap(res, np.maximum(xe, ye).astype(np.int32), self.__length, dom=ka)
+        return self._wrap(res, np.maximum(xe, ye).astype(np.int32), self.__length, dom=ka, others=(other,))
 
     def increase_exponent_to(self, x_ct, x_expo, exponent: int):
         """ipcl_python.py:528-568: raise every element of x to `exponent` (ct^(2^delta) where delta > 0)."""
-        words = x_ct.words if isinstance(x_ct, ipclCipherText) else x_ct
+        words = x_ct._t if isinstance(x_ct, ipclCipherText) else x_ct
         delta = (np.int64(exponent) - np.asarray(x_expo, dtype=np.int64)).astype(np.int32)
         if (delta > 0).any():
             h = self._h()
             words = words.clone()
             h.ct_pow2_(words, delta)
-        return ipclCipherText(self.public_key.pubkey, words) if isinstance(x_ct, ipclCipherText) else words
+        return ipclCipherText(self.public_key.pubkey, words, taint=x_ct._taint) if isinstance(x_ct, ipclCipherText) else words
 
     def __align_exponent(self, x_ct: torch.Tensor, x_expo, y_ct: torch.Tensor, y_expo):
         """ipcl_python.py:570-741: per element, the side with the smaller exponent is multiplied by
@@ -634,7 +648,7 @@ class PaillierEncryptedNumber:
 
     def sum(self) -> "PaillierEncryptedNumber":
         """ipcl_python.py:746-762 (intended behaviour)."""
-        out, e = self._aligned_tree(self.words, self._expo, 1)
+        out, e = self._aligned_tree(self._w, self._expo, 1)
         return self._wrap(out, [int(e[0])], 1)
 
     def mean(self) -> "PaillierEncryptedNumber":
@@ -688,12 +702,12 @@ class PaillierEncryptedNumber:
             # out(i, j) = sum_l other[i, l] * self[l*k + j]: rows of bases <-> j, members <-> l, columns <-> i
             R, K, M = k, n, m
             idx = (np.arange(n)[None, :] * k + np.arange(k)[:, None]).reshape(-1)             # [j][l] -> l*k + j
-            bases = self.words[torch.from_numpy(idx).to(dev)].contiguous()
+            bases = self._w[torch.from_numpy(idx).to(dev)].contiguous()
             e_a = np.asarray(self._expo, dtype=np.int64)[idx].reshape(R, K)
             w = (other.T if other.ndim == 2 else other.reshape(1, n).T)                         # [l][i]
         else:
             R, K, M = m, n, k
-            bases = self.words
+            bases = self._w
             e_a = np.asarray(self._expo, dtype=np.int64).reshape(R, K)
             w = other if other.ndim == 2 else other.reshape(n, 1)                               # [l][j]
         mant, pexpo = _fp.float64_mantissas(_fp.checked_float64(np.ascontiguousarray(w, dtype=np.float64).reshape(-1)))
@@ -722,15 +736,17 @@ class PaillierEncryptedNumber:
         del words, shift
         neg = mant_t < 0
         sign = inv = None
+        flags = []
         if bool(neg.any().item()):
+            flags.append(h.new_flag())
             if M == 1:
                 # one column: every base is used with one sign only — swap the inverted ciphertexts in (half the tables)
                 rows = torch.nonzero(neg[:, 0].repeat(R)).reshape(-1)
                 bases = bases.clone()
-                bases[rows] = h.ct_invert(bases[rows].contiguous(), sync=False)
+                bases[rows] = h.ct_invert(bases[rows].contiguous(), flag=flags[-1])
             else:
                 sign = neg.to(torch.uint8).contiguous()
-                inv = h.ct_invert(bases, sync=False)
+                inv = h.ct_invert(bases, flag=flags[-1])
         try:
             out = h.ct_multiexp(bases, inv, R, K, M, e_t, ebits, sign)
         except _native.NativeError as exc:
@@ -742,7 +758,7 @@ class PaillierEncryptedNumber:
             perm = (np.arange(k)[None, :] * m + np.arange(m)[:, None]).reshape(-1)              # (i, j) <- j*m + i
             out = out[torch.from_numpy(perm).to(dev)].contiguous()
             expo = expo.T
-        return self._wrap(out, np.ascontiguousarray(expo).reshape(-1), m * k)
+        return self._wrap(out, np.ascontiguousarray(expo).reshape(-1), m * k, flags=flags)
 
     def __matmul(self, other: np.ndarray, m: int, n: int, k: int, rhs: bool = False) -> "PaillierEncryptedNumber":
         """ipcl_python.py:829-880.  self is (m x n) row-major when rhs is False (result = self @ other,
@@ -762,11 +778,10 @@ class PaillierEncryptedNumber:
             idx_self = (i_idx * n + l_idx).reshape(-1)
             pts = (other[l_idx, j_idx] if other.ndim == 2 else other[l_idx]).reshape(-1)
         gather = torch.from_numpy(idx_self).to(h.device)
-        big = PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, self.words[gather].contiguous()),
-                                      self._expo[idx_self], idx_self.shape[0])
+        big = self._wrap(self._w[gather].contiguous(), self._expo[idx_self], idx_self.shape[0])
         prod = big * np.asarray(pts)
-        out, gmax = self._aligned_tree(prod.words, prod._expo, m * k)     # per output element (ipcl_python.py:868-870)
-        return self._wrap(out, gmax.astype(np.int32), m * k)
+        out, gmax = self._aligned_tree(prod._w, prod._expo, m * k)        # per output element (ipcl_python.py:868-870)
+        return self._wrap(out, gmax.astype(np.int32), m * k, others=(prod,))
 
     def __matmul__(self, other: Union[np.ndarray, list]) -> "PaillierEncryptedNumber":
         """ipcl_python.py:882-903."""

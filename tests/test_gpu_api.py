@@ -713,3 +713,40 @@ def test_plaintext_addends_are_aligned_in_the_plaintext_domain(fixed, monkeypatc
     wd = orc.api_sub_plain(okey, *oxx, y)
     assert (ct_ints(d), d.exponent()) == (wd[0], wd[1])
     assert np.allclose(sk.decrypt_to_numpy(exx + y), x * x + y, rtol=1e-12)
+
+
+def test_failed_inversion_is_raised_on_its_own_result(fixed):
+    """a negative multiplier inverts the ciphertext asynchronously (pai_ct_invert_flag).  A non-invertible input
+    must be reported on the ciphertext computed from it — on every export of it and of whatever was derived from it — and on
+    nothing else: an unrelated ciphertext of the same key decrypts before and after, and the faulty one keeps failing (the
+    outcome is not a per-handle word that the first reader clears)."""
+    from pailliercryptolib_python_amd import _native
+    from pailliercryptolib_python_amd.bindings import ipclCipherText
+
+    pk, sk, okey = fixed
+    good = pk.encrypt([1.5, -2.0, 3.25])
+    bad_rows = [int(b) for b in good.ciphertextBN()]
+    bad_rows[1] = okey.p * 977                                             # shares a factor with n: no inverse modulo n^2
+    bad = PaillierEncryptedNumber(pk, ipclCipherText(pk.pubkey, bad_rows), good.exponent(), 3)
+    res_bad = bad * -2.0                                                   # queued; nothing is read back here
+    res_good = good * -2.0
+    derived = res_bad + good                                               # the outcome travels with derived results
+    sliced = res_bad[0:2]
+    assert sk.decrypt(res_good) == [-3.0, 4.0, -6.5]                       # the unrelated result is not blamed ...
+    for obj in (res_bad, derived, sliced, res_bad):                        # ... the faulty ones are, every time
+        with pytest.raises(_native.NativeError, match="not invertible"):
+            sk.decrypt(obj)
+    with pytest.raises(_native.NativeError, match="not invertible"):
+        res_bad.ciphertextBN()
+    with pytest.raises(_native.NativeError, match="not invertible"):
+        res_bad.ciphertextBN(0)
+    with pytest.raises(_native.NativeError, match="not invertible"):
+        _ = res_bad.words
+    with pytest.raises(_native.NativeError, match="not invertible"):
+        pickle.dumps(derived)
+    with pytest.raises(_native.NativeError, match="not invertible"):
+        sk.prikey.decrypt(res_bad.ciphertext())
+    with pytest.raises(_native.NativeError, match="not invertible"):
+        sk.decrypt(good - bad)                                             # ct - ct inverts the subtrahend
+    assert sk.decrypt(good - good) == [0.0, 0.0, 0.0]
+    assert sk.decrypt(res_good + good) == [-1.5, 2.0, -3.25]

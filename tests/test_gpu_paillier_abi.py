@@ -788,6 +788,25 @@ def test_async_invert_and_sticky_status():
     _native.check(pub.lib.pai_ct_pow2_hint(pub.h, big.data_ptr(), d.data_ptr(), 0, M, 20, None))
     _native.check(pub.lib.pai_pubkey_status(pub.h, C.byref(st), 1, None))
     assert st.value == 0
+    # a hint BELOW the digit path's range runs the lane-group kernel, which serves any shift: correct powers, nothing flagged
+    # (the word used to be set for correct ciphertexts)
+    small = ct[:64].contiguous()
+    d2 = torch.full((M,), 3, dtype=torch.int32, device=pub.device)
+    d2[5] = 6
+    big = small[:1].expand(M, -1).contiguous()
+    _native.check(pub.lib.pai_ct_pow2_hint(pub.h, big.data_ptr(), d2.data_ptr(), 0, M, 4, None))
+    _native.check(pub.lib.pai_pubkey_status(pub.h, C.byref(st), 1, None))
+    assert st.value == 0
+    got = engine.words_to_ints(engine.to_host_words(big[[0, 5]]))
+    assert got == [pow(vals[0], 1 << 3, key.nsq), pow(vals[0], 1 << 6, key.nsq)]
+    # pai_ct_invert_flag: the outcome goes to the caller's word, not to the handle
+    f_ok, f_bad = pub.new_flag(), pub.new_flag()
+    got = pub.ct_invert(ct, flag=f_ok)
+    pub.ct_invert(ctb, flag=f_bad)
+    assert int(f_ok.item()) == 0 and int(f_bad.item()) & 1
+    assert engine.words_to_ints(engine.to_host_words(got)) == [pow(v, -1, key.nsq) for v in vals]
+    _native.check(pub.lib.pai_pubkey_status(pub.h, C.byref(st), 1, None))
+    assert st.value == 0
     rows = engine.words_to_ints(engine.to_host_words(big[[0, 5]]))
     assert rows == [pow(vals[0], 1 << 9, key.nsq), pow(vals[0], 1 << 20, key.nsq)]
 

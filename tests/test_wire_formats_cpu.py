@@ -41,3 +41,21 @@ def test_bulk_limb_matrix_is_little_endian_words_of_little_endian_limbs():
         assert row.tobytes() == v.to_bytes(4 * L, "little")
     with pytest.raises(OverflowError):
         engine.ints_to_words([1 << (32 * L)], L)
+
+
+def test_bignumber_word_accessors():
+    """ipclBigNumber.DwordSize / BitSize / __getitem__ / data and the list constructor
+    (bindings/ipcl_bindings_classes.cpp:386-393, 422-432, 458-471): 32-bit words, little-endian."""
+    import pytest
+
+    v = (0xDEADBEEF << 64) | (0x12345678 << 32) | 0x9ABCDEF0
+    b = ipclBigNumber([0x9ABCDEF0, 0x12345678, 0xDEADBEEF])
+    assert int(b) == v and b == ipclBigNumber(v)
+    assert b.DwordSize() == 3 and b.BitSize() == 96
+    assert [b[i] for i in range(3)] == [0x9ABCDEF0, 0x12345678, 0xDEADBEEF]
+    assert b.data() == (3, [0x9ABCDEF0, 0x12345678, 0xDEADBEEF])
+    with pytest.raises(IndexError):
+        b[3]
+    assert ipclBigNumber.Zero.DwordSize() == 1 and ipclBigNumber.Zero[0] == 0
+    with pytest.raises(TypeError):
+        ipclBigNumber([1 << 32])
