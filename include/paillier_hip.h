@@ -160,6 +160,18 @@ int pai_ct_invert_flag(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, uin
 int pai_ct_add_aligned(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
                        size_t N, uint32_t* d_out, void* stream);
 
+/* n-ary ciphertext sum in one pass — the aggregation sum_j E(x_j) over k parties' arrays, which the reference spells as a chain
+ * of PaillierEncryptedNumber.__add__ calls with their exponent alignments (ipcl_python.py:365-381, 490-526, 570-741;
+ * tests/ipcl_python_test.py:21-38):  d_out[i] = prod_{j<k} op_j[i]^(2^raise_j[i]) mod n^2, 2 <= k <= 16.
+ * h_ops: HOST array of k device pointers to [N][ct_words] rows; h_raise: NULL, or a HOST array of k device pointers (entries may
+ * be NULL) to int32 [N] squaring counts >= 0 — the caller raises every operand to the per-element maximum exponent of the sum.
+ * Lazy-domain bookkeeping as for pai_ct_mont_mul: operand 0 holds x R^tag0, the others x R^tag, the result x R^dom_out (any tags
+ * with |.| small: wire form is 0; tag0 + (k-1)(tag-1) is the tag that costs no extra product; a raised operand 0 needs tag0 ==
+ * tag).  k - 1 Montgomery products per element (+1 per raised operand and per squaring), one store.  d_out may alias an operand.
+ * Asynchronous on `stream`. */
+int pai_ct_addn(const pai_pubkey* pk, const uint32_t* const* h_ops, const int32_t* const* h_raise, int k, int tag0, int tag,
+                int dom_out, size_t N, uint32_t* d_out, void* stream);
+
 /* Lazy Montgomery domain for chains of additions (extension).  A ciphertext buffer may hold x R^k mod n^2
  * instead of x (R = 2^bits of pai_pubkey_mont_bits; the caller tracks the integer k per buffer — k = 0 is the wire form).
  * pai_ct_mont_mul: d_out[i] = d_a[i] * d_b[i] * R^-1 mod n^2 (canonical residue), ONE Montgomery product per element where

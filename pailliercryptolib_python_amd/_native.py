@@ -66,6 +66,7 @@ PROTOTYPES = {
     "pai_ct_add_aligned": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp]),
     "pai_ct_add_aligned_dom": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp, voidp]),
     "pai_ct_mont_mul": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_size_t, voidp, voidp]),
+    "pai_ct_addn": (C.c_int, [voidp, C.POINTER(voidp), C.POINTER(voidp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, voidp, voidp]),
     "pai_pubkey_mont_bits": (C.c_int, [voidp, C.POINTER(C.c_int)]),
     "pai_ct_prod": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp]),
     "pai_ct_multiexp": (C.c_int, [voidp, voidp, voidp, C.c_size_t, C.c_size_t, C.c_size_t, voidp, C.c_int, C.c_int, voidp, voidp,

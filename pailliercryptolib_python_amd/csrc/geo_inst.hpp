@@ -5,31 +5,12 @@
 #include "geo_ops.hpp"
 #include "kernels_modexp.hpp"
 
-#ifndef PAI_VARWIN_NMLDS
-#define PAI_VARWIN_NMLDS true
-#endif
-#ifndef PAI_MEXP_NMLDS
-#define PAI_MEXP_NMLDS false
-#endif
-#ifndef PAI_TILE_NMLDS
-#define PAI_TILE_NMLDS false
-#endif
-#ifndef PAI_MODMUL_W
-#define PAI_MODMUL_W false     // measured (profiles/r04/ctadd_ab_*.jsonl): 2.14-2.35 ms per 2^20 against 1.98 ms of the staged 36 x 4 kernel
-#endif
-#ifndef PAI_MODMUL_W_SPLIT8
-#define PAI_MODMUL_W_SPLIT8 true
-#endif
-
 namespace pai {
 
 template <class G>
 struct GeoInst {
-    // The tile-I/O kernels (k_modmul, k_pow2) re-read the modulus slice from LDS during the q*n step: the 36 VGPRs this
-    // frees keep the tile staging registers, both operands and the accumulator window out of scratch memory (whose
-    // reloads cost hundreds of cycles each in kernels this short), and the products run at the same rate
-    // (profiles/r01/mm_bench_dpp.jsonl: 24.5 vs 24.8 T MAC/s).
-    using GM = Geo<G::NLL, G::T, G::U, PAI_TILE_NMLDS>;
+    // the tile-I/O kernels (k_modmul, k_pow2, k_add_aligned, k_addn) keep the modulus slice in registers
+    using GM = Geo<G::NLL, G::T, G::U, false>;
     static void set_lds(const void* fn, int bytes) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
@@ -44,27 +25,14 @@ struct GeoInst {
         fprintf(stderr, "PAI_OCC %s<%dx%d>: blocks/CU=%d lds=%d B regs=%d scratch=%zu B\n", name, G::NLL, G::T, nb, bytes, fa.numRegs,
                 (size_t)fa.localSizeBytes);
     }
-    // wave-region form (kernels_modexp.hpp: k_modmul_w) for the lane-group geometries with canonical contexts; the
-    // single-lane and minus-one geometries keep the staged form
-    // 144-limb moduli (n^2 of 2048-bit keys) run it on EIGHT lanes of 18 limbs: ~110 VGPRs and 4.6 KB of LDS per wave, so
-    // four waves per SIMD cover each other's memory phases (the packed rows and the Montgomery constants do not depend on
-    // the geometry: same bits)
-    static constexpr bool SPLIT8 = PAI_MODMUL_W_SPLIT8 && G::T == 4 && G::NLL == 36;
-    using GW = typename std::conditional<SPLIT8, Geo<18, 8, 6, false>, Geo<G::NLL, G::T, G::U, true>>::type;
-    static constexpr bool MODMUL_W = PAI_MODMUL_W && G::T >= 2 && G::T <= 8 && !G::M1 && (G::NLL % 4 == 0);
+    // (measured and dropped, profiles/r04/ctadd_ab_*.jsonl: the same products on per-wave LDS regions with 18 limbs x 8 lanes at
+    // three or four waves per SIMD: 2.14-2.35 ms per 2^20 against 1.98 ms here)
     static void modmul(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, uint32_t* out,
                        int n, int w32, int b_bcast, int mode) {
-        if constexpr (MODMUL_W) {
-            constexpr int bytes = ModmulW<GW>::LDS_BYTES;
-            set_lds((const void*)k_modmul_w<GW>, bytes);
-            report_occupancy("k_modmul_w", (const void*)k_modmul_w<GW>, bytes);
-            hipLaunchKernelGGL(k_modmul_w<GW>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
-        } else {
-            constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
-            set_lds((const void*)k_modmul<GM>, bytes);
-            report_occupancy("k_modmul", (const void*)k_modmul<GM>, bytes);
-            hipLaunchKernelGGL(k_modmul<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
-        }
+        constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
+        set_lds((const void*)k_modmul<GM>, bytes);
+        report_occupancy("k_modmul", (const void*)k_modmul<GM>, bytes);
+        hipLaunchKernelGGL(k_modmul<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
     }
     static void modexp_fixed(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32,
                              const uint32_t* expo, int ewords, int ebits, uint32_t* out, int out_w32, int n,
@@ -137,7 +105,7 @@ struct GeoInst {
                                int ew, int ebits_max, int exp_bcast, uint32_t* out, int out_w32, int n, uint32_t* table, int wbits,
                                const MontCtx* fin) {
         // 8-lane geometries: modulus slice from LDS (3072 / 4096-bit ct * pt 20.8 -> 20.5 / 32.7 -> 31.8 ms per 65536)
-        using GV = Geo<G::NLL, G::T, G::U, (G::T >= 8 && G::NLL % 4 == 0) ? PAI_VARWIN_NMLDS : false>;
+        using GV = Geo<G::NLL, G::T, G::U, (G::T >= 8 && G::NLL % 4 == 0)>;
         if constexpr (G::T >= 16) {
             if (fin != nullptr) {        // wide-group geometries with a minus-one context (c) and the true modulus' context (fin)
                 using GM1 = Geo<G::NLL, G::T, G::U, false, true>;
@@ -183,6 +151,12 @@ struct GeoInst {
         set_lds((const void*)k_add_aligned<GM>, bytes);
         hipLaunchKernelGGL(k_add_aligned<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, b_bcast, delta, out, n, w32, entry);
     }
+    static void addn(hipStream_t s, int grid, const MontCtx* c, AddnArgs A, uint32_t* out, int n, int w32, const uint32_t* rpow) {
+        constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the domain-entry constant
+        set_lds((const void*)k_addn<GM>, bytes);
+        report_occupancy("k_addn", (const void*)k_addn<GM>, bytes);
+        hipLaunchKernelGGL(k_addn<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, A, out, n, w32, rpow);
+    }
     static void mexp_table(hipStream_t s, int grid, const MontCtx* c, const uint32_t* ct, const uint32_t* ct_inv, int w32,
                            uint32_t* table, int nentries, int nsigns, int wbits) {
         set_lds((const void*)k_mexp_table<G>, G::LDS_BYTES);
@@ -190,7 +164,7 @@ struct GeoInst {
     }
     static void mexp(hipStream_t s, int grid, const MontCtx* c, MexpParams P, const uint32_t* table, const uint32_t* e,
                      const uint8_t* sign, uint32_t* out, int nlanes) {
-        using GX = Geo<G::NLL, G::T, G::U, PAI_MEXP_NMLDS>;
+        using GX = Geo<G::NLL, G::T, G::U, false>;
         set_lds((const void*)k_mexp<GX>, GX::LDS_BYTES);
         hipLaunchKernelGGL(k_mexp<GX>, dim3(grid), dim3(BLOCK_THREADS), GX::LDS_BYTES, s, c, P, table, e, sign, out, nlanes);
     }
@@ -198,7 +172,7 @@ struct GeoInst {
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &sq_chain, &add_aligned, &table_words, &pair_finish, &mexp_table, &mexp};
+                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &sq_chain, &add_aligned, &addn, &table_words, &pair_finish, &mexp_table, &mexp};
         return &o;
     }
 };

@@ -40,6 +40,8 @@ struct GeoOps {
     void (*sq_chain)(hipStream_t, const MontCtx*, const MontCtx* fin, const uint32_t* base, int w32, uint32_t* out, int h, int nsnap);
     void (*add_aligned)(hipStream_t, int grid, const MontCtx*, const uint32_t* a, const uint32_t* b, int b_bcast,
                         const int32_t* delta, uint32_t* out, int n, int w32, const uint32_t* entry);
+    // n-ary sum (k_addn): out_i = prod_j op_j[i]^(2^raise_j[i]); rpow = the key's table of R^m, |m| <= RPOW_SPAN, NL limbs per row
+    void (*addn)(hipStream_t, int grid, const MontCtx*, AddnArgs, uint32_t* out, int n, int w32, const uint32_t* rpow);
     // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups
     size_t (*table_words)(size_t blocks);
     // ct = w + v n [or ct_in (w + v n)] from the plain digit pairs of the lane-group pair kernels (rows [2][wv_words])
@@ -78,10 +80,7 @@ bool launch_dec_a_wide(int nl, hipStream_t s, int gridx, const DecAParams& P, co
 
 // p-adic digit engine for CRT-decrypt stage A (mont_padic.hpp / kernels_padic.hpp)
 struct DecPadicParams;
-#ifndef PAI_PADIC_SLIDE_BITS
-#define PAI_PADIC_SLIDE_BITS 6
-#endif
-constexpr int PADIC_SLIDE_BITS = PAI_PADIC_SLIDE_BITS;    // sliding-window width of the decrypt exponent schedule (k_dec_a per 2^20: 486 / 478 / 489 ms at 5 / 6 / 7 bits)
+constexpr int PADIC_SLIDE_BITS = 6;    // sliding-window width of the decrypt exponent schedule (k_dec_a per 2^20: 486 / 478 / 489 ms at 5 / 6 / 7 bits)
 constexpr int PADIC_TBL_ENTRIES = 1 << (PADIC_SLIDE_BITS - 1);    // odd powers
 int padic_nl_for_prime_bits(int bits);
 size_t padic_table_words(int nl, size_t blocks);

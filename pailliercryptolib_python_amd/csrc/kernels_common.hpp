@@ -10,19 +10,13 @@ namespace pai {
 constexpr int BLOCK_THREADS = 256;
 constexpr int MODMUL_FULL = 0, MODMUL_MONT = 1;      // k_modmul modes (kernels_modexp.hpp)
 
-// Waves per SIMD the exponentiation-type lane-group kernels are compiled for.  At two waves per SIMD the 8-lane geometries
-// (28x8, 36x8: keys above 2048 bits) spill around their product loops; measured per kernel with -DPAI_WAVES_T8=1 (one wave,
-// 512 registers): k_mexp<36x8> 101 -> 54 ms (its spills sat INSIDE the row blocks), k_modexp_var_win<28x8> 22.1 -> 20.6 ms
-// per 65536, but k_modexp_var_win<36x8> 32.2 -> 34.4 and k_mexp<28x8> 31.7 -> 33.8 — hence per kernel and geometry.
-#ifndef PAI_WAVES_T8
-#define PAI_WAVES_T8 2
-#endif
-#define PAI_LG_WAVES(G) ((G::T) >= 8 ? PAI_WAVES_T8 : 2)
-#define PAI_MEXP_WAVES(G) (((G::T) >= 8 && (G::NLL) >= 36) ? 1 : PAI_LG_WAVES(G))
-#ifndef PAI_VARWIN_WAVES_28X8
-#define PAI_VARWIN_WAVES_28X8 1
-#endif
-#define PAI_VARWIN_WAVES(G) (((G::T) >= 8 && (G::NLL) < 36) ? PAI_VARWIN_WAVES_28X8 : PAI_LG_WAVES(G))
+// Waves per SIMD the exponentiation-type lane-group kernels are compiled for: two, except where the 8-lane geometries
+// (28x8, 36x8: keys above 2048 bits) spill INSIDE their row blocks at 256 registers — measured per kernel at one wave (512
+// registers): k_mexp<36x8> 101 -> 54 ms, k_modexp_var_win<28x8> 22.1 -> 20.6 ms per 65 536 (one wave each), but
+// k_modexp_var_win<36x8> 32.2 -> 34.4 and k_mexp<28x8> 31.7 -> 33.8 (they keep two).
+#define PAI_LG_WAVES(G) 2
+#define PAI_MEXP_WAVES(G) (((G::T) >= 8 && (G::NLL) >= 36) ? 1 : 2)
+#define PAI_VARWIN_WAVES(G) (((G::T) >= 8 && (G::NLL) < 36) ? 1 : 2)
 
 // shape of a multi-exponentiation on the lane-group engine (kernels_modexp.hpp: k_mexp)
 struct MexpParams {
@@ -169,51 +163,6 @@ template <class G>
 PAI_DEV void load_tile(uint32_t* stage, const uint32_t* __restrict__ src, int rows, int W32, bool bcast = false) {
     load_tile_at<G>(WaveTile<G>::slice(stage), src, rows, W32, bcast);
 }
-// The two halves of load_tile for aligned rows (W32 % 4 == 0, 16-byte aligned source): tile_fetch issues the tile's global
-// loads into registers and returns at once, tile_commit writes them to the wave's staging slice — so the loads of SEVERAL
-// tiles can be in flight together (one memory latency per set of operands instead of one per operand).
-template <class G>
-PAI_DEV void tile_fetch(uint4 (&v)[WaveTile<G>::IT4], const uint32_t* __restrict__ src, int rows, int W32) {
-    using WT = WaveTile<G>;
-    const int lane = WT::lane();
-    const int total = rows * (W32 >> 2);
-    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src);
-#pragma unroll
-    for (int it = 0; it < WT::IT4; ++it) {
-        const int c = lane + it * 64;
-        v[it] = s4[c < total ? c : total - 1];
-    }
-}
-template <class G>
-PAI_DEV void tile_commit(uint32_t* stage, const uint4 (&v)[WaveTile<G>::IT4], int rows, int W32) {
-    using WT = WaveTile<G>;
-    uint4* d4 = reinterpret_cast<uint4*>(WT::slice(stage));
-    const int lane = WT::lane();
-    const int wv = W32 >> 2;
-    const int total = rows * wv;
-    const uint32_t inv = (65536u + (uint32_t)wv - 1u) / (uint32_t)wv;
-    wave_lds_fence();
-#pragma unroll
-    for (int it = 0; it < WT::IT4; ++it) {
-        const int c = lane + it * 64;
-        const int e = (int)(((uint32_t)c * inv) >> 16), k = c - e * wv;
-        if (c < total) d4[e * WT::SV + k] = v[it];
-    }
-    wave_lds_fence();
-}
-
-// zeroes the pad words behind the W32 data words of every row of a wave's region (regions that are time-shared with
-// limb-form operands lose the zeros clear_stage wrote)
-template <class G>
-PAI_DEV void clear_row_pads(uint32_t* region, int W32) {
-    using WT = WaveTile<G>;
-    const int pad = G::SW - W32;
-    for (int i = WT::lane(); i < WT::EPW * pad; i += 64) {
-        const int e = i / pad, k = i - e * pad;
-        region[e * G::SW + W32 + k] = 0u;
-    }
-}
-
 // this lane's limb slice of its element's staged row
 template <class G>
 PAI_DEV void unpack_row_at(uint32_t (&x)[G::NLL], const uint32_t* row) {

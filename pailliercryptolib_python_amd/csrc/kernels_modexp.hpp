@@ -18,44 +18,6 @@ namespace pai {
 //   mode MODMUL_MONT   out = a*b*R^-1 mod M     (canonical residue of the Montgomery product: the body of the
 //                                               product trees of pai_ct_invert / pai_ct_prod, which keep track of
 //                                               the power of R per tree level on the host)
-// Dev builds only (-DPAI_PHASE_TIMING, tools/phase_probe.sh): thread 0 of block 0 accumulates cycle-counter deltas per
-// phase of the tile loop and prints them when the kernel ends; compiled out of the product library.
-#ifdef PAI_PHASE_TIMING
-#define PHASE_INIT() unsigned long long ph_t0 = __builtin_readcyclecounter()
-#define PHASE_DECL() unsigned long long ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PHASE_MARK(i)                                                       \
-    do {                                                                    \
-        unsigned long long ph_t1 = __builtin_readcyclecounter();            \
-        ph_acc[i] += ph_t1 - ph_t0;                                         \
-        ph_t0 = __builtin_readcyclecounter();                               \
-    } while (0)
-#define PHASE_REPORT(name)                                                                                          \
-    do {                                                                                                            \
-        if (blockIdx.x == 0 && threadIdx.x == 0)                                                                    \
-            printf("PHASES %s mode=%d bcast=%d: %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", name, mode, b_bcast, ph_acc[0], \
-                   ph_acc[1], ph_acc[2], ph_acc[3], ph_acc[4], ph_acc[5], ph_acc[6], ph_acc[7], ph_acc[8]);          \
-    } while (0)
-#else
-#define PHASE_INIT() do { } while (0)
-#define PHASE_DECL() do { } while (0)
-#define PHASE_MARK(i) do { } while (0)
-#define PHASE_REPORT(name) do { } while (0)
-#endif
-
-#ifndef PAI_MODMUL_LOAD2
-#define PAI_MODMUL_LOAD2 0
-#endif
-#ifndef PAI_MODMUL_PRIO
-#define PAI_MODMUL_PRIO 1
-#endif
-#ifndef PAI_MODMUL_STAGGER
-#define PAI_MODMUL_STAGGER 0      // s_sleep(127) units (~3.4 us each) the odd-slot wave of a SIMD waits before its first tile
-#endif
-#if PAI_MODMUL_PRIO
-#define PAI_MODMUL_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define PAI_MODMUL_SETPRIO(p) do { } while (0)
-#endif
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
@@ -72,7 +34,6 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
     constexpr int WPB = BLOCK_THREADS / 64;
     const int wtiles = (n + WT::EPW - 1) / WT::EPW;
     clear_stage<G>(stage);
-    PHASE_DECL();
     // Register plan: the left operand x lives in registers (the row engine's `a`), the right operand streams from
     // LDS — the per-element operand buffer for b, the workgroup's R^2 copy for the domain fix-up — so nothing but x,
     // the modulus slice and the accumulator window is live inside the row loops (no scratch traffic there).
@@ -97,56 +58,24 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
     const int per_wave = (wtiles + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
     const int wt_begin = ((int)blockIdx.x * WPB + WT::wave()) * per_wave;
     const int wt_end = min(wtiles, wt_begin + per_wave);
-#if PAI_MODMUL_STAGGER
-    // Every wave alternates a memory phase (tile loads / stores) with a product phase, all tiles cost the same, and all
-    // waves start together: left alone the whole chip runs in LOCKSTEP — two waves of a SIMD wait on memory at the same
-    // time (SIMD idle, HBM hit by every wave at once), then share the multiplier.  The wave in the odd hardware slot of
-    // its SIMD therefore starts half a product late: the pair settles in anti-phase, one wave's memory phase under the
-    // other's products.
-    if (per_wave > 1 && (__builtin_amdgcn_s_getreg(6148) & 1)) {            // HW_REG_HW_ID[3:0] = wave slot on the SIMD
-#pragma unroll 1
-        for (int k = 0; k < PAI_MODMUL_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     for (int wt = wt_begin; wt < wt_end; ++wt) {
         const int row0 = wt * WT::EPW;
         const int rows = min(WT::EPW, n - row0);
         uint32_t x[G::NLL];
-        PHASE_INIT();
         // The tile I/O phases are short on VALU work and long on memory latency: they run at raised priority so that
         // the multiply stream of the other wave on this SIMD does not starve their address arithmetic (VALU
         // arbitration is priority, then age); the products run at base priority.
-        PAI_MODMUL_SETPRIO(2);
-#if PAI_MODMUL_LOAD2
-        const bool fast = (w32 & 3) == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
-        if (!b_bcast && fast) {
-            // both operands' global loads in flight together: one memory latency per tile instead of two
-            uint4 va[WT::IT4], vb[WT::IT4];
-            tile_fetch<G>(vb, b + (size_t)row0 * w32, rows, w32);
-            tile_fetch<G>(va, a + (size_t)row0 * w32, rows, w32);
-            tile_commit<G>(stage, vb, rows, w32);
-            PHASE_MARK(2);
-            unpack_row<G>(x, stage);
-            stage_b<G>(x, lds);
-            PHASE_MARK(3);
-            tile_commit<G>(stage, va, rows, w32);
-            PHASE_MARK(0);
-        } else
-#endif
+        __builtin_amdgcn_s_setprio(2);
         {
             if (!b_bcast) {
                 load_tile<G>(stage, b + (size_t)row0 * w32, rows, w32);
-                PHASE_MARK(2);
                 unpack_row<G>(x, stage);
                 stage_b<G>(x, lds);
-                PHASE_MARK(3);
             }
             load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
-            PHASE_MARK(0);
         }
         unpack_row<G>(x, stage);
-        PHASE_MARK(1);
-        PAI_MODMUL_SETPRIO(0);
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll 1
         for (int pass = 0; pass < npass; ++pass) {
             uint32_t r[G::NLL];
@@ -154,116 +83,11 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
             mont_mul<G::NLL, G::U, G::T>(r, x, pass == 0 ? b_lds : r2_lds, pass == 0 ? G::EPB : 1, nm, n0inv);
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
-            PHASE_MARK(4 + pass);
         }
         cond_sub<G::NLL, G::T>(x, nm);
-        PAI_MODMUL_SETPRIO(2);
-        PHASE_MARK(6);
+        __builtin_amdgcn_s_setprio(2);
         pack_row<G>(x, stage);
-        PHASE_MARK(7);
-#ifndef PAI_PROBE_NOSTORE
         store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
-#endif
-        PHASE_MARK(8);
-    }
-    PAI_MODMUL_SETPRIO(0);
-    PHASE_REPORT("k_modmul");
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_modmul on WAVE REGIONS (round 4): the same products with one private LDS region per wave that is time-shared between
-// the packed rows of a tile (load_tile_at / pack_row_at / store_tile_at) and the limb-form multiplier operand
-// ([limb][element-of-the-wave], stride EPW) — 9.2 KB per wave at 36 x 4 instead of 8.4 KB staging + 9.2 KB operand
-// buffer — with the modulus slice re-read from LDS (NmLds): 40 KB of LDS per workgroup and <= 168 VGPRs, i.e. THREE (or
-// four) waves per SIMD instead of two at 254 VGPRs + scratch.  A wave still runs load -> product -> store serially; the
-// memory phases of one wave are now covered by the products of two or three others, and the products issue at the
-// multi-wave rate (4.4-4.5 cycles per v_mad_u64_u32 instead of 4.8 at two waves: profiles/r04/ubench_valu_sustained.jsonl).
-#ifndef PAI_MODMUL_W_WAVES
-#define PAI_MODMUL_W_WAVES 3
-#endif
-template <class G>
-struct ModmulW {
-    using WT = WaveTile<G>;
-    static constexpr int WPB = BLOCK_THREADS / 64;
-    static constexpr int REG = (G::NL * WT::EPW > WT::EPW * G::SW) ? G::NL * WT::EPW : WT::EPW * G::SW;   // words per wave region
-    static constexpr int LDS_WORDS = (2 + WPB) * G::NL + WPB * REG;     // modulus, R^2, one broadcast operand per wave, the regions
-    static constexpr int LDS_BYTES = LDS_WORDS * 4;
-};
-
-template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, PAI_MODMUL_W_WAVES)
-k_modmul_w(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
-           int n, int w32, int b_bcast, int mode) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    using WT = WaveTile<G>;
-    using MW = ModmulW<G>;
-    uint32_t* nm_lds = lds;
-    uint32_t* r2_lds = lds + G::NL;
-    uint32_t* bc_lds = lds + 2 * G::NL + WT::wave() * G::NL;             // this wave's broadcast operand (limb form, stride 1)
-    uint32_t* reg = lds + (2 + MW::WPB) * G::NL + WT::wave() * MW::REG;  // this wave's region
-    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) { nm_lds[i] = ctx->n[i]; r2_lds[i] = ctx->r2[i]; }
-    __syncthreads();
-    typename G::NM nm;
-    if constexpr (G::NMLDS) nm.p = nm_lds + G::NLL * G::gl();
-    else load_const_slice<G>(nm.v, ctx->n);
-    const uint32_t n0inv = ctx->n0inv;
-    const int el = WT::lane() / G::T;                                    // element of this lane group within the wave
-    uint32_t* myrow = reg + el * G::SW;                                  // its packed row while the region holds a tile
-    const uint32_t* b_col = reg + el;                                    // its column while the region holds limbs
-    const int wtiles = (n + WT::EPW - 1) / WT::EPW;
-    if (b_bcast) {                                                       // the shared operand, once per wave
-        uint32_t bb[G::NLL];
-        clear_row_pads<G>(reg, w32);
-        load_tile_at<G>(reg, b, 1, w32, true);
-        unpack_row_at<G>(bb, myrow);
-        if (mode == MODMUL_FULL) {                                       // b R: a broadcast addend then costs ONE product per element
-            uint32_t t[G::NLL];
-            mont_mul<G::NLL, G::U, G::T>(t, bb, r2_lds, 1, nm, n0inv);
-#pragma unroll
-            for (int j = 0; j < G::NLL; ++j) bb[j] = t[j];
-        }
-        wave_lds_fence();
-        if (el == 0) {
-#pragma unroll
-            for (int j = 0; j < G::NLL; ++j) bc_lds[G::NLL * G::gl() + j] = bb[j];
-        }
-        wave_lds_fence();
-    }
-    const int npass = (mode == MODMUL_FULL && !b_bcast) ? 2 : 1;
-    const int per_wave = (wtiles + (int)gridDim.x * MW::WPB - 1) / ((int)gridDim.x * MW::WPB);
-    const int wt_begin = ((int)blockIdx.x * MW::WPB + WT::wave()) * per_wave;
-    const int wt_end = min(wtiles, wt_begin + per_wave);
-    for (int wt = wt_begin; wt < wt_end; ++wt) {
-        const int row0 = wt * WT::EPW;
-        const int rows = min(WT::EPW, n - row0);
-        uint32_t x[G::NLL];
-        __builtin_amdgcn_s_setprio(2);
-        clear_row_pads<G>(reg, w32);
-        load_tile_at<G>(reg, a + (size_t)row0 * w32, rows, w32);
-        unpack_row_at<G>(x, myrow);
-        if (!b_bcast) {
-            uint32_t y[G::NLL];
-            load_tile_at<G>(reg, b + (size_t)row0 * w32, rows, w32);     // (fences inside: every lane has read its window of a)
-            unpack_row_at<G>(y, myrow);
-            wave_lds_fence();
-#pragma unroll
-            for (int j = 0; j < G::NLL; ++j) reg[(G::NLL * G::gl() + j) * WT::EPW + el] = y[j];   // limb form over the packed rows
-            wave_lds_fence();
-        }
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll 1
-        for (int pass = 0; pass < npass; ++pass) {
-            uint32_t r[G::NLL];
-            const uint32_t* bp = pass == 0 ? (b_bcast ? bc_lds : b_col) : r2_lds;
-            mont_mul<G::NLL, G::U, G::T>(r, x, bp, (pass == 0 && !b_bcast) ? WT::EPW : 1, nm, n0inv);
-#pragma unroll
-            for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
-        }
-        cond_sub<G::NLL, G::T>(x, nm);
-        __builtin_amdgcn_s_setprio(2);
-        wave_lds_fence();
-        pack_row_at<G>(x, myrow);
-        store_tile_at<G>(reg, out + (size_t)row0 * w32, rows, w32);
     }
     __builtin_amdgcn_s_setprio(0);
 }

@@ -17,7 +17,7 @@ struct DecPadicParams {
     int nops[2];
     int tbl_entries;             // odd powers base^(2i+1), i < tbl_entries; slot tbl_entries holds base^2
     int nd;                      // base-R digits of a ciphertext
-    uint4* wscratch;             // PADIC_WBUF: [2 NC][nslots] quotient digits + parked first result digit
+    uint4* wscratch;             // PADIC_WBUF: [NC][nslots] quotient digits of the digit-form entry and the exit
     int ct_words, u_words;
 };
 
@@ -80,41 +80,24 @@ PAI_DEV void padic_to_digit_form(uint4* A, uint4* B, typename E::MBuf M, const u
 }
 
 // MODE PADIC_LDS_M: digit pair + quotient digits in LDS (36-limb primes: 3 x 36 KB per workgroup).
-// MODE PADIC_WBUF:  LDS holds only the digit pair; quotient digits and the parked first result digit live in
-//                   strided global scratch (wider primes: 2 x 56 / 2 x 72 KB per workgroup).
-// Both run one wave per SIMD (a two-waves-per-SIMD variant was measured and dropped: DESIGN.md section 2).
-#ifndef PADIC_XLDS_FROM
-#define PADIC_XLDS_FROM 56          // LDS-qualified digit accesses from this limb count on (mont_padic.hpp: XLDS)
-#endif
-#ifndef PADIC_SQR_MUL_ABOVE
-#define PADIC_SQR_MUL_ABOVE 40      // squarings as rolled-loop products above this limb count (scratch-resident quotient digits)
-#endif
-#ifndef PADIC_SQR_SYM_MAX_NL
-#define PADIC_SQR_SYM_MAX_NL 56      // limb-class symmetric first half of the wide-digit squaring up to this limb count
-#endif
-// Fused product rule for the wide-digit (scratch-parked) kernels: PADIC_FUSED_56 / PADIC_FUSED_72 (mont_padic.hpp: mul_fused)
-#ifndef PADIC_FUSED_56
-#define PADIC_FUSED_56 true
-#endif
-#ifndef PADIC_FUSED_72
-#define PADIC_FUSED_72 true
-#endif
-#define PADIC_FUSED(NL) ((NL) == 56 ? PADIC_FUSED_56 : ((NL) == 72 ? PADIC_FUSED_72 : false))
-#ifndef PADIC_REGM_MUL_WBUF
-#define PADIC_REGM_MUL_WBUF 0       // PADIC_REGM: products through mul_wbuf (quotient digits AND first result digit in global scratch)
-#endif
-#ifndef PADIC_SGPR_MODULUS
-// measured per 65 536 decryptions with the modulus in SGPRs vs read from LDS: 36 limbs 488 vs 508 ms (x16), 72 limbs 364
-// vs 391 ms; 56 limbs (squaring as product, LDS-qualified accesses) 142 vs 151 ms
-#define PADIC_SGPR_MODULUS(NL) 1
-#endif
-// MODE PADIC_REGM (round 4): LDS holds only the digit pair; the squaring keeps its quotient digits in registers
-//                   (Padic::sqr_regm), the product parks them in a strided global scratch column: two workgroups per CU.
-// MODE PADIC_COMBA (round 4): as PADIC_REGM, but runs of squarings stay in registers (Padic::sqr_comba): the digit pair
-//                   is loaded from LDS before a run and stored after it; the products run the PADIC_REGM forms.
-constexpr int PADIC_LDS_M = 0, PADIC_REGM = 1, PADIC_WBUF = 2, PADIC_COMBA = 3;
+// MODE PADIC_WBUF:  LDS holds only the digit pair (wider primes: 2 x 56 / 2 x 72 KB per workgroup); the two halves of the
+//                   product rule run fused (mont_padic.hpp: mul_fused / sqr_fused / sqr_sym_fused — quotient digits go from
+//                   registers straight into the second window), only the digit-form entry and the exit park their
+//                   quotient digits in a strided global scratch column.
+// Both run one wave per SIMD.  Measured and dropped (profiles/r04/: bench_dec_regm.json, bench_dec_comba.jsonl,
+// dec72_variants.jsonl; the code is in the history): two workgroups per CU with the quotient digits in registers (527.9 vs
+// 476.6 ms per 2^20), product-scanning squarings entirely in registers (468-478 ms), 4-row blocks (506.9 ms), the unfused
+// scratch-parked forms at 56 / 72 limbs.
+constexpr int PADIC_XLDS_FROM = 56;          // LDS-qualified digit accesses from this limb count on (mont_padic.hpp: XLDS)
+// Wide digits square through rolled loops (a fully unrolled limb-class symmetric squaring is 62 KB of code at 72 limbs,
+// beyond the instruction cache): both halves in one pass, 4 NL^2 limb products instead of the product rule's 5.  Up to 56
+// limbs the first half is additionally limb-class symmetric (specialised a-parts behind a wave-uniform switch, 3.5 NL^2:
+// 121.0 -> 112.7 ms per 65 536 at 3072-bit keys); at 72 limbs the same code LOSES (282.6 -> 383.4 ms: the nine specialised
+// a-parts next to the 160-register window no longer fit), so 4096-bit keys keep the plain rolled first half.
+constexpr int PADIC_SQR_SYM_MAX_NL = 56;
+constexpr int PADIC_LDS_M = 0, PADIC_WBUF = 1;
 template <int NL, int U, int WB, int MODE>
-__global__ void __launch_bounds__(BLOCK_THREADS, (MODE == PADIC_REGM || MODE == PADIC_COMBA) ? 2 : 1)
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n,
               uint4* __restrict__ table) {
     using E = Padic<NL, U, (NL >= PADIC_XLDS_FROM)>;
@@ -128,15 +111,12 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     __syncthreads();
     // the modulus limbs are wave-uniform multiplier operands: pin them in SGPRs (every use is statically
     // indexed, so the array never leaves the register file) instead of letting the compiler hoist LDS
-    // loads into 36 VGPRs/AGPRs
-    constexpr bool SGPR_NM = PADIC_SGPR_MODULUS(NL);
-    uint32_t sn[SGPR_NM ? NL : 1];
-    const uint32_t* nm = ldsn;
-    if constexpr (SGPR_NM) {
+    // loads into 36 VGPRs/AGPRs (per 65 536 decryptions, SGPRs vs LDS: 36 limbs 488 vs 508 ms (x16), 56 limbs 142 vs 151 ms,
+    // 72 limbs 364 vs 391 ms)
+    uint32_t sn[NL];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
-        nm = sn;
-    }
+    for (int j = 0; j < NL; ++j) sn[j] = __builtin_amdgcn_readfirstlane(ldsn[j]);
+    const uint32_t* nm = sn;
     const uint32_t* pm1 = ldsn + NL;
     const uint32_t n0inv = ctx->n0inv;
     const uint32_t* __restrict__ kdig = P.kdig[which];
@@ -149,47 +129,19 @@ k_dec_a_padic(DecPadicParams P, const uint32_t* __restrict__ ct, uint32_t* __res
     const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK_THREADS + threadIdx.x;
     // M: quotient digits of the first half of the product rule: an LDS digit buffer, or (PADIC_WBUF) a strided global column
     const typename E::MBuf M = MODE != PADIC_LDS_M ? typename E::MBuf{P.wscratch + slot, nslots} : typename E::MBuf{B + E::NC * 64, 64};
-    const typename E::MBuf Wb{P.wscratch + (size_t)E::NC * nslots + slot, nslots};      // MODE 2 only
-    constexpr bool TWO_WG = MODE == PADIC_REGM || MODE == PADIC_COMBA;
     auto SQR = [&]() {
-        if constexpr (MODE == PADIC_REGM || MODE == PADIC_COMBA) {
-            E::sqr_regm(A, B, nm, pm1, n0inv);
-        } else if constexpr (MODE == PADIC_WBUF && NL > PADIC_SQR_MUL_ABOVE) {
-            // Wide digits: the fully unrolled limb-class symmetric squaring (sqr_wbuf) is 62 KB of code at 72 limbs
-            // (beyond the instruction cache), and at 56 limbs it made the compiler lose the LDS address space of the
-            // whole kernel (flat loads); round 1 therefore squared as a product (mul_wbuf(x, x), 5 NL^2).
-            // sqr_rolled_wbuf keeps both halves in rolled loops and does the second half in one pass (4 NL^2 limb
-            // products instead of the 5 NL^2 of the product rule applied to (x, x)).
-            // Up to 56 limbs the first half is additionally limb-class symmetric (sqr_sym_wbuf: specialised a-parts
-            // behind a wave-uniform switch, shared reduction body; 3.5 NL^2): 121.0 -> 112.7 ms per 65 536 at 3072-bit
-            // keys.  At 72 limbs the same code LOSES (282.6 -> 383.4 ms: the nine specialised a-parts next to the
-            // 160-register window no longer fit), so 4096-bit keys keep the plain rolled first half.
-            if constexpr (NL <= PADIC_SQR_SYM_MAX_NL) E::template sqr_sym_w<PADIC_FUSED(NL)>(A, B, M, Wb, nm, pm1, n0inv);
-            else E::template sqr_rolled_w<PADIC_FUSED(NL)>(A, B, M, Wb, nm, pm1, n0inv);
-        } else if constexpr (MODE == PADIC_WBUF) E::sqr_wbuf(A, B, M, Wb, nm, pm1, n0inv);
-        else E::sqr(A, B, M, nm, pm1, n0inv);
+        if constexpr (MODE == PADIC_WBUF) {
+            if constexpr (NL <= PADIC_SQR_SYM_MAX_NL) E::sqr_sym_fused(A, B, nm, pm1, n0inv);
+            else E::sqr_fused(A, B, nm, pm1, n0inv);
+        } else E::sqr(A, B, M, nm, pm1, n0inv);
     };
     auto MUL = [&](auto&& csrc, auto&& dsrc) {
-        if constexpr (MODE == PADIC_WBUF) E::template mul_w<PADIC_FUSED(NL)>(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);
-        else if constexpr (TWO_WG && PADIC_REGM_MUL_WBUF) E::mul_wbuf(A, B, M, Wb, csrc, dsrc, nm, pm1, n0inv);   // w parked too: no 36-register result digit across the second half
+        if constexpr (MODE == PADIC_WBUF) E::mul_fused(A, B, csrc, dsrc, nm, pm1, n0inv);
         else E::mul(A, B, M, csrc, dsrc, nm, pm1, n0inv);
     };
     auto SQRN = [&](int nsq) __attribute__((always_inline)) {
-        if constexpr (MODE == PADIC_COMBA) {
-            uint32_t a[NL], b[NL];
-            wave_lds_fence();
-            E::load_digit(A, a);
-            E::load_digit(B, b);
 #pragma unroll 1
-            for (int s = 0; s < nsq; ++s) E::sqr_comba(a, b, nm, n0inv);
-            wave_lds_fence();
-            E::store_digit(A, a);
-            E::store_digit(B, b);
-            wave_lds_fence();
-        } else {
-#pragma unroll 1
-            for (int s = 0; s < nsq; ++s) SQR();
-        }
+        for (int s = 0; s < nsq; ++s) SQR();
     };
     // table entry e: digit d (0 = first, 1 = second), chunk c
     auto tbl = [&](int e, int d, int c) -> uint4& { return table[(((size_t)e * 2 + d) * E::NC + c) * nslots + slot]; };

@@ -15,36 +15,15 @@
 
 namespace pai {
 
-// LDS-qualified digit accesses per kernel (mont_padic.hpp: XLDS), as measured at 72 limbs: ct * pt 92.8 vs 89.4 ms per
-// 2^20 with it (off), r^n 161 vs 167 ms per 65536 (on), encryption 70 vs 67 ms per 2^20 (off)
-#ifndef PAI_XLDS_CTMUL
-#define PAI_XLDS_CTMUL false
-#endif
-#ifndef PAI_XLDS_ENCRYPT
-#define PAI_XLDS_ENCRYPT false
-#endif
-#ifndef PAI_XLDS_POW
-#define PAI_XLDS_POW true
-#endif
-// Fused product rule (Padic::mul_fused: both halves in one pass, no quotient digits / parked digit in HBM scratch) per kernel
-#ifndef PAI_FUSED_ENCRYPT
-#define PAI_FUSED_ENCRYPT true
-#endif
-#ifndef PAI_FUSED_OBFUSCATE
-#define PAI_FUSED_OBFUSCATE true
-#endif
-#ifndef PAI_FUSED_EXPAND
-#define PAI_FUSED_EXPAND true
-#endif
-#ifndef PAI_FUSED_CTMUL
-#define PAI_FUSED_CTMUL true
-#endif
-#ifndef PAI_CTMUL_SQR_SYM
-#define PAI_CTMUL_SQR_SYM false
-#endif
-#ifndef PAI_FUSED_POW
-#define PAI_FUSED_POW(NL) ((NL) > 36)      // 36 limbs (1024-bit keys): r^n 25.1 ms unfused vs 29.0 fused per 65536
-#endif
+// Per-kernel forms, each measured at 72 limbs (profiles/r02 .. r04):
+//  * LDS-qualified digit accesses (mont_padic.hpp: XLDS) only in the r^n kernel (161 vs 167 ms per 65 536 with them; ct * pt
+//    92.8 vs 89.4 ms per 2^20 and encryption 70 vs 67 ms per 2^20 WITHOUT them);
+//  * the fused product rule (Padic::mul_fused / sqr_fused: both halves in one pass, no quotient digits or parked digit in
+//    HBM scratch) everywhere except r^n at 36 limbs (1024-bit keys: 25.1 ms unfused vs 29.0 fused per 65 536);
+//  * ct * pt squares with the plain rolled first half (the limb-class symmetric one measured slower there,
+//    profiles/r04/ctops_ctmul_sym.jsonl).
+constexpr bool PAI_XLDS_POW = true;
+constexpr bool pai_fused_pow(int nl) { return nl > 36; }
 
 struct EncPadicParams {
     const MontCtx* nctx;         // modulus n (NL limbs, R = 2^(29 NL))
@@ -59,8 +38,8 @@ struct EncPadicParams {
     int fb_gform;                // g-factored table (round 4): entry = (a, t) with x R == a (1 + t n) (mod n^2), see k_fb_g_*
 };
 
-// the g-factored product needs the fused product rule in both encryption kernels
-constexpr bool PAI_ENC_GFORM_OK = PAI_FUSED_ENCRYPT && PAI_FUSED_OBFUSCATE;
+// the g-factored product runs on the fused product rule of both encryption kernels
+constexpr bool PAI_ENC_GFORM_OK = true;
 
 // ---- table construction: one lane per window j ------------------------------------------------------
 template <int NL, int U>
@@ -189,7 +168,7 @@ k_fb_expand_padic(const MontCtx* __restrict__ nctx, const uint32_t* nm1g, const 
                 }
             };
         };
-        E::template mul_w<PAI_FUSED_EXPAND>(A, B, M, Wb, from_hi(0), from_hi(1), nm, nm1, n0inv);
+        E::mul_fused(A, B, from_hi(0), from_hi(1), nm, nm1, n0inv);
         if (live) {
             uint4* out = T + is * 2 * E::NC;
 #pragma unroll 1
@@ -427,7 +406,7 @@ template <int NL, int U, bool OBF, bool GFORM>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t* __restrict__ r,
                 const uint32_t* __restrict__ ct_in, uint32_t* __restrict__ ct_out, int n, int mode) {
-    using E = Padic<NL, U, PAI_XLDS_ENCRYPT>;
+    using E = Padic<NL, U, false>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // the modulus and n - 1 are read from LDS (broadcast reads): through the kernel-argument struct the
     // compiler cannot prove them unclobbered and would fetch them with vector global loads inside the loops
@@ -537,7 +516,7 @@ k_encrypt_padic(EncPadicParams P, const uint32_t* __restrict__ m, const uint32_t
                             }
                         };
                     };
-                    E::template mul_w<(OBF ? PAI_FUSED_OBFUSCATE : PAI_FUSED_ENCRYPT)>(A, B, M, Wb, from_ent(0), from_ent(1), nm, nm1, n0inv);
+                    E::mul_fused(A, B, from_ent(0), from_ent(1), nm, nm1, n0inv);
                 }
             }
             // times the plain digit pair (1, m) of 1 + m n  => plain digit pair of the ciphertext
@@ -626,7 +605,7 @@ struct CtMulPadicParams {
 template <int NL, int U>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ e, uint32_t* __restrict__ out, int n) {
-    using E = Padic<NL, U, PAI_XLDS_CTMUL>;
+    using E = Padic<NL, U, false>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
     for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
@@ -681,7 +660,7 @@ k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_
         }
 #pragma unroll 1
         for (int k = 2; k < NT; ++k) {
-            E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_table(1, 0), from_table(1, 1), nm, nm1, n0inv);
+            E::mul_fused(A, B, from_table(1, 0), from_table(1, 1), nm, nm1, n0inv);
 #pragma unroll 1
             for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
         }
@@ -697,12 +676,10 @@ k_ctmul_padic(CtMulPadicParams P, const uint32_t* __restrict__ ct, const uint32_
         for (int wi = nwin - 2; wi >= 0; --wi) {
 #pragma unroll 1
             for (int sq = 0; sq < W; ++sq) {
-                // 4 NL^2 instead of the product rule's 5; PAI_CTMUL_SQR_SYM: limb-class symmetric first half, 3.5 NL^2 (A/B r04)
-                if constexpr (PAI_CTMUL_SQR_SYM) E::template sqr_sym_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);
-                else E::template sqr_rolled_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);
+                E::sqr_fused(A, B, nm, nm1, n0inv);              // 4 NL^2 instead of the product rule's 5
             }
             const int d = (int)window(wi);
-            if (__any(d != 0)) E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_table(d, 0), from_table(d, 1), nm, nm1, n0inv);
+            if (__any(d != 0)) E::mul_fused(A, B, from_table(d, 0), from_table(d, 1), nm, nm1, n0inv);
         }
         // leave Montgomery form (times the plain pair (1, 0)), then ct = w + v n as one integer, canonical
         uint32_t w[NL], v[NL];
@@ -790,7 +767,7 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
         };
     };
     auto self = [&](const uint4* X) { return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); }; };
-    auto SQR = [&]() { E::template sqr_rolled_w<PAI_FUSED_POW(NL)>(A, B, M, Wb, nm, nm1, n0inv); };      // 4 NL^2 instead of the product rule's 5
+    auto SQR = [&]() { E::template sqr_rolled_w<pai_fused_pow(NL)>(A, B, M, Wb, nm, nm1, n0inv); };      // 4 NL^2 instead of the product rule's 5
     const int NT = P.tbl_entries;
     const int nd = (32 * P.in_words + RB * NL - 1) / (RB * NL);
     const int tiles = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
@@ -811,7 +788,7 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
         wave_lds_fence();
 #pragma unroll 1
         for (int k = 1; k < NT; ++k) {
-            E::template mul_w<PAI_FUSED_POW(NL)>(A, B, M, Wb, from_table(NT, 0), from_table(NT, 1), nm, nm1, n0inv);
+            E::template mul_w<pai_fused_pow(NL)>(A, B, M, Wb, from_table(NT, 0), from_table(NT, 1), nm, nm1, n0inv);
 #pragma unroll 1
             for (int c = 0; c < E::NC; ++c) { tbl(k, 0, c) = E::ld(A, c); tbl(k, 1, c) = E::ld(B, c); }
         }
@@ -828,7 +805,7 @@ k_pow_padic(PowPadicParams P, const uint32_t* __restrict__ base, uint32_t* __res
             const int nsq = op & 0xFF, idx = op >> 8;
 #pragma unroll 1
             for (int s_ = 0; s_ < nsq; ++s_) SQR();
-            if (idx != 0xFF) E::template mul_w<PAI_FUSED_POW(NL)>(A, B, M, Wb, from_table(idx, 0), from_table(idx, 1), nm, nm1, n0inv);
+            if (idx != 0xFF) E::template mul_w<pai_fused_pow(NL)>(A, B, M, Wb, from_table(idx, 0), from_table(idx, 1), nm, nm1, n0inv);
         }
         // leave Montgomery form, w + v n as one canonical integer, packed words (as in k_encrypt_padic)
         uint32_t w[NL], v[NL];
@@ -897,7 +874,7 @@ struct MexpPadicParams {
 template <int NL, int U>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_mexp_table_padic(MexpPadicParams P, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ ct_inv, int nlanes) {
-    using E = Padic<NL, U, PAI_XLDS_CTMUL>;
+    using E = Padic<NL, U, false>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
     for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
@@ -947,7 +924,7 @@ k_mexp_table_padic(MexpPadicParams P, const uint32_t* __restrict__ ct, const uin
         };
 #pragma unroll 1
         for (int d = 2; d < NT; ++d) {
-            E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_x(0), from_x(1), nm, nm1, n0inv);
+            E::mul_fused(A, B, from_x(0), from_x(1), nm, nm1, n0inv);
             if (live) {
 #pragma unroll 1
                 for (int c = 0; c < E::NC; ++c) { ent[(size_t)(2 * d) * E::NC + c] = E::ld(A, c); ent[(size_t)(2 * d + 1) * E::NC + c] = E::ld(B, c); }
@@ -962,7 +939,7 @@ k_mexp_table_padic(MexpPadicParams P, const uint32_t* __restrict__ ct, const uin
 template <int NL, int U>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_mexp_padic(MexpPadicParams P, const uint32_t* __restrict__ e, const uint8_t* __restrict__ sign, uint32_t* __restrict__ out, int nlanes) {
-    using E = Padic<NL, U, PAI_XLDS_CTMUL>;
+    using E = Padic<NL, U, false>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* ldsn = lds + (BLOCK_THREADS / 64) * 2 * E::DIGIT_WORDS;
     for (int i = threadIdx.x; i < NL; i += BLOCK_THREADS) { ldsn[i] = P.nctx->n[i]; ldsn[NL + i] = P.nm1[i]; }
@@ -1008,7 +985,7 @@ k_mexp_padic(MexpPadicParams P, const uint32_t* __restrict__ e, const uint8_t* _
         for (int wi = nwin - 1; wi >= 0; --wi) {
             if (started) {
 #pragma unroll 1
-                for (int sq = 0; sq < W; ++sq) E::template sqr_rolled_w<PAI_FUSED_CTMUL>(A, B, M, Wb, nm, nm1, n0inv);
+                for (int sq = 0; sq < W; ++sq) E::sqr_fused(A, B, nm, nm1, n0inv);
             }
             const int bit = wi * W, k = bit >> 5, sh = bit & 31;
 #pragma unroll 1
@@ -1032,7 +1009,7 @@ k_mexp_padic(MexpPadicParams P, const uint32_t* __restrict__ e, const uint8_t* _
                             }
                         };
                     };
-                    E::template mul_w<PAI_FUSED_CTMUL>(A, B, M, Wb, from_ent(0), from_ent(1), nm, nm1, n0inv);
+                    E::mul_fused(A, B, from_ent(0), from_ent(1), nm, nm1, n0inv);
                     started = true;
                 }
             }

@@ -520,21 +520,15 @@ k_dec_a(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_
 // the accumulator straight from the ring, half a product per squaring on average: the critical path is the squarings plus
 // one product.  Hand-over through two LDS words per wave pair (head: slots published by A; tail: first slot B still needs),
 // release / acquire at workgroup scope; a wait that does not end traps instead of hanging the device.
-#ifndef PAI_RL_RING
-#define PAI_RL_RING 16
-#endif
-#ifndef PAI_RL_DEBUG_NOB
-#define PAI_RL_DEBUG_NOB 0          // timing probe only: wave B skips its products (wrong results)
-#endif
-constexpr int RL_RING = PAI_RL_RING;
+constexpr int RL_RING = 16;
 PAI_DEV void rl_publish(uint32_t* flag, uint32_t v) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // waits until *flag >= need; returns the value seen (the flag is wave-uniform: the loop branches on a scalar)
-#ifndef PAI_RL_SLEEP_B
-#define PAI_RL_SLEEP_B 8            // s_sleep units (64 cycles) between wave B's polls of `head`: a polling wave costs the squaring wave
-#endif                              // of its CU scalar issue slots and LDS cycles (3.48 vs 3.37 ms with B polling all the time)
+// s_sleep units (64 cycles) between wave B's polls of `head`: a polling wave costs the squaring wave of its CU scalar issue
+// slots and LDS cycles (3.48 vs 3.37 ms with B polling all the time)
+constexpr int RL_SLEEP_B = 8;
 template <int SLEEP = 1>
 PAI_DEV uint32_t rl_wait(uint32_t* flag, uint32_t need) {
     int spins = 0;
@@ -618,13 +612,13 @@ k_dec_a_rl(DecAParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__
             bool first = true;
 #pragma unroll 1
             while (i < ebits) {
-                rl_wait<PAI_RL_SLEEP_B>(head, (uint32_t)(i + 1));
+                rl_wait<RL_SLEEP_B>(head, (uint32_t)(i + 1));
                 const uint32_t* slot = ring + (i % RL_RING) * G::LDS_WORDS;
                 if (first) {
 #pragma unroll
                     for (int j = 0; j < G::NLL; ++j) acc[j] = slot[(G::NLL * t + j) * G::EPB + col];
                     first = false;
-                } else if (!PAI_RL_DEBUG_NOB) {
+                } else {
                     uint32_t r[G::NLL];
                     mont_mul_m1<G::NLL, G::U, G::T>(r, acc, slot + col, G::EPB, nm, (int)nblk);
 #pragma unroll
@@ -708,7 +702,7 @@ k_modexp_rl(const MontCtx* __restrict__ ctx, const uint32_t* __restrict__ base, 
             rl_publish(tail, (uint32_t)i);
 #pragma unroll 1
             while (i < ebits_max) {
-                rl_wait<PAI_RL_SLEEP_B>(head, (uint32_t)(i + 1));
+                rl_wait<RL_SLEEP_B>(head, (uint32_t)(i + 1));
                 const uint32_t* slot = ring + (i % RL_RING) * G::LDS_WORDS;
                 uint32_t r[G::NLL];
                 mont_mul_m1<G::NLL, G::U, G::T>(r, acc, slot + col, G::EPB, nm, (int)nblk);
@@ -995,6 +989,111 @@ k_add_aligned(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t
         cond_sub<G::NLL, G::T>(x, nm);
         __builtin_amdgcn_s_setprio(2);
         pack_row<G>(x, stage);
+        store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// n-ary ciphertext sum (round 5): out_i = prod_{j < k} op_j[i]^(2^raise_j[i]) mod n^2 in ONE pass — the aggregation
+// sum_j E(x_j) over k parties' arrays, which the reference spells as a chain of k - 1 __add__ calls with their exponent
+// alignments (ipcl_python.py:365-381, 490-526, 570-741; tests/ipcl_python_test.py:21-38).  A wave tile loads the k operand
+// rows in turn and keeps the running product in registers: k - 1 Montgomery products per element, one tile store, no
+// intermediate arrays — against k - 1 launches of k_modmul, each with two tile loads, a store and its pack / unpack.
+//
+// Montgomery bookkeeping: operand 0 holds x R^tag0, the others x R^tag; a product of the accumulator (x R^c) with an operand
+// (y R^t) is (x y) R^(c + t - 1).  c is wave-uniform and tracked per tile.  An operand that some element of the tile has to
+// raise (raise_j > 0: the target exponent of the sum is the per-element maximum, computed by the caller) enters the domain
+// first (one product with R^(2 - t), `conv`), is squared max(raise) times (kept only by the elements that still need it)
+// and then joins the product as y R, so such a tile ends at a different c than the plain path; the last step brings every
+// tile to the caller's dom_out through one product with R^(1 + dom_out - c) from the key's table of powers of R (skipped when
+// c already is dom_out — the common case when dom_out is the natural tag tag0 + (k - 1)(tag - 1) and nothing is raised).
+// All products of a tile run through ONE rolled loop body (a second inlined copy of the row engine spills: k_modmul).
+constexpr int ADDN_MAX = 16;                 // operands per launch
+constexpr int RPOW_SPAN = 48;                // the key's table holds R^m mod n^2 for |m| <= RPOW_SPAN (limb form, NL limbs per row)
+struct AddnArgs {
+    const uint32_t* op[ADDN_MAX];
+    const int32_t* raise[ADDN_MAX];          // per operand: int32 [n] of squarings per element (>= 0), or NULL
+    int k, tag0, tag, dom_out;
+};
+
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_addn(const MontCtx* __restrict__ ctx, AddnArgs A, uint32_t* out, int n, int w32, const uint32_t* __restrict__ rpow) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using WT = WaveTile<G>;
+    uint32_t* stage = lds + G::LDS_WORDS + G::NL;
+    uint32_t* conv_lds = stage + G::STAGE_WORDS;         // R^(2 - tag): the domain entry of an operand that is to be raised
+    typename G::NM nm;
+    load_modulus<G>(nm, ctx, lds);
+    const uint32_t n0inv = ctx->n0inv;
+    constexpr int WPB = BLOCK_THREADS / 64;
+    const int wtiles = (n + WT::EPW - 1) / WT::EPW;
+    clear_stage<G>(stage);
+    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) conv_lds[i] = rpow[(size_t)(RPOW_SPAN + 2 - A.tag) * G::NL + i];
+    __syncthreads();
+    const uint32_t* o_lds = lds + G::elem();             // column of this element in the [limb][element] operand buffer
+    const int per_wave = (wtiles + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
+    const int wt_begin = ((int)blockIdx.x * WPB + WT::wave()) * per_wave;
+    const int wt_end = min(wtiles, wt_begin + per_wave);
+    for (int wt = wt_begin; wt < wt_end; ++wt) {
+        const int row0 = wt * WT::EPW;
+        const int rows = min(WT::EPW, n - row0);
+        const int ei = row0 + (WT::lane() / G::T);
+        uint32_t acc[G::NLL];
+        int c = 0;                                       // the accumulator holds (product so far) R^c
+        // operands 0 .. k-1, then pseudo-operand k: the constant that brings the tile to dom_out
+#pragma unroll 1
+        for (int j = 0; j <= A.k; ++j) {
+            uint32_t y[G::NLL];
+            int rj = 0, dmax = 0;
+            if (j < A.k) {
+                const int32_t* rz = A.raise[j];
+                if (rz != nullptr) {
+                    rj = ei < n ? rz[ei] : 0;
+                    rj = rj > 0 ? rj : 0;
+                    dmax = rj;
+                    for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(dmax, off, 64); dmax = o > dmax ? o : dmax; }
+                }
+                __builtin_amdgcn_s_setprio(2);
+                load_tile<G>(stage, A.op[j] + (size_t)row0 * w32, rows, w32);
+                unpack_row<G>(y, stage);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                if (c == A.dom_out) break;               // wave-uniform
+                load_const_slice<G>(y, rpow + (size_t)(RPOW_SPAN + 1 + A.dom_out - c) * G::NL);
+            }
+            // steps of this operand: [conv, dmax squarings] when it is raised, then the product with the accumulator (j > 0)
+            const int npre = dmax > 0 ? 1 + dmax : 0;
+            const int nsteps = npre + (j > 0 ? 1 : 0);
+#pragma unroll 1
+            for (int s = 0; s < nsteps; ++s) {
+                const bool conv = dmax > 0 && s == 0;
+                const bool mul = s == npre;              // the last step of operands j > 0
+                uint32_t lhs[G::NLL], r[G::NLL];
+#pragma unroll
+                for (int i = 0; i < G::NLL; ++i) lhs[i] = mul ? acc[i] : y[i];
+                if (!conv) stage_b<G>(y, lds);           // right operand of squarings and of the product: y itself
+                mont_mul<G::NLL, G::U, G::T>(r, lhs, conv ? conv_lds : o_lds, conv ? 1 : G::EPB, nm, n0inv);
+                const bool keep_y = conv || (!mul && s - 1 < rj);
+#pragma unroll
+                for (int i = 0; i < G::NLL; ++i) {
+                    acc[i] = mul ? r[i] : acc[i];
+                    y[i] = keep_y ? r[i] : y[i];
+                }
+            }
+            const int ty = j == A.k ? 1 + A.dom_out - c : (dmax > 0 ? 1 : (j == 0 ? A.tag0 : A.tag));   // y holds (operand) R^ty
+            if (j == 0) {
+#pragma unroll
+                for (int i = 0; i < G::NLL; ++i) acc[i] = y[i];
+                c = ty;
+            } else {
+                c += ty - 1;
+            }
+        }
+        cond_sub<G::NLL, G::T>(acc, nm);
+        __builtin_amdgcn_s_setprio(2);
+        pack_row<G>(acc, stage);
         store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
         __builtin_amdgcn_s_setprio(0);
     }

@@ -16,13 +16,7 @@
 namespace pai {
 
 // waves per SIMD the pair kernels are compiled for, by group size (tools/variant_tu.sh for A/B timing)
-#ifndef PAIR_WAVES_T8
-#define PAIR_WAVES_T8 2
-#endif
-#define PAIR_WAVES_PER_SIMD(T) ((T) >= 8 ? PAIR_WAVES_T8 : 1)
-#ifndef PAIR_PREFETCH
-#define PAIR_PREFETCH 1             // the next window's table entry is loaded while the current product runs
-#endif
+#define PAIR_WAVES_PER_SIMD(T) ((T) >= 8 ? 2 : 1)
 
 struct PairParams {
     const MontCtx* nctx;         // modulus n on the pair geometry (NL limbs, R = 2^(29 NL))
@@ -39,12 +33,9 @@ struct PairParams {
 // (the compiler spilled it straight after the load, i.e. waited for HBM once per window: 26 % of the wave cycles in
 // profiles/r02/pmc_k4096_r02.json): there the next entry is STREAMED into a second pair of LDS operand buffers, two words per
 // row block (RowStream, mont_dev.hpp).
-#ifndef PAIR_STREAM_T
-#define PAIR_STREAM_T 8
-#endif
 template <class G>
 struct PairLds {
-    static constexpr bool STREAM = G::T >= PAIR_STREAM_T;
+    static constexpr bool STREAM = G::T >= 8;
     static constexpr int BYTES = (2 * G::LDS_WORDS + 2 * G::NL) * 4;
     static constexpr int BYTES_FB = BYTES + (STREAM ? 2 * G::LDS_WORDS * 4 : 0);      // k_pair_fixed_base: + the second buffer pair
     static constexpr int BYTES_CT = BYTES + 2 * G::LDS_WORDS * 4;                     // k_pair_ctmul: always two buffer pairs
@@ -160,7 +151,7 @@ PAI_DEV void pair_times(uint32_t (&a)[G::NLL], uint32_t (&b)[G::NLL], const uint
     stage_b<G>(c, PairLds<G>::c(lds));
     stage_b<G>(d, PairLds<G>::d(lds));
     pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
-                                 PairLds<G>::nm1(lds), nm, n0inv);
+                                 nm, n0inv);
 }
 
 // ---- first table level: element i walks S[i][e] = S[i][e - 1] (x) B_i, S[i][0] = pair(1) -------------------------------
@@ -215,7 +206,7 @@ k_pair_fb_chain(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ n
             stage_b<G>(c, PairLds<G>::c(lds));
             stage_b<G>(d, PairLds<G>::d(lds));
             pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
-                                         PairLds<G>::nm1(lds), nm, n0inv, (NoStream*)nullptr, true);       // a squaring: 4 NL^2
+                                         nm, n0inv, (NoStream*)nullptr, true);       // a squaring: 4 NL^2
             const bool keep = sq < h * is;
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) { c[j] = keep ? a[j] : c[j]; d[j] = keep ? b[j] : d[j]; }
@@ -228,7 +219,7 @@ k_pair_fb_chain(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ n
 #pragma unroll 1
         for (int e = 1; e < E1; ++e) {
             pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
-                                         PairLds<G>::nm1(lds), nm, n0inv);
+                                         nm, n0inv);
             if (live) pair_store<G>(a, b, out + (size_t)e * 2 * G::NL);
         }
     }
@@ -442,7 +433,7 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
                     uint32_t tn[G::NLL];                           // the next entry's exponent slice travels during the product
                     digit_load<G>(tn, ent + G::NL);                // (measured: 37.4 ms against 38.5 ms with the load after it)
                     pair_mul<G::NLL, G::U, G::T>(a, b, lds + cur + G::elem(), lds + cur + G::elem(), G::EPB,
-                                                 PairLds<G>::nm1(lds), nm, n0inv, &pf, false, true);
+                                                 nm, n0inv, &pf, false, true);
 #pragma unroll
                     for (int j = 0; j < G::NLL; ++j) tacc[j] += more ? tn[j] : 0u;
                 } else {
@@ -453,7 +444,7 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
                     pf.dst1 = lds + nxt + G::LDS_WORDS + col;
                     pf.stride = G::EPB;
                     pair_mul<G::NLL, G::U, G::T>(a, b, lds + cur + G::elem(), lds + cur + G::LDS_WORDS + G::elem(), G::EPB,
-                                                 PairLds<G>::nm1(lds), nm, n0inv, &pf);
+                                                 nm, n0inv, &pf);
                 }
                 wave_lds_fence();
             }
@@ -466,7 +457,7 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
                 stage_b<G>(c, PairLds<G>::c(lds));
                 if (jw + 1 < P.fb_windows) digit_load<G>(c, entry(jw + 1));
                 pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::c(lds) + G::elem(), G::EPB,
-                                             PairLds<G>::nm1(lds), nm, n0inv, (NoStream*)nullptr, false, true);
+                                             nm, n0inv, (NoStream*)nullptr, false, true);
                 digit_load<G>(d, entry(jw) + G::NL);
 #pragma unroll
                 for (int j = 0; j < G::NLL; ++j) tl[j * BLOCK_THREADS] += d[j];
@@ -475,18 +466,12 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
         if (P.fb_windows > 1) pair_load<G>(c, d, entry(1));
 #pragma unroll 1
         for (int jw = 1; jw < P.fb_windows; ++jw) {
-#if PAIR_PREFETCH
             stage_b<G>(c, PairLds<G>::c(lds));
             stage_b<G>(d, PairLds<G>::d(lds));
             // the next window's entry travels from HBM while this product runs
             if (jw + 1 < P.fb_windows) pair_load<G>(c, d, entry(jw + 1));
-#else
-            if (jw > 1) pair_load<G>(c, d, entry(jw));
-            stage_b<G>(c, PairLds<G>::c(lds));
-            stage_b<G>(d, PairLds<G>::d(lds));
-#endif
             pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
-                                         PairLds<G>::nm1(lds), nm, n0inv);
+                                         nm, n0inv);
         }
         }
         set_plain_one<G>(c);
@@ -549,7 +534,6 @@ k_pair_ctmul(PairCtMulParams P, const uint32_t* __restrict__ ct, const uint32_t*
     const size_t slot = (size_t)blockIdx.x * G::EPB + G::elem();
     uint32_t* trow = P.table + slot * (size_t)NT * 2 * G::NL;
     const int col = (G::NLL * t) * G::EPB + G::elem();
-    const uint32_t* mm1 = PairLds<G>::nm1(lds);
     const int tiles = (n + G::EPB - 1) / G::EPB;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int ei = tile * G::EPB + G::elem();
@@ -591,7 +575,7 @@ k_pair_ctmul(PairCtMulParams P, const uint32_t* __restrict__ ct, const uint32_t*
             for (int j = 0; j < G::NLL; ++j) { a[j] = sa[j]; b[j] = sb[j]; }
 #pragma unroll 1
             for (int k = 2; k < NT; ++k) {
-                pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB, mm1, nm, n0inv);
+                pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB, nm, n0inv);
                 pair_store<G>(a, b, trow + (size_t)k * 2 * G::NL);
             }
         }
@@ -618,7 +602,7 @@ k_pair_ctmul(PairCtMulParams P, const uint32_t* __restrict__ ct, const uint32_t*
                 }
                 pf.on = any && s == W - 1;
                 const int off = is_mul ? PAIR_OFF : 0;
-                pair_mul<G::NLL, G::U, G::T>(a, b, lds + off + G::elem(), lds + off + G::LDS_WORDS + G::elem(), G::EPB, mm1, nm, n0inv,
+                pair_mul<G::NLL, G::U, G::T>(a, b, lds + off + G::elem(), lds + off + G::LDS_WORDS + G::elem(), G::EPB, nm, n0inv,
                                              &pf, !is_mul);
             }
         }

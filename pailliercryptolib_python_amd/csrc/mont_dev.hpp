@@ -39,9 +39,6 @@ constexpr uint32_t RMASK = (1u << RB) - 1u;
 constexpr int NORM_ROWS = 24;                   // rows between carry normalisations (must stay < 30)
 
 #define PAI_DEV __device__ __forceinline__
-#ifndef PAI_BCAST8_SWIZZLE
-#define PAI_BCAST8_SWIZZLE 0       // 1: quotient-digit broadcast in groups of 8 lanes through ds_swizzle_b32 (A/B r04)
-#endif
 
 // Per-modulus constants in device memory (all limbs radix 2^29, zero-padded to NLMAX).
 constexpr int NLMAX = 288;                      // 8192-bit moduli (+2 bits) => 283 limbs, padded
@@ -70,17 +67,12 @@ template <int T> PAI_DEV uint32_t bcast0(uint32_t v) {
     else if constexpr (T == 2) return dpp_mov<0xA0>(v);          // quad_perm [0,0,2,2]
     else if constexpr (T == 4) return dpp_mov<0x00>(v);          // quad_perm [0,0,0,0]
     else if constexpr (T == 8) {
-#if PAI_BCAST8_SWIZZLE
-        // ONE LDS-crossbar instruction (ds_swizzle_b32, bit mode: source lane = lane & 0b11000 inside each half wave; no
-        // memory access, no VALU issue slot) instead of two DPP moves and a select: the 8-lane row blocks are bound by
-        // VALU issue, and the swizzle's latency hides behind the other wave of the SIMD
-        return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x18);
-#endif
-        // two DPP moves instead of ds_bpermute: lane 0 / 4 of each quad pair, then the upper quad fetches from 4 lanes below
-        // (groups of 8 are aligned halves of a 16-lane DPP row)
+        // two DPP moves instead of ds_bpermute (one ds_swizzle_b32 measured no better: profiles/r04/keysize_bcast8_swizzle.jsonl):
+        // lane 0 / 4 of each quad pair, then the upper quad fetches from 4 lanes below
+        // (groups of 8 are aligned halves of a 16-lane DPP row); the second move writes banks 1 and 3 only (lanes 4-7, 12-15),
+        // the other lanes keep q: no select
         const uint32_t q = dpp_mov<0x00>(v);
-        const uint32_t w = dpp_mov<0x114>(q);                    // row_shr:4
-        return (threadIdx.x & 4) ? w : q;
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)q, (int)q, 0x114, 0xF, 0xA, false);   // row_shr:4, bank_mask 0b1010
     } else if constexpr (T == 64) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);      // through an SGPR: no LDS-pipe latency
     else if constexpr (T == 32) {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
@@ -104,6 +96,13 @@ template <int T> PAI_DEV uint32_t from_next(uint32_t v) {
         if constexpr (T == 64) return r;                         // bound_ctrl: the wave's last lane already reads 0
         return (group_lane<T>() == T - 1) ? 0u : r;
     }
+}
+// from_next for values that are ZERO in every group's lane 0 (the limb a Montgomery row retires: the quotient digit makes it
+// so): lane T-1 then reads the next group's zero (or the DPP row's / wave's edge, bound_ctrl: 0) and needs no select
+template <int T> PAI_DEV uint32_t from_next_z(uint32_t v) {
+    if constexpr (T == 4 || T == 8) return dpp_mov<0x101>(v);    // row_shl:1
+    else if constexpr (T >= 16) return dpp_mov<0x130>(v);        // wave_shl:1
+    else return from_next<T>(v);
 }
 // value held by the previous lane of the group (lane 0 receives 0)
 template <int T> PAI_DEV uint32_t from_prev(uint32_t v) {
@@ -186,7 +185,7 @@ struct Rows {
         for (int j = 0; j < NLL; ++j) acc[j] = acc[j + U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if constexpr (T > 1) acc[NLL - U + u] += (uint64_t)from_next<T>(low[u]);
+            if constexpr (T > 1) acc[NLL - U + u] += (uint64_t)(QN ? from_next_z<T>(low[u]) : from_next<T>(low[u]));
             acc[NLL + u] = 0;
         }
     }
@@ -198,15 +197,10 @@ struct Rows {
     // The wide-group (latency) geometries spend 80 % of their instructions outside the multiplier; this halves them.
     template <class NM>
     PAI_DEV static void block_m1(uint64_t (&acc)[NW], const uint32_t (&a)[NLL], const uint32_t (&bv)[U], const NM& npp) {
-#ifndef PAI_M1_DEBUG_HALF
-#define PAI_M1_DEBUG_HALF 0        // timing probes only (wrong results): 1 = without the a*b products, 2 = without the q*(M+1) products
-#endif
-        if constexpr (PAI_M1_DEBUG_HALF != 1) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int j = 0; j < NLL; ++j) acc[j + u] += (uint64_t)a[j] * bv[u];
-        }
         }
         uint32_t low[U], q[U];
         uint64_t c = 0;
@@ -226,10 +220,8 @@ struct Rows {
             acc[NLL + u] = 0;
             if constexpr (T > 1) acc[NLL - U + u] += (uint64_t)from_next<T>(low[u]);
         }
-        if constexpr (PAI_M1_DEBUG_HALF != 2) {
 #pragma unroll
         for (int u = 0; u < U; ++u) npp.template mac<NLL>(acc, u, q[u]);
-        }
     }
 
     // full carry propagation into canonical 29-bit limbs (across the T lanes of the group)
@@ -448,74 +440,142 @@ PAI_DEV void mont_mul_m1(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uin
 // (a, b) in registers (lane slices), (c, d) as LDS rows c_ptr / d_ptr [limb * stride], M - 1 as LDS limbs (uniform).
 // Inputs lazy (< 2M + eps), outputs lazy; R / M >= 2^20 required.
 constexpr int PAIR_NORM_MAX = 18;              // three 2^58 products per row and column: 18 rows (54 x 2^58 + the normalised rest < 2^29 + 2^35) stay below 2^64
+constexpr int PAIR_NORM_MAX2 = 24;             // two products per row and column (squarings, g-factored operands): 24 rows
+
+// One row block of the fused product rule on a window that is addressed THROUGH an offset: column k of the window is
+// register (O + k) mod NW.  With O a compile-time constant the slide of the window after a block is a renaming, not NLL
+// 64-bit moves per window (round 5: 33-72 of the ~840 instructions of an 18 x 8 block were those moves).
+template <int NLL, int U, int T, int O, class NM>
+PAI_DEV void pair_block(uint64_t (&acc1)[NLL + U], uint64_t (&acc2)[NLL + U], const uint32_t (&a)[NLL], const uint32_t (&b)[NLL],
+                        const uint32_t (&cv)[U], const uint32_t (&dv)[U], const NM& nm, uint32_t n0inv, bool lane0, bool sqr, bool c0) {
+    constexpr int NW = NLL + U;
+#define PAIR_C(k) ((O + (k)) % NW)
+    uint32_t low1[U], low2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) acc1[PAIR_C(j + u)] += (uint64_t)a[j] * cv[u];
+        const uint32_t q1 = bcast0<T>(((uint32_t)acc1[PAIR_C(u)] * n0inv) & RMASK);
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) acc1[PAIR_C(j + u)] += (uint64_t)nm.limb(j) * q1;
+        acc1[PAIR_C(u + 1)] += acc1[PAIR_C(u)] >> RB;
+        low1[u] = (uint32_t)acc1[PAIR_C(u)] & RMASK;
+        acc2[PAIR_C(u)] += lane0 ? (uint64_t)(RMASK - q1) : 0ull;
+        if (!c0) {
+#pragma unroll
+            for (int j = 0; j < NLL; ++j) acc2[PAIR_C(j + u)] += (uint64_t)a[j] * dv[u];
+        }
+        if (!sqr) {
+#pragma unroll
+            for (int j = 0; j < NLL; ++j) acc2[PAIR_C(j + u)] += (uint64_t)b[j] * cv[u];
+        }
+        const uint32_t q2 = bcast0<T>(((uint32_t)acc2[PAIR_C(u)] * n0inv) & RMASK);
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) acc2[PAIR_C(j + u)] += (uint64_t)nm.limb(j) * q2;
+        acc2[PAIR_C(u + 1)] += acc2[PAIR_C(u)] >> RB;
+        low2[u] = (uint32_t)acc2[PAIR_C(u)] & RMASK;
+    }
+    // the retired limbs (zero in the group's lane 0) go to the previous lane's top columns; the retired columns become the
+    // window's new top
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if constexpr (T > 1) {
+            acc1[PAIR_C(NLL + u)] += (uint64_t)from_next_z<T>(low1[u]);
+            acc2[PAIR_C(NLL + u)] += (uint64_t)from_next_z<T>(low2[u]);
+        }
+        acc1[PAIR_C(u)] = 0;
+        acc2[PAIR_C(u)] = 0;
+    }
+#undef PAIR_C
+}
+// carry-save normalisation of a window at offset O (Rows::normalize in window order)
+template <int NLL, int U, int O>
+PAI_DEV void pair_normalize(uint64_t (&acc)[NLL + U]) {
+    constexpr int NW = NLL + U;
+#pragma unroll
+    for (int k = NW - 1; k >= 1; --k) {
+        const uint64_t keep = (k == NW - 1) ? acc[(O + k) % NW] : (acc[(O + k) % NW] & RMASK);
+        acc[(O + k) % NW] = keep + (acc[(O + k - 1) % NW] >> RB);
+    }
+    acc[O % NW] &= RMASK;
+}
+// PER = NLL / U + 1 consecutive blocks bring the offset back to 0: one period, fully unrolled
+template <int NLL, int U, int T, int B, class NM, class PF>
+PAI_DEV void pair_period(uint64_t (&acc1)[NLL + U], uint64_t (&acc2)[NLL + U], const uint32_t (&a)[NLL], const uint32_t (&b)[NLL],
+                         const uint32_t* c_ptr, const uint32_t* d_ptr, int stride, int blk0, const NM& nm, uint32_t n0inv,
+                         bool lane0, bool sqr, bool c0, PF* pf) {
+    constexpr int PER = NLL / U + 1;
+    if constexpr (B < PER) {
+        if constexpr (!std::is_same<PF, NoStream>::value) pf->step(blk0 + B);
+        uint32_t cv[U], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cv[u] = c_ptr[((blk0 + B) * U + u) * stride];
+            dv[u] = c0 ? 0u : d_ptr[((blk0 + B) * U + u) * stride];
+            dv[u] = sqr ? dv[u] << 1 : dv[u];
+        }
+        pair_block<NLL, U, T, (B * U) % (NLL + U)>(acc1, acc2, a, b, cv, dv, nm, n0inv, lane0, sqr, c0);
+        // three products per row and column in the second window of a full product: it cannot wait for the period's end
+        if constexpr ((B + 1) * U <= PAIR_NORM_MAX && (B + 2) * U > PAIR_NORM_MAX && B + 1 < PER) {
+            if (!sqr && !c0) pair_normalize<NLL, U, ((B + 1) * U) % (NLL + U)>(acc2);
+        }
+        pair_period<NLL, U, T, B + 1>(acc1, acc2, a, b, c_ptr, d_ptr, stride, blk0, nm, n0inv, lane0, sqr, c0, pf);
+    }
+}
 
 // sqr (wave-uniform): the rows at c_ptr / d_ptr are (a, b) themselves — a d + b c is then 2 a d, one multiply-accumulate
 // per limb pair less (4 NL^2 instead of 5 NL^2); both forms share this one body.
 template <int NLL, int U, int T, class NM, class PF = NoStream>
 // c0 (wave-uniform): the right operand has no second digit (g-factored table entries, kernels_pair.hpp): a d drops out,
 // 4 NL^2 as well, and d_ptr is not read.
+// Round 5: the window is renamed instead of moved where the geometry allows it (pair_block), the (M - 1) R term joins once
+// at the end (it adds M - 1 to the second result digit) instead of one LDS read, select and 64-bit add per row, the
+// cross-lane moves need no selects (from_next_z, bcast0), and the two-product forms normalise every 24 rows.
 PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_ptr, const uint32_t* d_ptr, int stride,
-                      const uint32_t* mm1, const NM& nm, uint32_t n0inv, PF* pf = nullptr, bool sqr = false, bool c0 = false) {
+                      const NM& nm, uint32_t n0inv, PF* pf = nullptr, bool sqr = false, bool c0 = false) {
     static_assert(NLL % U == 0 && U <= PAIR_NORM_MAX, "row-block size");
     using RW = Rows<NLL, U, T>;
     constexpr int NW = RW::NW;
     uint64_t acc1[NW], acc2[NW];
     RW::zero(acc1);
     RW::zero(acc2);
-    const bool lane0 = (group_lane<T>() == 0), top = (group_lane<T>() == T - 1);
+    const bool lane0 = (group_lane<T>() == 0);
     if (lane0) acc2[0] = 1;
     constexpr int NB = RW::NL / U;
-    constexpr int NORM_BLOCKS = PAIR_NORM_MAX / U;
-    int since = 0;
+    constexpr int PER = NLL / U + 1;
+    if constexpr (NB % PER == 0 && PER * U <= PAIR_NORM_MAX2) {
 #pragma unroll 1
-    for (int blk = 0; blk < NB; ++blk) {
-        if constexpr (!std::is_same<PF, NoStream>::value) pf->step(blk);
-        uint32_t cv[U], dv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            cv[u] = c_ptr[(blk * U + u) * stride];
-            dv[u] = c0 ? 0u : d_ptr[(blk * U + u) * stride];
-            dv[u] = sqr ? dv[u] << 1 : dv[u];
-            const uint32_t f = mm1[blk * U + u];
-            acc2[NLL + u] += top ? (uint64_t)f : 0ull;           // (M - 1) R: column NL + row
+        for (int blk = 0; blk < NB; blk += PER) {
+            pair_period<NLL, U, T, 0>(acc1, acc2, a, b, c_ptr, d_ptr, stride, blk, nm, n0inv, lane0, sqr, c0, pf);
+            if (blk + PER < NB) { pair_normalize<NLL, U, 0>(acc1); pair_normalize<NLL, U, 0>(acc2); }
         }
-        uint32_t low1[U], low2[U];
+    } else {
+        const int norm_blocks = ((sqr || c0) ? PAIR_NORM_MAX2 : PAIR_NORM_MAX) / U;
+        int since = 0;
+#pragma unroll 1
+        for (int blk = 0; blk < NB; ++blk) {
+            if constexpr (!std::is_same<PF, NoStream>::value) pf->step(blk);
+            uint32_t cv[U], dv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int j = 0; j < NLL; ++j) acc1[j + u] += (uint64_t)a[j] * cv[u];
-            const uint32_t q1 = bcast0<T>(((uint32_t)acc1[u] * n0inv) & RMASK);
-            nm.template mac<NLL>(acc1, u, q1);
-            acc1[u + 1] += acc1[u] >> RB;
-            low1[u] = (uint32_t)acc1[u] & RMASK;
-            acc2[u] += lane0 ? (uint64_t)(RMASK - q1) : 0ull;
-            if (!c0) {
-#pragma unroll
-                for (int j = 0; j < NLL; ++j) acc2[j + u] += (uint64_t)a[j] * dv[u];
+            for (int u = 0; u < U; ++u) {
+                cv[u] = c_ptr[(blk * U + u) * stride];
+                dv[u] = c0 ? 0u : d_ptr[(blk * U + u) * stride];
+                dv[u] = sqr ? dv[u] << 1 : dv[u];
             }
-            if (!sqr) {
+            pair_block<NLL, U, T, 0>(acc1, acc2, a, b, cv, dv, nm, n0inv, lane0, sqr, c0);
+            // slide: the block left its retired (zeroed) columns at the bottom
 #pragma unroll
-                for (int j = 0; j < NLL; ++j) acc2[j + u] += (uint64_t)b[j] * cv[u];
-            }
-            const uint32_t q2 = bcast0<T>(((uint32_t)acc2[u] * n0inv) & RMASK);
-            nm.template mac<NLL>(acc2, u, q2);
-            acc2[u + 1] += acc2[u] >> RB;
-            low2[u] = (uint32_t)acc2[u] & RMASK;
+            for (int j = 0; j < NLL; ++j) { acc1[j] = acc1[j + U]; acc2[j] = acc2[j + U]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { acc1[NLL + u] = 0; acc2[NLL + u] = 0; }
+            if (++since == norm_blocks && blk != NB - 1) { RW::normalize(acc1); RW::normalize(acc2); since = 0; }
         }
-#pragma unroll
-        for (int j = 0; j < NLL; ++j) { acc1[j] = acc1[j + U]; acc2[j] = acc2[j + U]; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if constexpr (T > 1) {
-                acc1[NLL - U + u] += (uint64_t)from_next<T>(low1[u]);
-                acc2[NLL - U + u] += (uint64_t)from_next<T>(low2[u]);
-            }
-            acc1[NLL + u] = 0;
-            acc2[NLL + u] = 0;
-        }
-        if (++since == NORM_BLOCKS && blk != NB - 1) { RW::normalize(acc1); RW::normalize(acc2); since = 0; }
     }
     if constexpr (!std::is_same<PF, NoStream>::value) pf->template drain_from<NB>();
+    // + (M - 1) R, i.e. M - 1 on the second result digit (lazy columns: finish() carries)
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) acc2[j] += (uint64_t)nm.limb(j);
+    if (lane0) acc2[0] -= 1;
     RW::finish(acc1, a);
     RW::finish(acc2, b);
 }

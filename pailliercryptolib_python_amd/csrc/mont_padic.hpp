@@ -20,9 +20,6 @@
 #pragma once
 #include "mont_dev.hpp"
 
-#ifndef PADIC_FENCE_CHUNKS
-#define PADIC_FENCE_CHUNKS 0       // 1: the chunk-streaming (scheduler-fenced) rank update also below 48 limbs (register-lean builds)
-#endif
 
 namespace pai {
 
@@ -159,7 +156,7 @@ struct Padic {
             }
         }
         // remaining chunks: a pure rank-(2U or 3U) update
-        if constexpr (NL <= 48 && !PADIC_FENCE_CHUNKS) {
+        if constexpr (NL <= 48) {
 #pragma unroll
             for (int c = UC; c < NC; ++c) {
                 uint32_t xa[4] = {0, 0, 0, 0}, ya[4] = {0, 0, 0, 0};
@@ -424,32 +421,20 @@ struct Padic {
         }
     }
 
-    // squaring counterpart of mul_wbuf: quotient digits and the first result digit in strided scratch
-    PAI_DEV static void sqr_wbuf(uint4* A, uint4* B, MBuf M, MBuf Wb, const uint32_t* __restrict__ nm,
-                                 const uint32_t* __restrict__ pm1, uint32_t n0inv) {
-        {
-            uint64_t acc[NW];
-            zero(acc);
-            mm1_sqr_blocks<0>(acc, M, A, nm, n0inv);
-            finish_to_buf(acc, Wb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            uint64_t acc[NW];
-            mm2_init(acc, M);
-            uint32_t dummy[U];
+    // second result digit over B, the parked first digit back from the scratch column over A
+    PAI_DEV static void finish_into(const uint64_t (&acc)[NW], uint4* Bdst, uint4* Adst, MBuf Wb) {
+        uint64_t c = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) dummy[u] = 0;
-#pragma unroll 1
-            for (int blk = 0; blk < NB; ++blk) {
-                uint32_t xv[U], q[U];
-                digits(B, blk, xv);
-                block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);
-                if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
+        for (int ch = 0; ch < NC; ++ch) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t t = acc[4 * ch + k] + c;
+                w[k] = (uint32_t)t & RMASK;
+                c = t >> RB;
             }
-            wave_lds_fence();
-            finish_into(acc, B, A, Wb);
-            wave_lds_fence();
+            st(Bdst, ch, make_uint4(w[0], w[1], w[2], w[3]));
+            st(Adst, ch, Wb.p[(size_t)ch * Wb.stride]);
         }
     }
 
@@ -530,148 +515,6 @@ struct Padic {
     PAI_DEV static void sqr_apart_dispatch(uint64_t (&acc)[NW], const uint4* X, const uint32_t (&xv)[U], int blk) {
         if (blk == B) sqr_apart<B>(acc, X, xv);
         else if constexpr (B + 1 < NB) sqr_apart_dispatch<B + 1>(acc, X, xv, blk);
-    }
-    PAI_DEV static void sqr_sym_wbuf(uint4* A, uint4* B, MBuf M, MBuf Wb, const uint32_t* __restrict__ nm,
-                                     const uint32_t* __restrict__ pm1, uint32_t n0inv) {
-        {
-            uint64_t acc[NW];
-            zero(acc);
-            uint32_t dummy[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) dummy[u] = 0;
-#pragma unroll 1
-            for (int blk = 0; blk < NB; ++blk) {
-                uint32_t xv[U], q[U];
-                digits(A, blk, xv);
-                sqr_apart_dispatch<0>(acc, A, xv, blk);
-                __builtin_amdgcn_sched_barrier(0);
-                block<false, 0, NL, false, false>(acc, A, dummy, A, dummy, nm, n0inv, nm, blk, q);
-                store_q(M, blk, q);
-                if (sqr1_normalize_after(blk)) normalize(acc);
-            }
-            finish_to_buf(acc, Wb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            uint64_t acc[NW];
-            mm2_init(acc, M);
-            uint32_t dummy[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) dummy[u] = 0;
-#pragma unroll 1
-            for (int blk = 0; blk < NB; ++blk) {
-                uint32_t xv[U], q[U];
-                digits(B, blk, xv);
-                block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);   // HI = 0: every limb doubled
-                if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
-            }
-            wave_lds_fence();
-            finish_into(acc, B, A, Wb);
-            wave_lds_fence();
-        }
-    }
-
-    // ---- register-lean variant (two waves per SIMD; EXPERIMENTAL — exercised by tools/padic_bench.hip only: it gains
-    // 10 % in isolation and nothing inside the decrypt kernel): quotient digits m stay in VGPRs (the first half is fully
-    // unrolled so that they can be indexed statically), the first result digit is parked in a global scratch
-    // column Wb while the second half runs, and the second digit is written straight over B.  LDS then holds
-    // only the digit pair itself (2 x NL limbs per lane).
-    template <int B_, bool SQR, class CSrc>
-    PAI_DEV static void mm1_unrolled(uint64_t (&acc)[NW], uint32_t (&m)[NL], const uint4* X, CSrc& csrc,
-                                     const uint32_t* __restrict__ nm, uint32_t n0inv) {
-        if constexpr (B_ < NB) {
-            uint32_t xv[U], q[U], dummy[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) dummy[u] = 0;
-            if constexpr (SQR) {
-                digits(X, B_, xv);
-                block<true, U * B_, U * (B_ + 1), false, false, true>(acc, X, xv, X, dummy, nm, n0inv, nm, B_, q);
-            } else {
-                csrc(B_, xv);
-                block<true, 0, NL, false, false>(acc, X, xv, X, dummy, nm, n0inv, nm, B_, q);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) m[U * B_ + u] = q[u];
-            if (SQR ? sqr1_normalize_after(B_) : (B_ != NB - 1 && ((B_ + 1) * U) % P1 == 0)) normalize(acc);
-            mm1_unrolled<B_ + 1, SQR>(acc, m, X, csrc, nm, n0inv);
-        }
-    }
-    PAI_DEV static void init_from_m(uint64_t (&acc)[NW], const uint32_t (&m)[NL]) {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) acc[j] = (uint64_t)(RMASK - m[j]);
-        acc[0] += 1;
-#pragma unroll
-        for (int j = NL; j < NW; ++j) acc[j] = 0;
-    }
-    PAI_DEV static void finish_into(const uint64_t (&acc)[NW], uint4* Bdst, uint4* Adst, MBuf Wb) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-            uint32_t w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t t = acc[4 * ch + k] + c;
-                w[k] = (uint32_t)t & RMASK;
-                c = t >> RB;
-            }
-            st(Bdst, ch, make_uint4(w[0], w[1], w[2], w[3]));
-            st(Adst, ch, Wb.p[(size_t)ch * Wb.stride]);
-        }
-    }
-    PAI_DEV static void sqr_lean(uint4* A, uint4* B, MBuf Wb, const uint32_t* __restrict__ nm,
-                                 const uint32_t* __restrict__ pm1, uint32_t n0inv) {
-        uint32_t m[NL];
-        {
-            uint64_t acc[NW];
-            zero(acc);
-            int none = 0;
-            mm1_unrolled<0, true>(acc, m, A, none, nm, n0inv);
-            finish_to_buf(acc, Wb);
-        }
-        uint64_t acc[NW];
-        init_from_m(acc, m);
-        uint32_t dummy[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) dummy[u] = 0;
-#pragma unroll 1
-        for (int blk = 0; blk < NB; ++blk) {
-            uint32_t xv[U], q[U];
-            digits(B, blk, xv);
-            block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);
-            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
-        }
-        wave_lds_fence();
-        finish_into(acc, B, A, Wb);
-        wave_lds_fence();
-    }
-    template <class CSrc, class DSrc>
-    PAI_DEV static void mul_lean(uint4* A, uint4* B, MBuf Wb, CSrc&& csrc, DSrc&& dsrc, const uint32_t* __restrict__ nm,
-                                 const uint32_t* __restrict__ pm1, uint32_t n0inv) {
-        uint32_t m[NL];
-        {
-            uint64_t acc[NW];
-            zero(acc);
-            mm1_unrolled<0, false>(acc, m, A, csrc, nm, n0inv);
-            finish_to_buf(acc, Wb);
-        }
-        uint64_t acc[NW];
-        init_from_m(acc, m);
-        uint32_t xn[U], yn[U];
-        dsrc(0, xn);
-        csrc(0, yn);
-#pragma unroll 1
-        for (int blk = 0; blk < NB; ++blk) {
-            uint32_t xv[U], yv[U], q[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { xv[u] = xn[u]; yv[u] = yn[u]; }
-            dsrc(blk + 1 < NB ? blk + 1 : blk, xn);
-            csrc(blk + 1 < NB ? blk + 1 : blk, yn);
-            block<true, 0, NL, true, true>(acc, A, xv, B, yv, nm, n0inv, pm1, blk, q);
-            if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
-        }
-        wave_lds_fence();
-        finish_into(acc, B, A, Wb);
-        wave_lds_fence();
     }
 
     // ---- both halves of the product rule in ONE pass over the row blocks -------------------------------------------
@@ -829,146 +672,6 @@ struct Padic {
                                      const uint32_t* __restrict__ pm1, uint32_t n0inv) {
         if constexpr (FUSED) sqr_fused(A, B, nm, pm1, n0inv);
         else sqr_rolled_wbuf(A, B, M, Wb, nm, pm1, n0inv);
-    }
-    template <bool FUSED>
-    PAI_DEV static void sqr_sym_w(uint4* A, uint4* B, MBuf M, MBuf Wb, const uint32_t* __restrict__ nm,
-                                  const uint32_t* __restrict__ pm1, uint32_t n0inv) {
-        if constexpr (FUSED) sqr_sym_fused(A, B, nm, pm1, n0inv);
-        else sqr_sym_wbuf(A, B, M, Wb, nm, pm1, n0inv);
-    }
-
-    // (A, B) <- (A, B)^2 with the quotient digits of the first half in REGISTERS: both halves of the squaring are fully
-    // unrolled anyway (mm1_sqr_blocks / mm2_sqr), so m[] is indexed statically and never needs a buffer.  With the
-    // product's quotient digits parked in a global scratch column (mul() on a strided MBuf) the LDS then holds only the
-    // digit pair itself: 2 x NL limbs per lane, 72 KB per workgroup at 36 limbs — TWO workgroups per CU (round 4,
-    // kernels_padic.hpp MODE PADIC_REGM).  Unlike sqr_lean the first result digit w stays in registers too.
-    PAI_DEV static void sqr_regm(uint4* A, uint4* B, const uint32_t* __restrict__ nm, const uint32_t* __restrict__ pm1,
-                                 uint32_t n0inv) {
-        uint32_t m[NL], w[NL], v[NL];
-        {
-            uint64_t acc[NW];
-            zero(acc);
-            int none = 0;
-            mm1_unrolled<0, true>(acc, m, A, none, nm, n0inv);
-            finish(acc, w);
-        }
-        {
-            uint64_t acc[NW];
-            init_from_m(acc, m);
-            uint32_t dummy[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) dummy[u] = 0;
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
-                uint32_t xv[U], q[U];
-                digits(B, blk, xv);
-                block<true, 0, 0, false, true>(acc, A, xv, A, dummy, nm, n0inv, pm1, blk, q);   // HI = 0: every limb doubled
-                if (blk != NB - 1 && ((blk + 1) * U) % P2 == 0) normalize(acc);
-            }
-            finish(acc, v);
-        }
-        wave_lds_fence();
-        store_digit(A, w);
-        store_digit(B, v);
-        wave_lds_fence();
-    }
-
-    // (a, b) <- (a, b)^2 entirely in registers, product scanning (Comba): column k of  a^2 + m p  and of
-    // 2 a b - m + R p + m' p  is summed in two lazy 64-bit accumulators (s: the doubled limb pairs, once; d: carry, square /
-    // constant terms, quotient products), the quotient digit falls out of the column's low word, and the column is folded as
-    //     sum = d + 2 (s mod 2^29),   d' = sum >> 29,   s' = s >> 29   (the doubled carry stays with the doubled accumulator)
-    // (s <= NL 2^58 + 2^36, d <= (NL + 1) 2^58 + 2^36: nothing wraps for NL <= 62).  No accumulator window, no LDS or scratch
-    // traffic, ~5 NL + 30 live registers; the modulus limbs are the SGPR array of the caller (p - 1 differs from p in limb
-    // 0 only, p being odd).  Bounds as in the row-wise forms: a, b < 2p + eps in, same out.
-    // One pass of the product-scanning squaring.  SECOND = false: w = (a^2 + m p) / R with the quotient digits to mq;
-    // SECOND = true: v = (2 a b - min + R p + m' p) / R.  x = a, y = a (first) or b (second), dbl = 2 y.
-    // Column k: the first part (limb products, independent of the quotient digits) is accumulated ONE COLUMN AHEAD,
-    // statement by statement between the quotient products of column k - 1: two dependent chains per wave instead of one
-    // (a lone chain of v_mad_u64_u32 is latency-bound: the first version of this routine ran at 5.8 cycles per multiply with
-    // two waves per SIMD whatever its instruction count).
-    template <bool SECOND>
-    PAI_DEV static void comba_pass(uint32_t (&out)[NL], uint32_t (&mq)[NL], const uint32_t (&x)[NL], const uint32_t (&y)[NL],
-                                   const uint32_t (&dbl)[NL], const uint32_t (&min)[NL], const uint32_t* __restrict__ nm, uint32_t n0inv) {
-        constexpr int PW = SECOND ? 3 : 2;                                   // units per index of a full column
-        auto lo_of = [](int k) { return k < NL ? 0 : k - NL + 1; };
-        auto hi_of = [](int k) { return k < NL ? k : NL - 1; };
-        auto central = [](int k) { return k >= 0 && k < 2 * NL - 1 && PW * comba_terms(k) > 63; };
-        // first-part term t of column k (returns false past the end): outer columns add to `f` (doubled limbs), central ones to `s`
-        auto first_count = [&](int k) -> int {
-            if (k >= 2 * NL - 1) return 0;
-            if (SECOND) return hi_of(k) - lo_of(k) + 1;
-            return (k + 1) / 2 - lo_of(k) + (k % 2 == 0 ? 1 : 0);           // pairs i < k - i, then the square of an even column
-        };
-#ifndef PADIC_COMBA_CHAINS
-#define PADIC_COMBA_CHAINS 2         // dependent chains per wave: 2 (quotient products / next column's first part) or 4 (each split by parity)
-#endif
-        constexpr bool SPLIT = PADIC_COMBA_CHAINS == 4;
-        uint64_t carry = 0, s = 0, f = 0, fn = 0, sn = 0;
-        // column 0's first part
-        if (SECOND) f = (uint64_t)x[0] * dbl[0];
-        else f = (uint64_t)x[0] * x[0];
-#pragma unroll
-        for (int k = 0; k < 2 * NL - 1; ++k) {
-            const int lo = lo_of(k), hi = hi_of(k);
-            const bool cen = central(k), cen_n = central(k + 1);
-            uint64_t d = carry, d1 = 0, x1 = 0;                             // d1 / x1: the odd terms' chains (SPLIT)
-            if (SECOND) d += (k < NL ? (uint64_t)((RMASK - min[k]) + (k == 0 ? 1u : 0u)) : (uint64_t)(nm[k - NL] - (k == NL ? 1u : 0u)));
-            fn = 0;
-            sn = cen ? (s >> RB) : 0;                                       // (the doubled carry stays with the doubled accumulator)
-            const int nq = (hi - lo + 1) - (k < NL ? 1 : 0);                 // quotient products of this column
-            const int nf = first_count(k + 1);
-            const int lo_n = lo_of(k + 1);
-#pragma unroll
-            for (int t = 0; t < (nq > nf ? nq : nf); ++t) {
-                const bool odd = SPLIT && (t & 1);
-                if (t < nq) (odd ? d1 : d) += (uint64_t)mq[lo + t] * nm[k - lo - t];
-                if (t < nf) {
-                    const int kn = k + 1;
-                    const int i = lo_n + t;
-                    if (SECOND || 2 * i < kn) {
-                        const uint64_t pr = (uint64_t)x[i] * (cen_n ? y[kn - i] : dbl[kn - i]);
-                        if (odd) x1 += pr;
-                        else if (cen_n) sn += pr;
-                        else fn += pr;
-                    } else {
-                        fn += (uint64_t)x[kn / 2] * x[kn / 2];                   // the square of an even column (last term)
-                    }
-                }
-            }
-            if (SPLIT) {
-                asm volatile("" : "+v"(d1), "+v"(x1));                      // (keeps the optimiser from re-associating the four chains into two)
-                d += d1;
-                if (cen_n) sn += x1; else fn += x1;
-            }
-            uint64_t sum = d + f + (cen ? ((uint64_t)((uint32_t)s & RMASK) << 1) : 0);
-            if (k < NL) {
-                mq[k] = ((uint32_t)sum * n0inv) & RMASK;
-                sum += (uint64_t)mq[k] * nm[0];
-            } else {
-                out[k - NL] = (uint32_t)sum & RMASK;
-            }
-            carry = sum >> RB;
-            if (cen && !cen_n) { carry += sn << 1; sn = 0; }              // leaving the central band
-            f = fn;
-            s = sn;
-        }
-        out[NL - 1] = (uint32_t)carry + (SECOND ? nm[NL - 1] : 0u);
-    }
-    PAI_DEV static constexpr int comba_terms(int k) { return k < NL ? k + 1 : 2 * NL - 1 - k; }
-    PAI_DEV static void sqr_comba(uint32_t (&a)[NL], uint32_t (&b)[NL], const uint32_t* __restrict__ nm, uint32_t n0inv) {
-        uint32_t m[NL], w[NL], m2[NL], v[NL], dbl[NL];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) dbl[j] = a[j] << 1;
-        comba_pass<false>(w, m, a, a, dbl, m, nm, n0inv);
-#pragma unroll
-        for (int j = 0; j < NL; ++j) dbl[j] = b[j] << 1;
-        comba_pass<true>(v, m2, a, b, dbl, m, nm, n0inv);
-#pragma unroll
-        for (int j = 0; j < NL; ++j) { a[j] = w[j]; b[j] = v[j]; }
-    }
-    PAI_DEV static void load_digit(const uint4* x, uint32_t (&r)[NL]) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { const uint4 t = ld(x, c); r[4 * c] = t.x; r[4 * c + 1] = t.y; r[4 * c + 2] = t.z; r[4 * c + 3] = t.w; }
     }
 
     // (A, B) <- (A, B)^2

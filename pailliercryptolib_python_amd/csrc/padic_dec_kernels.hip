@@ -1,5 +1,5 @@
 // Instantiations of the digit-pair decrypt kernel (kernels_padic.hpp).  Own translation unit: the kernels are large
-// (seconds of compile time each) and their scheduler flags can be varied independently (build.py, tools/build_variants.sh).
+// (seconds of compile time each) and their scheduler flags can be varied independently (build.py).
 #include "geo_ops.hpp"
 #include "kernels_padic.hpp"
 
@@ -16,19 +16,9 @@ int padic_nl_for_prime_bits(int bits) {
     return 0;
 }
 size_t padic_table_words(int nl, size_t blocks) { return (size_t)(PADIC_TBL_ENTRIES + 1) * 2 * nl * blocks * BLOCK_THREADS; }
-#ifndef PADIC_DEC36_MODE
-#define PADIC_DEC36_MODE PADIC_LDS_M      // PADIC_REGM: digit pair only in LDS, two workgroups per CU (A/B: tools/variant_dec.sh)
-#endif
-int padic_blocks_per_cu(int nl) { return (nl <= 36 && PADIC_DEC36_MODE != PADIC_LDS_M) ? 2 : 1; }
-size_t padic_scratch_words(int nl, size_t blocks) {
-    return (nl <= 36 && PADIC_DEC36_MODE == PADIC_LDS_M) ? 0 : 2 * (size_t)nl * blocks * BLOCK_THREADS;
-}
-#ifndef PADIC_U72
-#define PADIC_U72 8
-#endif
-#ifndef PADIC_U36
-#define PADIC_U36 12     // row-block size of the 36-limb decrypt kernel (A/B r04: 4-row blocks, profiles/r04/README.md)
-#endif
+int padic_blocks_per_cu(int) { return 1; }
+size_t padic_scratch_words(int nl, size_t blocks) { return nl <= 36 ? 0 : (size_t)nl * blocks * BLOCK_THREADS; }
+// rows per block: 12 at 24 / 36 limbs (4-row blocks: 506.9 vs 477.8 ms per 2^20, profiles/r04/README.md), 8 at 56 / 72
 template <int NL, int U, int MODE>
 static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table) {
     constexpr int bytes = (MODE == PADIC_LDS_M ? 3 : 2) * NL * BLOCK_THREADS * 4 + 2 * NL * 4;
@@ -39,10 +29,10 @@ static void launch_padic(hipStream_t s, int gridx, const DecPadicParams& P, cons
 bool launch_dec_a_padic(int nl, hipStream_t s, int gridx, const DecPadicParams& P, const uint32_t* ct,
                         uint32_t* u_out, int n, uint32_t* table) {
     switch (nl) {
-        case 24: launch_padic<24, 12, PADIC_DEC36_MODE>(s, gridx, P, ct, u_out, n, table); return true;
-        case 36: launch_padic<36, PADIC_U36, PADIC_DEC36_MODE>(s, gridx, P, ct, u_out, n, table); return true;
+        case 24: launch_padic<24, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
+        case 36: launch_padic<36, 12, PADIC_LDS_M>(s, gridx, P, ct, u_out, n, table); return true;
         case 56: launch_padic<56, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
-        case 72: launch_padic<72, PADIC_U72, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
+        case 72: launch_padic<72, 8, PADIC_WBUF>(s, gridx, P, ct, u_out, n, table); return true;
         default: return false;
     }
 }

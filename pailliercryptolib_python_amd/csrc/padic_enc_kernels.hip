@@ -5,17 +5,11 @@
 
 namespace pai {
 
-#ifndef PAI_ENC_U
-#define PAI_ENC_U 8
-#endif
-using L72 = EncLaunch<72, PAI_ENC_U>;     // rows per block of the 72-limb products: 8
+using L72 = EncLaunch<72, 8>;     // rows per block of the 72-limb products: 8
 // k_encrypt_padic runs 12-row blocks: with the fused product rule (two accumulator windows, 320+ registers, parked in
 // AGPRs between row blocks) fewer, larger blocks mean fewer window round trips — 67.2 vs 69.8 ms per 2^20; ct x pt
 // prefers 8 rows (4.87 vs 5.07 ms per 65536) and r^n does not care (144-150 ms per 65536 either way)
-#ifndef PAI_ENCRYPT_U
-#define PAI_ENCRYPT_U 12
-#endif
-using L72E = EncLaunch<72, PAI_ENCRYPT_U>;
+using L72E = EncLaunch<72, 12>;
 
 int padic_enc_nl_for_n_bits(int bits) {
     if (bits >= 700 && RB * 36 >= bits + 20) return 36;

@@ -317,6 +317,34 @@ struct ScopedKernelTimer {
     }
 };
 
+// ---- run-time knobs ----------------------------------------------------------------------
+// Sizing knobs have their own variables (PAI_FB_CACHE_MB, PAI_FB_TABLE_MB, PAI_FB_BIG_KEYS, PAI_FB_SMALL_TABLE_MB,
+// PAI_LATENCY_MAX, PAI_LAT_ADD_MAX, PAI_POW2_DIGIT_MIN).  Everything the tests and probes use to steer a call onto a
+// particular path lives in two lists, read at every use (tests change them between calls):
+//   PAI_DISABLE="padic,pair,..."   engines / forms to leave out: padic (digit-pair engines: lane-group and wide fallbacks
+//                                  serve), pair, pair_ctmul, wide, gform (plain fixed-base tables), fb_chain, lat_dense, lat_enc_m1
+//   PAI_TUNE="name=value,..."      fb_wbits, fb_digit_wbits, lat_fb_wbits, fb_gform_k, invert_chunk, mexp_wbits, mexp_lanes,
+//                                  mexp_by_rows, lat_rl, lat_mul_rl, lat_enc_tree (largest batch of that small-batch form, 0 = off)
+static const char* list_find(const char* list, const char* name) {       // -> the character behind `name` in the list, or NULL
+    if (!list) return nullptr;
+    const size_t n = std::strlen(name);
+    for (const char* p = list; *p;) {
+        while (*p == ',' || *p == ' ') ++p;
+        const char* e = p;
+        while (*e && *e != ',') ++e;
+        if ((size_t)(e - p) >= n && std::strncmp(p, name, n) == 0 && (p[n] == '=' || p[n] == ',' || p[n] == 0 || p[n] == ' ')) return p + n;
+        p = e;
+    }
+    return nullptr;
+}
+static bool knob_disabled(const char* name) { return list_find(std::getenv("PAI_DISABLE"), name) != nullptr; }
+static bool knob_tune(const char* name, long long* v) {
+    const char* q = list_find(std::getenv("PAI_TUNE"), name);
+    if (!q || *q != '=') return false;
+    *v = std::strtoll(q + 1, nullptr, 10);
+    return true;
+}
+
 // Batches up to this many elements take the latency path: every integer spread over 16-64 lanes, (element, prime)
 // pairs filling the device instead of lanes (PAI_LATENCY_MAX overrides; 0 disables it).  Measured on MI355X at
 // 2048-bit keys: decrypt 3.8 ms up to 512 elements, 7.0 ms at 2048, 12.2 ms at 4096 (decrypt takes the path up to twice
@@ -453,6 +481,7 @@ struct pai_pubkey {
     static constexpr int TREE_LEVELS = 40;
     uint32_t* d_tree_c = nullptr;
     uint32_t* d_tree_fix = nullptr;
+    mutable uint32_t* d_rpow = nullptr;  // R^m mod n^2 for |m| <= RPOW_SPAN in limb form (k_addn), built by the first pai_ct_addn
     mutable bool fb_ready = false;     // fixed-base tables are built by the first obfuscating call (build_fb_tables)
     mutable size_t fb_bytes = 0;       // device bytes of the built tables (the per-device table cache accounts with it)
     mutable size_t fb_table_budget = 0;  // non-zero: this build takes the small operating point (build_fb_tables)
@@ -732,34 +761,30 @@ int pai_modexp_fixed(pai_modulus* m, const uint32_t* d_base, const uint32_t* h_e
     });
 }
 // window width of the per-element-exponent kernels: table build 2^w - 2 products, then w squarings + 1 product per window
-static bool lat_dense_disabled() {                  // PAI_LAT_DENSE=0: small-batch stage A always on one integer per wavefront
-    const char* env = std::getenv("PAI_LAT_DENSE");
-    return env && env[0] == '0';
+static bool lat_dense_disabled() {                  // PAI_DISABLE=lat_dense: small-batch stage A always on one integer per wavefront
+    return knob_disabled("lat_dense");
 }
-static size_t lat_rl_max(size_t ncu) {              // PAI_LAT_RL: largest batch of the wave-pair small-batch decryption (0 disables)
-    if (const char* env = std::getenv("PAI_LAT_RL")) return (size_t)std::strtoull(env, nullptr, 10);
-    return ncu;
+static size_t lat_rl_max(size_t ncu) {              // PAI_TUNE lat_rl: largest batch of the wave-pair small-batch decryption (0 disables)
+    long long v;
+    return knob_tune("lat_rl", &v) ? (size_t)v : ncu;
 }
-static size_t lat_enc_tree_max(size_t ncu) {        // PAI_LAT_ENC_TREE: largest batch of the wave-shared small-batch encryption (0 disables)
-    if (const char* env = std::getenv("PAI_LAT_ENC_TREE")) return (size_t)std::strtoull(env, nullptr, 10);
+static size_t lat_enc_tree_max(size_t ncu) {        // PAI_TUNE lat_enc_tree: largest batch of the wave-shared small-batch encryption (0 disables)
+    long long v;
     (void)ncu;
-    return (size_t)1 << 30;                         // measured ahead over the whole latency range (2048-bit keys: 0.29 vs 0.98 ms up to 256
+    return knob_tune("lat_enc_tree", &v) ? (size_t)v : (size_t)1 << 30;                         // measured ahead over the whole latency range (2048-bit keys: 0.29 vs 0.98 ms up to 256
 }                                                   // elements, 0.54 vs 1.01 at 1024, 1.63 vs 1.91 at 4096; profiles/r04/lat_enc_tree.jsonl)
-static size_t lat_mul_rl_max(size_t ncu) {          // PAI_LAT_MUL_RL: largest batch of the wave-pair small-batch ct * pt (0 disables)
-    if (const char* env = std::getenv("PAI_LAT_MUL_RL")) return (size_t)std::strtoull(env, nullptr, 10);
-    return 2 * ncu;
+static size_t lat_mul_rl_max(size_t ncu) {          // PAI_TUNE lat_mul_rl: largest batch of the wave-pair small-batch ct * pt (0 disables)
+    long long v;
+    return knob_tune("lat_mul_rl", &v) ? (size_t)v : 2 * ncu;
 }
-static bool lat_enc_m1_disabled() {                 // PAI_LAT_ENC_M1=0: the wave-shared small-batch encryption on the conventional context
-    const char* env = std::getenv("PAI_LAT_ENC_M1");
-    return env && env[0] == '0';
+static bool lat_enc_m1_disabled() {                 // PAI_DISABLE=lat_enc_m1: the wave-shared small-batch encryption on the conventional context
+    return knob_disabled("lat_enc_m1");
 }
-static bool fb_chain_disabled() {                   // PAI_DISABLE_FB_CHAIN=1: window bases by the table kernel's own squaring chain
-    const char* env = std::getenv("PAI_DISABLE_FB_CHAIN");
-    return env && env[0] == '1';
+static bool fb_chain_disabled() {                   // PAI_DISABLE=fb_chain: window bases by the table kernel's own squaring chain
+    return knob_disabled("fb_chain");
 }
-static bool pair_ctmul_disabled() {                 // PAI_DISABLE_PAIR_CTMUL=1: ct * pt above 2048-bit keys as products modulo n^2
-    const char* env = std::getenv("PAI_DISABLE_PAIR_CTMUL");
-    return env && env[0] == '1';
+static bool pair_ctmul_disabled() {                 // PAI_DISABLE=pair_ctmul: ct * pt above 2048-bit keys as products modulo n^2
+    return knob_disabled("pair_ctmul");
 }
 static int var_window_bits(int ebits_max) { return ebits_max <= 24 ? 2 : (ebits_max <= 80 ? 3 : (ebits_max <= 240 ? 4 : 5)); }
 
@@ -842,7 +867,7 @@ uint32_t* upload_vec(const std::vector<uint32_t>& h) {
 // radix-29 rows of ms.nl limbs).  Two levels when the window width is even: half-width windows
 // S[i][e] = hs^(e 2^(h i)) (2 J windows of 2^h entries, binary method, a few thousand entries), then ONE product per
 // entry, T[j][hi 2^h + lo] = S[2 j + 1][hi] * S[2 j][lo] (k_fb_expand).  Odd widths (only reachable through
-// PAI_FB_WBITS) keep the one-level build.
+// PAI_TUNE fb_wbits) keep the one-level build.
 uint32_t* build_lane_group_fb(const pai_pubkey* pk, const ModSetup& ms, int wb, int J) {
     const int nl = ms.nl;
     const size_t ENT = (size_t)1 << wb;
@@ -1030,18 +1055,17 @@ static const ModSetup* lat_add_ctx(const pai_pubkey* pk, size_t N, bool tagged, 
 // ciphertext or public key on the receiving side of a federated exchange — never pays the multi-GB table.
 // g-factoring of the finished digit-form table (kernels_padic_enc.hpp: k_fb_g_prefix / k_fb_g_finish + the wave-parallel
 // extended GCD on the chunk totals): entries (a, d) become (a, t = d a^-1 mod n), after which every table product of an
-// encryption is the 4 NL^2 rule.  Slabs bound the scratch (one digit per entry).  PAI_FB_GFORM=0 keeps the plain table;
+// encryption is the 4 NL^2 rule.  Slabs bound the scratch (one digit per entry).  PAI_DISABLE=gform keeps the plain table;
 // any failure (a non-unit would mean a broken key) leaves the table as it was built.
 static void gfactor_digit_table(pai_pubkey* pk, size_t NE, int dwb) {
-    if (const char* env = std::getenv("PAI_FB_GFORM")) { if (env[0] == '0') return; }
+    if (knob_disabled("gform")) return;
     if (!padic_enc_gform_supported()) return;
     const int pnl = pk->penc_nl;
     // chunk length: divides the entries of a window, hence NE; one extended GCD per K entries.  64 measured best (first 2^20
     // encryption of a 2048-bit key 0.188 s; 256-entry chunks measured slower)
     int K = (int)std::min<size_t>(64, (size_t)1 << dwb);
-    if (const char* env = std::getenv("PAI_FB_GFORM_K")) {               // experiments: a power of two up to the window's entry count
-        const int v = std::atoi(env);
-        if (v >= 2 && (v & (v - 1)) == 0 && (size_t)v <= ((size_t)1 << dwb)) K = v;
+    if (long long v; knob_tune("fb_gform_k", &v)) {                     // a power of two up to the window's entry count
+        if (v >= 2 && (v & (v - 1)) == 0 && (size_t)v <= ((size_t)1 << dwb)) K = (int)v;
     }
     const int tw = pk->n_words;
     if ((tw + 63) / 64 > 4) return;                                      // inv_eea instantiations: up to 256 words
@@ -1087,7 +1111,7 @@ static void gfactor_digit_table(pai_pubkey* pk, size_t NE, int dwb) {
 
 // the same for the lane-group pair table of keys above 2048 bits (kernels_pair.hpp: k_pair_g_prefix / k_pair_g_finish)
 static void gfactor_pair_table(pai_pubkey* pk, size_t NE, int wb) {
-    if (const char* env = std::getenv("PAI_FB_GFORM")) { if (env[0] == '0') return; }
+    if (knob_disabled("gform")) return;
     const int nl = pk->pair_nl;
     const int K = (int)std::min<size_t>(64, (size_t)1 << wb);
     const int tw = pk->n_words;
@@ -1261,7 +1285,7 @@ static void build_fb_tables_body(pai_pubkey* pk) {
     }
     int wb = pk->penc_nl ? 12 : 16;
     while (wb > 4 && (double)((randbits + wb - 1) / wb) * (double)((size_t)1 << wb) * pk->msq.nl * 4.0 > lg_budget) wb -= (wb > 8 ? 2 : 1);
-    if (const char* env = std::getenv("PAI_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 16) wb = v; }
+    if (long long v; knob_tune("fb_wbits", &v) && v >= 4 && v <= 16) wb = (int)v;
     pk->fb_wbits = wb;
     const int J = (randbits + wb - 1) / wb;
     const size_t ENT = (size_t)1 << wb;
@@ -1288,7 +1312,7 @@ static void build_fb_tables_body(pai_pubkey* pk) {
         // budget — 1/32 of the device memory unless PAI_FB_TABLE_MB says otherwise (MI355X, 288 GB:
         // 9 GB => 2048-bit keys get 18 bits, 57 windows x 262144 entries x 576 B = 8.6 GB; measured
         // k_encrypt per 2^20: 109 / 95 / 84 / 75 / 70 ms at 12 / 14 / 16 / 18 / 20 bits).
-        // PAI_FB_DIGIT_WBITS pins the width (<= 12, or an even value up to 20).
+        // PAI_TUNE fb_digit_wbits pins the width (<= 12, or an even value up to 20).
         const size_t ent_bytes = 2 * (size_t)pnl * 4;
         auto table_bytes = [&](int w) { return (double)((randbits + w - 1) / w) * (double)((size_t)1 << w) * (double)ent_bytes; };
         size_t mem_free = 0, mem_total = 0;
@@ -1299,9 +1323,8 @@ static void build_fb_tables_body(pai_pubkey* pk) {
         int dwb = wb;
         for (int cand = 20; cand > 12; cand -= 2)
             if (table_bytes(cand) <= budget) { dwb = cand; break; }
-        if (const char* env = std::getenv("PAI_FB_DIGIT_WBITS")) {
-            int v = std::atoi(env);
-            if ((v >= 4 && v <= 12) || (v > 12 && v <= 20 && v % 2 == 0)) dwb = v;
+        if (long long v; knob_tune("fb_digit_wbits", &v)) {
+            if ((v >= 4 && v <= 12) || (v > 12 && v <= 20 && v % 2 == 0)) dwb = (int)v;
         }
         const int DJ = (randbits + dwb - 1) / dwb;
         pk->fbd_wbits = dwb;
@@ -1397,9 +1420,9 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             pk->d_tree_fix = upload_vec(hf);
         }
         // ---- base-n digit engine (kernels_padic_enc.hpp): raw / DJN encryption and ct * pt run on it when n fits 72
-        // limbs (PAI_DISABLE_PADIC=1 falls back to the lane-group kernels, which serve every other key size)
+        // limbs (PAI_DISABLE=padic falls back to the lane-group kernels, which serve every other key size)
         pk->penc_nl = padic_enc_nl_for_n_bits(hbn::bitlen(pk->n));
-        if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') pk->penc_nl = 0; }
+        if (knob_disabled("padic")) pk->penc_nl = 0;
         if (pk->penc_nl) {
             const int pnl = pk->penc_nl;
             pk->nmod.init(pk->n, pnl);
@@ -1421,10 +1444,10 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             pk->d_ct_kdig = upload_vec(kd);
         }
         if (!pk->penc_nl) {
-            // wider moduli: DJN obfuscation on base-n digit pairs spread over lane groups (PAI_DISABLE_PAIR=1: lane-group
+            // wider moduli: DJN obfuscation on base-n digit pairs spread over lane groups (PAI_DISABLE=pair: lane-group
             // products modulo n^2 as in round 1)
             pk->pair_nl = pair_nl_for_n_bits(hbn::bitlen(pk->n));
-            if (const char* env = std::getenv("PAI_DISABLE_PAIR")) { if (env[0] == '1') pk->pair_nl = 0; }
+            if (knob_disabled("pair")) pk->pair_nl = 0;
             if (pk->pair_nl) {
                 pk->npair.init(pk->n, pk->pair_nl);
                 pk->d_pair_nm1 = upload_r29(hbn::sub(pk->n, Limbs{1u}), pk->pair_nl);
@@ -1507,6 +1530,7 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_nsq_words) (void)hipFree(pk->d_nsq_words);
     if (pk->d_tree_c) (void)hipFree(pk->d_tree_c);
     if (pk->d_tree_fix) (void)hipFree(pk->d_tree_fix);
+    if (pk->d_rpow) (void)hipFree(pk->d_rpow);
     pk->prod_a.release();
     pk->prod_b.release();
     pk->lat_msq.release();
@@ -1600,18 +1624,18 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
             if (!pk->lat_fb_ready) {
                 // window width of the small-batch table: every window is one sequential product (~11 us at 2048-bit keys, 6 us on
                 // a minus-one context) of the call's latency; 12 bits = 86 windows x 4096 entries (0.2 GB at 2048-bit keys; 10
-                // bits: 103 windows, 60 MB; 14 bits: 74 windows, 0.7 GB).  PAI_LAT_FB_WBITS pins it (4..16).
+                // bits: 103 windows, 60 MB; 14 bits: 74 windows, 0.7 GB).  PAI_TUNE lat_fb_wbits pins it (4..16).
                 int lw = 12;
-                if (const char* env = std::getenv("PAI_LAT_FB_WBITS")) { int v = std::atoi(env); if (v >= 4 && v <= 16) lw = v; }
+                if (long long v; knob_tune("lat_fb_wbits", &v) && v >= 4 && v <= 16) lw = (int)v;
                 pk->lat_fb_wbits = lw;
                 pk->lat_fb_windows = (pk->randbits + pk->lat_fb_wbits - 1) / pk->lat_fb_wbits;
                 pk->lat_fb_ready = true;
             }
             // the four waves of a workgroup share one wave's integers (k_encrypt_tree: a quarter of the windows each, two
-            // levels of combining products); PAI_LAT_ENC_TREE=0 keeps one chain per integer
+            // levels of combining products); PAI_TUNE lat_enc_tree=0 keeps one chain per integer
             const bool tree = gl->t >= 16 && gl->t <= 64 && N <= lat_enc_tree_max((size_t)pk->dev.ncu);
             // ... and on a minus-one context of n^2 where one fits (ensure_lat_ctx): the table is converted once into that
-            // context's Montgomery form and the conventional copy is dropped (rebuilt only if PAI_LAT_ENC_M1 / _TREE ask for it)
+            // context's Montgomery form and the conventional copy is dropped (rebuilt only if PAI_DISABLE=lat_enc_m1 / PAI_TUNE lat_enc_tree ask for it)
             ensure_lat_ctx(pk);
             const bool m1 = tree && pk->lat_m1_ok && !lat_enc_m1_disabled();
             if ((m1 && !pk->d_lat_fb_m1) || (!m1 && !pk->d_lat_fb)) {
@@ -2162,6 +2186,62 @@ int pai_ct_mont_mul(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d
     });
 }
 
+// table of R^m mod n^2, |m| <= RPOW_SPAN, in limb form (caller holds pk->mu)
+static const uint32_t* rpow_table(const pai_pubkey* pk) {
+    if (pk->d_rpow) return pk->d_rpow;
+    const int nl = pk->msq.nl;
+    const Limbs one{1u};
+    hbn::Mont32 mt(pk->nsq);
+    const Limbs inv2 = hbn::shr(hbn::add(pk->nsq, one), 1);
+    const Limbs rinv = mt.powmod(inv2, hbn::from_u64((uint64_t)hbn::RB * (uint64_t)nl));
+    require(hbn::cmp(hbn::mulmod(rinv, pk->msq.R, pk->nsq), one) == 0, "R^-1 check failed");
+    std::vector<uint32_t> h((size_t)(2 * RPOW_SPAN + 1) * nl, 0);
+    auto put = [&](int m, const Limbs& v) {
+        const std::vector<uint32_t> r = hbn::to_r29(v, nl);
+        std::memcpy(&h[(size_t)(RPOW_SPAN + m) * nl], r.data(), (size_t)nl * 4);
+    };
+    Limbs up = one, dn = one;
+    put(0, one);
+    for (int m = 1; m <= RPOW_SPAN; ++m) {
+        up = hbn::mulmod(up, pk->msq.R, pk->nsq);
+        dn = hbn::mulmod(dn, rinv, pk->nsq);
+        put(m, up);
+        put(-m, dn);
+    }
+    pk->d_rpow = upload_vec(h);
+    return pk->d_rpow;
+}
+
+int pai_ct_addn(const pai_pubkey* pk, const uint32_t* const* h_ops, const int32_t* const* h_raise, int k, int tag0, int tag,
+                int dom_out, size_t N, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && h_ops && d_out, "NULL argument");
+        require(k >= 2 && k <= ADDN_MAX, "pai_ct_addn: between 2 and 16 operands per call");
+        for (int j = 0; j < k; ++j) require(h_ops[j] != nullptr, "pai_ct_addn: NULL operand");
+        require(!(h_raise && h_raise[0]) || tag0 == tag, "pai_ct_addn: a raised first operand must share the others' domain tag");
+        // every domain tag a tile can pass through must have its fix-up constant R^(1 + dom_out - c) in the table
+        const int c_lo = std::min(tag0, 1) + (k - 1) * std::min(tag - 1, 0), c_hi = std::max(tag0, 1) + (k - 1) * std::max(tag - 1, 0);
+        require(std::abs(2 - tag) <= RPOW_SPAN && std::abs(1 + dom_out - c_lo) <= RPOW_SPAN && std::abs(1 + dom_out - c_hi) <= RPOW_SPAN,
+                "pai_ct_addn: domain tags out of range");
+        if (N == 0) return;
+        DeviceScope scope_(pk->device);
+        const uint32_t* rpow;
+        {
+            std::lock_guard<std::mutex> lk(pk->mu);
+            rpow = rpow_table(pk);
+        }
+        AddnArgs A{};
+        for (int j = 0; j < k; ++j) { A.op[j] = h_ops[j]; A.raise[j] = h_raise ? h_raise[j] : nullptr; }
+        A.k = k; A.tag0 = tag0; A.tag = tag; A.dom_out = dom_out;
+        const GeoOps* g = pk->msq.geo;
+        g_last_times.clear();
+        ScopedKernelTimer t("k_addn", (hipStream_t)stream);
+        g->addn((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, A, d_out, (int)N, pk->ct_words, rpow);
+        t.stop();
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 int pai_pubkey_mont_bits(const pai_pubkey* pk, int* bits) {
     return guarded([&] {
         require(pk && bits, "NULL argument");
@@ -2246,7 +2326,7 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
         // members per lane: enough lanes to fill the device (one workgroup of 256 lanes per CU, several rounds), the
         // rest of the sharing goes into longer chunks (the squarings are shared by a chunk)
         size_t want_lanes = (size_t)pk->dev.ncu * lanes_per_wg * (digit ? 2 : 4);
-        if (const char* env = std::getenv("PAI_MEXP_LANES")) { const size_t v = (size_t)std::strtoull(env, nullptr, 10); if (v) want_lanes = v; }
+        if (long long v; knob_tune("mexp_lanes", &v) && v > 0) want_lanes = (size_t)v;
         size_t chunk = std::max<size_t>(1, (G * K + want_lanes - 1) / want_lanes);
         chunk = std::min(chunk, K);
         const size_t chunks = (K + chunk - 1) / chunk;
@@ -2264,7 +2344,7 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
                 const double cost = (double)((ebits_max + w - 1) / w) + (double)nsigns * (double)(((size_t)1 << w) - 2) / (double)M;
                 if (cost < best) { best = cost; wbits = w; }
             }
-            if (const char* env = std::getenv("PAI_MEXP_WBITS")) { const int v = std::atoi(env); if (v >= 1 && v <= 8) wbits = v; }
+            if (long long v; knob_tune("mexp_wbits", &v) && v >= 1 && v <= 8) wbits = (int)v;
         }
         const size_t table_bytes = bases * nsigns * ((size_t)1 << wbits) * 2 * (size_t)pnl * 4;
         if (table_bytes > mem_total / 8 || table_bytes + nlanes * (size_t)pk->ct_words * 4 > mem_free + pk->mexp_table.bytes + pk->mexp_partial.bytes)
@@ -2289,7 +2369,7 @@ int pai_ct_multiexp(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* 
             Q.ebits_max = ebits_max;
             Q.by_rows = 0;
             Q.wbits = wbits;
-            if (const char* env = std::getenv("PAI_MEXP_BY_ROWS")) Q.by_rows = env[0] == '1';
+            if (long long v; knob_tune("mexp_by_rows", &v)) Q.by_rows = v != 0;
             {
                 const size_t tl = bases * nsigns, tiles = (tl + BLOCK_THREADS - 1) / BLOCK_THREADS;
                 const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
@@ -2375,10 +2455,7 @@ static int ct_invert_impl(const pai_pubkey* pk, const uint32_t* d_ct, size_t N, 
         // way down level k holds (true inverse) * R^(2^k - 1) — the powers of R telescope, so the leaves come out as
         // plain canonical inverses.
         size_t top = 64;
-        if (const char* env = std::getenv("PAI_INVERT_CHUNK")) {     // test hook: where the tree stops
-            int k = std::atoi(env);
-            if (k >= 1 && k <= 65536) top = (size_t)k;
-        }
+        if (long long v; knob_tune("invert_chunk", &v) && v >= 1 && v <= 65536) top = (size_t)v;     // test hook: where the tree stops
         std::vector<size_t> cnt{N};
         while (cnt.back() > top) cnt.push_back((cnt.back() + 1) / 2);
         const int L = (int)cnt.size() - 1;
@@ -2464,7 +2541,7 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
         // both primes share the geometry of the wider one
         Limbs q2 = hbn::mul(q, q);
         sk->wide_nl = wide_nl_for_bits(hbn::bitlen(q2));       // 0: fall back to the lane-group kernel
-        if (const char* env = std::getenv("PAI_DISABLE_WIDE")) { if (env[0] == '1') sk->wide_nl = 0; }
+        if (knob_disabled("wide")) sk->wide_nl = 0;
         for (int w = 0; w < 2; ++w) {
             const Limbs& s = prime[w];
             Limbs s2 = hbn::mul(s, s);
@@ -2501,7 +2578,7 @@ int pai_privkey_create(const pai_pubkey* pk, const uint32_t* h_p, int p_words, c
         }
         // p-adic digit engine: digit pairs of R^(i+2) mod s^2 and s - 1 as limbs
         sk->padic_nl = padic_nl_for_prime_bits(std::max(hbn::bitlen(p), hbn::bitlen(q)));
-        if (const char* env = std::getenv("PAI_DISABLE_PADIC")) { if (env[0] == '1') sk->padic_nl = 0; }
+        if (knob_disabled("padic")) sk->padic_nl = 0;
         if (sk->padic_nl) {
             const int nl = sk->padic_nl;
             sk->padic_nd = (32 * pk->ct_words + hbn::RB * nl - 1) / (hbn::RB * nl);

@@ -209,6 +209,31 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_ct_mont_mul(self.h, _ptr(a), _ptr(b), bcast, a.shape[0], _ptr(out), _stream(self.device)))
         return out
 
+    def ct_addn(self, ops, raises=None, tag0: int = 0, tag: int = 0, dom_out: int = 0,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """prod_j ops[j][i]^(2^raises[j][i]) mod n^2 in one pass (pai_ct_addn: 2..16 operands, k - 1 products per element).
+        ops[0] holds x R^tag0, the others x R^tag, the result x R^dom_out; raises: None, or one int32 [N] device tensor (or
+        None) per operand."""
+        k = len(ops)
+        if not 2 <= k <= 16:
+            raise ValueError("ct_addn: between 2 and 16 operands")
+        n = ops[0].shape[0]
+        for t in ops:
+            self._chk(t, self.ct_words, "operand")
+            if t.shape[0] != n:
+                raise RuntimeError("Size mismatch")
+        ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in ops])
+        rz = None
+        if raises is not None and any(r is not None for r in raises):
+            for r in raises:
+                if r is not None and (r.dtype != torch.int32 or r.dim() != 1 or r.shape[0] != n or not r.is_contiguous()
+                                      or r.device != self.device):
+                    raise ValueError("raises: expected contiguous int32 [N] on %s" % self.device)
+            rz = (C.c_void_p * k)(*[None if r is None else r.data_ptr() for r in raises])
+        out = self.empty_ct(n) if out is None else out
+        _native.check(self.lib.pai_ct_addn(self.h, ptrs, rz, k, int(tag0), int(tag), int(dom_out), n, _ptr(out), _stream(self.device)))
+        return out
+
     def ct_retag(self, a: torch.Tensor, k_from: int, k_to: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x R^k_from -> x R^k_to (one product with the broadcast constant R^(1 + k_to - k_from)); k_to = 0 is the wire form."""
         if k_from == k_to:

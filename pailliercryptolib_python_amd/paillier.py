@@ -646,6 +646,75 @@ class PaillierEncryptedNumber:
                 x, e = prod, em
         return x.reshape(groups, W).contiguous(), e.reshape(groups)
 
+    # n-ary sums of at least this many elements per operand go through pai_ct_addn (below: the pairwise kernels, which serve
+    # small batches on the latency geometry)
+    ADDN_MIN = 4096
+
+    @staticmethod
+    def add_many(items) -> "PaillierEncryptedNumber":
+        """Extension: items[0] + items[1] + ... + items[k-1] for equally long ciphertext arrays of one key — the aggregation the
+        reference spells as a chain of __add__ (ipcl_python.py:365-381, 490-526; tests/ipcl_python_test.py:21-38) — in ONE
+        pass per 16 operands (pai_ct_addn: k - 1 products per element, one store, no intermediate arrays, the result in the
+        wire form).  Exponents are aligned to the per-element maximum as the chain does (:570-741), so ciphertext bits and
+        exponents equal those of the chain.  Operand sets whose alignment would cost more inside the one-pass kernel than in
+        the pairwise kernels (exponents that differ by more than a squaring per operand on average), short arrays and
+        broadcasts take the chain itself."""
+        items = list(items)
+        if not items:
+            raise ValueError("PaillierEncryptedNumber.add_many: nothing to add")
+        first = items[0]
+        if not all(isinstance(x, PaillierEncryptedNumber) for x in items):
+            raise TypeError("PaillierEncryptedNumber.add_many: operands must be PaillierEncryptedNumber")
+        k, n = len(items), len(first)
+        same = all(x.public_key == first.public_key and len(x) == n for x in items)
+
+        def chain():
+            acc = items[0]
+            for x in items[1:]:
+                acc = acc + x
+            return acc
+
+        if k < 3 or not same or n < PaillierEncryptedNumber.ADDN_MIN:
+            return chain()
+        E = items[0]._expo.astype(np.int64)
+        for x in items[1:]:
+            E = np.maximum(E, x._expo)
+        raises = [(E - x._expo).astype(np.int32) for x in items]
+        peak = [int(r.max()) for r in raises]
+        # one-pass cost of the alignment: a domain entry + max(raise) squarings per raised operand and tile
+        if sum(1 + p for p in peak if p > 0) > 2 * (k - 1):
+            return chain()
+        h = first._h()
+        acc_t, acc_tag, acc_raise = None, 0, None
+        pos = 0
+        while pos < k:
+            take = items[pos:pos + (16 if acc_t is None else 15)]
+            ops, tags, rz = [], [], []
+            for x, r, p in zip(take, raises[pos:pos + len(take)], peak[pos:pos + len(take)]):
+                t, tag = x.ciphertext()._raw()
+                ops.append(t)
+                tags.append(tag)
+                rz.append(torch.from_numpy(r).to(h.device) if p > 0 else None)
+            pos += len(take)
+            # operands 1.. share one tag (the most common one; the others are retagged: one product each, rare)
+            rest = tags if acc_t is not None else tags[1:]
+            tag = max(set(rest), key=rest.count) if rest else 0
+            for i in range(len(ops)):
+                own_first = acc_t is None and i == 0
+                if tags[i] != tag and not (own_first and rz[0] is None):
+                    ops[i] = h.ct_retag(ops[i], tags[i], tag)
+                    tags[i] = tag
+            if acc_t is not None:
+                ops, rz, tag0 = [acc_t] + ops, [None] + rz, acc_tag
+            else:
+                tag0 = tags[0]
+            last = pos >= k
+            # intermediate chunks keep their natural tag (no fix-up product); the final result is the wire form
+            dom_out = 0 if last else max(-DOM_MAX, min(DOM_MAX, tag0 + (len(ops) - 1) * (tag - 1)))
+            acc_t = h.ct_addn(ops, rz, tag0, tag, dom_out)
+            acc_tag = dom_out
+        return first._wrap(acc_t, E.astype(np.int32), n, dom=acc_tag, others=items[1:])
+
     def sum(self) -> "PaillierEncryptedNumber":
         """ipcl_python.py:746-762 (intended behaviour)."""
         out, e = self._aligned_tree(self._w, self._expo, 1)

@@ -21,6 +21,7 @@ from pailliercryptolib_python_amd import (
     hybridMode,
 )
 from pailliercryptolib_python_amd.bindings import ipclPublicKey
+from tests._util import tune
 
 pytestmark = pytest.mark.gpu
 
@@ -243,7 +244,7 @@ def test_reductions_match_the_oracle_bit_for_bit(fixed, mexp_min, monkeypatch):
     mexp_min = "1" sends every float matrix product through pai_ct_multiexp (large products take it by default)."""
     if mexp_min is not None:
         monkeypatch.setenv("PAI_MEXP_MIN_TERMS", mexp_min)
-        monkeypatch.setenv("PAI_MEXP_LANES", "3")                        # chunks of several members on these small shapes
+        tune(monkeypatch, "mexp_lanes", 3)                        # chunks of several members on these small shapes
     pk, sk, okey = fixed
     rng = np.random.default_rng(77)
     for N in (1, 2, 5, 8, 13):
@@ -329,7 +330,7 @@ def test_matrix_product_routes_agree_at_other_key_sizes(bits, monkeypatch):
     got = {}
     for route, env in (("multiexp", "1"), ("terms", str(1 << 60))):
         monkeypatch.setenv("PAI_MEXP_MIN_TERMS", env)
-        monkeypatch.setenv("PAI_MEXP_LANES", "5")
+        tune(monkeypatch, "mexp_lanes", 5)
         a, b, c = en @ y, x @ en_y, en.dot(v)
         got[route] = [(ct_ints(t), list(np.atleast_1d(t.exponent()))) for t in (a, b, c)]
         assert np.allclose(np.array(sk.decrypt(a)).reshape(m, k), x @ y) and np.allclose(np.array(sk.decrypt(b)).reshape(m, k), x @ y)
@@ -750,3 +751,53 @@ def test_failed_inversion_is_raised_on_its_own_result(fixed):
         sk.decrypt(good - bad)                                             # ct - ct inverts the subtrahend
     assert sk.decrypt(good - good) == [0.0, 0.0, 0.0]
     assert sk.decrypt(res_good + good) == [-1.5, 2.0, -3.25]
+
+
+def test_add_many_equals_the_chain_of_additions(fixed, monkeypatch):
+    """PaillierEncryptedNumber.add_many (pai_ct_addn: the k-party aggregation in one pass) returns the ciphertext bits and
+    exponents of the reference's chain a + b + c + ... (ipcl_python.py:365-381, 490-526), which the oracle restates:
+    equal exponents, mixed exponents within the one-pass budget, lazily tagged operands, more than 16 operands, and the
+    fallbacks (wide exponent spread, short arrays)."""
+    pk, sk, okey = fixed
+    monkeypatch.setattr(PaillierEncryptedNumber, "ADDN_MIN", 64)
+    rng = np.random.default_rng(77)
+    N = 200
+
+    def oracle_chain(arrays):
+        ct, ex = orc.api_encrypt(okey, arrays[0], None)
+        for a in arrays[1:]:
+            c2, e2 = orc.api_encrypt(okey, a, None)
+            ct, ex = orc.api_add_ct(okey, ct, ex, c2, e2)
+        return ct, ex
+
+    # equal exponents (integers), 5 operands
+    arrs = [[int(v) for v in rng.integers(-1000, 1000, N)] for _ in range(5)]
+    encs = [pk.raw_encrypt(a) for a in arrs]
+    got = PaillierEncryptedNumber.add_many(encs)
+    want_ct, want_e = oracle_chain(arrs)
+    assert ct_ints(got) == want_ct and got.exponent() == want_e
+    assert sk.decrypt(got) == [sum(col) for col in zip(*arrs)]
+    # mixed exponents inside the budget: one operand one binade lower on part of the range
+    f = [list(rng.uniform(512.0, 1023.0, N)) for _ in range(4)]
+    f[2] = [v / 2 if i % 3 == 0 else v for i, v in enumerate(f[2])]
+    encs = [pk.raw_encrypt(a) for a in f]
+    got = PaillierEncryptedNumber.add_many(encs)
+    want_ct, want_e = oracle_chain(f)
+    assert ct_ints(got) == want_ct and got.exponent() == want_e
+    # lazily tagged operands (sums of sums) and 19 operands (two chunks)
+    many = [[int(v) for v in rng.integers(0, 50, N)] for _ in range(19)]
+    encs = [pk.raw_encrypt(a) for a in many]
+    encs[3] = encs[3] + pk.raw_encrypt([0] * N)                             # tag -1
+    encs[0] = (encs[0] + pk.raw_encrypt([0] * N)) + pk.raw_encrypt([0] * N)     # tag -2 on the first operand
+    got = PaillierEncryptedNumber.add_many(encs)
+    assert sk.decrypt(got) == [sum(col) for col in zip(*many)]
+    chain = encs[0]
+    for e_ in encs[1:]:
+        chain = chain + e_
+    assert ct_ints(got) == ct_ints(chain) and got.exponent() == chain.exponent()
+    # wide exponent spread: the chain itself (same bits by construction), still correct
+    wide = [list(rng.uniform(-1000.0, 1000.0, N)) for _ in range(4)]
+    encs = [pk.raw_encrypt(a) for a in wide]
+    got = PaillierEncryptedNumber.add_many(encs)
+    want_ct, want_e = oracle_chain(wide)
+    assert ct_ints(got) == want_ct and got.exponent() == want_e

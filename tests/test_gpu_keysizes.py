@@ -63,12 +63,13 @@ def test_lane_group_digit_pair_obfuscator(bits, wbits, monkeypatch):
     import ctypes as C
 
     from pailliercryptolib_python_amd import _native
-    from tests._util import DevArray, ints_to_limbs, limbs_to_ints
+    from tests._util import DevArray, djn_encrypt_many, djn_obfuscate_many, ints_to_limbs, limbs_to_ints, tune
+    from tests._util import disable as knob_disable
     from tests.test_gpu_paillier_abi import NativeKey, plaintexts
 
     monkeypatch.setenv("PAI_LATENCY_MAX", "0")
     if wbits is not None:
-        monkeypatch.setenv("PAI_FB_WBITS", wbits)
+        tune(monkeypatch, "fb_wbits", wbits)
     key, _, _ = make(bits)
     N = 70 if bits < 4000 else 37                         # a full and a ragged workgroup tile at either geometry (64 / 32 elements)
     m = plaintexts(key, N, bits)
@@ -78,10 +79,11 @@ def test_lane_group_digit_pair_obfuscator(bits, wbits, monkeypatch):
     if key.randbits % 32:
         r[1, -1] = (1 << (key.randbits % 32)) - 1
     r_int = orc.limbs_to_ints(r)
-    want = [orc.encrypt(key, x, rr) for x, rr in zip(m, r_int)]
-    want2 = [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, r_int)]
+    want = djn_encrypt_many(key, m, r_int)                # the oracle's formula; bulk powers through the C oracle, spot-checked
+    assert want[:2] == [orc.encrypt(key, x, rr) for x, rr in zip(m[:2], r_int[:2])]
+    want2 = djn_obfuscate_many(key, want, r_int)
     for disable in ("0", "1"):
-        monkeypatch.setenv("PAI_DISABLE_PAIR", disable)
+        knob_disable(monkeypatch, "pair", disable == "1")
         nk = NativeKey(key)
         dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
         ct = DevArray(shape=(N, nk.cw))
@@ -103,7 +105,8 @@ def test_lane_group_digit_pair_ct_times_pt(bits, monkeypatch):
     (2 / 3 / 4 / 5 bits), per-element and broadcast exponents, zero digits and zero exponents, a full and a ragged tile,
     in place — and the same bits with the pair path switched off (products modulo n^2)."""
     from pailliercryptolib_python_amd import _native
-    from tests._util import DevArray, ints_to_limbs, limbs_to_ints, rand_below
+    from tests._util import DevArray, ints_to_limbs, limbs_to_ints, pow_many, rand_below
+    from tests._util import disable as knob_disable
     from tests.test_gpu_paillier_abi import NativeKey
 
     monkeypatch.setenv("PAI_LATENCY_MAX", "0")
@@ -114,7 +117,7 @@ def test_lane_group_digit_pair_ct_times_pt(bits, monkeypatch):
     c = rand_below(rng, M, N)
     c[0], c[1] = 1, M - 1
     for disable in ("0", "1"):
-        monkeypatch.setenv("PAI_DISABLE_PAIR_CTMUL", disable)
+        knob_disable(monkeypatch, "pair_ctmul", disable == "1")
         nk = NativeKey(key)
         dc = DevArray(ints_to_limbs(c, nk.cw))
         for ebits in (12, 53, 130, 300):
@@ -124,13 +127,13 @@ def test_lane_group_digit_pair_ct_times_pt(bits, monkeypatch):
             de = DevArray(ints_to_limbs(e, ew))
             out = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
-            assert limbs_to_ints(out.get()) == [pow(a, b, M) for a, b in zip(c, e)], (bits, ebits, disable)
+            assert limbs_to_ints(out.get()) == pow_many(c, e, M), (bits, ebits, disable)
             db = DevArray(ints_to_limbs([e[4]], ew))
             _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, db.ptr, ew, ebits, 1, N, out.ptr, None))
-            assert limbs_to_ints(out.get()) == [pow(a, e[4], M) for a in c], (bits, ebits, disable, "bcast")
+            assert limbs_to_ints(out.get()) == pow_many(c, e[4], M), (bits, ebits, disable, "bcast")
         d2 = DevArray(ints_to_limbs(c, nk.cw))
         e = [int(v) for v in rng.integers(1, 1 << 53, N)]
         de = DevArray(ints_to_limbs(e, 2))
         _native.check(nk.lib.pai_ct_mul(nk.pk, d2.ptr, de.ptr, 2, 53, 0, N, d2.ptr, None))                # in place
-        assert limbs_to_ints(d2.get()) == [pow(a, b, M) for a, b in zip(c, e)], (bits, disable, "in place")
+        assert limbs_to_ints(d2.get()) == pow_many(c, e, M), (bits, disable, "in place")
         del nk

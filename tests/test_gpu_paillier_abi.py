@@ -9,7 +9,8 @@ import pytest
 
 from oracle import paillier_oracle as orc
 from pailliercryptolib_python_amd import _native
-from tests._util import DevArray, host_ptr, ints_to_limbs, limbs_to_ints, rand_below
+from tests._util import DevArray, djn_encrypt_many, djn_obfuscate_many, host_ptr, ints_to_limbs, limbs_to_ints, pow_many, rand_below, tune
+from tests._util import disable as knob_disable
 
 pytestmark = pytest.mark.gpu
 
@@ -112,7 +113,7 @@ def test_djn_encrypt_every_table_geometry_2048(wbits, monkeypatch):
     """The digit-form fixed-base table is built directly (<= 12 bits, odd widths included) or in two levels
     (even widths above 12; the default picks 18 bits on a 288 GB device): the ciphertext bits must not
     depend on the geometry."""
-    monkeypatch.setenv("PAI_FB_DIGIT_WBITS", wbits)
+    tune(monkeypatch, "fb_digit_wbits", wbits)
     nk = NativeKey(bench_key())
     key, N = nk.key, 130
     m = plaintexts(key, N, 21)
@@ -192,10 +193,10 @@ def test_ct_mul_every_window_width_and_exponent_shape(k2048, ebits):
     da, de = DevArray(ints_to_limbs(a, k2048.cw)), DevArray(ints_to_limbs(es, ew))
     out = DevArray(shape=(N, k2048.cw))
     _native.check(k2048.lib.pai_ct_mul(k2048.pk, da.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
-    assert limbs_to_ints(out.get()) == [pow(x, e, key.nsq) for x, e in zip(a, es)]
+    assert limbs_to_ints(out.get()) == pow_many(a, es, key.nsq)
     db = DevArray(ints_to_limbs([es[3 if ebits > 8 else 1]], ew))
     _native.check(k2048.lib.pai_ct_mul(k2048.pk, da.ptr, db.ptr, ew, ebits, 1, N, da.ptr, None))     # broadcast, in place
-    assert limbs_to_ints(da.get()) == [pow(x, es[3 if ebits > 8 else 1], key.nsq) for x in a]
+    assert limbs_to_ints(da.get()) == pow_many(a, es[3 if ebits > 8 else 1], key.nsq)
 
 
 @pytest.mark.parametrize("bits", [1024, 3072, 4096])
@@ -271,10 +272,7 @@ def test_ct_invert_2048(k2048, chunk, N, monkeypatch):
     moves the level at which the tree stops) against pow(x, -1, n^2)."""
     import os
 
-    if chunk is None:
-        monkeypatch.delenv("PAI_INVERT_CHUNK", raising=False)
-    else:
-        monkeypatch.setenv("PAI_INVERT_CHUNK", str(chunk))
+    tune(monkeypatch, "invert_chunk", chunk)
     key = k2048.key
     rng = np.random.default_rng(1000 + N)
     a = rand_below(rng, key.nsq, N)
@@ -295,10 +293,7 @@ def test_ct_invert_2048(k2048, chunk, N, monkeypatch):
 def test_ct_invert_in_place(k2048, N, top, monkeypatch):
     """d_out == d_ct: the product tree reads both halves of a level after writing one of them, so the library
     stages the leaves."""
-    if top is None:
-        monkeypatch.delenv("PAI_INVERT_CHUNK", raising=False)
-    else:
-        monkeypatch.setenv("PAI_INVERT_CHUNK", str(top))
+    tune(monkeypatch, "invert_chunk", top)
     key = k2048.key
     a = rand_below(np.random.default_rng(77 + N), key.nsq, N)
     da = DevArray(ints_to_limbs(a, k2048.cw))
@@ -502,11 +497,11 @@ def test_decrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
         # short randomness keeps the oracle's CPython pow cheap; decryption does not care how a ciphertext was obfuscated
         ct = [orc.encrypt(key, x, int.from_bytes(rng.bytes(16), "little")) for x in m]
         dct = DevArray(ints_to_limbs(ct, nk.cw))
-        # PAI_LAT_RL: up to one integer per CU the latency path runs right to left on wave pairs (k_dec_a_rl: squarings on
+        # PAI_TUNE lat_rl: up to one integer per CU the latency path runs right to left on wave pairs (k_dec_a_rl: squarings on
         # one wave, products on another); 0 keeps the left-to-right window kernel
         for switch, rl in (("0", "100000"), ("100000", "100000"), ("100000", "0")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
-            monkeypatch.setenv("PAI_LAT_RL", rl)
+            tune(monkeypatch, "lat_rl", rl)
             out = DevArray(shape=(N, nk.nw))
             _native.check(nk.lib.pai_decrypt(nk.sk, dct.ptr, N, out.ptr, None))
             assert limbs_to_ints(out.get()) == m, (bits, N, switch, rl)
@@ -523,19 +518,19 @@ def test_ct_mul_latency_and_throughput_paths_agree(bits, monkeypatch):
         e[0] = 0
         ew = (ebits + 31) // 32
         dc, de = DevArray(ints_to_limbs(c, nk.cw)), DevArray(ints_to_limbs(e, ew))
-        # PAI_LAT_MUL_RL: the smallest batches run right to left on wave pairs (k_modexp_rl, no table); 0 = windowed kernel
-        want = [pow(a, b, key.nsq) for a, b in zip(c, e)]
+        # PAI_TUNE lat_mul_rl: the smallest batches run right to left on wave pairs (k_modexp_rl, no table); 0 = windowed kernel
+        want = pow_many(c, e, key.nsq)
         for switch, rl in (("0", "100000"), ("100000", "100000"), ("100000", "0")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
-            monkeypatch.setenv("PAI_LAT_MUL_RL", rl)
+            tune(monkeypatch, "lat_mul_rl", rl)
             out = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
             assert limbs_to_ints(out.get()) == want, (bits, N, ebits, switch, rl)
         # one broadcast exponent
-        monkeypatch.setenv("PAI_LAT_MUL_RL", "100000")
+        tune(monkeypatch, "lat_mul_rl", 100000)
         out = DevArray(shape=(N, nk.cw))
         _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, C.c_void_p(de.ptr.value + 4 * ew), ew, ebits, 1, N, out.ptr, None))
-        assert limbs_to_ints(out.get()) == [pow(a, e[1], key.nsq) for a in c], (bits, N, ebits, "bcast")
+        assert limbs_to_ints(out.get()) == pow_many(c, e[1], key.nsq), (bits, N, ebits, "bcast")
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
@@ -549,19 +544,22 @@ def test_djn_encrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
         r[0] = 0                                                   # r = 0: obfuscator 1
         r[1] = 0xFFFFFFFF
         r[1, -1] &= np.uint32((1 << (key.randbits - 32 * (r.shape[1] - 1))) - 1) if key.randbits % 32 else np.uint32(0xFFFFFFFF)
-        want = [orc.encrypt(key, x, rr) for x, rr in zip(m, orc.limbs_to_ints(r))]
+        r_int = orc.limbs_to_ints(r)
+        want = djn_encrypt_many(key, m, r_int)                     # the oracle's formula; bulk powers through the C oracle
+        assert want[:2] == [orc.encrypt(key, x, rr) for x, rr in zip(m[:2], r_int[:2])]
+        want2 = djn_obfuscate_many(key, want, r_int)
         dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
-        # PAI_LAT_ENC_TREE: the four waves of a workgroup share one wave's integers (k_encrypt_tree); 0 = one chain per integer
-        # PAI_LAT_ENC_M1: the shared chain on a minus-one context of n^2 (table converted once) or on the conventional one
+        # PAI_TUNE lat_enc_tree: the four waves of a workgroup share one wave's integers (k_encrypt_tree); 0 = one chain per integer
+        # PAI_DISABLE lat_enc_m1: the shared chain on a minus-one context of n^2 (table converted once) or on the conventional one
         for switch, tree, m1 in (("0", "100000", "1"), ("100000", "100000", "1"), ("100000", "100000", "0"), ("100000", "0", "1")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
-            monkeypatch.setenv("PAI_LAT_ENC_TREE", tree)
-            monkeypatch.setenv("PAI_LAT_ENC_M1", m1)
+            tune(monkeypatch, "lat_enc_tree", tree)
+            knob_disable(monkeypatch, "lat_enc_m1", m1 == "0")
             ct = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
             assert limbs_to_ints(ct.get()) == want, (bits, N, switch, tree, m1)
             _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
-            assert limbs_to_ints(ct.get()) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, orc.limbs_to_ints(r))], (bits, N, switch, tree, m1)
+            assert limbs_to_ints(ct.get()) == want2, (bits, N, switch, tree, m1)
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
@@ -619,12 +617,12 @@ def test_buf_slice_and_rotate_are_row_copies():
                                                     (3072, 2, 13, 3, "6", None), (4096, 1, 9, 5, "4", "5"), (3072, 1, 3, 2, None, "2")])
 def test_ct_multiexp_matches_the_product_of_powers(bits, R, K, M, lanes, wbits, monkeypatch):
     """pai_ct_multiexp: out[r*M + j] = prod_l base(r, l, j)^e[r][l][j] with the inverse's table where the sign byte is
-    set; exponents of up to 75 bits with zero windows, zeros and ones; PAI_MEXP_LANES forces chunks of several members
-    (shared squarings) on these small shapes, PAI_MEXP_WBITS the table width (windows that straddle exponent words)."""
+    set; exponents of up to 75 bits with zero windows, zeros and ones; PAI_TUNE mexp_lanes forces chunks of several members
+    (shared squarings) on these small shapes, PAI_TUNE mexp_wbits the table width (windows that straddle exponent words)."""
     if lanes is not None:
-        monkeypatch.setenv("PAI_MEXP_LANES", lanes)
+        tune(monkeypatch, "mexp_lanes", lanes)
     if wbits is not None:
-        monkeypatch.setenv("PAI_MEXP_WBITS", wbits)                     # the default follows the shape (2 .. 7 bits)
+        tune(monkeypatch, "mexp_wbits", wbits)                     # the default follows the shape (2 .. 7 bits)
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     key = nk.key
     rng = np.random.default_rng(1000 * R + K)
@@ -788,6 +786,8 @@ def test_async_invert_and_sticky_status():
     _native.check(pub.lib.pai_ct_pow2_hint(pub.h, big.data_ptr(), d.data_ptr(), 0, M, 20, None))
     _native.check(pub.lib.pai_pubkey_status(pub.h, C.byref(st), 1, None))
     assert st.value == 0
+    rows = engine.words_to_ints(engine.to_host_words(big[[0, 5]]))
+    assert rows == [pow(vals[0], 1 << 9, key.nsq), pow(vals[0], 1 << 20, key.nsq)]
     # a hint BELOW the digit path's range runs the lane-group kernel, which serves any shift: correct powers, nothing flagged
     # (the word used to be set for correct ciphertexts)
     small = ct[:64].contiguous()
@@ -807,8 +807,6 @@ def test_async_invert_and_sticky_status():
     assert engine.words_to_ints(engine.to_host_words(got)) == [pow(v, -1, key.nsq) for v in vals]
     _native.check(pub.lib.pai_pubkey_status(pub.h, C.byref(st), 1, None))
     assert st.value == 0
-    rows = engine.words_to_ints(engine.to_host_words(big[[0, 5]]))
-    assert rows == [pow(vals[0], 1 << 9, key.nsq), pow(vals[0], 1 << 20, key.nsq)]
 
 
 def test_fixed_base_table_cache_evicts_least_recently_used(monkeypatch):
@@ -851,8 +849,8 @@ def test_fixed_base_table_cache_evicts_least_recently_used(monkeypatch):
 
 @pytest.mark.parametrize("wbits", [5, 10, 14])
 def test_small_batch_table_widths_give_the_same_bits(wbits, monkeypatch):
-    """PAI_LAT_FB_WBITS: the window width of the small-batch DJN table (default 12 bits) only trades memory for latency."""
-    monkeypatch.setenv("PAI_LAT_FB_WBITS", str(wbits))
+    """PAI_TUNE lat_fb_wbits: the window width of the small-batch DJN table (default 12 bits) only trades memory for latency."""
+    tune(monkeypatch, "lat_fb_wbits", wbits)
     monkeypatch.setenv("PAI_LATENCY_MAX", "100000")
     nk = NativeKey(bench_key())
     key = nk.key
@@ -865,16 +863,16 @@ def test_small_batch_table_widths_give_the_same_bits(wbits, monkeypatch):
     assert limbs_to_ints(ct.get()) == want
 
 
-@pytest.mark.parametrize("bits,env", [(1024, {}), (2048, {"PAI_FB_DIGIT_WBITS": "4"}), (2048, {"PAI_FB_DIGIT_WBITS": "12"}), (2048, {}),
-                                      (3072, {"PAI_FB_WBITS": "6"}), (3072, {}), (4096, {"PAI_FB_WBITS": "5"}), (4096, {})])
+@pytest.mark.parametrize("bits,env", [(1024, {}), (2048, {"fb_digit_wbits": 4}), (2048, {"fb_digit_wbits": 12}), (2048, {}),
+                                      (3072, {"fb_wbits": 6}), (3072, {}), (4096, {"fb_wbits": 5}), (4096, {})])
 def test_g_factored_tables_give_the_bits_of_the_plain_tables(bits, env, monkeypatch):
     """Round 4: the fixed-base tables hold g-factored entries (a, t) — x R == a (1 + n)^t — so that a table product is
     the 4 NL^2 rule and the exponents are summed on the side (kernels_padic_enc.hpp / kernels_pair.hpp; conversion by
     simultaneous inversion: k_fb_g_prefix / k_fb_g_finish, k_pair_g_*).  Same ciphertext bits as the plain table
-    (PAI_FB_GFORM=0) and as the oracle, for encryption and apply_obfuscator, over table widths that make the inversion
+    (PAI_DISABLE=gform) and as the oracle, for encryption and apply_obfuscator, over table widths that make the inversion
     chunks 16 / 32 / 64 entries long, r = 0 and r = all ones included."""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tune(monkeypatch, k, v)
     monkeypatch.setenv("PAI_LATENCY_MAX", "0")                      # the big tables for every batch size
     key = (bench_key() if bits == 2048 else seeded_key(bits))
     N = 70 if bits <= 2048 else 20
@@ -885,7 +883,7 @@ def test_g_factored_tables_give_the_bits_of_the_plain_tables(bits, env, monkeypa
     r[1, -1] &= np.uint32((1 << (key.randbits - 32 * (r.shape[1] - 1))) - 1) if key.randbits % 32 else np.uint32(0xFFFFFFFF)
     got = {}
     for g in ("1", "0"):
-        monkeypatch.setenv("PAI_FB_GFORM", g)
+        knob_disable(monkeypatch, "gform", g == "0")
         nk = NativeKey(key)
         dm, dr = DevArray(ints_to_limbs(m, nk.nw)), DevArray(r)
         ct = DevArray(shape=(N, nk.cw))
@@ -900,3 +898,72 @@ def test_g_factored_tables_give_the_bits_of_the_plain_tables(bits, env, monkeypa
     want = [orc.encrypt(key, x, rr) for x, rr in zip(m[:nchk], rs[:nchk])]
     assert limbs_to_ints(got["1"][0][:nchk]) == want
     assert limbs_to_ints(got["1"][1][:nchk]) == [orc.apply_obfuscator(key, c, rr) for c, rr in zip(want, rs[:nchk])]
+
+
+def _addn_call(nk, ops, raises, tag0, tag, dom_out, N, out):
+    k = len(ops)
+    ptrs = (C.c_void_p * k)(*[o.ptr.value for o in ops])
+    rz = None
+    if raises is not None:
+        rz = (C.c_void_p * k)(*[None if r is None else r.ptr.value for r in raises])
+    return nk.lib.pai_ct_addn(nk.pk, ptrs, rz, k, tag0, tag, dom_out, N, out.ptr, None)
+
+
+@pytest.mark.parametrize("bits,k,N", [(2048, 8, 1000), (2048, 2, 17), (2048, 16, 130), (1024, 3, 300), (3072, 5, 100), (4096, 4, 70)])
+def test_ct_addn_is_the_product_of_its_operands(bits, k, N):
+    """pai_ct_addn (the n-ary ciphertext sum, ipcl_python.py:365-381 as one pass): out = prod_j op_j mod n^2 in the wire form,
+    in every lazy-domain arrangement (operand tags, result tag), with per-operand exponent raises (op_j^(2^raise_j), the
+    alignment of :570-741), on ragged sizes and with the output aliasing an operand — against CPython integers."""
+    key = bench_key() if bits == 2048 else seeded_key(bits)
+    nk = NativeKey(key)
+    rng = np.random.default_rng(bits + k)
+    vals = [rand_below(rng, key.nsq, N) for _ in range(k)]
+    ops = [DevArray(ints_to_limbs(v, nk.cw)) for v in vals]
+    out = DevArray(shape=(N, nk.cw))
+    bits_r = C.c_int(0)
+    _native.check(nk.lib.pai_pubkey_mont_bits(nk.pk, C.byref(bits_r)))
+    R = pow(2, bits_r.value, key.nsq)
+
+    def rpow(m):
+        return pow(R, m, key.nsq) if m >= 0 else pow(pow(R, -1, key.nsq), -m, key.nsq)
+
+    want = [1] * N
+    for v in vals:
+        want = [a * b % key.nsq for a, b in zip(want, v)]
+    # wire form in, wire form out
+    _native.check(_addn_call(nk, ops, None, 0, 0, 0, N, out))
+    assert limbs_to_ints(out.get()) == want
+    # the natural tag: operands x R^0, result (prod) R^(1-k) with no fix-up product
+    _native.check(_addn_call(nk, ops, None, 0, 0, 1 - k, N, out))
+    assert limbs_to_ints(out.get()) == [w * rpow(1 - k) % key.nsq for w in want]
+    # tagged operands: operand 0 holds x R^-2, the others x R^1; result asked at tag 3
+    t_ops = [DevArray(ints_to_limbs([x * rpow(-2 if j == 0 else 1) % key.nsq for x in v], nk.cw)) for j, v in enumerate(vals)]
+    _native.check(_addn_call(nk, t_ops, None, -2, 1, 3, N, out))
+    assert limbs_to_ints(out.get()) == [w * rpow(3) % key.nsq for w in want]
+    # exponent raises: some operands without, some with zeros only, some mixed (a whole tile without raise, ragged maxima)
+    rz_h = []
+    for j in range(k):
+        if j % 3 == 0:
+            rz_h.append(None)
+        elif j % 3 == 1:
+            r_ = rng.integers(0, 4, N).astype(np.int32)
+            r_[: min(N, 40)] = 0
+            rz_h.append(r_)
+        else:
+            rz_h.append(np.zeros(N, dtype=np.int32) if j > 3 else rng.integers(0, 7, N).astype(np.int32))
+    if k == 2:
+        rz_h = [rng.integers(0, 5, N).astype(np.int32), rng.integers(0, 3, N).astype(np.int32)]     # operand 0 raised too
+    rz_d = [None if r_ is None else DevArray(r_) for r_ in rz_h]
+    want_r = [1] * N
+    for j, v in enumerate(vals):
+        want_r = [a * pow(b, 1 << (0 if rz_h[j] is None else int(rz_h[j][i])), key.nsq) % key.nsq for i, (a, b) in enumerate(zip(want_r, v))]
+    _native.check(_addn_call(nk, ops, rz_d, 0, 0, 0, N, out))
+    assert limbs_to_ints(out.get()) == want_r
+    _native.check(_addn_call(nk, ops, rz_d, 0, 0, 1 - k, N, out))                    # raised tiles are brought to the same tag
+    assert limbs_to_ints(out.get()) == [w * rpow(1 - k) % key.nsq for w in want_r]
+    # in place: the output aliases operand 1
+    _native.check(_addn_call(nk, ops, None, 0, 0, 0, N, ops[1]))
+    assert limbs_to_ints(ops[1].get()) == want
+    # argument checks
+    assert _addn_call(nk, ops[:1], None, 0, 0, 0, N, out) == _native.PAI_E_INVALID
+    assert _addn_call(nk, ops, None, 0, 0, 500, N, out) == _native.PAI_E_INVALID

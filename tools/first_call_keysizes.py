@@ -1,4 +1,4 @@
-"""Dev probe: first DJN encryption (fixed-base table build included) vs steady state per key size; PAI_DISABLE_FB_CHAIN=1 gives
+"""Dev probe: first DJN encryption (fixed-base table build included) vs steady state per key size; PAI_DISABLE=fb_chain gives
 the table kernels' own squaring chains back."""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -18,5 +18,5 @@ for bits in [int(a) for a in sys.argv[1:]] or [1024, 2048, 3072, 4096]:
     ts = []
     for i in range(3):
         t0 = time.perf_counter(); pub.encrypt(m, r, out=out); torch.cuda.synchronize(); ts.append(round(time.perf_counter() - t0, 4))
-    print(json.dumps({"bits": bits, "batch": B, "first_s": ts[0], "steady_s": ts[2], "chain": os.environ.get("PAI_DISABLE_FB_CHAIN", "0") != "1"}), flush=True)
+    print(json.dumps({"bits": bits, "batch": B, "first_s": ts[0], "steady_s": ts[2], "chain": "fb_chain" not in os.environ.get("PAI_DISABLE", "")}), flush=True)
     del pub

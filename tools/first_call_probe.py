@@ -1,5 +1,5 @@
 """First-call cost of DJN encryption at the engine level (handle creation, lazy fixed-base table build, steady state):
-    python tools/first_call_probe.py   ->  handle 0.07 s, first encrypt of 2^20 0.13 s (0.07 s of it the table; 0.18 s with PAI_DISABLE_FB_CHAIN=1), then 0.062 s"""
+    python tools/first_call_probe.py   ->  handle 0.07 s, first encrypt of 2^20 0.13 s (0.07 s of it the table; 0.18 s with PAI_DISABLE=fb_chain), then 0.062 s"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch

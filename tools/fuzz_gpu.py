@@ -112,8 +112,7 @@ while time.time() - t0 < budget:
             for l_ in range(K):
                 for j_ in range(Mc):
                     for w_ in range(ew2): e_l[r_, l_, j_, w_] = (ee[r_][l_][j_] >> (32 * w_)) & 0xFFFFFFFF
-        os.environ["PAI_MEXP_LANES"] = str(int(rng.integers(1, 50)))
-        os.environ["PAI_MEXP_WBITS"] = str(int(rng.integers(1, 8)))
+        os.environ["PAI_TUNE"] = f"mexp_lanes={int(rng.integers(1, 50))},mexp_wbits={int(rng.integers(1, 8))}"
         dcb, dib, deb, dsb = DevArray(ints_to_limbs(base, nk.cw)), DevArray(ints_to_limbs(inv, nk.cw)), DevArray(e_l), DevArray(sg)
         ob = DevArray(shape=(R * Mc, nk.cw))
         _native.check(lib.pai_ct_multiexp(nk.pk, dcb.ptr, dib.ptr, R, K, Mc, deb.ptr, ew2, eb, dsb.ptr, ob.ptr, None))

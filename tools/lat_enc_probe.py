@@ -1,4 +1,4 @@
-"""Dev probe: small-batch DJN encrypt latency, wave-shared chains (k_encrypt_tree, default) against one chain per integer (PAI_LAT_ENC_TREE=0)."""
+"""Dev probe: small-batch DJN encrypt latency, wave-shared chains (k_encrypt_tree, default) against one chain per integer (PAI_TUNE=lat_enc_tree=0)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
@@ -22,8 +22,8 @@ for N in (16, 256, 1024, 4096):
     row = {"bits": bits, "N": N}
     ref = None
     for tree, m1 in (("1000000", "1"), ("1000000", "0"), ("0", "1")):
-        os.environ["PAI_LAT_ENC_TREE"] = tree
-        os.environ["PAI_LAT_ENC_M1"] = m1
+        os.environ["PAI_TUNE"] = f"lat_enc_tree={tree}"
+        os.environ["PAI_DISABLE"] = "lat_enc_m1" if m1 == "0" else ""
         ct = pub.encrypt(m, r)
         if ref is None: ref = ct.clone()
         assert torch.equal(ct, ref), (N, tree, m1)

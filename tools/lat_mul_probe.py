@@ -1,4 +1,4 @@
-"""Dev probe: small-batch ct*pt latency (dense 53-bit exponents), right-to-left wave pairs (k_modexp_rl) against the windowed kernel (PAI_LAT_MUL_RL=0)."""
+"""Dev probe: small-batch ct*pt latency (dense 53-bit exponents), right-to-left wave pairs (k_modexp_rl) against the windowed kernel (PAI_TUNE=lat_mul_rl=0)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
@@ -25,7 +25,7 @@ for N in (1, 16, 64, 256, 512, 1024, 2048, 4096):
     row = {"bits": bits, "N": N}
     ref = None
     for rl in ("1000000", "0"):
-        os.environ["PAI_LAT_MUL_RL"] = rl
+        os.environ["PAI_TUNE"] = f"lat_mul_rl={rl}"
         out = pub.ct_mul(ct, e, 53)
         if ref is None: ref = out.clone()
         assert torch.equal(out, ref), (N, rl)

@@ -1,4 +1,4 @@
-"""Dev probe: small-batch decrypt latency, right-to-left wave pairs (PAI_LAT_RL=1, default) against the left-to-right window kernel."""
+"""Dev probe: small-batch decrypt latency, right-to-left wave pairs (default; PAI_TUNE=lat_rl=0 switches them off) against the left-to-right window kernel."""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
@@ -22,7 +22,7 @@ for N in (16, 256, 257, 384, 512, 513, 768, 1024, 2048, 4096):
     ct = pub.encrypt(m, pub.random_r(N, generator=g))
     row = {"bits": bits, "N": N}
     for rl in ("100000", "0"):
-        os.environ["PAI_LAT_RL"] = rl
+        os.environ["PAI_TUNE"] = f"lat_rl={rl}"
         assert torch.equal(priv.decrypt(ct), m), (N, rl)
         row[f"dec_rl{'1' if rl != '0' else '0'}_ms"] = round(tm(lambda: priv.decrypt(ct)), 3)
     print(json.dumps(row), flush=True)

@@ -11,7 +11,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 using namespace pai;
 
-// MODE 0: mul (M in LDS), 1: mul_wbuf (M, W global), 2: sqr (M in LDS), 3: sqr_lean, 4: mul_lean (two waves per SIMD)
+// MODE 0: mul (M in LDS), 1: mul_wbuf (M, W global), 2: sqr (M in LDS), 3: sqr_fused, 4: mul_fused (both halves in one pass)
 template <int NL, int U, int MODE>
 __global__ void __launch_bounds__(BLOCK_THREADS, MODE >= 3 ? 2 : 1)
 k_chain(const uint32_t* __restrict__ mod, const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint4* scratch, int iters) {
@@ -49,9 +49,8 @@ k_chain(const uint32_t* __restrict__ mod, const uint32_t* __restrict__ in, uint3
         if constexpr (MODE == 0) E::mul(A, B, Ml, self(A), self(B), nm, pm1, n0inv);
         else if constexpr (MODE == 1) E::mul_wbuf(A, B, Mg, Wg, self(A), self(B), nm, pm1, n0inv);
         else if constexpr (MODE == 2) E::sqr(A, B, Ml, nm, pm1, n0inv);
-        else if constexpr (MODE == 3) E::sqr_lean(A, B, Wg, nm, pm1, n0inv);
-        else if constexpr (MODE == 4) E::mul_lean(A, B, Wg, self(A), self(B), nm, pm1, n0inv);
-        else if constexpr (MODE == 5) E::sqr_wbuf(A, B, Mg, Wg, nm, pm1, n0inv);
+        else if constexpr (MODE == 3) E::sqr_fused(A, B, nm, pm1, n0inv);
+        else if constexpr (MODE == 4) E::mul_fused(A, B, self(A), self(B), nm, pm1, n0inv);
         else E::mul_wbuf(A, B, Mg, Wg, self(A), self(B), nm, pm1, n0inv);
     }
     for (int c = 0; c < E::NC; ++c) {
@@ -101,9 +100,7 @@ int main(int argc, char** argv) {
     run<36, 12, 0>("mul <36,12> M in LDS", iters, ncu);
     run<36, 12, 2>("sqr <36,12> M in LDS", iters, ncu);
     run<72, 8, 1>("mul_wbuf <72,8> M,W global", iters, ncu);
-    run<36, 12, 3>("sqr_lean <36,12> 2 waves/SIMD", iters, ncu);
-    run<36, 12, 4>("mul_lean <36,12> 2 waves/SIMD", iters, ncu);
-    run<36, 12, 5>("sqr_wbuf <36,12> 2 waves/SIMD", iters, ncu);
-    run<36, 12, 6>("mul_wbuf <36,12> 2 waves/SIMD", iters, ncu);
+    run<72, 8, 3>("sqr_fused <72,8>", iters, ncu);
+    run<72, 8, 4>("mul_fused <72,8>", iters, ncu);
     return 0;
 }
