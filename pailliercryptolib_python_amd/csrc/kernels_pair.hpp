@@ -150,8 +150,8 @@ PAI_DEV void pair_times(uint32_t (&a)[G::NLL], uint32_t (&b)[G::NLL], const uint
                         const uint32_t (&d)[G::NLL], uint32_t* lds, const typename G::NM& nm, uint32_t n0inv) {
     stage_b<G>(c, PairLds<G>::c(lds));
     stage_b<G>(d, PairLds<G>::d(lds));
-    pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
-                                 nm, n0inv);
+    pair_mul<G::NLL, G::U, G::T, PAIR_FULL, false>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB, nm,
+                                                   n0inv);                   // one-off products: the compact form
 }
 
 // ---- first table level: element i walks S[i][e] = S[i][e - 1] (x) B_i, S[i][0] = pair(1) -------------------------------
@@ -205,8 +205,8 @@ k_pair_fb_chain(const MontCtx* __restrict__ nctx, const uint32_t* __restrict__ n
             for (int j = 0; j < G::NLL; ++j) { a[j] = c[j]; b[j] = d[j]; }
             stage_b<G>(c, PairLds<G>::c(lds));
             stage_b<G>(d, PairLds<G>::d(lds));
-            pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
-                                         nm, n0inv, (NoStream*)nullptr, true);       // a squaring: 4 NL^2
+            pair_mul<G::NLL, G::U, G::T, PAIR_SQR, false>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB,
+                                                          nm, n0inv);       // a squaring: 4 NL^2
             const bool keep = sq < h * is;
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) { c[j] = keep ? a[j] : c[j]; d[j] = keep ? b[j] : d[j]; }
@@ -432,8 +432,7 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
                     const bool more = jw + 1 < P.fb_windows;
                     uint32_t tn[G::NLL];                           // the next entry's exponent slice travels during the product
                     digit_load<G>(tn, ent + G::NL);                // (measured: 37.4 ms against 38.5 ms with the load after it)
-                    pair_mul<G::NLL, G::U, G::T>(a, b, lds + cur + G::elem(), lds + cur + G::elem(), G::EPB,
-                                                 nm, n0inv, &pf, false, true);
+                    pair_mul<G::NLL, G::U, G::T, PAIR_C0>(a, b, lds + cur + G::elem(), lds + cur + G::elem(), G::EPB, nm, n0inv, &pf);
 #pragma unroll
                     for (int j = 0; j < G::NLL; ++j) tacc[j] += more ? tn[j] : 0u;
                 } else {
@@ -456,8 +455,8 @@ k_pair_fixed_base(PairParams P, const uint32_t* __restrict__ m, const uint32_t* 
             for (int jw = 1; jw < P.fb_windows; ++jw) {
                 stage_b<G>(c, PairLds<G>::c(lds));
                 if (jw + 1 < P.fb_windows) digit_load<G>(c, entry(jw + 1));
-                pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::c(lds) + G::elem(), G::EPB,
-                                             nm, n0inv, (NoStream*)nullptr, false, true);
+                pair_mul<G::NLL, G::U, G::T, PAIR_C0>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::c(lds) + G::elem(), G::EPB,
+                                                      nm, n0inv);
                 digit_load<G>(d, entry(jw) + G::NL);
 #pragma unroll
                 for (int j = 0; j < G::NLL; ++j) tl[j * BLOCK_THREADS] += d[j];
@@ -575,7 +574,8 @@ k_pair_ctmul(PairCtMulParams P, const uint32_t* __restrict__ ct, const uint32_t*
             for (int j = 0; j < G::NLL; ++j) { a[j] = sa[j]; b[j] = sb[j]; }
 #pragma unroll 1
             for (int k = 2; k < NT; ++k) {
-                pair_mul<G::NLL, G::U, G::T>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(), G::EPB, nm, n0inv);
+                pair_mul<G::NLL, G::U, G::T, PAIR_FULL, false>(a, b, PairLds<G>::c(lds) + G::elem(), PairLds<G>::d(lds) + G::elem(),
+                                                               G::EPB, nm, n0inv);
                 pair_store<G>(a, b, trow + (size_t)k * 2 * G::NL);
             }
         }
@@ -601,9 +601,11 @@ k_pair_ctmul(PairCtMulParams P, const uint32_t* __restrict__ ct, const uint32_t*
                     wave_lds_fence();
                 }
                 pf.on = any && s == W - 1;
-                const int off = is_mul ? PAIR_OFF : 0;
-                pair_mul<G::NLL, G::U, G::T>(a, b, lds + off + G::elem(), lds + off + G::LDS_WORDS + G::elem(), G::EPB, nm, n0inv,
-                                             &pf, !is_mul);
+                // two straight-line forms (no wave-uniform branches inside the rows): the squaring streams the window's table
+                // entry into the second buffer pair, the multiplication reads it from there
+                if (!is_mul) pair_mul<G::NLL, G::U, G::T, PAIR_SQR>(a, b, lds + G::elem(), lds + G::LDS_WORDS + G::elem(), G::EPB, nm, n0inv, &pf);
+                else pair_mul<G::NLL, G::U, G::T, PAIR_FULL>(a, b, lds + PAIR_OFF + G::elem(), lds + PAIR_OFF + G::LDS_WORDS + G::elem(), G::EPB,
+                                                             nm, n0inv);
             }
         }
         {   // leave Montgomery form: times the plain pair (1, 0)

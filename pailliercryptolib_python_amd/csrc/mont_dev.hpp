@@ -440,14 +440,16 @@ PAI_DEV void mont_mul_m1(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uin
 // (a, b) in registers (lane slices), (c, d) as LDS rows c_ptr / d_ptr [limb * stride], M - 1 as LDS limbs (uniform).
 // Inputs lazy (< 2M + eps), outputs lazy; R / M >= 2^20 required.
 constexpr int PAIR_NORM_MAX = 18;              // three 2^58 products per row and column: 18 rows (54 x 2^58 + the normalised rest < 2^29 + 2^35) stay below 2^64
-constexpr int PAIR_NORM_MAX2 = 24;             // two products per row and column (squarings, g-factored operands): 24 rows
+constexpr int PAIR_NORM_MAX2 = 24;
+constexpr int PAIR_FULL = 0, PAIR_SQR = 1, PAIR_C0 = 2;       // forms of pair_mul             // two products per row and column (squarings, g-factored operands): 24 rows
 
 // One row block of the fused product rule on a window that is addressed THROUGH an offset: column k of the window is
 // register (O + k) mod NW.  With O a compile-time constant the slide of the window after a block is a renaming, not NLL
 // 64-bit moves per window (round 5: 33-72 of the ~840 instructions of an 18 x 8 block were those moves).
-template <int NLL, int U, int T, int O, class NM>
+template <int NLL, int U, int T, int O, int FORM, class NM>
 PAI_DEV void pair_block(uint64_t (&acc1)[NLL + U], uint64_t (&acc2)[NLL + U], const uint32_t (&a)[NLL], const uint32_t (&b)[NLL],
-                        const uint32_t (&cv)[U], const uint32_t (&dv)[U], const NM& nm, uint32_t n0inv, bool lane0, bool sqr, bool c0) {
+                        const uint32_t (&cv)[U], const uint32_t (&dv)[U], const NM& nm, uint32_t n0inv, bool lane0) {
+    constexpr bool sqr = FORM == PAIR_SQR, c0 = FORM == PAIR_C0;
     constexpr int NW = NLL + U;
 #define PAIR_C(k) ((O + (k)) % NW)
     uint32_t low1[U], low2[U];
@@ -461,11 +463,11 @@ PAI_DEV void pair_block(uint64_t (&acc1)[NLL + U], uint64_t (&acc2)[NLL + U], co
         acc1[PAIR_C(u + 1)] += acc1[PAIR_C(u)] >> RB;
         low1[u] = (uint32_t)acc1[PAIR_C(u)] & RMASK;
         acc2[PAIR_C(u)] += lane0 ? (uint64_t)(RMASK - q1) : 0ull;
-        if (!c0) {
+        if constexpr (!c0) {
 #pragma unroll
             for (int j = 0; j < NLL; ++j) acc2[PAIR_C(j + u)] += (uint64_t)a[j] * dv[u];
         }
-        if (!sqr) {
+        if constexpr (!sqr) {
 #pragma unroll
             for (int j = 0; j < NLL; ++j) acc2[PAIR_C(j + u)] += (uint64_t)b[j] * cv[u];
         }
@@ -500,11 +502,12 @@ PAI_DEV void pair_normalize(uint64_t (&acc)[NLL + U]) {
     acc[O % NW] &= RMASK;
 }
 // PER = NLL / U + 1 consecutive blocks bring the offset back to 0: one period, fully unrolled
-template <int NLL, int U, int T, int B, class NM, class PF>
+template <int NLL, int U, int T, int B, int FORM, class NM, class PF>
 PAI_DEV void pair_period(uint64_t (&acc1)[NLL + U], uint64_t (&acc2)[NLL + U], const uint32_t (&a)[NLL], const uint32_t (&b)[NLL],
                          const uint32_t* c_ptr, const uint32_t* d_ptr, int stride, int blk0, const NM& nm, uint32_t n0inv,
-                         bool lane0, bool sqr, bool c0, PF* pf) {
+                         bool lane0, PF* pf) {
     constexpr int PER = NLL / U + 1;
+    constexpr bool sqr = FORM == PAIR_SQR, c0 = FORM == PAIR_C0;
     if constexpr (B < PER) {
         if constexpr (!std::is_same<PF, NoStream>::value) pf->step(blk0 + B);
         uint32_t cv[U], dv[U];
@@ -514,26 +517,33 @@ PAI_DEV void pair_period(uint64_t (&acc1)[NLL + U], uint64_t (&acc2)[NLL + U], c
             dv[u] = c0 ? 0u : d_ptr[((blk0 + B) * U + u) * stride];
             dv[u] = sqr ? dv[u] << 1 : dv[u];
         }
-        pair_block<NLL, U, T, (B * U) % (NLL + U)>(acc1, acc2, a, b, cv, dv, nm, n0inv, lane0, sqr, c0);
+        pair_block<NLL, U, T, (B * U) % (NLL + U), FORM>(acc1, acc2, a, b, cv, dv, nm, n0inv, lane0);
+        // (keeps the scheduler from hoisting the next blocks' operand reads over this block: at 256 registers they spill)
+        __builtin_amdgcn_sched_barrier(0);
         // three products per row and column in the second window of a full product: it cannot wait for the period's end
         if constexpr ((B + 1) * U <= PAIR_NORM_MAX && (B + 2) * U > PAIR_NORM_MAX && B + 1 < PER) {
-            if (!sqr && !c0) pair_normalize<NLL, U, ((B + 1) * U) % (NLL + U)>(acc2);
+            if constexpr (FORM == PAIR_FULL) pair_normalize<NLL, U, ((B + 1) * U) % (NLL + U)>(acc2);
         }
-        pair_period<NLL, U, T, B + 1>(acc1, acc2, a, b, c_ptr, d_ptr, stride, blk0, nm, n0inv, lane0, sqr, c0, pf);
+        pair_period<NLL, U, T, B + 1, FORM>(acc1, acc2, a, b, c_ptr, d_ptr, stride, blk0, nm, n0inv, lane0, pf);
     }
 }
 
-// sqr (wave-uniform): the rows at c_ptr / d_ptr are (a, b) themselves — a d + b c is then 2 a d, one multiply-accumulate
-// per limb pair less (4 NL^2 instead of 5 NL^2); both forms share this one body.
-template <int NLL, int U, int T, class NM, class PF = NoStream>
-// c0 (wave-uniform): the right operand has no second digit (g-factored table entries, kernels_pair.hpp): a d drops out,
-// 4 NL^2 as well, and d_ptr is not read.
+// FORM (compile time: every variant is straight-line code, no wave-uniform branches inside the rows):
+//   PAIR_FULL  the product rule as above, 5 NL^2;
+//   PAIR_SQR   the rows at c_ptr / d_ptr are (a, b) themselves — a d + b c is then 2 a d, one multiply-accumulate per limb
+//              pair less: 4 NL^2;
+//   PAIR_C0    the right operand has no second digit (g-factored table entries, kernels_pair.hpp): a d drops out, 4 NL^2 as
+//              well, and d_ptr is not read.
 // Round 5: the window is renamed instead of moved where the geometry allows it (pair_block), the (M - 1) R term joins once
 // at the end (it adds M - 1 to the second result digit) instead of one LDS read, select and 64-bit add per row, the
 // cross-lane moves need no selects (from_next_z, bcast0), and the two-product forms normalise every 24 rows.
+// ROT = false keeps the compact sliding form (the one-off products around a kernel's hot loop: a renamed period is PER
+// copies of the block).
+template <int NLL, int U, int T, int FORM = PAIR_FULL, bool ROT = true, class NM, class PF = NoStream>
 PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_ptr, const uint32_t* d_ptr, int stride,
-                      const NM& nm, uint32_t n0inv, PF* pf = nullptr, bool sqr = false, bool c0 = false) {
+                      const NM& nm, uint32_t n0inv, PF* pf = nullptr) {
     static_assert(NLL % U == 0 && U <= PAIR_NORM_MAX, "row-block size");
+    constexpr bool sqr = FORM == PAIR_SQR, c0 = FORM == PAIR_C0;
     using RW = Rows<NLL, U, T>;
     constexpr int NW = RW::NW;
     uint64_t acc1[NW], acc2[NW];
@@ -543,14 +553,14 @@ PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_
     if (lane0) acc2[0] = 1;
     constexpr int NB = RW::NL / U;
     constexpr int PER = NLL / U + 1;
-    if constexpr (NB % PER == 0 && PER * U <= PAIR_NORM_MAX2) {
+    if constexpr (ROT && NB % PER == 0 && PER * U <= PAIR_NORM_MAX2) {
 #pragma unroll 1
         for (int blk = 0; blk < NB; blk += PER) {
-            pair_period<NLL, U, T, 0>(acc1, acc2, a, b, c_ptr, d_ptr, stride, blk, nm, n0inv, lane0, sqr, c0, pf);
+            pair_period<NLL, U, T, 0, FORM>(acc1, acc2, a, b, c_ptr, d_ptr, stride, blk, nm, n0inv, lane0, pf);
             if (blk + PER < NB) { pair_normalize<NLL, U, 0>(acc1); pair_normalize<NLL, U, 0>(acc2); }
         }
     } else {
-        const int norm_blocks = ((sqr || c0) ? PAIR_NORM_MAX2 : PAIR_NORM_MAX) / U;
+        constexpr int norm_blocks = ((sqr || c0) ? PAIR_NORM_MAX2 : PAIR_NORM_MAX) / U;
         int since = 0;
 #pragma unroll 1
         for (int blk = 0; blk < NB; ++blk) {
@@ -562,7 +572,7 @@ PAI_DEV void pair_mul(uint32_t (&a)[NLL], uint32_t (&b)[NLL], const uint32_t* c_
                 dv[u] = c0 ? 0u : d_ptr[(blk * U + u) * stride];
                 dv[u] = sqr ? dv[u] << 1 : dv[u];
             }
-            pair_block<NLL, U, T, 0>(acc1, acc2, a, b, cv, dv, nm, n0inv, lane0, sqr, c0);
+            pair_block<NLL, U, T, 0, FORM>(acc1, acc2, a, b, cv, dv, nm, n0inv, lane0);
             // slide: the block left its retired (zeroed) columns at the bottom
 #pragma unroll
             for (int j = 0; j < NLL; ++j) { acc1[j] = acc1[j + U]; acc2[j] = acc2[j + U]; }
