@@ -714,6 +714,39 @@ def main() -> None:
                 "ct_mul_53bit_ms": 1e3 * wall(lambda: pub.ct_mul(cts_, es_, 53), reps=5),
             }
 
+    # ---- DJN encryption at the two table operating points: the big table a device's first keys
+    # get, and the small one a handle takes when many keys are resident — a second handle of the same key, forced small
+    table_points = None
+    if extras:
+        def enc_ms(h_):
+            h_.encrypt(m, r, out=ct)
+            engine.profile_enable(True)
+            h_.encrypt(m, r, out=ct)
+            ms_ = engine.profile_last().get("k_encrypt(djn)")
+            engine.profile_enable(False)
+            return ms_
+
+        big = dict(pub.table_info(), k_encrypt_ms=enc_ms(pub), batch=B)
+        os.environ["PAI_FB_BIG_KEYS"] = "0"                      # every further key of this process: the small operating point
+        try:
+            pub_s = engine.PublicKeyHandle(key.n, KEY_BITS, key.hs, key.randbits, device=device)
+            ct_small = pub.empty_ct(B)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pub_s.encrypt(m, r, out=ct_small)
+            torch.cuda.synchronize()
+            first_s = time.perf_counter() - t1
+            if not torch.equal(ct_small, ct):
+                raise SystemExit("bench.py: the small-table encryption differs from the big-table one")
+            small_pt = dict(pub_s.table_info(), k_encrypt_ms=enc_ms(pub_s), first_call_s=first_s, batch=B)
+            del pub_s, ct_small
+        finally:
+            os.environ.pop("PAI_FB_BIG_KEYS", None)
+        table_points = {"big": big, "small": small_pt,
+                        "note": "same key, same ciphertext bits; big = the table of a device's first PAI_FB_BIG_KEYS (8) keys, small = "
+                                "what a handle builds when that many tables are resident or the cache budget is short "
+                                "(PAI_FB_SMALL_TABLE_MB, default 256); first_call_s includes the table build"}
+
     ref_bench = None
     if extras and KEY_BITS == 2048 and not args.no_reference_bench:
         ref_bench = reference_bench(key, okey, device)
@@ -827,6 +860,7 @@ def main() -> None:
             "api_level": api,
             "other_ops": other,
             "small_batch": small,
+            "fixed_base_table_points": table_points,
             "reference_bench": ref_bench,
             "parity_checked": True,
         }

@@ -91,6 +91,10 @@ int pai_pubkey_trim(pai_pubkey* pk, size_t* freed_bytes);
 /* fills any non-NULL out-parameter */
 int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_words, int* r_words,
                     int* randbits, int* is_djn, int* device);
+/* The DJN fixed-base table this handle holds right now (zeros before its first obfuscating call and after a trim or an
+ * eviction): device bytes, window width in bits, number of windows.  The first keys of a device get the big table (1/32 of
+ * the device memory), later ones the small operating point (PAI_FB_BIG_KEYS / PAI_FB_SMALL_TABLE_MB). */
+int pai_pubkey_table_info(const pai_pubkey* pk, size_t* table_bytes, int* window_bits, int* windows);
 
 /* ipclKeypair.generate_keypair(n_length, enable_DJN) — bindings/ipcl_bindings.cpp:12-15 -> ipcl::generateKeypair
  * (timed by the reference's BM_KeyGen, bench/bench_ipcl_python.py:13-19).  Host-only (no device work): two random primes

@@ -1600,6 +1600,17 @@ int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_w
     });
 }
 
+int pai_pubkey_table_info(const pai_pubkey* pk, size_t* table_bytes, int* window_bits, int* windows) {
+    return guarded([&] {
+        require(pk != nullptr, "pk is NULL");
+        std::lock_guard<std::mutex> lk(pk->mu);
+        const bool digit = pk->fb_ready && pk->d_fb_dig != nullptr;
+        if (table_bytes) *table_bytes = pk->fb_ready ? pk->fb_bytes : 0;
+        if (window_bits) *window_bits = !pk->fb_ready ? 0 : (digit ? pk->fbd_wbits : pk->fb_wbits);
+        if (windows) *windows = !pk->fb_ready ? 0 : (digit ? pk->fbd_windows : pk->fb_windows);
+    });
+}
+
 static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint32_t* d_r, const uint32_t* d_ct_in,
                            uint32_t* d_ct_out, size_t N, void* stream, bool from_plain) {
     DeviceScope scope_(pk->device);

@@ -174,6 +174,12 @@ class PublicKeyHandle:
         self.__dict__.pop("_dom_consts", None)          # the cached R^k rows go too
         return int(v.value)
 
+    def table_info(self) -> dict:
+        """The DJN fixed-base table held right now: {"bytes", "window_bits", "windows"} (zeros before the first obfuscating call)."""
+        b, w, j = C.c_size_t(0), C.c_int(0), C.c_int(0)
+        _native.check(self.lib.pai_pubkey_table_info(self.h, C.byref(b), C.byref(w), C.byref(j)))
+        return {"bytes": int(b.value), "window_bits": int(w.value), "windows": int(j.value)}
+
     # ---- lazy Montgomery domain (include/paillier_hip.h: pai_ct_mont_mul).  A buffer with tag k holds x R^k mod n^2. ----
     @property
     def mont_bits(self) -> int:

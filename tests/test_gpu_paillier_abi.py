@@ -967,3 +967,42 @@ def test_ct_addn_is_the_product_of_its_operands(bits, k, N):
     # argument checks
     assert _addn_call(nk, ops[:1], None, 0, 0, 0, N, out) == _native.PAI_E_INVALID
     assert _addn_call(nk, ops, None, 0, 0, 500, N, out) == _native.PAI_E_INVALID
+
+
+def test_many_keys_take_the_small_table_and_do_not_thrash(monkeypatch):
+    """A process that holds many DJN keys on one device (a federated server: one key per party): the first keys get the big
+    fixed-base table, later ones the small operating point, under a 16 GB cache budget nothing is evicted and rebuilt on the
+    second round of encryptions, and every key's ciphertexts are the oracle's — VERDICT r04 #6 / ADVICE r04 (cache accounting
+    from the real allocation sizes)."""
+    import torch
+
+    from pailliercryptolib_python_amd import engine
+
+    monkeypatch.setenv("PAI_FB_CACHE_MB", "16384")
+    monkeypatch.setenv("PAI_LATENCY_MAX", "0")                      # the fixed-base tables for every batch size
+    base = bench_key()
+    NK, N = 32, 64
+    keys = [orc.make_key(orc.BENCH_P, orc.BENCH_Q, djn_x=0x1000 + 7 * i, bits=2048) for i in range(NK)]
+    pubs = [engine.PublicKeyHandle(k.n, 2048, k.hs, k.randbits, device="cuda:0") for k in keys]
+    m = plaintexts(base, N, 5)
+    r_l = orc.synth_r_limbs(9, N, base.randbits)
+    dm = engine.to_device_words(ints_to_limbs(m, pubs[0].n_words), pubs[0].device)
+    dr = engine.to_device_words(r_l, pubs[0].device)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    first = [engine.to_host_words(p.encrypt(dm, dr)) for p in pubs]
+    info = [p.table_info() for p in pubs]
+    assert all(i["bytes"] > 0 for i in info), "a table was evicted during the first round"
+    big = [i for i in info if i["bytes"] > (1 << 30)]
+    small = [i for i in info if i["bytes"] <= (256 << 20)]
+    assert 1 <= len(big) <= 8 and len(big) + len(small) == NK, [i["bytes"] >> 20 for i in info]
+    assert sum(i["bytes"] for i in info) <= 16384 << 20
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used <= (20 << 30), used                                  # tables + per-key scratch stay near the budget
+    second = [engine.to_host_words(p.encrypt(dm, dr)) for p in pubs]
+    assert [p.table_info() for p in pubs] == info, "tables were rebuilt between the rounds"
+    for k, a, b in zip(keys, first, second):
+        assert np.array_equal(a, b)
+    r_int = orc.limbs_to_ints(r_l)
+    for idx in (0, 1, 9, NK - 1):                                   # a big-table key and small-table keys against the oracle
+        assert limbs_to_ints(first[idx][:4]) == [orc.encrypt(keys[idx], x, rr) for x, rr in zip(m[:4], r_int[:4])]

@@ -6,7 +6,7 @@ TAG=${1:-final}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-B="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+B="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-configs"
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $B > $OUT/bench_under_rocprofv3.json 2> $OUT/trace.err)
 DB=$(find $OUT/trace -name "*.db" | head -1)
