@@ -19,6 +19,7 @@
 #include "kernels_padic_enc.hpp"
 #include "kernels_pair.hpp"
 #include "kernels_codec.hpp"
+#include "kernels_declat.hpp"
 
 using namespace pai;
 using hbn::Limbs;
@@ -241,7 +242,7 @@ struct ModSetup {
     // M' = M k, k = -M^-1 mod 2^(29 U), so that M' == -1 (mod 2^(29 U)) and the quotient digits of a row block are the
     // limbs the block retires.  Residues modulo M' are residues modulo M; R = 2^(29 rows) with rows = the limbs M' needs
     // (+ 4 bits of head-room: R > 16 M'), not the geometry's capacity.  M, R, R2, R3 of this object then refer to M'.
-    void init_m1(const Limbs& mod_, const GeoOps* g) {
+    void init_m1(const Limbs& mod_, const GeoOps* g, int headroom_bits = 4) {
         require(hbn::is_odd(mod_), "modulus must be odd");
         geo = g;
         nl = g->nl;
@@ -251,7 +252,7 @@ struct ModSetup {
         M = hbn::mul(mod_, k);
         bits = hbn::bitlen(M);
         w32 = words_for_bits(bits);
-        int rows = (bits + 4 + hbn::RB - 1) / hbn::RB;
+        int rows = (bits + headroom_bits + hbn::RB - 1) / hbn::RB;
         rows = (rows + g->u - 1) / g->u * g->u;
         require(rows <= nl, "minus-one modulus does not fit the geometry");
         const Limbs mp1 = hbn::add(M, Limbs{1u});
@@ -561,6 +562,12 @@ struct pai_privkey {
         bool dense = false;
         ModSetup sq2[2], sq2_true[2];
         uint32_t* d_r3_2[2] = {nullptr, nullptr};
+        // smallest batches: stage A on digit pairs with base s' = s k, four waves per (ciphertext, prime) (kernels_declat.hpp)
+        bool pp_ok = false;
+        ModSetup pp[2];
+        uint32_t* d_pp_kdig[2] = {nullptr, nullptr};
+        uint32_t* d_pp_kx[2] = {nullptr, nullptr};
+        int pp_nd = 0, pp_nch = 0;
     } lat;
     ScratchOrder order;
     std::mutex mu;
@@ -767,6 +774,10 @@ static bool lat_dense_disabled() {                  // PAI_DISABLE=lat_dense: sm
 static size_t lat_rl_max(size_t ncu) {              // PAI_TUNE lat_rl: largest batch of the wave-pair small-batch decryption (0 disables)
     long long v;
     return knob_tune("lat_rl", &v) ? (size_t)v : ncu;
+}
+static size_t lat_pp_max(size_t ncu) {              // PAI_TUNE lat_pp: most (ciphertext, prime) chains of the four-wave digit-pair decryption (0 disables)
+    long long v;
+    return knob_tune("lat_pp", &v) ? (size_t)v : ncu;
 }
 static size_t lat_enc_tree_max(size_t ncu) {        // PAI_TUNE lat_enc_tree: largest batch of the wave-shared small-batch encryption (0 disables)
     long long v;
@@ -2648,6 +2659,9 @@ void pai_privkey_destroy(pai_privkey* sk) {
     if (sk->d_pinvqR) (void)hipFree(sk->d_pinvqR);
     for (int w = 0; w < 2; ++w) {
         sk->lat.sq[w].release();
+        sk->lat.pp[w].release();
+        if (sk->lat.d_pp_kdig[w]) (void)hipFree(sk->lat.d_pp_kdig[w]);
+        if (sk->lat.d_pp_kx[w]) (void)hipFree(sk->lat.d_pp_kx[w]);
         sk->lat.sq_true[w].release();
         sk->lat.sq2[w].release();
         sk->lat.sq2_true[w].release();
@@ -2704,6 +2718,52 @@ static void build_latency_consts(pai_privkey* sk) {
     }
     L.d_pinvqR = upload_r29(hbn::mulmod(sk->pinvq_host, L.pr[1].R, sk->q), gb->nl);
     L.usable = true;
+    if (ga == geo_ops_3x64() && !knob_disabled("lat_pp")) {
+        // digit pairs with base s' = s k (minus-one context of s itself, R = 2^(29 r) >= 2^8 s'): the digits of R^(i+2) mod
+        // s'^2 take a ciphertext into digit form; R^-1 R_sq^(j+2) mod (s^2 k2) take a + b s' into L.sq's Montgomery form
+        bool ok = true;
+        const int ct_bits = 32 * sk->pk->ct_words;
+        for (int w = 0; w < 2 && ok; ++w) {
+            L.pp[w].init_m1(prime[w], ga, 8);
+            const int r = L.pp[w].m1_rows;
+            const int nd = (ct_bits + hbn::RB * r - 1) / (hbn::RB * r);
+            const int rows_sq = L.sq[w].m1_rows;
+            const int nch = (2 * r + 2 + rows_sq - 1) / rows_sq;
+            if (r > PP_RMAX || nd > PP_MAXND || nch > PP_MAXCH || 2 * r + 2 > PP_YBUF) { ok = false; break; }
+            if (w == 1 && (nd != L.pp_nd || nch != L.pp_nch)) { ok = false; break; }
+            L.pp_nd = nd;
+            L.pp_nch = nch;
+            const Limbs& Mp = L.pp[w].M;
+            const Limbs Mp2 = hbn::mul(Mp, Mp);
+            const Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * r), Mp2);
+            Limbs K = hbn::mulmod(Rm, Rm, Mp2);
+            std::vector<uint32_t> host((size_t)nd * 2 * r, 0);
+            for (int i = 0; i < nd; ++i) {
+                Limbs rem;
+                Limbs quo = hbn::divq(K, Mp, &rem);
+                auto ra = hbn::to_r29(rem, r), rb = hbn::to_r29(quo, r);
+                std::memcpy(&host[(size_t)(2 * i) * r], ra.data(), (size_t)r * 4);
+                std::memcpy(&host[(size_t)(2 * i + 1) * r], rb.data(), (size_t)r * 4);
+                K = hbn::mulmod(K, Rm, Mp2);
+            }
+            L.d_pp_kdig[w] = upload_vec(host);
+            const Limbs& Msq = L.sq[w].M;
+            hbn::Mont32 mt(Msq);
+            const Limbs inv2 = hbn::shr(hbn::add(Msq, one), 1);
+            const Limbs rinv = mt.powmod(inv2, hbn::from_u64((uint64_t)hbn::RB * (uint64_t)r));      // R^-1 mod s^2 k2
+            const Limbs Rsq = hbn::mod(hbn::shl(one, hbn::RB * rows_sq), Msq);
+            Limbs Kx = hbn::mulmod(rinv, hbn::mulmod(Rsq, Rsq, Msq), Msq);
+            const int nl = ga->nl;
+            std::vector<uint32_t> hx((size_t)nch * nl, 0);
+            for (int j = 0; j < nch; ++j) {
+                auto rk = hbn::to_r29(Kx, nl);
+                std::memcpy(&hx[(size_t)j * nl], rk.data(), (size_t)nl * 4);
+                Kx = hbn::mulmod(Kx, Rsq, Msq);
+            }
+            L.d_pp_kx[w] = upload_vec(hx);
+        }
+        L.pp_ok = ok;
+    }
     const GeoOps* gd = geo_latency_for_bits(sq_bits + hbn::RB * 3 + 8);
     if (gd && gd != ga && gd->t >= 16 && gd->t < ga->t) {
         for (int w = 0; w < 2; ++w) {
@@ -2773,7 +2833,26 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 B.pt_words = pk->n_words;
                 B.u_is_L = 0;
                 g_last_times.clear();
-                {
+                // the smallest batches (one workgroup per (ciphertext, prime) fits the device): digit pairs on four waves
+                if (L.pp_ok && !dense && 2 * N <= lat_pp_max((size_t)dev.ncu)) {
+                    DecPPParams Q;
+                    for (int w = 0; w < 2; ++w) {
+                        Q.pp[w] = L.pp[w].d_ctx;
+                        Q.kdig[w] = L.d_pp_kdig[w];
+                        Q.kx[w] = L.d_pp_kx[w];
+                        Q.sq[w] = L.sq[w].d_ctx;
+                        Q.fin[w] = L.sq_true[w].d_ctx;
+                        Q.expo[w] = sk->d_expo[w];
+                        Q.ebits[w] = sk->ebits[w];
+                    }
+                    Q.nd = L.pp_nd;
+                    Q.nch = L.pp_nch;
+                    Q.ct_words = pk->ct_words;
+                    Q.u_words = u_words;
+                    ScopedKernelTimer t("k_dec_a", s);
+                    launch_dec_a_pp(s, (int)N, Q, d_ct, sk->ubuf.as<uint32_t>());
+                    t.stop();
+                } else {
                     ScopedKernelTimer t("k_dec_a", s);
                     ga->dec_a(s, gridx, A, d_ct, sk->ubuf.as<uint32_t>(), (int)N, L.table.as<uint32_t>());
                     t.stop();

@@ -499,12 +499,15 @@ def test_decrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
         dct = DevArray(ints_to_limbs(ct, nk.cw))
         # PAI_TUNE lat_rl: up to one integer per CU the latency path runs right to left on wave pairs (k_dec_a_rl: squarings on
         # one wave, products on another); 0 keeps the left-to-right window kernel
-        for switch, rl in (("0", "100000"), ("100000", "100000"), ("100000", "0")):
+        # PAI_TUNE lat_pp: the smallest batches (one workgroup per (ciphertext, prime)) run stage A on digit pairs with base
+        # s k, pipelined over four waves (k_dec_a_pp); 0 leaves them to the wave-pair / window kernels
+        for switch, rl, pp in (("0", "100000", "0"), ("100000", "100000", "100000"), ("100000", "100000", "0"), ("100000", "0", "0")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
             tune(monkeypatch, "lat_rl", rl)
+            tune(monkeypatch, "lat_pp", pp)
             out = DevArray(shape=(N, nk.nw))
             _native.check(nk.lib.pai_decrypt(nk.sk, dct.ptr, N, out.ptr, None))
-            assert limbs_to_ints(out.get()) == m, (bits, N, switch, rl)
+            assert limbs_to_ints(out.get()) == m, (bits, N, switch, rl, pp)
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 4096])
