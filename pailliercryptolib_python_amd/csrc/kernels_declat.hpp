@@ -239,8 +239,7 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
     for (int i = threadIdx.x; i < P.nch * G::NL; i += BLOCK_THREADS) lds[L::KX + i] = P.kx[which][i];
     for (int i = threadIdx.x; i < PP_YBUF; i += BLOCK_THREADS) lds[L::YBUF + i] = 0u;
     uint32_t* flags = lds + L::FLAGS;
-    uint32_t* headA = flags, *headB = flags + 1, *headP = flags + 2, *tailW2 = flags + 3, *tailB1 = flags + 4, *tailB2 = flags + 5,
-            *tailP = flags + 6;
+    uint32_t* headA = flags, *headB = flags + 1, *headP = flags + 2, *tailB1 = flags + 4, *tailB2 = flags + 5, *tailP = flags + 6;
     auto bit_of = [&](int i) -> uint32_t { return (expo[i >> 5] >> (i & 31)) & 1u; };
     auto next_set = [&](int i) -> int {
         while (i < ebits && !bit_of(i)) ++i;
@@ -295,7 +294,7 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
             for (int i = 0; i + 1 < ebits; ++i) {
                 if (i >= PP_RING - 1) {                               // slot (i + 1) % RING still holds index i + 1 - RING
                     const uint32_t need = (uint32_t)(i + 2 - PP_RING);
-                    if (seen2 < need) PP_WAIT(seen2 = rl_wait(tailW2, need));
+                    if (seen2 < need) PP_WAIT(seen2 = rl_wait(headB, need + 1) - 1);      // W2 is done with index headB - 2
                     if (seen3 < need) PP_WAIT(seen3 = rl_wait(tailB1, need));
                     if (seen4 < need) PP_WAIT(seen4 = rl_wait(tailB2, need));
                 }
@@ -329,9 +328,7 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
 #pragma unroll
                 for (int j = 0; j < NLL; ++j) b[j] = v[j];
                 rl_publish(headB, (uint32_t)(i + 2));
-                rl_publish(tailW2, (uint32_t)(i + 1));
             }
-            rl_publish(tailW2, (uint32_t)(ebits + PP_RING));
             PP_REPORT("W2");
         } else if (wave == 2) {
             // ---- B1: first digit of the accumulator: the a_i at the set bits of s - 1 -----------------------------------
