@@ -90,6 +90,7 @@ while time.time() - t0 < budget:
     oe = DevArray(shape=(n2, nk.cw))
     for sw in ("0", "100000"):
         os.environ["PAI_LATENCY_MAX"] = sw
+        os.environ["PAI_TUNE"] = f"lat_pp={int(rng.choice([0, 100000]))},lat_rl={int(rng.choice([0, 100000]))}"   # every small-batch stage A
         _native.check(lib.pai_encrypt(nk.pk, dmm.ptr, drr.ptr, n2, oe.ptr, None))
         assert limbs_to_ints(oe.get()) == want_enc, ("encrypt", bits, n2, sw)
         _native.check(lib.pai_decrypt(nk.sk, dct.ptr, n2, om.ptr, None))
@@ -97,6 +98,27 @@ while time.time() - t0 < budget:
         _native.check(lib.pai_ct_mul(nk.pk, dct.ptr, de.ptr, ew, ebits, 0, n2, oc.ptr, None))
         assert limbs_to_ints(oc.get()) == [pow(c, x, M) for c, x in zip(cts, e)], ("ct_mul", bits, n2, ebits, sw)
     os.environ.pop("PAI_LATENCY_MAX", None)
+    os.environ.pop("PAI_TUNE", None)
+    # n-ary sum: random operand count, domain tags, result tag and exponent raises
+    kk = int(rng.integers(2, 17)); Nn = int(rng.integers(1, 200))
+    t0_, t_ = int(rng.integers(-3, 4)), int(rng.integers(-1, 2))      # (|1 + dom_out - c| must stay within the table of R^m: 48)
+    dom_out = int(rng.integers(-6, 7))
+    def rp(m_): return pow(Rm, m_, M) if m_ >= 0 else pow(Ri, -m_, M)
+    vals = [pattern(M, Nn) for _ in range(kk)]
+    rz = [None if rng.integers(0, 3) == 0 else rng.integers(0, 4, Nn).astype(np.int32) for _ in range(kk)]
+    if rz[0] is not None: t0_ = t_
+    ops = [DevArray(ints_to_limbs([x * rp(t0_ if j == 0 else t_) % M for x in v], nk.cw)) for j, v in enumerate(vals)]
+    rzd = [None if r_ is None else DevArray(r_) for r_ in rz]
+    ptrs = (C.c_void_p * kk)(*[o.ptr.value for o in ops])
+    rzp = (C.c_void_p * kk)(*[None if r_ is None else r_.ptr.value for r_ in rzd])
+    on = DevArray(shape=(Nn, nk.cw))
+    _native.check(lib.pai_ct_addn(nk.pk, ptrs, rzp, kk, t0_, t_, dom_out, Nn, on.ptr, None))
+    wantn = []
+    for i in range(Nn):
+        acc = 1
+        for j in range(kk): acc = acc * pow(vals[j][i], 1 << (0 if rz[j] is None else int(rz[j][i])), M) % M
+        wantn.append(acc * rp(dom_out) % M)
+    assert limbs_to_ints(on.get()) == wantn, ("ct_addn", bits, kk, Nn, t0_, t_, dom_out)
     # multi-exponentiation (digit engine up to 2048-bit keys, lane groups above) with forced chunking and random table
     # widths, and pow2 on the digit engine
     if True:
@@ -132,5 +154,5 @@ while time.time() - t0 < budget:
         for i in range(0, N, max(1, N // 30)):
             assert got2[i] == (pow(a[i], 1 << int(dl2[i]), M) if dl2[i] > 0 else a[i]), ("pow2_digit", bits, N, i)
         os.environ.pop("PAI_POW2_DIGIT_MIN", None)
-    rounds += 1; checks += 12
+    rounds += 1; checks += 13
 print(json.dumps({"rounds": rounds, "checks": checks, "seconds": round(time.time() - t0, 1), "failures": 0}))
