@@ -72,18 +72,29 @@ struct PPLds {
 // One row block of pp_half on a window split into its low half L (the U columns the block retires) and its high half H
 // (NLL == U): afterwards H is the new low half and L — cleared, then holding the first q s' products — the new high half, so two
 // consecutive blocks swap the roles of the two register sets and the window never moves.
+// The block's own digits arrive in `cur` (read from LDS during the previous block); the next block's digits are read into
+// `nxt` here, before the multiplies — a lone wave has nobody to hide an LDS round trip behind, and the two digit sets swap
+// roles from block to block like the window halves do (no copies).
+template <int U>
+struct PPDigits { uint32_t b1[U], b2[U], f[U]; };
+template <class G, bool TWO, bool FEED>
+PAI_DEV void pp_fetch(PPDigits<G::U>& d, const uint32_t* lds, int d1, int d2, int fd) {
+#pragma unroll
+    for (int u = 0; u < G::U; ++u) {
+        d.b1[u] = lds[d1 + u];
+        if constexpr (TWO) d.b2[u] = lds[d2 + u];
+        if constexpr (FEED) d.f[u] = lds[fd + u];
+    }
+}
 template <class G, bool TWO, bool FEED, bool EXPORT>
 PAI_DEV void pp_block(uint64_t (&L)[G::U], uint64_t (&H)[G::U], const uint32_t (&x1)[G::NLL], const uint32_t (&x2)[G::NLL], uint32_t* lds,
-                      int d1, int d2, int fd, int mq, const NmRegs<G::NLL>& npp) {
+                      const PPDigits<G::U>& cur, PPDigits<G::U>& nxt, int d1, int d2, int fd, int mq, const NmRegs<G::NLL>& npp) {
     constexpr int U = G::U;
     static_assert(G::NLL == U, "window of two halves");
-    uint32_t bv1[U], bv2[U], fv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        bv1[u] = lds[d1 + u];
-        if constexpr (TWO) bv2[u] = lds[d2 + u];
-        if constexpr (FEED) fv[u] = lds[fd + u];
-    }
+    pp_fetch<G, TWO, FEED>(nxt, lds, d1 + U, d2 + U, fd + U);       // (one block beyond the last: in-bounds reads of unused words)
+    const uint32_t (&bv1)[U] = cur.b1;
+    const uint32_t (&bv2)[U] = cur.b2;
+    const uint32_t (&fv)[U] = cur.f;
     auto col = [&](int k) -> uint64_t& { return k < U ? L[k] : H[k - U]; };
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -155,17 +166,19 @@ PAI_DEV void pp_half(uint32_t (&r)[G::NLL], const uint32_t (&x1)[G::NLL], int di
     constexpr int NORMB = (TWO || HEAVY) ? 21 / U : 30 / U;
     int since = 0;
     int blk = 0;
+    PPDigits<U> da, db;
+    pp_fetch<G, TWO, FEED>(da, lds, dig1, dig2, fd_off);
 #pragma unroll 1
     for (; blk + 1 < nblk; blk += 2) {
-        pp_block<G, TWO, FEED, EXPORT>(A, B, x1, x2, lds, dig1 + blk * U, dig2 + blk * U, fd_off + blk * U, mq_off + blk * U, npp);
+        pp_block<G, TWO, FEED, EXPORT>(A, B, x1, x2, lds, da, db, dig1 + blk * U, dig2 + blk * U, fd_off + blk * U, mq_off + blk * U, npp);
         if (++since == NORMB) { pp_normalize<U>(B, A); since = 0; }
-        pp_block<G, TWO, FEED, EXPORT>(B, A, x1, x2, lds, dig1 + (blk + 1) * U, dig2 + (blk + 1) * U, fd_off + (blk + 1) * U,
+        pp_block<G, TWO, FEED, EXPORT>(B, A, x1, x2, lds, db, da, dig1 + (blk + 1) * U, dig2 + (blk + 1) * U, fd_off + (blk + 1) * U,
                                        mq_off + (blk + 1) * U, npp);
         if (++since == NORMB && blk + 2 < nblk) { pp_normalize<U>(A, B); since = 0; }
     }
     uint64_t acc[RW::NW];
     if (blk < nblk) {                                                 // an odd block count: the halves end up swapped
-        pp_block<G, TWO, FEED, EXPORT>(A, B, x1, x2, lds, dig1 + blk * U, dig2 + blk * U, fd_off + blk * U, mq_off + blk * U, npp);
+        pp_block<G, TWO, FEED, EXPORT>(A, B, x1, x2, lds, da, db, dig1 + blk * U, dig2 + blk * U, fd_off + blk * U, mq_off + blk * U, npp);
 #pragma unroll
         for (int u = 0; u < U; ++u) { acc[u] = B[u]; acc[U + u] = A[u]; }
     } else {

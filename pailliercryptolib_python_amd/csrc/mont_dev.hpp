@@ -408,6 +408,9 @@ PAI_DEV void mont_mul_m1(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uin
     RW::zero(acc);
     constexpr int NORM_BLOCKS = NORM_ROWS / U;          // two products per row and column, as in mont_mul
     int since = 0;
+    // (reading the digits of block k + 1 while block k multiplies — which pays in kernels_declat.hpp's split-window blocks —
+    // measured NEGATIVE here: the two-block loop body loses the compiler's renaming of the window slide: k_dec_a_rl 3.37 ->
+    // 3.63 ms, ct x pt 0.372 -> 0.393 ms, profiles/r05/README.md)
 #pragma unroll 1
     for (int blk = 0; blk < nblk; ++blk) {
         uint32_t bv[U];

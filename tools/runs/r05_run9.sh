@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 9: k_dec_a_pp variants (profile builds): per-wave cycles
 cd "$(dirname "$0")/../.."
-for v in base solo; do
+for v in base nob; do
 echo "== $v"
 PAI_NATIVE_LIB=$PWD/pailliercryptolib_python_amd/lib/alt/lib_pp_$v.so timeout 120 python - <<'PY' 2>&1 | grep -E "^PP|ok" | sort | uniq -c | head -8
 import torch, sys
