@@ -776,8 +776,8 @@ static size_t lat_rl_max(size_t ncu) {              // PAI_TUNE lat_rl: largest 
     return knob_tune("lat_rl", &v) ? (size_t)v : ncu;
 }
 static size_t lat_pp_max(size_t ncu) {              // PAI_TUNE lat_pp: most (ciphertext, prime) chains of the four-wave digit-pair decryption (0 disables)
-    long long v;
-    return knob_tune("lat_pp", &v) ? (size_t)v : ncu;
+    long long v;                                    // two workgroups (70 KB of LDS each) share a CU up to 2 x CUs chains: 3.23 against 3.45 ms at
+    return knob_tune("lat_pp", &v) ? (size_t)v : 2 * ncu;       // 160 .. 256 ciphertexts (2.5 ms up to 128); beyond, the window kernel is ahead
 }
 static size_t lat_enc_tree_max(size_t ncu) {        // PAI_TUNE lat_enc_tree: largest batch of the wave-shared small-batch encryption (0 disables)
     long long v;
@@ -2833,7 +2833,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 B.pt_words = pk->n_words;
                 B.u_is_L = 0;
                 g_last_times.clear();
-                // the smallest batches (one workgroup per (ciphertext, prime) fits the device): digit pairs on four waves
+                // the smallest batches (a workgroup per (ciphertext, prime), at most two per CU): digit pairs on four waves
                 if (L.pp_ok && !dense && 2 * N <= lat_pp_max((size_t)dev.ncu)) {
                     DecPPParams Q;
                     for (int w = 0; w < 2; ++w) {
