@@ -13,4 +13,11 @@ void launch_dec_a_pp(hipStream_t s, int n, const DecPPParams& P, const uint32_t*
     (void)hipFuncSetAttribute((const void*)k_dec_a_pp<GP>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     hipLaunchKernelGGL(k_dec_a_pp<GP>, dim3(n, 2), dim3(BLOCK_THREADS), bytes, s, P, ct, u_out, n);
 }
+// ct * pt of the smallest batches on the same four-wave pipeline, one workgroup per ciphertext (pp_chain<G, true>)
+void launch_ctmul_pp(hipStream_t s, int n, const DecPPParams& P, const uint32_t* ct, uint32_t* out) {
+    using GP = Geo<3, 64, 3, false, true>;
+    constexpr int bytes = PPLds<GP>::BYTES;
+    (void)hipFuncSetAttribute((const void*)k_ctmul_pp<GP>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL(k_ctmul_pp<GP>, dim3(n), dim3(BLOCK_THREADS), bytes, s, P, ct, out, n);
+}
 }  // namespace pai

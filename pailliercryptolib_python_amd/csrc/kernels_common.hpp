@@ -336,22 +336,60 @@ PAI_DEV void mm_times(uint32_t (&x)[G::NLL], const uint32_t (&y)[G::NLL], uint32
     for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
 }
 
-// Minus-one geometries: x (lazy, a residue modulo M k) -> the canonical residue modulo M itself, by two conventional
-// Montgomery products with M's own context: x R^2 R^-1 = x R (mod M), then * 1 * R^-1.
+// Minus-one geometries: x (a residue modulo M k, x <= M k < 2^(29 (m + U)), m the limbs of M) -> the canonical residue
+// modulo M itself.  The quotient x / M is SHORT (k < 2^(29 U)): Barrett on the top U + 3 limbs of x with
+// mu = floor(2^(29 (m + U + 1)) / M) gives q^ in {q - 2 .. q} as U + 1 limbs, x - q^ M costs U + 1 products per limb, and two
+// conditional subtractions finish.  (Rounds 3-5 did this by two conventional Montgomery products with M's own context —
+// 2 NL rows with a dependent quotient digit each: the larger part of the exit of every small-batch kernel.)
 template <class G>
 PAI_DEV void m1_reduce_to_true_modulus(uint32_t (&x)[G::NLL], uint32_t* lds, const MontCtx* __restrict__ f) {
-    NmRegs<G::NLL> nf;
+    constexpr int NLL = G::NLL, U = G::U, T = G::T, S = U + 3;
+    static_assert(U <= NLL && S <= 12, "window of the modulus from one neighbour lane; mu[] of the context");
+    NmRegs<NLL> nf;
     load_const_slice<G>(nf.v, f->n);
-    uint32_t c[G::NLL], r[G::NLL], one[G::NLL];
-    load_const_slice<G>(c, f->r2);
-#pragma unroll
-    for (int j = 0; j < G::NLL; ++j) one[j] = 0;
-    if (G::gl() == 0) one[0] = 1;
+    const int m = (int)f->mlimbs;
     stage_b<G>(x, lds);
-    mont_mul<G::NLL, G::U, G::T>(r, c, lds + G::elem(), G::EPB, nf, f->n0inv);
-    stage_b<G>(r, lds);
-    mont_mul<G::NLL, G::U, G::T>(x, one, lds + G::elem(), G::EPB, nf, f->n0inv);
-    cond_sub<G::NLL, G::T>(x, nf);
+    uint32_t xt[S];
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+        const int idx = m - 2 + a;
+        xt[a] = idx < G::NL ? lds[idx * G::EPB + G::elem()] : 0u;
+    }
+    wave_lds_fence();
+    uint64_t col[2 * S];
+#pragma unroll
+    for (int k = 0; k < 2 * S; ++k) col[k] = 0;
+#pragma unroll
+    for (int b = 0; b < S; ++b) {
+        const uint32_t mb = f->mu[b];
+#pragma unroll
+        for (int a = 0; a < S; ++a) col[a + b] += (uint64_t)xt[a] * mb;
+    }
+    uint64_t c = 0;
+    uint32_t q[U + 1];
+#pragma unroll
+    for (int k = 0; k < S + U + 1; ++k) {
+        const uint64_t t = col[k] + c;
+        if (k >= S) q[k - S] = (uint32_t)t & RMASK;
+        c = t >> RB;
+    }
+    // this lane's limbs of q^ M need the U limbs of M below its own: the neighbour's top ones
+    uint32_t w[NLL + U];
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) w[U + j] = nf.v[j];
+#pragma unroll
+    for (int t = 0; t < U; ++t) w[U - 1 - t] = T > 1 ? from_prev<T>(nf.v[NLL - 1 - t]) : 0u;
+    int64_t d[NLL];
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) {
+        uint64_t p = 0;
+#pragma unroll
+        for (int i = 0; i <= U; ++i) p += (uint64_t)q[i] * w[U + j - i];
+        d[j] = (int64_t)x[j] - (int64_t)p;
+    }
+    Rows<NLL, U, T>::finish_signed(d, x);
+    cond_sub<NLL, T>(x, nf);
+    cond_sub<NLL, T>(x, nf);
 }
 
 // plain integer 1 spread over the group (lane 0, limb 0)

@@ -28,9 +28,10 @@ struct DecPPParams {
     const uint32_t* kx[2];       // [nch][NL]: R^-1 R_sq^(j+2) mod (s^2 k2): takes chunk j (base R_sq) of a + b s' into the Montgomery form of sq[]
     const MontCtx* sq[2];        // minus-one contexts of s^2 (exit)
     const MontCtx* fin[2];       // conventional contexts of s^2 (exit: the canonical residue)
-    const uint32_t* expo[2];     // s - 1, packed words
-    int ebits[2];
+    const uint32_t* expo[2];     // s - 1, packed words (VAR: [0] = the exponents, e_words each, one row when e_bcast)
+    int ebits[2];                // (VAR: [0] = ebits_max)
     int nd, nch, ct_words, u_words;
+    int e_words = 0, e_bcast = 0;
 };
 
 constexpr int PP_RMAX = 80;      // limbs of s' (4096-bit keys: 75 rows)
@@ -41,6 +42,7 @@ constexpr int PP_PRING = 8;      // (A, m) slots between the product waves
 constexpr int PP_MAXND = 6;
 constexpr int PP_MAXCH = 3;      // base-R_sq chunks of a + b s' at the exit
 constexpr int PP_YBUF = 2 * PP_RMAX + 16;
+constexpr int PP_EWORDS = 128;   // exponent words (4096 bits)
 
 
 template <class G>
@@ -58,7 +60,8 @@ struct PPLds {
     static constexpr int KX = MLIM + PP_RMAX;                         // exit constants, [nch][NL]
     static constexpr int ZERO = KX + PP_MAXCH * G::NL;                          // RMAX zero words (the feed of lanes != 0)
     static constexpr int TMPM = ZERO + PP_RMAX;                       // quotient digits of the entry products
-    static constexpr int FLAGS = TMPM + PP_RMAX;
+    static constexpr int EXPO = TMPM + PP_RMAX;                       // the exponent's words (the product waves scan its bits)
+    static constexpr int FLAGS = EXPO + PP_EWORDS;
     static constexpr int WORDS = FLAGS + 16;
     static constexpr int BYTES = WORDS * 4;
 };
@@ -218,21 +221,32 @@ PAI_DEV void pp_store(uint32_t* lds, int off, const uint32_t (&x)[G::NLL]) {
 #ifdef PP_PROFILE
 #define PP_T0() const unsigned long long pp_t0 = __builtin_readcyclecounter(); unsigned long long pp_wait = 0
 #define PP_WAIT(expr) do { const unsigned long long w0_ = __builtin_readcyclecounter(); expr; pp_wait += __builtin_readcyclecounter() - w0_; } while (0)
+#define PP_DECL(a, b) unsigned long long a = 0, b = 0
+#define PP_STAMP(var) var = __builtin_readcyclecounter() - pp_t0
+#define PP_REPORT2(role, a, b) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) printf("PP %s: cycles %llu, waiting %llu; stamps %llu %llu\n", role, __builtin_readcyclecounter() - pp_t0, pp_wait, a, b); } while (0)
 #define PP_REPORT(role) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) printf("PP %s: cycles %llu, waiting %llu\n", role, __builtin_readcyclecounter() - pp_t0, pp_wait); } while (0)
 #else
 #define PP_T0() do { } while (0)
 #define PP_WAIT(expr) expr
+#define PP_DECL(a, b) unsigned long long a = 0, b = 0
+#define PP_STAMP(var) var = __builtin_readcyclecounter() - pp_t0
+#define PP_REPORT2(role, a, b) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) printf("PP %s: cycles %llu, waiting %llu; stamps %llu %llu\n", role, __builtin_readcyclecounter() - pp_t0, pp_wait, a, b); } while (0)
 #define PP_REPORT(role) do { } while (0)
+#define PP_STAMP(var) do { } while (0)
+#define PP_DECL(a, b) do { } while (0)
+#define PP_REPORT2(role, a, b) do { } while (0)
 #endif
 
-template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, 1)
-k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out /*[2][n][u_words]*/, int n) {
+// VAR = false: decrypt stage A (workgroup (i, w): ciphertext i to the power s_w - 1 modulo s_w^2, s_0 = p, s_1 = q).
+// VAR = true: ct * pt for the smallest batches (ipclCipherText.__mul__ -> CipherText::operator*(PlainText), classes.cpp /
+// the reference's BM_Mul_CTPT): ONE modulus (s = n, the power modulo n^2) and the exponent of each element its own; exponent 0
+// gives 1.
+template <class G, bool VAR>
+PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n, uint32_t* lds) {
     static_assert(G::M1 && G::T == 64 && G::NLL == G::U && BLOCK_THREADS == 256, "one integer per wavefront, four waves per chain");
     constexpr int NLL = G::NLL, U = G::U;
     using L = PPLds<G>;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int which = blockIdx.y;
+    const int which = VAR ? 0 : (int)blockIdx.y;
     const MontCtx* ctx = P.pp[which];
     const uint32_t* expo = P.expo[which];
     const int ebits = P.ebits[which];
@@ -253,10 +267,18 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
     for (int i = threadIdx.x; i < PP_YBUF; i += BLOCK_THREADS) lds[L::YBUF + i] = 0u;
     uint32_t* flags = lds + L::FLAGS;
     uint32_t* headA = flags, *headB = flags + 1, *headP = flags + 2, *tailB1 = flags + 4, *tailB2 = flags + 5, *tailP = flags + 6;
-    auto bit_of = [&](int i) -> uint32_t { return (expo[i >> 5] >> (i & 31)) & 1u; };
+    const int ewords = VAR ? P.e_words : (ebits + 31) / 32;
+    // lowest set bit of the exponent at or above i (ebits: none): one LDS word per call, mostly
     auto next_set = [&](int i) -> int {
-        while (i < ebits && !bit_of(i)) ++i;
-        return i;
+        while (i < ebits) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[L::EXPO + (i >> 5)]) >> (i & 31);
+            if (w) {
+                i += __builtin_ctz(w);
+                return i < ebits ? i : ebits;
+            }
+            i = (i | 31) + 1;
+        }
+        return ebits;
     };
     // lane 0 feeds from / exports to the quotient-digit buffer, the other lanes read zeros / write to their dump rows
     auto feed_off = [&](int m_off) -> int { return lane0 ? m_off : (int)L::ZERO; };
@@ -271,13 +293,16 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
     for (int j = 0; j < NLL; ++j) none[j] = 0;
     const int tiles = n;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        if (threadIdx.x < 16) flags[threadIdx.x] = 0;
-        __syncthreads();
         const int ei = tile;
+        if constexpr (VAR) expo = P.expo[0] + (P.e_bcast ? (size_t)0 : (size_t)ei * P.e_words);
+        if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+        if ((int)threadIdx.x < ewords) lds[L::EXPO + threadIdx.x] = expo[threadIdx.x];
+        __syncthreads();
         if (wave == 0) {
             // ---- W1: the ciphertext's digit form, then the chain of first digits --------------------------------------
             const uint32_t* row = ct + (size_t)ei * P.ct_words;
             uint32_t sa[NLL], sb[NLL];
+            PP_T0();
 #pragma unroll
             for (int j = 0; j < NLL; ++j) { sa[j] = 0; sb[j] = 0; }
 #pragma unroll 1
@@ -302,7 +327,7 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
 #pragma unroll
             for (int j = 0; j < NLL; ++j) x[j] = sa[j];
             uint32_t seen2 = 0, seen3 = 0, seen4 = 0;
-            PP_T0();
+            PP_REPORT("W1 (entry)");
 #pragma unroll 1
             for (int i = 0; i + 1 < ebits; ++i) {
                 if (i >= PP_RING - 1) {                               // slot (i + 1) % RING still holds index i + 1 - RING
@@ -387,6 +412,7 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
             rl_publish(tailB2, (uint32_t)i);
             bool first = true;
             PP_T0();
+            PP_DECL(pp_s1, pp_s2);
 #pragma unroll 1
             while (i < ebits) {
                 PP_WAIT(rl_wait<RL_SLEEP_B>(headB, (uint32_t)(i + 1)));
@@ -407,8 +433,12 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
                 i = next_set(i + 1);
                 rl_publish(tailB2, (uint32_t)(i < ebits ? i : ebits + PP_RING));
             }
-            PP_REPORT("B2 (products)");
+            PP_STAMP(pp_s1);
             rl_wait<RL_SLEEP_B>(headP, (uint32_t)(k + 1));
+            uint32_t acc2[NLL];
+            if (VAR && first) {                                       // exponent 0
+                set_plain_one<G>(acc2);
+            } else {
             uint32_t A[NLL];
             pp_load<G>(A, lds, slotPA(k));
             // y = A + Bv s' (plain, 2 r limbs): r rows retire the low limbs through lane 0, the window keeps y >> 29 r
@@ -441,6 +471,7 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
                 }
             }
             wave_lds_fence();
+            PP_STAMP(pp_s2);
             // into the Montgomery form of the s^2 context chunk by chunk (y = sum_j y_j R_sq^j, y_j < R_sq: every product
             // comes out lazy), then k_dec_a_rl's tail: leave the form, reduce modulo s^2 itself
             const MontCtx* cs = P.sq[which];
@@ -448,7 +479,6 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
 #pragma unroll
             for (int j = 0; j < NLL; ++j) nsq.v[j] = cs->npp[NLL * lane + j];
             const int rows_sq = (int)cs->rows, nblk_sq = rows_sq / U;
-            uint32_t acc2[NLL];
 #pragma unroll
             for (int j = 0; j < NLL; ++j) acc2[j] = 0;
 #pragma unroll 1
@@ -466,10 +496,25 @@ k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict_
             set_plain_one<G>(one);
             mm_times<G>(acc2, one, lds + L::STAGE, nsq, (uint32_t)nblk_sq);
             m1_reduce_to_true_modulus<G>(acc2, lds + L::STAGE, P.fin[which]);
+            }
             store_elem<G>(acc2, u_out + ((size_t)which * n + ei) * P.u_words, P.u_words, lds + L::STAGE);
+            PP_REPORT2("B2 (stamps: products done, a + b s' done)", pp_s1, pp_s2);
         }
         __syncthreads();
     }
+}
+
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out /*[2][n][u_words]*/, int n) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    pp_chain<G, false>(P, ct, u_out, n, lds);
+}
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 1)
+k_ctmul_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ out /*[n][u_words]*/, int n) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    pp_chain<G, true>(P, ct, out, n, lds);
 }
 
 }  // namespace pai

@@ -51,6 +51,8 @@ struct MontCtx {
     uint32_t bits;            // bit length of M
     uint32_t rows;            // "minus-one" contexts (Rows::block_m1): rows per product, R = 2^(29 rows); else 0
     uint32_t npp[NLMAX];      // "minus-one" contexts: (M + 1) / 2^(29 U), the multiplier of the quotient digits
+    uint32_t mlimbs;          // conventional contexts: m = radix-2^29 limbs of M ...
+    uint32_t mu[12];          // ... and floor(2^(29 (m + U + 1)) / M), U the geometry's rows per block (m1_reduce_to_true_modulus)
 };
 
 // ---- lane-group helpers -------------------------------------------------------------------------
@@ -670,7 +672,26 @@ PAI_DEV void cond_sub(uint32_t (&x)[NLL], const NM& nm) {
         d[j] = (uint32_t)t & RMASK;
         borrow = t >> RB;
     }
-    if constexpr (T > 1) {
+    if constexpr (T == 64) {
+        // one integer per wavefront: borrow look-ahead over the lanes by one 64-bit addition — lane l GENERATES a borrow
+        // (bit l of g) or PROPAGATES one it is handed (all its limbs zero: bit l of p); with x = g | p, y = g the carry
+        // into bit l of x + y is the borrow into lane l, the carry out the borrow out of the integer
+        const uint64_t g = __ballot(borrow != 0);
+        bool allz = borrow == 0;
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) allz = allz && d[j] == 0;
+        const uint64_t pm = __ballot(allz);
+        const uint64_t xs = g | pm, sum = xs + g;
+        const uint64_t cin = sum ^ pm;
+        int32_t bo = (int32_t)((cin >> (threadIdx.x & 63)) & 1u) ? -1 : 0;
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) {
+            int32_t t = (int32_t)d[j] + bo;
+            d[j] = (uint32_t)t & RMASK;
+            bo = t >> RB;
+        }
+        borrow = (sum < xs) ? -1 : 0;
+    } else if constexpr (T > 1) {
         // ripple the borrow through the group, lane by lane (T <= 8, once per operation)
         for (int step = 1; step < T; ++step) {
             int32_t bin = (int32_t)from_prev<T>((uint32_t)borrow);   // 0 or 0xffffffff(-1)

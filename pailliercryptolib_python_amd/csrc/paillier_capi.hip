@@ -235,6 +235,14 @@ struct ModSetup {
         h.n0inv = hbn::neg_inv32(M[0]) & ((1u << hbn::RB) - 1u);
         h.nl = (uint32_t)nl;
         h.bits = (uint32_t)bits;
+        if (geo->u + 3 <= 12) {
+            // Barrett constant of the minus-one geometries' way out (kernels_common.hpp: m1_reduce_to_true_modulus)
+            const int m = (bits + hbn::RB - 1) / hbn::RB;
+            h.mlimbs = (uint32_t)m;
+            const Limbs mu = hbn::divq(hbn::shl(Limbs{1u}, hbn::RB * (m + geo->u + 1)), M, nullptr);
+            auto r = hbn::to_r29(mu, 12);
+            std::memcpy(h.mu, r.data(), sizeof(h.mu));
+        }
         HIP_CHECK(hipMalloc((void**)&d_ctx, sizeof(MontCtx)));
         HIP_CHECK(hipMemcpy(d_ctx, &h, sizeof(MontCtx), hipMemcpyHostToDevice));
     }
@@ -491,6 +499,12 @@ struct pai_pubkey {
     mutable ModSetup lat_msq;
     mutable ModSetup lat_msq_m1;       // minus-one context of n^2 for the small-batch ct * pt
     mutable bool lat_m1_tried = false, lat_m1_ok = false;
+    // smallest ct * pt batches: the four-wave digit-pair pipeline with base n' = n k (k_ctmul_pp; 3 x 64 geometry only)
+    mutable bool lat_pp_tried = false, lat_pp_ok = false;
+    mutable ModSetup lat_pp;
+    mutable uint32_t* d_lat_pp_kdig = nullptr;
+    mutable uint32_t* d_lat_pp_kx = nullptr;
+    mutable int lat_pp_nd = 0, lat_pp_nch = 0;
     // small-batch ct + ct: n^2 on the latency geometry; the "tag" context multiplies by R_lat^2 / R instead of R_lat^2, so that
     // MODMUL_FULL there returns a b R^-1 in terms of the throughput geometry's R (the lazy domain tags of the containers)
     mutable ModSetup lat_msq_tag;
@@ -784,6 +798,10 @@ static size_t lat_enc_tree_max(size_t ncu) {        // PAI_TUNE lat_enc_tree: la
     (void)ncu;
     return knob_tune("lat_enc_tree", &v) ? (size_t)v : (size_t)1 << 30;                         // measured ahead over the whole latency range (2048-bit keys: 0.29 vs 0.98 ms up to 256
 }                                                   // elements, 0.54 vs 1.01 at 1024, 1.63 vs 1.91 at 4096; profiles/r04/lat_enc_tree.jsonl)
+static size_t lat_mul_pp_max(size_t ncu) {          // PAI_TUNE lat_mul_pp: largest batch of the four-wave digit-pair ct * pt (0 disables)
+    long long v;
+    return knob_tune("lat_mul_pp", &v) ? (size_t)v : 2 * ncu;
+}
 static size_t lat_mul_rl_max(size_t ncu) {          // PAI_TUNE lat_mul_rl: largest batch of the wave-pair small-batch ct * pt (0 disables)
     long long v;
     return knob_tune("lat_mul_rl", &v) ? (size_t)v : 2 * ncu;
@@ -1010,6 +1028,51 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
     pk->pair_wbits = wb;
 }
 
+// Constants of the four-wave digit-pair pipeline (kernels_declat.hpp) for one modulus s: the minus-one context of s' = s k
+// (R = 2^(29 r) >= 2^8 s'), the base-s' digits of R^(i+2) mod s'^2 (an integer of in_bits bits into digit form) and
+// R^-1 R_sq^(j+2) mod (s^2 k2) (a + b s' into the Montgomery form of sq_m1, the minus-one context of s^2).
+static bool build_pp_consts(const Limbs& smod, const ModSetup& sq_m1, const GeoOps* ga, int in_bits, ModSetup& pp,
+                            uint32_t** d_kdig, uint32_t** d_kx, int* nd_out, int* nch_out) {
+    const Limbs one{1u};
+    pp.init_m1(smod, ga, 8);
+    const int r = pp.m1_rows;
+    const int nd = (in_bits + hbn::RB * r - 1) / (hbn::RB * r);
+    const int rows_sq = sq_m1.m1_rows;
+    const int nch = (2 * r + 2 + rows_sq - 1) / rows_sq;
+    if (r > PP_RMAX || nd > PP_MAXND || nch > PP_MAXCH || 2 * r + 2 > PP_YBUF) return false;
+    *nd_out = nd;
+    *nch_out = nch;
+    const Limbs& Mp = pp.M;
+    const Limbs Mp2 = hbn::mul(Mp, Mp);
+    const Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * r), Mp2);
+    Limbs K = hbn::mulmod(Rm, Rm, Mp2);
+    std::vector<uint32_t> host((size_t)nd * 2 * r, 0);
+    for (int i = 0; i < nd; ++i) {
+        Limbs rem;
+        Limbs quo = hbn::divq(K, Mp, &rem);
+        auto ra = hbn::to_r29(rem, r), rb = hbn::to_r29(quo, r);
+        std::memcpy(&host[(size_t)(2 * i) * r], ra.data(), (size_t)r * 4);
+        std::memcpy(&host[(size_t)(2 * i + 1) * r], rb.data(), (size_t)r * 4);
+        K = hbn::mulmod(K, Rm, Mp2);
+    }
+    *d_kdig = upload_vec(host);
+    const Limbs& Msq = sq_m1.M;
+    hbn::Mont32 mt(Msq);
+    const Limbs inv2 = hbn::shr(hbn::add(Msq, one), 1);
+    const Limbs rinv = mt.powmod(inv2, hbn::from_u64((uint64_t)hbn::RB * (uint64_t)r));      // R^-1 mod s^2 k2
+    const Limbs Rsq = hbn::mod(hbn::shl(one, hbn::RB * rows_sq), Msq);
+    Limbs Kx = hbn::mulmod(rinv, hbn::mulmod(Rsq, Rsq, Msq), Msq);
+    const int nl = ga->nl;
+    std::vector<uint32_t> hx((size_t)nch * nl, 0);
+    for (int j = 0; j < nch; ++j) {
+        auto rk = hbn::to_r29(Kx, nl);
+        std::memcpy(&hx[(size_t)j * nl], rk.data(), (size_t)nl * 4);
+        Kx = hbn::mulmod(Kx, Rsq, Msq);
+    }
+    *d_kx = upload_vec(hx);
+    return true;
+}
+
 // Contexts of n^2 on the integer-per-wavefront (latency) geometry, built on first need under pk->mu: the conventional one
 // (lat_msq) and, where it fits, the minus-one one (lat_msq_m1).  Returns false when no latency geometry is wide enough.
 static bool ensure_lat_ctx(const pai_pubkey* pk) {
@@ -1028,6 +1091,12 @@ static bool ensure_lat_ctx(const pai_pubkey* pk) {
             pk->lat_msq_m1.init_m1(pk->nsq, g);
             pk->lat_m1_ok = true;
         }
+    }
+    if (pk->lat_m1_ok && !pk->lat_pp_tried) {
+        pk->lat_pp_tried = true;
+        if (pk->lat_msq.geo == geo_ops_3x64() && !knob_disabled("lat_pp"))
+            pk->lat_pp_ok = build_pp_consts(pk->n, pk->lat_msq_m1, pk->lat_msq.geo, 32 * pk->ct_words, pk->lat_pp, &pk->d_lat_pp_kdig,
+                                            &pk->d_lat_pp_kx, &pk->lat_pp_nd, &pk->lat_pp_nch);
     }
     return pk->lat_usable;
 }
@@ -1546,6 +1615,9 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->prod_b.release();
     pk->lat_msq.release();
     pk->lat_msq_m1.release();
+    pk->lat_pp.release();
+    if (pk->d_lat_pp_kdig) (void)hipFree(pk->d_lat_pp_kdig);
+    if (pk->d_lat_pp_kx) (void)hipFree(pk->d_lat_pp_kx);
     pk->lat_msq_tag.release();
     pk->lat_table.release();
     if (pk->d_lat_nR) (void)hipFree(pk->d_lat_nR);
@@ -1987,6 +2059,31 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         if (N <= 4 * latency_max_elements() && ebits_max > 8) {          // 0.9 ms against 4.8 ms up to ~8192 elements
             // small batch: windowed exponentiation with n^2 spread over a whole wavefront per ciphertext
             std::lock_guard<std::mutex> lk(pk->mu);
+            if (ensure_lat_ctx(pk) && pk->lat_pp_ok && e_words <= PP_EWORDS && N <= lat_mul_pp_max((size_t)pk->dev.ncu)) {
+                // smallest batches: digit pairs with base n' = n k, the chain pipelined over the four waves of a workgroup per
+                // ciphertext (kernels_declat.hpp)
+                DecPPParams Q{};
+                Q.pp[0] = pk->lat_pp.d_ctx;
+                Q.kdig[0] = pk->d_lat_pp_kdig;
+                Q.kx[0] = pk->d_lat_pp_kx;
+                Q.sq[0] = pk->lat_msq_m1.d_ctx;
+                Q.fin[0] = pk->lat_msq.d_ctx;
+                Q.expo[0] = d_e;
+                Q.ebits[0] = ebits_max;
+                Q.nd = pk->lat_pp_nd;
+                Q.nch = pk->lat_pp_nch;
+                Q.ct_words = pk->ct_words;
+                Q.u_words = pk->ct_words;
+                Q.e_words = e_words;
+                Q.e_bcast = e_bcast;
+                pk->order.begin(s);
+                ScopedKernelTimer t("k_ctmul", s);
+                launch_ctmul_pp(s, (int)N, Q, d_ct, d_out);
+                t.stop();
+                HIP_CHECK(hipGetLastError());
+                pk->order.end(s);
+                return;
+            }
             if (ensure_lat_ctx(pk)) {
                 const GeoOps* g = pk->lat_msq.geo;
                 // right to left on wave pairs (k_modexp_rl: squarings on one wave, products on another, no table) for the
@@ -2724,43 +2821,11 @@ static void build_latency_consts(pai_privkey* sk) {
         bool ok = true;
         const int ct_bits = 32 * sk->pk->ct_words;
         for (int w = 0; w < 2 && ok; ++w) {
-            L.pp[w].init_m1(prime[w], ga, 8);
-            const int r = L.pp[w].m1_rows;
-            const int nd = (ct_bits + hbn::RB * r - 1) / (hbn::RB * r);
-            const int rows_sq = L.sq[w].m1_rows;
-            const int nch = (2 * r + 2 + rows_sq - 1) / rows_sq;
-            if (r > PP_RMAX || nd > PP_MAXND || nch > PP_MAXCH || 2 * r + 2 > PP_YBUF) { ok = false; break; }
-            if (w == 1 && (nd != L.pp_nd || nch != L.pp_nch)) { ok = false; break; }
+            int nd = 0, nch = 0;
+            ok = build_pp_consts(prime[w], L.sq[w], ga, ct_bits, L.pp[w], &L.d_pp_kdig[w], &L.d_pp_kx[w], &nd, &nch);
+            if (ok && w == 1 && (nd != L.pp_nd || nch != L.pp_nch)) ok = false;
             L.pp_nd = nd;
             L.pp_nch = nch;
-            const Limbs& Mp = L.pp[w].M;
-            const Limbs Mp2 = hbn::mul(Mp, Mp);
-            const Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * r), Mp2);
-            Limbs K = hbn::mulmod(Rm, Rm, Mp2);
-            std::vector<uint32_t> host((size_t)nd * 2 * r, 0);
-            for (int i = 0; i < nd; ++i) {
-                Limbs rem;
-                Limbs quo = hbn::divq(K, Mp, &rem);
-                auto ra = hbn::to_r29(rem, r), rb = hbn::to_r29(quo, r);
-                std::memcpy(&host[(size_t)(2 * i) * r], ra.data(), (size_t)r * 4);
-                std::memcpy(&host[(size_t)(2 * i + 1) * r], rb.data(), (size_t)r * 4);
-                K = hbn::mulmod(K, Rm, Mp2);
-            }
-            L.d_pp_kdig[w] = upload_vec(host);
-            const Limbs& Msq = L.sq[w].M;
-            hbn::Mont32 mt(Msq);
-            const Limbs inv2 = hbn::shr(hbn::add(Msq, one), 1);
-            const Limbs rinv = mt.powmod(inv2, hbn::from_u64((uint64_t)hbn::RB * (uint64_t)r));      // R^-1 mod s^2 k2
-            const Limbs Rsq = hbn::mod(hbn::shl(one, hbn::RB * rows_sq), Msq);
-            Limbs Kx = hbn::mulmod(rinv, hbn::mulmod(Rsq, Rsq, Msq), Msq);
-            const int nl = ga->nl;
-            std::vector<uint32_t> hx((size_t)nch * nl, 0);
-            for (int j = 0; j < nch; ++j) {
-                auto rk = hbn::to_r29(Kx, nl);
-                std::memcpy(&hx[(size_t)j * nl], rk.data(), (size_t)nl * 4);
-                Kx = hbn::mulmod(Kx, Rsq, Msq);
-            }
-            L.d_pp_kx[w] = upload_vec(hx);
         }
         L.pp_ok = ok;
     }

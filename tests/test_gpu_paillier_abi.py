@@ -515,25 +515,34 @@ def test_ct_mul_latency_and_throughput_paths_agree(bits, monkeypatch):
     nk = NativeKey(bench_key() if bits == 2048 else seeded_key(bits))
     key = nk.key
     rng = np.random.default_rng(bits)
-    for N, ebits in ((5, 53), (40, 12), (64, 300)):
+    for N, ebits in ((5, 53), (40, 12), (64, 300), (3, 9), (300, 64)):
         c = rand_below(rng, key.nsq, N)
         e = [int.from_bytes(rng.bytes(ebits // 8 + 1), "little") % (1 << ebits) for _ in range(N)]
         e[0] = 0
+        e[2] = 1
+        c[1] = key.nsq - 1
+        if N > 4:
+            e[3], e[4] = (1 << ebits) - 1, 1 << (ebits - 1)
         ew = (ebits + 31) // 32
         dc, de = DevArray(ints_to_limbs(c, nk.cw)), DevArray(ints_to_limbs(e, ew))
-        # PAI_TUNE lat_mul_rl: the smallest batches run right to left on wave pairs (k_modexp_rl, no table); 0 = windowed kernel
+        # PAI_TUNE lat_mul_pp: the smallest batches (keys up to 2048 bits) run on digit pairs with base n k, one workgroup per
+        # ciphertext and the chain pipelined over its four waves (k_ctmul_pp); 0 leaves them to the kernels below
+        # PAI_TUNE lat_mul_rl: right to left on wave pairs (k_modexp_rl, no table); 0 = windowed kernel
         want = pow_many(c, e, key.nsq)
-        for switch, rl in (("0", "100000"), ("100000", "100000"), ("100000", "0")):
+        for switch, pp, rl in (("0", "0", "100000"), ("100000", "100000", "100000"), ("100000", "0", "100000"), ("100000", "0", "0")):
             monkeypatch.setenv("PAI_LATENCY_MAX", switch)
+            tune(monkeypatch, "lat_mul_pp", pp)
             tune(monkeypatch, "lat_mul_rl", rl)
             out = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
-            assert limbs_to_ints(out.get()) == want, (bits, N, ebits, switch, rl)
+            assert limbs_to_ints(out.get()) == want, (bits, N, ebits, switch, pp, rl)
         # one broadcast exponent
-        tune(monkeypatch, "lat_mul_rl", 100000)
-        out = DevArray(shape=(N, nk.cw))
-        _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, C.c_void_p(de.ptr.value + 4 * ew), ew, ebits, 1, N, out.ptr, None))
-        assert limbs_to_ints(out.get()) == pow_many(c, e[1], key.nsq), (bits, N, ebits, "bcast")
+        for pp in ("100000", "0"):
+            tune(monkeypatch, "lat_mul_pp", pp)
+            tune(monkeypatch, "lat_mul_rl", 100000)
+            out = DevArray(shape=(N, nk.cw))
+            _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, C.c_void_p(de.ptr.value + 4 * ew), ew, ebits, 1, N, out.ptr, None))
+            assert limbs_to_ints(out.get()) == pow_many(c, e[1], key.nsq), (bits, N, ebits, "bcast", pp)
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])

@@ -1,4 +1,4 @@
-"""Dev probe: small-batch ct*pt latency (dense 53-bit exponents), right-to-left wave pairs (k_modexp_rl) against the windowed kernel (PAI_TUNE=lat_mul_rl=0)."""
+"""Dev probe: small-batch ct*pt latency (dense 53-bit exponents), the four-wave digit-pair pipeline (k_ctmul_pp) against right-to-left wave pairs (k_modexp_rl, PAI_TUNE=lat_mul_pp=0) and the windowed kernel (lat_mul_rl=0 too)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
@@ -24,10 +24,10 @@ for N in (1, 16, 64, 256, 512, 1024, 2048, 4096):
     e[:, 1] |= 1 << 20
     row = {"bits": bits, "N": N}
     ref = None
-    for rl in ("1000000", "0"):
-        os.environ["PAI_TUNE"] = f"lat_mul_rl={rl}"
+    for name, knobs in (("pp", "lat_mul_pp=1000000"), ("rl", "lat_mul_pp=0,lat_mul_rl=1000000"), ("win", "lat_mul_pp=0,lat_mul_rl=0")):
+        os.environ["PAI_TUNE"] = knobs
         out = pub.ct_mul(ct, e, 53)
         if ref is None: ref = out.clone()
-        assert torch.equal(out, ref), (N, rl)
-        row[f"mul_rl{'1' if rl != '0' else '0'}_ms"] = round(tm(lambda: pub.ct_mul(ct, e, 53)), 3)
+        assert torch.equal(out, ref), (N, name)
+        row[f"mul_{name}_ms"] = round(tm(lambda: pub.ct_mul(ct, e, 53)), 3)
     print(json.dumps(row), flush=True)
