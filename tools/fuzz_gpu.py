@@ -90,7 +90,8 @@ while time.time() - t0 < budget:
     oe = DevArray(shape=(n2, nk.cw))
     for sw in ("0", "100000"):
         os.environ["PAI_LATENCY_MAX"] = sw
-        os.environ["PAI_TUNE"] = f"lat_pp={int(rng.choice([0, 100000]))},lat_rl={int(rng.choice([0, 100000]))}"   # every small-batch stage A
+        os.environ["PAI_TUNE"] = (f"lat_pp={int(rng.choice([0, 100000]))},lat_rl={int(rng.choice([0, 100000]))},"   # every small-batch stage A
+                                 f"lat_mul_pp={int(rng.choice([0, 100000]))},lat_mul_rl={int(rng.choice([0, 100000]))}")   # ... and ct * pt kernel
         _native.check(lib.pai_encrypt(nk.pk, dmm.ptr, drr.ptr, n2, oe.ptr, None))
         assert limbs_to_ints(oe.get()) == want_enc, ("encrypt", bits, n2, sw)
         _native.check(lib.pai_decrypt(nk.sk, dct.ptr, n2, om.ptr, None))
