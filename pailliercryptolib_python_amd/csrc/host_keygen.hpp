@@ -1,7 +1,7 @@
 // Host-side key generation for the C ABI (pai_keygen, pai_host_modexp): the native counterpart of
 // ipcl::generateKeypair (reference bindings/ipcl_bindings.cpp:12-15, timed by bench/bench_ipcl_python.py:13-19 BM_KeyGen).
 // Not a hot operation (one call per key): radix-2^64 Montgomery arithmetic on the host cores, fixed 4-bit windows,
-// incremental prime search over a small-prime sieve with Miller-Rabin, the two primes searched on two threads.
+// incremental prime search over a small-prime sieve with Miller-Rabin, the survivors of the sieve tested on up to 16 threads.
 // Randomness: getrandom(2) (the kernel CSPRNG) unless the caller supplies a seed (tests: reproducible keys through
 // a ChaCha-free splitmix stream — NOT for production keys, and the ABI says so).
 #pragma once
@@ -163,7 +163,7 @@ inline const std::vector<uint32_t>& small_primes() {
 }
 
 // Miller-Rabin: `rounds` random bases after base 2 (n odd, > 3)
-inline bool miller_rabin(const uint64_t* n, int L, int rounds, Rng& rng) {
+inline bool miller_rabin(const uint64_t* n, int L, int rounds, Rng& rng, bool base2 = true) {
     Mont mt(n, L);
     uint64_t nm1[MAXL], d[MAXL], mone[MAXL];
     std::memcpy(nm1, n, 8 * L);
@@ -176,7 +176,7 @@ inline bool miller_rabin(const uint64_t* n, int L, int rounds, Rng& rng) {
     }
     sub_n(mone, mt.m, mt.r1, L);                            // -1 in Montgomery form
     const int nb = bitlen(n, L);
-    for (int it = 0; it <= rounds; ++it) {
+    for (int it = base2 ? 0 : 1; it <= rounds; ++it) {
         uint64_t a[MAXL];
         if (it == 0) {
             std::memset(a, 0, 8 * L);
@@ -215,16 +215,30 @@ inline bool miller_rabin(const uint64_t* n, int L, int rounds, Rng& rng) {
     return true;
 }
 
+// Worker threads of a prime search (the two primes of a key are searched one after the other)
+inline int search_threads() {
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hw));
+}
+
 // A random prime of exactly `bits` bits with the two top bits set (so a product of two has exactly 2 bits bits);
-// mod4_3: congruent to 3 modulo 4.  Incremental search from a random start over a sieve of the odd primes < 2^16.
-inline void random_prime(uint64_t* out, int bits, bool mod4_3, int rounds, Rng& rng, const std::atomic<bool>* cancel = nullptr) {
+// mod4_3: congruent to 3 modulo 4.  Incremental search from a random start over a sieve of the odd primes < 2^16: the
+// result is the FIRST prime at or after the start in steps of 2 (4), whatever the number of threads — the sieve's
+// survivors are handed out in order to `threads` workers (base-2 Miller-Rabin each), the smallest index that passes wins,
+// and its `rounds` random-base rounds are split over the same workers.  Seeded searches are reproducible: the bases come
+// from generators derived from the caller's, and a prime is a prime under any bases.
+inline void random_prime(uint64_t* out, int bits, bool mod4_3, int rounds, Rng& rng, int threads = 0,
+                         const std::vector<uint32_t>* not_one_mod = nullptr) {
     const int L = (bits + 63) / 64;
     const auto& sp = small_primes();
     const uint32_t step = mod4_3 ? 4 : 2;
     const int WIN = 4096;                                   // candidates per sieve window
+    const int T = threads > 0 ? threads : search_threads();
     for (;;) {
         uint64_t c[MAXL];
         rng.fill(c, L);
+        uint64_t base_seed = 0;
+        rng.fill(&base_seed, 1);
         const int top = bits % 64;
         if (top) c[L - 1] &= (1ull << top) - 1;
         const int hb = (bits - 1) % 64, hb2 = (bits - 2) % 64;
@@ -243,23 +257,78 @@ inline void random_prime(uint64_t* out, int bits, bool mod4_3, int rounds, Rng& 
             uint64_t k = ((p - r) % p) * inv_step % p;
             for (; k < (uint64_t)WIN; k += p) comp[k] = 1;
         }
-        for (int k = 0; k < WIN; ++k) {
-            if (cancel && cancel->load(std::memory_order_relaxed)) return;
-            if (comp[k]) continue;
-            uint64_t cand[MAXL];
+        if (not_one_mod) {
+            // ... and no candidate congruent to 1 modulo these primes (the small odd prime factors of the other prime's
+            // p - 1: gcd(p - 1, q - 1) = 2 then only fails on a common LARGE factor)
+            for (uint32_t l : *not_one_mod) {
+                const uint64_t r = mod_small(c, L, l), half = (l + 1) / 2;
+                const uint64_t inv_step = step == 2 ? half : (half * half) % l;
+                uint64_t k = ((l + 1 - r) % l) * inv_step % l;
+                for (; k < (uint64_t)WIN; k += l) comp[k] = 1;
+            }
+        }
+        std::vector<int> ks;                                // the survivors, in order
+        for (int k = 0; k < WIN; ++k) if (!comp[k]) ks.push_back(k);
+        // candidate number k; false when it runs over the top (every later one does too)
+        auto candidate = [&](int k, uint64_t* cand) -> bool {
             u128 carry = (u128)k * step;
             for (int i = 0; i < L; ++i) {
                 carry += c[i];
                 cand[i] = (uint64_t)carry;
                 carry >>= 64;
             }
-            if (carry || bitlen(cand, L) != bits) break;    // ran over the top: new start
-            if (miller_rabin(cand, L, 0, rng) && miller_rabin(cand, L, rounds, rng)) {
+            return !carry && bitlen(cand, L) == bits;
+        };
+        auto run = [&](int n, auto&& body) {                // body(t) on n threads, exceptions re-thrown here
+            std::vector<std::thread> th;
+            std::vector<std::exception_ptr> err((size_t)n);
+            for (int t = 1; t < n; ++t) th.emplace_back([&, t] { try { body(t); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+            try { body(0); } catch (...) { err[0] = std::current_exception(); }
+            for (auto& x : th) x.join();
+            for (auto& e : err) if (e) std::rethrow_exception(e);
+        };
+        int from = 0;
+        const int nk = (int)ks.size();
+        while (from < nk) {
+            // smallest index >= from whose candidate passes base 2
+            std::atomic<int> next(from), best(nk);
+            run(T, [&](int) {
+                Rng none(&base_seed);                       // (base 2 draws nothing)
+                for (;;) {
+                    const int i = next.fetch_add(1, std::memory_order_relaxed);
+                    if (i >= nk || i > best.load(std::memory_order_relaxed)) return;
+                    uint64_t cand[MAXL];
+                    const bool in_range = candidate(ks[(size_t)i], cand);
+                    const bool pass = in_range && miller_rabin(cand, L, 0, none);
+                    explicit_bzero(cand, sizeof(cand));
+                    if (!in_range) return;                   // ran over the top: nothing beyond
+                    if (pass) {
+                        int cur = best.load(std::memory_order_relaxed);
+                        while (i < cur && !best.compare_exchange_weak(cur, i, std::memory_order_relaxed)) {}
+                    }
+                }
+            });
+            const int hit = best.load();
+            if (hit >= nk) break;                            // nothing in this window: new start
+            uint64_t cand[MAXL];
+            candidate(ks[(size_t)hit], cand);
+            // `rounds` random bases, split over the workers
+            std::atomic<bool> composite(false);
+            const int VT = std::max(1, std::min(T, rounds));
+            run(VT, [&](int t) {
+                const int mine = rounds / VT + (t < rounds % VT ? 1 : 0);
+                if (mine == 0) return;
+                uint64_t sd = base_seed + 0xD1B54A32D192ED03ull * (uint64_t)(t + 1) + (uint64_t)hit;
+                Rng r(rng.seeded ? &sd : nullptr);
+                if (!miller_rabin(cand, L, mine, r, false)) composite.store(true);
+            });
+            if (!composite.load()) {
                 std::memcpy(out, cand, 8 * L);
                 explicit_bzero(cand, sizeof(cand));             // the prime and its search start leave this stack frame
                 explicit_bzero(c, sizeof(c));
                 return;
             }
+            from = hit + 1;                                  // a base-2 pseudoprime (never seen): carry on behind it
         }
     }
 }
@@ -293,16 +362,19 @@ inline bool gcd_is_two(const uint64_t* a_, const uint64_t* b_, int L) {
 inline void generate_primes(int n_bits, bool djn, const uint64_t* seed, uint64_t* p, uint64_t* q) {
     const int half = n_bits / 2, L = (half + 63) / 64;
     const int rounds = 24;
+    uint64_t s1 = seed ? *seed * 2 : 0;
+    Rng r1(seed ? &s1 : nullptr);
+    random_prime(p, half, djn, rounds, r1);
+    std::vector<uint32_t> avoid;
+    if (djn) {
+        for (uint32_t l : small_primes()) {
+            if (l > 2 && mod_small(p, L, l) == 1) avoid.push_back(l);
+        }
+    }
     for (int attempt = 0;; ++attempt) {
-        uint64_t s1 = seed ? *seed * 2 + 0x1000ull * attempt : 0, s2 = s1 + 1;
-        Rng r1(seed ? &s1 : nullptr), r2(seed ? &s2 : nullptr);
-        std::exception_ptr err;
-        std::thread th([&] {
-            try { random_prime(q, half, djn, rounds, r2); } catch (...) { err = std::current_exception(); }
-        });
-        try { random_prime(p, half, djn, rounds, r1); } catch (...) { th.join(); throw; }
-        th.join();
-        if (err) std::rethrow_exception(err);
+        uint64_t s2 = seed ? *seed * 2 + 1 + 0x1000ull * attempt : 0;
+        Rng r2(seed ? &s2 : nullptr);
+        random_prime(q, half, djn, rounds, r2, 0, djn ? &avoid : nullptr);
         if (cmp(p, q, L) == 0) continue;
         if (djn) {
             uint64_t pm1[MAXL], qm1[MAXL];
