@@ -816,6 +816,29 @@ def _random_prime(bits: int, congruent_3_mod_4: bool) -> int:
             return c
 
 
+def _djn_hs_from_primes(p: int, q: int) -> int:
+    """hs = (-x^2)^n mod n^2 for a random unit x (the DJN set-up of ipclPublicKey.__init__) with the primes in hand: the two
+    powers modulo p^2 and q^2 (exponent reduced modulo the group orders, a quarter of the limb products each) on two host
+    threads, then the CRT — the same integer as the single power modulo n^2."""
+    n = p * q
+    x = _random_unit(n)
+    base = (-x * x) % (n * n)
+    mods = (p * p, q * q)
+    exps = (n % (p * (p - 1)), n % (q * (q - 1)))
+    native_ok = all(m.bit_length() <= 32 * _native.HOST_MODEXP_MAX_WORDS for m in mods)
+    out = [0, 0]
+
+    def work(i: int) -> None:
+        out[i] = _native.host_modexp(base % mods[i], exps[i], mods[i]) if native_ok else pow(base % mods[i], exps[i], mods[i])
+
+    th = threading.Thread(target=work, args=(1,))
+    th.start()
+    work(0)
+    th.join()
+    a, b = out
+    return a + mods[0] * (((b - a) * pow(mods[0], -1, mods[1])) % mods[1])
+
+
 class ipclKeypair:
     @staticmethod
     def generate_keypair(n_length: int = 1024, enable_DJN: bool = True):
@@ -839,7 +862,8 @@ class ipclKeypair:
             if math.gcd(p * q, (p - 1) * (q - 1)) != 1:
                 continue
             break
-        pk = ipclPublicKey(p * q, n_length, enable_DJN)
+        hs = _djn_hs_from_primes(p, q) if enable_DJN else None
+        pk = ipclPublicKey(p * q, n_length, enable_DJN, hs=hs)
         return pk, ipclPrivateKey(pk, p, q)
 
 

@@ -354,13 +354,22 @@ static bool knob_tune(const char* name, long long* v) {
     return true;
 }
 
-// Batches up to this many elements take the latency path: every integer spread over 16-64 lanes, (element, prime)
-// pairs filling the device instead of lanes (PAI_LATENCY_MAX overrides; 0 disables it).  Measured on MI355X at
-// 2048-bit keys: decrypt 3.8 ms up to 512 elements, 7.0 ms at 2048, 12.2 ms at 4096 (decrypt takes the path up to twice
-// this value), against 14.7 ms on the throughput kernels.
-size_t latency_max_elements() {
-    if (const char* env = std::getenv("PAI_LATENCY_MAX")) return (size_t)std::strtoull(env, nullptr, 10);
-    return (size_t)2048;
+// Batches up to this many elements take the latency paths: every integer spread over 16-64 lanes, (element, prime) pairs
+// filling the device instead of lanes.  The switch to the throughput kernels depends on the operation and on the key size —
+// measured cross-overs on MI355X (profiles/r05/path_switch_sweep.jsonl: tools/latency_sweep.py, default against both forced
+// paths at 1024 / 2048 / 3072 / 4096-bit keys).  PAI_LATENCY_MAX overrides (tests: 0 disables the latency paths, a huge value
+// forces them): decryption and DJN encryption switch at twice, ct * pt at four times its value.
+enum LatOp { LAT_DEC, LAT_ENC, LAT_MUL };
+size_t latency_max_elements(LatOp op, int key_bits) {
+    if (const char* env = std::getenv("PAI_LATENCY_MAX")) return (size_t)std::strtoull(env, nullptr, 10) * (op == LAT_MUL ? 4 : 2);
+    static const struct { int bits; size_t v[3]; } T[] = {
+        {1024, {6400, 8704, 13312}},          // decrypt 3.4 ms at 6144 against 3.6; encrypt 0.45 at 8192 against 0.48; ct * pt 1.13 at 12288 against 1.23
+        {2048, {5120, 11776, 18944}},         // 12.1 ms at 4096 against 14.8; 3.4 at 12288 against 3.3; 4.0 at 16384 against 4.6
+        {3072, {6144, 4864, 5632}},           // 55.9 at 6144 against 55.9; 3.3 at 4096 against 4.0; 2.1 at 4096 against 3.0 (3.1 at 6144)
+        {4096, {7936, 3200, 2944}},           // 98 at 6144 against 127; 4.6 at 3072 against 4.9; 1.8 at 2048 against 2.7 (2.8 at 3072)
+    };
+    for (const auto& t : T) if (key_bits <= t.bits) return t.v[op];
+    return T[3].v[op];
 }
 
 // pai_ct_pow2 goes through the digit engine from this batch size on (PAI_POW2_DIGIT_MIN) when the largest shift is
@@ -1704,7 +1713,7 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
     // every path below shares per-key device scratch (quotient-digit columns, window tables): one at a time per
     // handle, ordered across streams by pk->order
     std::lock_guard<std::mutex> lk(pk->mu);
-    if (d_r && pk->djn && N <= 2 * latency_max_elements()) {      // 1.2 ms against 3.5 ms up to 1024 elements, 2.4 against 3.6 at 4096
+    if (d_r && pk->djn && N <= latency_max_elements(LAT_ENC, pk->key_bits)) {
         // small DJN batch: n^2 spread over a wavefront per ciphertext, 10-bit fixed-base windows in that geometry
         if (!pk->lat_ready) {
             pk->lat_ready = true;
@@ -2056,7 +2065,7 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         DeviceScope scope_(pk->device);
         hipStream_t s = (hipStream_t)stream;
         g_last_times.clear();
-        if (N <= 4 * latency_max_elements() && ebits_max > 8) {          // 0.9 ms against 4.8 ms up to ~8192 elements
+        if (N <= latency_max_elements(LAT_MUL, pk->key_bits) && ebits_max > 8) {
             // small batch: windowed exponentiation with n^2 spread over a whole wavefront per ciphertext
             std::lock_guard<std::mutex> lk(pk->mu);
             if (ensure_lat_ctx(pk) && pk->lat_pp_ok && e_words <= PP_EWORDS && N <= lat_mul_pp_max((size_t)pk->dev.ncu)) {
@@ -2850,7 +2859,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         DeviceScope scope_(pk->device);
         DeviceInfo dev = scope_.info;
         hipStream_t s = (hipStream_t)stream;
-        if (N <= 2 * latency_max_elements()) {                            // measured cross-over at 2048-bit keys: ~4900 elements
+        if (N <= latency_max_elements(LAT_DEC, pk->key_bits)) {
             build_latency_consts(sk);
             if (sk->lat.usable) {
                 // small batch: every integer is spread over 16-64 lanes, one product takes microseconds instead of
