@@ -68,8 +68,8 @@ const GeoOps* geo_ops_9x32();
 
 // stage A of the smallest decryptions on digit pairs, pipelined over four waves (kernels_declat.hpp; 3 x 64 geometry only)
 struct DecPPParams;
-void launch_dec_a_pp(hipStream_t s, int n, const DecPPParams& P, const uint32_t* ct, uint32_t* u_out);
-void launch_ctmul_pp(hipStream_t s, int n, const DecPPParams& P, const uint32_t* ct, uint32_t* out);
+void launch_dec_a_pp(hipStream_t s, int n, const DecPPParams& P, const uint32_t* ct, uint32_t* u_out, int chain_limbs);
+void launch_ctmul_pp(hipStream_t s, int n, const DecPPParams& P, const uint32_t* ct, uint32_t* out, int chain_limbs);
 
 // smallest geometry whose capacity covers a modulus of `bits` bits (R = 2^(29 NL) > 4 M), or nullptr
 const GeoOps* geo_for_bits(int bits);

@@ -13,10 +13,11 @@
 // (a_i, b_i) at the set bits of s - 1 into the accumulator pair the same way (first digit ahead, second digit behind).
 // The critical path is ~1023 half-size steps instead of 1023 full-size ones.
 //
-// The base is s' = s k with k = -s^-1 mod 2^(29 U) (a minus-one context, Rows::block_m1: the quotient digits of a row block
-// ARE the limbs it retires); everything is arithmetic modulo s'^2, of which s^2 is a divisor, so the power modulo s^2 — what
-// stage B expects — comes out of one plain product a + b s', one reduction and the conventional tail of k_dec_a_rl.
-// One (ciphertext, prime) per workgroup; an integer is 3 limbs x 64 lanes (geo_3x64).
+// The base is s' = s k with k = -s^-1 mod 2^29 (a minus-one context: the quotient digit of a row IS the limb it retires);
+// everything is arithmetic modulo s'^2, of which s^2 is a divisor, so the power modulo s^2 — what stage B expects — comes out
+// of one plain product a + b s', one reduction (on the 3 x 64 geometry s^2 needs) and a short-quotient Barrett step.
+// One (ciphertext, prime) per workgroup; in the chain an integer is ONE limb per lane (s' of at most 64 limbs: 2048- and
+// 3072-bit keys) or two (4096-bit keys; ct * pt with base n k at 2048-bit keys).
 #pragma once
 #include "kernels_paillier.hpp"
 
@@ -35,8 +36,6 @@ struct DecPPParams {
 };
 
 constexpr int PP_RMAX = 80;      // limbs of s' (4096-bit keys: 75 rows)
-constexpr int PP_ROW = 192;      // words per ring slot: one lane-sliced integer of the 3 x 64 geometry (loads / stores without bounds)
-constexpr int PP_DSTR = 81;      // per-lane stride of the export dump (odd: conflict-free)
 constexpr int PP_RING = 16;      // (a_i, m_i, b_i) slots between the squaring waves and the product waves
 constexpr int PP_PRING = 8;      // (A, m) slots between the product waves
 constexpr int PP_MAXND = 6;
@@ -45,162 +44,94 @@ constexpr int PP_YBUF = 2 * PP_RMAX + 16;
 constexpr int PP_EWORDS = 128;   // exponent words (4096 bits)
 
 
-template <class G>
+// G: the geometry of the exit (s^2 / n^2 on 3 x 64); GC: the geometry of the chain — ONE limb per lane where s' fits 64 limbs
+// (decryption with keys up to ~3600 bits), else two.
+template <class G, class GC>
 struct PPLds {
+    static constexpr int ROW = GC::NL;                                // words per ring slot: one lane-sliced integer of the chain geometry
     static constexpr int STAGE = 0;                                   // G::LDS_WORDS: operand staging of the exit products
     static constexpr int YBUF = STAGE + G::LDS_WORDS;                 // a + b s' assembled (2 r + 2 limbs)
     static constexpr int RING_A = YBUF + PP_YBUF;
-    static constexpr int RING_M = RING_A + PP_RING * PP_ROW;
+    static constexpr int RING_M = RING_A + PP_RING * ROW;
     static constexpr int RING_B = RING_M + PP_RING * PP_RMAX;
-    static constexpr int PRING_A = RING_B + PP_RING * PP_ROW;
-    static constexpr int PRING_M = PRING_A + PP_PRING * PP_ROW;
-    static constexpr int DUMP = PRING_M + PP_PRING * PP_RMAX;         // where the lanes other than 0 drop their "quotient digits"
-    static constexpr int KD = DUMP + 64 * PP_DSTR;                    // [nd][2][RMAX]
+    static constexpr int PRING_A = RING_B + PP_RING * ROW;
+    static constexpr int PRING_M = PRING_A + PP_PRING * ROW;
+    static constexpr int KD = PRING_M + PP_PRING * PP_RMAX;           // [nd][2][RMAX]
     static constexpr int MLIM = KD + PP_MAXND * 2 * PP_RMAX;          // limbs of s'
     static constexpr int KX = MLIM + PP_RMAX;                         // exit constants, [nch][NL]
-    static constexpr int ZERO = KX + PP_MAXCH * G::NL;                          // RMAX zero words (the feed of lanes != 0)
+    static constexpr int ZERO = KX + PP_MAXCH * G::NL;                // RMAX zero words (the feed of lanes != 0)
     static constexpr int TMPM = ZERO + PP_RMAX;                       // quotient digits of the entry products
     static constexpr int EXPO = TMPM + PP_RMAX;                       // the exponent's words (the product waves scan its bits)
     static constexpr int FLAGS = EXPO + PP_EWORDS;
     static constexpr int WORDS = FLAGS + 16;
     static constexpr int BYTES = WORDS * 4;
+    static_assert(YBUF % 4 == 0 && RING_A % 4 == 0 && RING_M % 4 == 0 && RING_B % 4 == 0 && PRING_A % 4 == 0 && PRING_M % 4 == 0 &&
+                  KD % 4 == 0 && ZERO % 4 == 0 && TMPM % 4 == 0 && PP_RMAX % 4 == 0 && ROW % 4 == 0, "digit rows are read 16 bytes at a time");
 };
 
-// One half of the product rule on a minus-one context, T = 64 (quotient digits through SGPRs):
+// One half of the product rule on a minus-one context with k of ONE limb (s' == -1 mod 2^29), the integer spread over the wave
+// with NLL limbs per lane (1 where s' fits 64 limbs, else 2):
 //   r = (x1 * dig1 [+ x2 * dig2] [+ R - m] + q s') / R  [+ s' - 1]
-// x1, x2: this lane's limb slices; dig1, dig2: LDS limbs (stride 1, nblk * U of them); FEED: m arrives as complemented digits
+// x1, x2: this lane's limb slices; dig1, dig2: LDS limbs (stride 1, nrows of them); FEED: m arrives as complemented digits
 // (2^29 - 1 - m_i) at lds[fd_off ..] for lane 0 and as zeros for the other lanes (fd_off is per lane); EXPORT: this half's own
-// quotient digits leave, complemented, to mq (written by lane 0).  HEAVY: operands that make three 2^58 products per row
-// and column (two products, or a doubled operand): normalise more often.
-// One row block of pp_half on a window split into its low half L (the U columns the block retires) and its high half H
-// (NLL == U): afterwards H is the new low half and L — cleared, then holding the first q s' products — the new high half, so two
-// consecutive blocks swap the roles of the two register sets and the window never moves.
-// The block's own digits arrive in `cur` (read from LDS during the previous block); the next block's digits are read into
-// `nxt` here, before the multiplies — a lone wave has nobody to hide an LDS round trip behind, and the two digit sets swap
-// roles from block to block like the window halves do (no copies).
-template <int U>
-struct PPDigits { uint32_t b1[U], b2[U], f[U]; };
-template <class G, bool TWO, bool FEED>
-PAI_DEV void pp_fetch(PPDigits<G::U>& d, const uint32_t* lds, int d1, int d2, int fd) {
-#pragma unroll
-    for (int u = 0; u < G::U; ++u) {
-        d.b1[u] = lds[d1 + u];
-        if constexpr (TWO) d.b2[u] = lds[d2 + u];
-        if constexpr (FEED) d.f[u] = lds[fd + u];
-    }
-}
-template <class G, bool TWO, bool FEED, bool EXPORT>
-PAI_DEV void pp_block(uint64_t (&L)[G::U], uint64_t (&H)[G::U], const uint32_t (&x1)[G::NLL], const uint32_t (&x2)[G::NLL], uint32_t* lds,
-                      const PPDigits<G::U>& cur, PPDigits<G::U>& nxt, int d1, int d2, int fd, int mq, const NmRegs<G::NLL>& npp) {
-    constexpr int U = G::U;
-    static_assert(G::NLL == U, "window of two halves");
-    pp_fetch<G, TWO, FEED>(nxt, lds, d1 + U, d2 + U, fd + U);       // (one block beyond the last: in-bounds reads of unused words)
-    const uint32_t (&bv1)[U] = cur.b1;
-    const uint32_t (&bv2)[U] = cur.b2;
-    const uint32_t (&fv)[U] = cur.f;
-    auto col = [&](int k) -> uint64_t& { return k < U ? L[k] : H[k - U]; };
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            col(j + u) += (uint64_t)x1[j] * bv1[u];
-            if constexpr (TWO) col(j + u) += (uint64_t)x2[j] * bv2[u];
-        }
-    }
-    if constexpr (FEED) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) L[u] += (uint64_t)fv[u];
-    }
-    uint32_t low[U], q[U];
-    uint64_t c = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint64_t t = L[u] + c;
-        low[u] = (uint32_t)t & RMASK;
-        c = t >> RB;
-    }
-    H[0] += c;
-#pragma unroll
-    for (int u = 0; u < U; ++u) q[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)low[u]);
-    if constexpr (EXPORT) {
-        // every lane stores (no exec masking inside the block): lane 0 to the consumer's buffer, the others to a dump
-#pragma unroll
-        for (int u = 0; u < U; ++u) lds[mq + u] = RMASK - low[u];
-    }
-    // the window moves up by U columns: H is the low half now, L the (empty) high half
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        L[u] = 0;
-        H[u] += (uint64_t)from_next<64>(low[u]);
-    }
-    auto ncol = [&](int k) -> uint64_t& { return k < U ? H[k] : L[k - U]; };
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) ncol(j + u) += (uint64_t)npp.v[j] * q[u];
-    }
-}
-// Rows::normalize on the split window (low half first)
-template <int U>
-PAI_DEV void pp_normalize(uint64_t (&L)[U], uint64_t (&H)[U]) {
-    uint64_t w[2 * U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { w[u] = L[u]; w[U + u] = H[u]; }
-#pragma unroll
-    for (int k = 2 * U - 1; k >= 1; --k) w[k] = ((k == 2 * U - 1) ? w[k] : (w[k] & RMASK)) + (w[k - 1] >> RB);
-    w[0] &= RMASK;
-#pragma unroll
-    for (int u = 0; u < U; ++u) { L[u] = w[u]; H[u] = w[U + u]; }
-}
-
-template <class G, bool TWO, bool FEED, bool EXPORT, bool HEAVY>
-PAI_DEV void pp_half(uint32_t (&r)[G::NLL], const uint32_t (&x1)[G::NLL], int dig1, const uint32_t (&x2)[G::NLL], int dig2,
-                     uint32_t* lds, int fd_off, int mq_off, const NmRegs<G::NLL>& npp, const uint32_t (&mtrue)[G::NLL], int nblk) {
-    // (every LDS operand is an OFFSET from the one base pointer: a run-time choice between LDS pointers costs the address space)
-    constexpr int NLL = G::NLL, U = G::U;
-    using RW = Rows<NLL, U, 64>;
-    uint64_t A[U], B[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { A[u] = 0; B[u] = 0; }
+// quotient digits leave, complemented, to lds[mq_off ..].
+// The window is ONE 64-bit column per limb: with col = lo + 2^29 hi, dividing by 2^29 after the quotient digit q = lo of the
+// wave's first column has zeroed that column is   col_k <- lo_(k+1) + hi_k + q npp_k   (lo of the NEXT lane's first column for a
+// lane's last one) — per row and lane NLL x (multiply, mask, shift, multiply, add) plus one broadcast and one cross-lane move,
+// nothing to slide, zero or normalise (a column lives one row: < 3 * 2^58 + 2^36).  Rounds 5's first version ran blocks of
+// three rows on three limbs per lane (64 instructions for 18 multiplies per block, 13 of 64 lanes holding limbs at 2048-bit
+// keys): 21 instructions per row against 12 here.  Four rows per loop iteration, their digits read 16 bytes at a time one
+// iteration ahead (a lone wave has nobody to hide an LDS round trip behind); the quotient digits leave as the UNIFORM value
+// every lane holds after the broadcast — all lanes store the same words: no dump rows, no exec masking.
+// nrows is a multiple of 4 (the host rounds R up).
+template <class GC, bool TWO, bool FEED, bool EXPORT>
+PAI_DEV void pp_half(uint32_t (&r)[GC::NLL], const uint32_t (&x1)[GC::NLL], int dig1, const uint32_t (&x2)[GC::NLL], int dig2,
+                     uint32_t* lds, int fd_off, int mq_off, const NmRegs<GC::NLL>& npp, const uint32_t (&mtrue)[GC::NLL], int nrows) {
+    constexpr int NLL = GC::NLL;
+    static_assert(GC::U == 1 && GC::T == 64, "one limb retired per row, one integer per wavefront");
     const bool lane0 = (threadIdx.x & 63) == 0;
-    if (FEED && lane0) A[0] = 1;                                      // R - m = sum (2^29 - 1 - m_i) 2^(29 i) + 1
-    // rows between normalisations: 2^58 per product and row — three products (two operand pairs, or a doubled operand, plus the
-    // quotient's) allow 21 rows, two allow 30
-    constexpr int NORMB = (TWO || HEAVY) ? 21 / U : 30 / U;
-    int since = 0;
-    int blk = 0;
-    PPDigits<U> da, db;
-    pp_fetch<G, TWO, FEED>(da, lds, dig1, dig2, fd_off);
+    uint64_t col[NLL];
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) col[j] = 0;
+    if (FEED && lane0) col[0] = 1;                                    // R - m = sum (2^29 - 1 - m_i) 2^(29 i) + 1
+    auto ld4 = [&](int off) -> uint4 { return *reinterpret_cast<const uint4*>(lds + off); };
+    uint4 b1 = ld4(dig1), b2 = TWO ? ld4(dig2) : make_uint4(0, 0, 0, 0), f = FEED ? ld4(fd_off) : make_uint4(0, 0, 0, 0);
 #pragma unroll 1
-    for (; blk + 1 < nblk; blk += 2) {
-        pp_block<G, TWO, FEED, EXPORT>(A, B, x1, x2, lds, da, db, dig1 + blk * U, dig2 + blk * U, fd_off + blk * U, mq_off + blk * U, npp);
-        if (++since == NORMB) { pp_normalize<U>(B, A); since = 0; }
-        pp_block<G, TWO, FEED, EXPORT>(B, A, x1, x2, lds, db, da, dig1 + (blk + 1) * U, dig2 + (blk + 1) * U, fd_off + (blk + 1) * U,
-                                       mq_off + (blk + 1) * U, npp);
-        if (++since == NORMB && blk + 2 < nblk) { pp_normalize<U>(A, B); since = 0; }
-    }
-    uint64_t acc[RW::NW];
-    if (blk < nblk) {                                                 // an odd block count: the halves end up swapped
-        pp_block<G, TWO, FEED, EXPORT>(A, B, x1, x2, lds, da, db, dig1 + blk * U, dig2 + blk * U, fd_off + blk * U, mq_off + blk * U, npp);
+    for (int g = 0; g < nrows; g += 4) {
+        const uint4 n1 = ld4(dig1 + g + 4);                           // (one group beyond the last: in-bounds reads of unused words)
+        const uint4 n2 = TWO ? ld4(dig2 + g + 4) : make_uint4(0, 0, 0, 0);
+        const uint4 nf = FEED ? ld4(fd_off + g + 4) : make_uint4(0, 0, 0, 0);
+        const uint32_t c1[4] = {b1.x, b1.y, b1.z, b1.w}, c2[4] = {b2.x, b2.y, b2.z, b2.w}, cf[4] = {f.x, f.y, f.z, f.w};
+        uint32_t q[4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { acc[u] = B[u]; acc[U + u] = A[u]; }
-    } else {
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) { acc[u] = A[u]; acc[U + u] = B[u]; }
-    }
-    // the window's top U columns are the next lane's lowest (mont_mul_m1)
+            for (int j = 0; j < NLL; ++j) {
+                col[j] += (uint64_t)x1[j] * c1[u];
+                if constexpr (TWO) col[j] += (uint64_t)x2[j] * c2[u];
+            }
+            if constexpr (FEED) col[0] += (uint64_t)cf[u];
+            uint32_t lo[NLL];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint64_t top = acc[NLL + u];
-        const uint32_t lo = from_prev<64>((uint32_t)top), hi = from_prev<64>((uint32_t)(top >> 32));
-        acc[u] += ((uint64_t)hi << 32) | lo;
+            for (int j = 0; j < NLL; ++j) lo[j] = (uint32_t)col[j] & RMASK;
+            q[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo[0]);
+            const uint32_t t = from_next<64>(lo[0]);
+#pragma unroll
+            for (int j = 0; j < NLL; ++j) col[j] = (col[j] >> RB) + (uint64_t)(j + 1 < NLL ? lo[j + 1] : t) + (uint64_t)npp.v[j] * q[u];
+        }
+        if constexpr (EXPORT) *reinterpret_cast<uint4*>(lds + mq_off + g) = make_uint4(RMASK - q[0], RMASK - q[1], RMASK - q[2], RMASK - q[3]);
+        b1 = n1; b2 = n2; f = nf;
     }
+    uint64_t acc[NLL + 1];
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) acc[j] = col[j];
+    acc[NLL] = 0;
     if constexpr (FEED) {                                             // + (s' - 1) R on the numerator
 #pragma unroll
         for (int j = 0; j < NLL; ++j) acc[j] += (uint64_t)mtrue[j];
         if (lane0) acc[0] -= 1;
     }
-    RW::finish(acc, r);
+    Rows<NLL, 1, 64>::finish(acc, r);
 }
 
 // this lane's slices of a ring slot (PP_ROW words: the whole lane-sliced integer, limbs beyond the value are zero)
@@ -228,9 +159,6 @@ PAI_DEV void pp_store(uint32_t* lds, int off, const uint32_t (&x)[G::NLL]) {
 #else
 #define PP_T0() do { } while (0)
 #define PP_WAIT(expr) expr
-#define PP_DECL(a, b) unsigned long long a = 0, b = 0
-#define PP_STAMP(var) var = __builtin_readcyclecounter() - pp_t0
-#define PP_REPORT2(role, a, b) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) printf("PP %s: cycles %llu, waiting %llu; stamps %llu %llu\n", role, __builtin_readcyclecounter() - pp_t0, pp_wait, a, b); } while (0)
 #define PP_REPORT(role) do { } while (0)
 #define PP_STAMP(var) do { } while (0)
 #define PP_DECL(a, b) do { } while (0)
@@ -241,11 +169,12 @@ PAI_DEV void pp_store(uint32_t* lds, int off, const uint32_t (&x)[G::NLL]) {
 // VAR = true: ct * pt for the smallest batches (ipclCipherText.__mul__ -> CipherText::operator*(PlainText), classes.cpp /
 // the reference's BM_Mul_CTPT): ONE modulus (s = n, the power modulo n^2) and the exponent of each element its own; exponent 0
 // gives 1.
-template <class G, bool VAR>
+template <class G, class GC, bool VAR>
 PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out, int n, uint32_t* lds) {
-    static_assert(G::M1 && G::T == 64 && G::NLL == G::U && BLOCK_THREADS == 256, "one integer per wavefront, four waves per chain");
-    constexpr int NLL = G::NLL, U = G::U;
-    using L = PPLds<G>;
+    static_assert(G::M1 && G::T == 64 && GC::T == 64 && GC::U == 1 && BLOCK_THREADS == 256, "one integer per wavefront, four waves per chain");
+    constexpr int NLL = GC::NLL, U = GC::U;          // the chain's geometry; the exit (B2's tail) runs on G
+    constexpr int GN = G::NLL, GU = G::U;
+    using L = PPLds<G, GC>;
     const int which = VAR ? 0 : (int)blockIdx.y;
     const MontCtx* ctx = P.pp[which];
     const uint32_t* expo = P.expo[which];
@@ -280,13 +209,13 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
         }
         return ebits;
     };
-    // lane 0 feeds from / exports to the quotient-digit buffer, the other lanes read zeros / write to their dump rows
+    // lane 0 feeds from the quotient-digit buffer, the other lanes read zeros
     auto feed_off = [&](int m_off) -> int { return lane0 ? m_off : (int)L::ZERO; };
-    auto mq_off = [&](int m_off) -> int { return lane0 ? m_off : (int)L::DUMP + lane * PP_DSTR; };
-    auto slotA = [](int i) -> int { return L::RING_A + (i % PP_RING) * PP_ROW; };
+    auto mq_off = [](int m_off) -> int { return m_off; };                    // (the export is a uniform store)
+    auto slotA = [](int i) -> int { return L::RING_A + (i % PP_RING) * L::ROW; };
     auto slotM = [](int i) -> int { return L::RING_M + (i % PP_RING) * PP_RMAX; };
-    auto slotB = [](int i) -> int { return L::RING_B + (i % PP_RING) * PP_ROW; };
-    auto slotPA = [](int k) -> int { return L::PRING_A + (k % PP_PRING) * PP_ROW; };
+    auto slotB = [](int i) -> int { return L::RING_B + (i % PP_RING) * L::ROW; };
+    auto slotPA = [](int k) -> int { return L::PRING_A + (k % PP_PRING) * L::ROW; };
     auto slotPM = [](int k) -> int { return L::PRING_M + (k % PP_PRING) * PP_RMAX; };
     uint32_t none[NLL];
 #pragma unroll
@@ -308,19 +237,19 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
 #pragma unroll 1
             for (int i = 0; i < P.nd; ++i) {
                 uint32_t c[NLL], w[NLL], v[NLL];
-                load_elem_off<G>(c, row, P.ct_words, r * i);
+                load_elem_off<GC>(c, row, P.ct_words, r * i);
 #pragma unroll
                 for (int j = 0; j < NLL; ++j) c[j] = (NLL * lane + j < r) ? c[j] : 0u;
                 wave_lds_fence();
-                pp_half<G, false, false, true, false>(w, c, L::KD + (2 * i) * PP_RMAX, none, 0, lds, 0, mq_off(L::TMPM), npp, mtrue, nblk);
+                pp_half<GC, false, false, true>(w, c, L::KD + (2 * i) * PP_RMAX, none, 0, lds, 0, mq_off(L::TMPM), npp, mtrue, nblk);
                 wave_lds_fence();
-                pp_half<G, false, true, false, false>(v, c, L::KD + (2 * i + 1) * PP_RMAX, none, 0, lds, feed_off(L::TMPM), 0, npp, mtrue,
+                pp_half<GC, false, true, false>(v, c, L::KD + (2 * i + 1) * PP_RMAX, none, 0, lds, feed_off(L::TMPM), 0, npp, mtrue,
                                                       nblk);
-                add_limbs<G>(sa, w);
-                add_limbs<G>(sb, v);
+                add_limbs<GC>(sa, w);
+                add_limbs<GC>(sb, v);
             }
-            pp_store<G>(lds, slotA(0), sa);
-            pp_store<G>(lds, slotB(0), sb);
+            pp_store<GC>(lds, slotA(0), sa);
+            pp_store<GC>(lds, slotB(0), sb);
             rl_publish(headB, 1u);
             rl_publish(headA, 1u);
             uint32_t x[NLL];
@@ -337,8 +266,8 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
                     if (seen4 < need) PP_WAIT(seen4 = rl_wait(tailB2, need));
                 }
                 uint32_t w[NLL];
-                pp_half<G, false, false, true, false>(w, x, slotA(i), none, 0, lds, 0, mq_off(slotM(i)), npp, mtrue, nblk);
-                pp_store<G>(lds, slotA(i + 1), w);
+                pp_half<GC, false, false, true>(w, x, slotA(i), none, 0, lds, 0, mq_off(slotM(i)), npp, mtrue, nblk);
+                pp_store<GC>(lds, slotA(i + 1), w);
 #pragma unroll
                 for (int j = 0; j < NLL; ++j) x[j] = w[j];
                 rl_publish(headA, (uint32_t)(i + 2));
@@ -348,7 +277,7 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
             // ---- W2: the second digits, one step behind ---------------------------------------------------------------
             rl_wait(headB, 1u);
             uint32_t b[NLL];
-            pp_load<G>(b, lds, slotB(0));
+            pp_load<GC>(b, lds, slotB(0));
             uint32_t seen = 0;
             PP_T0();
 #pragma unroll 1
@@ -361,8 +290,8 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
                 uint32_t b2[NLL], v[NLL];
 #pragma unroll
                 for (int j = 0; j < NLL; ++j) b2[j] = b[j] << 1;      // 2 a b
-                pp_half<G, false, true, false, true>(v, b2, slotA(i), none, 0, lds, feed_off(slotM(i)), 0, npp, mtrue, nblk);
-                pp_store<G>(lds, slotB(i + 1), v);
+                pp_half<GC, false, true, false>(v, b2, slotA(i), none, 0, lds, feed_off(slotM(i)), 0, npp, mtrue, nblk);
+                pp_store<GC>(lds, slotB(i + 1), v);
 #pragma unroll
                 for (int j = 0; j < NLL; ++j) b[j] = v[j];
                 rl_publish(headB, (uint32_t)(i + 2));
@@ -380,16 +309,16 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
             while (i < ebits) {
                 PP_WAIT(rl_wait<RL_SLEEP_B>(headA, (uint32_t)(i + 1)));
                 if (first) {
-                    pp_load<G>(A, lds, slotA(i));
+                    pp_load<GC>(A, lds, slotA(i));
                     first = false;
                 } else {
                     if (k >= PP_PRING - 1) {                          // (one slot stays free for the final A)
                         const uint32_t need = (uint32_t)(k + 2 - PP_PRING);
                         if (seenP < need) seenP = rl_wait(tailP, need);
                     }
-                    pp_store<G>(lds, slotPA(k), A);
+                    pp_store<GC>(lds, slotPA(k), A);
                     uint32_t w[NLL];
-                    pp_half<G, false, false, true, false>(w, A, slotA(i), none, 0, lds, 0, mq_off(slotPM(k)), npp, mtrue, nblk);
+                    pp_half<GC, false, false, true>(w, A, slotA(i), none, 0, lds, 0, mq_off(slotPM(k)), npp, mtrue, nblk);
 #pragma unroll
                     for (int j = 0; j < NLL; ++j) A[j] = w[j];
                     ++k;
@@ -402,7 +331,7 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
                 const uint32_t need = (uint32_t)(k + 2 - PP_PRING);
                 if (seenP < need) seenP = rl_wait(tailP, need);
             }
-            pp_store<G>(lds, slotPA(k), A);                          // the final first digit
+            pp_store<GC>(lds, slotPA(k), A);                          // the final first digit
             rl_publish(headP, (uint32_t)(k + 1));
             PP_REPORT("B1");
         } else {
@@ -417,14 +346,14 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
             while (i < ebits) {
                 PP_WAIT(rl_wait<RL_SLEEP_B>(headB, (uint32_t)(i + 1)));
                 if (first) {
-                    pp_load<G>(Bv, lds, slotB(i));
+                    pp_load<GC>(Bv, lds, slotB(i));
                     first = false;
                 } else {
                     PP_WAIT(rl_wait<RL_SLEEP_B>(headP, (uint32_t)(k + 1)));
                     uint32_t Ao[NLL], v[NLL];
-                    pp_load<G>(Ao, lds, slotPA(k));
+                    pp_load<GC>(Ao, lds, slotPA(k));
                     // v = (A b_i + B a_i - m + R s' + m' s') / R
-                    pp_half<G, true, true, false, false>(v, Bv, slotA(i), Ao, slotB(i), lds, feed_off(slotPM(k)), 0, npp, mtrue, nblk);
+                    pp_half<GC, true, true, false>(v, Bv, slotA(i), Ao, slotB(i), lds, feed_off(slotPM(k)), 0, npp, mtrue, nblk);
 #pragma unroll
                     for (int j = 0; j < NLL; ++j) Bv[j] = v[j];
                     ++k;
@@ -435,12 +364,12 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
             }
             PP_STAMP(pp_s1);
             rl_wait<RL_SLEEP_B>(headP, (uint32_t)(k + 1));
-            uint32_t acc2[NLL];
+            uint32_t acc2[GN];
             if (VAR && first) {                                       // exponent 0
                 set_plain_one<G>(acc2);
             } else {
             uint32_t A[NLL];
-            pp_load<G>(A, lds, slotPA(k));
+            pp_load<GC>(A, lds, slotPA(k));
             // y = A + Bv s' (plain, 2 r limbs): r rows retire the low limbs through lane 0, the window keeps y >> 29 r
             {
                 using RW = Rows<NLL, U, 64>;
@@ -475,24 +404,24 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
             // into the Montgomery form of the s^2 context chunk by chunk (y = sum_j y_j R_sq^j, y_j < R_sq: every product
             // comes out lazy), then k_dec_a_rl's tail: leave the form, reduce modulo s^2 itself
             const MontCtx* cs = P.sq[which];
-            NmRegs<NLL> nsq;
+            NmRegs<GN> nsq;
 #pragma unroll
-            for (int j = 0; j < NLL; ++j) nsq.v[j] = cs->npp[NLL * lane + j];
-            const int rows_sq = (int)cs->rows, nblk_sq = rows_sq / U;
+            for (int j = 0; j < GN; ++j) nsq.v[j] = cs->npp[GN * lane + j];
+            const int rows_sq = (int)cs->rows, nblk_sq = rows_sq / GU;
 #pragma unroll
-            for (int j = 0; j < NLL; ++j) acc2[j] = 0;
+            for (int j = 0; j < GN; ++j) acc2[j] = 0;
 #pragma unroll 1
             for (int ch = 0; ch < P.nch; ++ch) {
-                uint32_t y[NLL], t[NLL];
+                uint32_t y[GN], t[GN];
 #pragma unroll
-                for (int j = 0; j < NLL; ++j) {
-                    const int li = NLL * lane + j, idx = ch * rows_sq + li;
+                for (int j = 0; j < GN; ++j) {
+                    const int li = GN * lane + j, idx = ch * rows_sq + li;
                     y[j] = (li < rows_sq && idx < PP_YBUF) ? lds[L::YBUF + idx] : 0u;
                 }
-                mont_mul_m1<NLL, U, 64>(t, y, lds + L::KX + ch * G::NL, 1, nsq, nblk_sq);
+                mont_mul_m1<GN, GU, 64>(t, y, lds + L::KX + ch * G::NL, 1, nsq, nblk_sq);
                 add_limbs<G>(acc2, t);
             }
-            uint32_t one[NLL];
+            uint32_t one[GN];
             set_plain_one<G>(one);
             mm_times<G>(acc2, one, lds + L::STAGE, nsq, (uint32_t)nblk_sq);
             m1_reduce_to_true_modulus<G>(acc2, lds + L::STAGE, P.fin[which]);
@@ -504,17 +433,17 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
     }
 }
 
-template <class G>
+template <class G, class GC>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_dec_a_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ u_out /*[2][n][u_words]*/, int n) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    pp_chain<G, false>(P, ct, u_out, n, lds);
+    pp_chain<G, GC, false>(P, ct, u_out, n, lds);
 }
-template <class G>
+template <class G, class GC>
 __global__ void __launch_bounds__(BLOCK_THREADS, 1)
 k_ctmul_pp(DecPPParams P, const uint32_t* __restrict__ ct, uint32_t* __restrict__ out /*[n][u_words]*/, int n) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    pp_chain<G, true>(P, ct, out, n, lds);
+    pp_chain<G, GC, true>(P, ct, out, n, lds);
 }
 
 }  // namespace pai

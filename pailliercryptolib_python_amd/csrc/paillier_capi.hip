@@ -250,7 +250,7 @@ struct ModSetup {
     // M' = M k, k = -M^-1 mod 2^(29 U), so that M' == -1 (mod 2^(29 U)) and the quotient digits of a row block are the
     // limbs the block retires.  Residues modulo M' are residues modulo M; R = 2^(29 rows) with rows = the limbs M' needs
     // (+ 4 bits of head-room: R > 16 M'), not the geometry's capacity.  M, R, R2, R3 of this object then refer to M'.
-    void init_m1(const Limbs& mod_, const GeoOps* g, int headroom_bits = 4) {
+    void init_m1(const Limbs& mod_, const GeoOps* g, int headroom_bits = 4, int row_multiple = 0) {
         require(hbn::is_odd(mod_), "modulus must be odd");
         geo = g;
         nl = g->nl;
@@ -261,7 +261,8 @@ struct ModSetup {
         bits = hbn::bitlen(M);
         w32 = words_for_bits(bits);
         int rows = (bits + headroom_bits + hbn::RB - 1) / hbn::RB;
-        rows = (rows + g->u - 1) / g->u * g->u;
+        const int rmul = row_multiple ? row_multiple : g->u;
+        rows = (rows + rmul - 1) / rmul * rmul;
         require(rows <= nl, "minus-one modulus does not fit the geometry");
         const Limbs mp1 = hbn::add(M, Limbs{1u});
         require(hbn::is_zero(hbn::low_bits(mp1, ub)), "minus-one modulus: construction failed");
@@ -514,6 +515,7 @@ struct pai_pubkey {
     mutable uint32_t* d_lat_pp_kdig = nullptr;
     mutable uint32_t* d_lat_pp_kx = nullptr;
     mutable int lat_pp_nd = 0, lat_pp_nch = 0;
+    mutable int lat_pp_chain = 1;
     // small-batch ct + ct: n^2 on the latency geometry; the "tag" context multiplies by R_lat^2 / R instead of R_lat^2, so that
     // MODMUL_FULL there returns a b R^-1 in terms of the throughput geometry's R (the lazy domain tags of the containers)
     mutable ModSetup lat_msq_tag;
@@ -591,6 +593,7 @@ struct pai_privkey {
         uint32_t* d_pp_kdig[2] = {nullptr, nullptr};
         uint32_t* d_pp_kx[2] = {nullptr, nullptr};
         int pp_nd = 0, pp_nch = 0;
+        int pp_chain = 1;                 // limbs per lane of the chain's contexts (both primes)
     } lat;
     ScratchOrder order;
     std::mutex mu;
@@ -1040,10 +1043,22 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
 // Constants of the four-wave digit-pair pipeline (kernels_declat.hpp) for one modulus s: the minus-one context of s' = s k
 // (R = 2^(29 r) >= 2^8 s'), the base-s' digits of R^(i+2) mod s'^2 (an integer of in_bits bits into digit form) and
 // R^-1 R_sq^(j+2) mod (s^2 k2) (a + b s' into the Montgomery form of sq_m1, the minus-one context of s^2).
+// The chain's contexts: k of ONE limb (s' == -1 mod 2^29), the rows a multiple of the four the row loop takes at a time, one limb
+// per lane where s' fits 64 limbs, else two.
+static const GeoOps* pp_chain_geo(int limbs) {
+    static const GeoOps g1 = [] { GeoOps o{}; o.nll = 1; o.t = 64; o.u = 1; o.nl = 64; o.epb = 4; return o; }();
+    static const GeoOps g2 = [] { GeoOps o{}; o.nll = 2; o.t = 64; o.u = 1; o.nl = 128; o.epb = 4; return o; }();
+    return limbs == 1 ? &g1 : &g2;
+}
 static bool build_pp_consts(const Limbs& smod, const ModSetup& sq_m1, const GeoOps* ga, int in_bits, ModSetup& pp,
-                            uint32_t** d_kdig, uint32_t** d_kx, int* nd_out, int* nch_out) {
+                            uint32_t** d_kdig, uint32_t** d_kx, int* nd_out, int* nch_out, int* chain_limbs_out) {
     const Limbs one{1u};
-    pp.init_m1(smod, ga, 8);
+    const int rows = ((hbn::bitlen(smod) + hbn::RB + 8 + hbn::RB - 1) / hbn::RB + 3) / 4 * 4;
+    if (rows > PP_RMAX) return false;
+    const int chain = rows <= 64 ? 1 : 2;
+    *chain_limbs_out = chain;
+    pp.init_m1(smod, pp_chain_geo(chain), 8, 4);
+    (void)ga;
     const int r = pp.m1_rows;
     const int nd = (in_bits + hbn::RB * r - 1) / (hbn::RB * r);
     const int rows_sq = sq_m1.m1_rows;
@@ -1105,7 +1120,7 @@ static bool ensure_lat_ctx(const pai_pubkey* pk) {
         pk->lat_pp_tried = true;
         if (pk->lat_msq.geo == geo_ops_3x64() && !knob_disabled("lat_pp"))
             pk->lat_pp_ok = build_pp_consts(pk->n, pk->lat_msq_m1, pk->lat_msq.geo, 32 * pk->ct_words, pk->lat_pp, &pk->d_lat_pp_kdig,
-                                            &pk->d_lat_pp_kx, &pk->lat_pp_nd, &pk->lat_pp_nch);
+                                            &pk->d_lat_pp_kx, &pk->lat_pp_nd, &pk->lat_pp_nch, &pk->lat_pp_chain);
     }
     return pk->lat_usable;
 }
@@ -2087,7 +2102,7 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
                 Q.e_bcast = e_bcast;
                 pk->order.begin(s);
                 ScopedKernelTimer t("k_ctmul", s);
-                launch_ctmul_pp(s, (int)N, Q, d_ct, d_out);
+                launch_ctmul_pp(s, (int)N, Q, d_ct, d_out, pk->lat_pp_chain);
                 t.stop();
                 HIP_CHECK(hipGetLastError());
                 pk->order.end(s);
@@ -2831,8 +2846,10 @@ static void build_latency_consts(pai_privkey* sk) {
         const int ct_bits = 32 * sk->pk->ct_words;
         for (int w = 0; w < 2 && ok; ++w) {
             int nd = 0, nch = 0;
-            ok = build_pp_consts(prime[w], L.sq[w], ga, ct_bits, L.pp[w], &L.d_pp_kdig[w], &L.d_pp_kx[w], &nd, &nch);
-            if (ok && w == 1 && (nd != L.pp_nd || nch != L.pp_nch)) ok = false;
+            int chain = 1;
+            ok = build_pp_consts(prime[w], L.sq[w], ga, ct_bits, L.pp[w], &L.d_pp_kdig[w], &L.d_pp_kx[w], &nd, &nch, &chain);
+            if (ok && w == 1 && (nd != L.pp_nd || nch != L.pp_nch || chain != L.pp_chain)) ok = false;
+            L.pp_chain = chain;
             L.pp_nd = nd;
             L.pp_nch = nch;
         }
@@ -2924,7 +2941,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                     Q.ct_words = pk->ct_words;
                     Q.u_words = u_words;
                     ScopedKernelTimer t("k_dec_a", s);
-                    launch_dec_a_pp(s, (int)N, Q, d_ct, sk->ubuf.as<uint32_t>());
+                    launch_dec_a_pp(s, (int)N, Q, d_ct, sk->ubuf.as<uint32_t>(), L.pp_chain);
                     t.stop();
                 } else {
                     ScopedKernelTimer t("k_dec_a", s);
