@@ -69,6 +69,51 @@ struct PPLds {
                   KD % 4 == 0 && ZERO % 4 == 0 && TMPM % 4 == 0 && PP_RMAX % 4 == 0 && ROW % 4 == 0, "digit rows are read 16 bytes at a time");
 };
 
+// Lazy 64-bit columns (< 2^61 each) of an integer spread over the wave, NLL limbs per lane -> canonical 29-bit limbs, without a
+// data-dependent loop: the carry out of a lane is < 2^32 after its own pass, < 8 after the neighbour's first visit, 0 or 1
+// after the second, and the 0 / 1 ripple is ONE 64-bit addition of the lanes' generate / propagate ballots (cond_sub's
+// look-ahead).  Rows::finish loops "while any lane still has a carry": three or four rounds of compare, branch and a 64-bit
+// add per call — a tenth of a chain step once a row costs 12 instructions.
+template <int NLL>
+PAI_DEV void pp_finish(const uint64_t (&col)[NLL], uint32_t (&r)[NLL]) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) {
+        const uint64_t t = col[j] + c;
+        r[j] = (uint32_t)t & RMASK;
+        c = t >> RB;
+    }
+    uint32_t cout = (uint32_t)c;                                      // < 2^32
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        uint32_t cin = from_prev<64>(cout);
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) {
+            const uint32_t t = r[j] + cin;                            // < 2^29 + 2^32 - 2^29 in the first pass (r[0] only), < 2^30 after
+            r[j] = t & RMASK;
+            cin = t >> RB;
+        }
+        cout = cin;
+    }
+    bool allones = true;
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) allones = allones && r[j] == RMASK;
+    const uint64_t g = __ballot(cout != 0), pm = __ballot(allones);
+    const uint64_t xs = g | pm, sum = xs + g;
+    uint32_t cin = (uint32_t)(((sum ^ pm) >> (threadIdx.x & 63)) & 1u);
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) {
+        const uint32_t t = r[j] + cin;
+        r[j] = t & RMASK;
+        cin = t >> RB;
+    }
+}
+// rl_publish without the exec mask around lane 0's store: every lane stores the same word
+PAI_DEV void pp_publish(uint32_t* flag, uint32_t v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // One half of the product rule on a minus-one context with k of ONE limb (s' == -1 mod 2^29), the integer spread over the wave
 // with NLL limbs per lane (1 where s' fits 64 limbs, else 2):
 //   r = (x1 * dig1 [+ x2 * dig2] [+ R - m] + q s') / R  [+ s' - 1]
@@ -122,16 +167,12 @@ PAI_DEV void pp_half(uint32_t (&r)[GC::NLL], const uint32_t (&x1)[GC::NLL], int 
         if constexpr (EXPORT) *reinterpret_cast<uint4*>(lds + mq_off + g) = make_uint4(RMASK - q[0], RMASK - q[1], RMASK - q[2], RMASK - q[3]);
         b1 = n1; b2 = n2; f = nf;
     }
-    uint64_t acc[NLL + 1];
-#pragma unroll
-    for (int j = 0; j < NLL; ++j) acc[j] = col[j];
-    acc[NLL] = 0;
     if constexpr (FEED) {                                             // + (s' - 1) R on the numerator
 #pragma unroll
-        for (int j = 0; j < NLL; ++j) acc[j] += (uint64_t)mtrue[j];
-        if (lane0) acc[0] -= 1;
+        for (int j = 0; j < NLL; ++j) col[j] += (uint64_t)mtrue[j];
+        if (lane0) col[0] -= 1;
     }
-    Rows<NLL, 1, 64>::finish(acc, r);
+    pp_finish<NLL>(col, r);
 }
 
 // this lane's slices of a ring slot (PP_ROW words: the whole lane-sliced integer, limbs beyond the value are zero)
@@ -212,11 +253,11 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
     // lane 0 feeds from the quotient-digit buffer, the other lanes read zeros
     auto feed_off = [&](int m_off) -> int { return lane0 ? m_off : (int)L::ZERO; };
     auto mq_off = [](int m_off) -> int { return m_off; };                    // (the export is a uniform store)
-    auto slotA = [](int i) -> int { return L::RING_A + (i % PP_RING) * L::ROW; };
-    auto slotM = [](int i) -> int { return L::RING_M + (i % PP_RING) * PP_RMAX; };
-    auto slotB = [](int i) -> int { return L::RING_B + (i % PP_RING) * L::ROW; };
-    auto slotPA = [](int k) -> int { return L::PRING_A + (k % PP_PRING) * L::ROW; };
-    auto slotPM = [](int k) -> int { return L::PRING_M + (k % PP_PRING) * PP_RMAX; };
+    auto slotA = [](int i) -> int { return L::RING_A + (int)((unsigned)i % PP_RING) * L::ROW; };
+    auto slotM = [](int i) -> int { return L::RING_M + (int)((unsigned)i % PP_RING) * PP_RMAX; };
+    auto slotB = [](int i) -> int { return L::RING_B + (int)((unsigned)i % PP_RING) * L::ROW; };
+    auto slotPA = [](int k) -> int { return L::PRING_A + (int)((unsigned)k % PP_PRING) * L::ROW; };
+    auto slotPM = [](int k) -> int { return L::PRING_M + (int)((unsigned)k % PP_PRING) * PP_RMAX; };
     uint32_t none[NLL];
 #pragma unroll
     for (int j = 0; j < NLL; ++j) none[j] = 0;
@@ -250,8 +291,8 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
             }
             pp_store<GC>(lds, slotA(0), sa);
             pp_store<GC>(lds, slotB(0), sb);
-            rl_publish(headB, 1u);
-            rl_publish(headA, 1u);
+            pp_publish(headB, 1u);
+            pp_publish(headA, 1u);
             uint32_t x[NLL];
 #pragma unroll
             for (int j = 0; j < NLL; ++j) x[j] = sa[j];
@@ -270,7 +311,7 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
                 pp_store<GC>(lds, slotA(i + 1), w);
 #pragma unroll
                 for (int j = 0; j < NLL; ++j) x[j] = w[j];
-                rl_publish(headA, (uint32_t)(i + 2));
+                pp_publish(headA, (uint32_t)(i + 2));
             }
             PP_REPORT("W1");
         } else if (wave == 1) {
@@ -294,14 +335,14 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
                 pp_store<GC>(lds, slotB(i + 1), v);
 #pragma unroll
                 for (int j = 0; j < NLL; ++j) b[j] = v[j];
-                rl_publish(headB, (uint32_t)(i + 2));
+                pp_publish(headB, (uint32_t)(i + 2));
             }
             PP_REPORT("W2");
         } else if (wave == 2) {
             // ---- B1: first digit of the accumulator: the a_i at the set bits of s - 1 -----------------------------------
             uint32_t A[NLL];
             int i = next_set(0), k = 0;
-            rl_publish(tailB1, (uint32_t)i);
+            pp_publish(tailB1, (uint32_t)i);
             bool first = true;
             uint32_t seenP = 0;
             PP_T0();
@@ -322,23 +363,23 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
 #pragma unroll
                     for (int j = 0; j < NLL; ++j) A[j] = w[j];
                     ++k;
-                    rl_publish(headP, (uint32_t)k);
+                    pp_publish(headP, (uint32_t)k);
                 }
                 i = next_set(i + 1);
-                rl_publish(tailB1, (uint32_t)(i < ebits ? i : ebits + PP_RING));
+                pp_publish(tailB1, (uint32_t)(i < ebits ? i : ebits + PP_RING));
             }
             if (k >= PP_PRING - 1) {
                 const uint32_t need = (uint32_t)(k + 2 - PP_PRING);
                 if (seenP < need) seenP = rl_wait(tailP, need);
             }
             pp_store<GC>(lds, slotPA(k), A);                          // the final first digit
-            rl_publish(headP, (uint32_t)(k + 1));
+            pp_publish(headP, (uint32_t)(k + 1));
             PP_REPORT("B1");
         } else {
             // ---- B2: second digit of the accumulator, then the way out ---------------------------------------------------
             uint32_t Bv[NLL];
             int i = next_set(0), k = 0;
-            rl_publish(tailB2, (uint32_t)i);
+            pp_publish(tailB2, (uint32_t)i);
             bool first = true;
             PP_T0();
             PP_DECL(pp_s1, pp_s2);
@@ -357,10 +398,10 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
 #pragma unroll
                     for (int j = 0; j < NLL; ++j) Bv[j] = v[j];
                     ++k;
-                    rl_publish(tailP, (uint32_t)k);
+                    pp_publish(tailP, (uint32_t)k);
                 }
                 i = next_set(i + 1);
-                rl_publish(tailB2, (uint32_t)(i < ebits ? i : ebits + PP_RING));
+                pp_publish(tailB2, (uint32_t)(i < ebits ? i : ebits + PP_RING));
             }
             PP_STAMP(pp_s1);
             rl_wait<RL_SLEEP_B>(headP, (uint32_t)(k + 1));
