@@ -128,41 +128,50 @@ PAI_DEV void pp_publish(uint32_t* flag, uint32_t v) {
 // keys): 21 instructions per row against 12 here.  Four rows per loop iteration, their digits read 16 bytes at a time one
 // iteration ahead (a lone wave has nobody to hide an LDS round trip behind); the quotient digits leave as the UNIFORM value
 // every lane holds after the broadcast — all lanes store the same words: no dump rows, no exec masking.
-// nrows is a multiple of 4 (the host rounds R up).
+// nrows is a multiple of 4 (the host rounds R up) and smaller than the limbs of the geometry.
 template <class GC, bool TWO, bool FEED, bool EXPORT>
 PAI_DEV void pp_half(uint32_t (&r)[GC::NLL], const uint32_t (&x1)[GC::NLL], int dig1, const uint32_t (&x2)[GC::NLL], int dig2,
                      uint32_t* lds, int fd_off, int mq_off, const NmRegs<GC::NLL>& npp, const uint32_t (&mtrue)[GC::NLL], int nrows) {
     constexpr int NLL = GC::NLL;
     static_assert(GC::U == 1 && GC::T == 64, "one limb retired per row, one integer per wavefront");
     const bool lane0 = (threadIdx.x & 63) == 0;
-    uint64_t col[NLL];
-#pragma unroll
-    for (int j = 0; j < NLL; ++j) col[j] = 0;
-    if (FEED && lane0) col[0] = 1;                                    // R - m = sum (2^29 - 1 - m_i) 2^(29 i) + 1
     auto ld4 = [&](int off) -> uint4 { return *reinterpret_cast<const uint4*>(lds + off); };
     uint4 b1 = ld4(dig1), b2 = TWO ? ld4(dig2) : make_uint4(0, 0, 0, 0), f = FEED ? ld4(fd_off) : make_uint4(0, 0, 0, 0);
+    // col[] always holds the columns WITH the current row's products: the next row's products (and feed digit) do not depend
+    // on this row's quotient digit, so they join the sum the quotient product is added to — the chain from row to row is
+    // mask -> broadcast -> one multiply-add.  (The row after the last one reads a zero digit: every digit row is followed by
+    // zero words, the limbs of the operand beyond nrows.)
+    uint64_t col[NLL];
+#pragma unroll
+    for (int j = 0; j < NLL; ++j) {
+        col[j] = (uint64_t)x1[j] * b1.x;
+        if constexpr (TWO) col[j] += (uint64_t)x2[j] * b2.x;
+    }
+    if constexpr (FEED) col[0] += (uint64_t)f.x + (lane0 ? 1u : 0u);  // R - m = sum (2^29 - 1 - m_i) 2^(29 i) + 1
 #pragma unroll 1
     for (int g = 0; g < nrows; g += 4) {
-        const uint4 n1 = ld4(dig1 + g + 4);                           // (one group beyond the last: in-bounds reads of unused words)
+        const uint4 n1 = ld4(dig1 + g + 4);                           // (the group beyond the last: zeros, see above)
         const uint4 n2 = TWO ? ld4(dig2 + g + 4) : make_uint4(0, 0, 0, 0);
         const uint4 nf = FEED ? ld4(fd_off + g + 4) : make_uint4(0, 0, 0, 0);
-        const uint32_t c1[4] = {b1.x, b1.y, b1.z, b1.w}, c2[4] = {b2.x, b2.y, b2.z, b2.w}, cf[4] = {f.x, f.y, f.z, f.w};
+        const uint32_t c1[5] = {b1.x, b1.y, b1.z, b1.w, n1.x}, c2[5] = {b2.x, b2.y, b2.z, b2.w, n2.x}, cf[5] = {f.x, f.y, f.z, f.w, nf.x};
         uint32_t q[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int j = 0; j < NLL; ++j) {
-                col[j] += (uint64_t)x1[j] * c1[u];
-                if constexpr (TWO) col[j] += (uint64_t)x2[j] * c2[u];
-            }
-            if constexpr (FEED) col[0] += (uint64_t)cf[u];
             uint32_t lo[NLL];
 #pragma unroll
             for (int j = 0; j < NLL; ++j) lo[j] = (uint32_t)col[j] & RMASK;
             q[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo[0]);
             const uint32_t t = from_next<64>(lo[0]);
+            uint64_t sum[NLL];
 #pragma unroll
-            for (int j = 0; j < NLL; ++j) col[j] = (col[j] >> RB) + (uint64_t)(j + 1 < NLL ? lo[j + 1] : t) + (uint64_t)npp.v[j] * q[u];
+            for (int j = 0; j < NLL; ++j) {
+                sum[j] = (col[j] >> RB) + (uint64_t)x1[j] * c1[u + 1];
+                if constexpr (TWO) sum[j] += (uint64_t)x2[j] * c2[u + 1];
+                sum[j] += (uint64_t)(j + 1 < NLL ? lo[j + 1] : t);
+            }
+            if constexpr (FEED) sum[0] += (uint64_t)cf[u + 1];
+#pragma unroll
+            for (int j = 0; j < NLL; ++j) col[j] = (uint64_t)npp.v[j] * q[u] + sum[j];
         }
         if constexpr (EXPORT) *reinterpret_cast<uint4*>(lds + mq_off + g) = make_uint4(RMASK - q[0], RMASK - q[1], RMASK - q[2], RMASK - q[3]);
         b1 = n1; b2 = n2; f = nf;
@@ -235,6 +244,10 @@ PAI_DEV void pp_chain(const DecPPParams& P, const uint32_t* __restrict__ ct, uin
     for (int i = threadIdx.x; i < PP_RMAX; i += BLOCK_THREADS) { lds[L::MLIM + i] = ctx->n[i]; lds[L::ZERO + i] = 0u; }
     for (int i = threadIdx.x; i < P.nch * G::NL; i += BLOCK_THREADS) lds[L::KX + i] = P.kx[which][i];
     for (int i = threadIdx.x; i < PP_YBUF; i += BLOCK_THREADS) lds[L::YBUF + i] = 0u;
+    // (the quotient-digit rows are read one group beyond their nrows words: zeros)
+    for (int i = threadIdx.x; i < PP_RING * PP_RMAX; i += BLOCK_THREADS) lds[L::RING_M + i] = 0u;
+    for (int i = threadIdx.x; i < PP_PRING * PP_RMAX; i += BLOCK_THREADS) lds[L::PRING_M + i] = 0u;
+    for (int i = threadIdx.x; i < PP_RMAX; i += BLOCK_THREADS) lds[L::TMPM + i] = 0u;
     uint32_t* flags = lds + L::FLAGS;
     uint32_t* headA = flags, *headB = flags + 1, *headP = flags + 2, *tailB1 = flags + 4, *tailB2 = flags + 5, *tailP = flags + 6;
     const int ewords = VAR ? P.e_words : (ebits + 31) / 32;

@@ -1054,8 +1054,8 @@ static bool build_pp_consts(const Limbs& smod, const ModSetup& sq_m1, const GeoO
                             uint32_t** d_kdig, uint32_t** d_kx, int* nd_out, int* nch_out, int* chain_limbs_out) {
     const Limbs one{1u};
     const int rows = ((hbn::bitlen(smod) + hbn::RB + 8 + hbn::RB - 1) / hbn::RB + 3) / 4 * 4;
-    if (rows > PP_RMAX) return false;
-    const int chain = rows <= 64 ? 1 : 2;
+    if (rows + 4 > PP_RMAX) return false;                 // (a digit row is read one group of four beyond its end)
+    const int chain = rows <= 60 ? 1 : 2;                 // (rows < the limbs of the chain's geometry: the digit rows end in zeros)
     *chain_limbs_out = chain;
     pp.init_m1(smod, pp_chain_geo(chain), 8, 4);
     (void)ga;
