@@ -128,7 +128,8 @@ PAI_DEV void pp_publish(uint32_t* flag, uint32_t v) {
 // keys): 21 instructions per row against 12 here.  Four rows per loop iteration, their digits read 16 bytes at a time one
 // iteration ahead (a lone wave has nobody to hide an LDS round trip behind); the quotient digits leave as the UNIFORM value
 // every lane holds after the broadcast — all lanes store the same words: no dump rows, no exec masking.
-// nrows is a multiple of 4 (the host rounds R up) and smaller than the limbs of the geometry.
+// nrows is a multiple of 4 (the host rounds R up: a tail of single rows measured slower than the rows it saves) and smaller
+// than the limbs of the geometry.
 template <class GC, bool TWO, bool FEED, bool EXPORT>
 PAI_DEV void pp_half(uint32_t (&r)[GC::NLL], const uint32_t (&x1)[GC::NLL], int dig1, const uint32_t (&x2)[GC::NLL], int dig2,
                      uint32_t* lds, int fd_off, int mq_off, const NmRegs<GC::NLL>& npp, const uint32_t (&mtrue)[GC::NLL], int nrows) {
@@ -148,6 +149,25 @@ PAI_DEV void pp_half(uint32_t (&r)[GC::NLL], const uint32_t (&x1)[GC::NLL], int 
         if constexpr (TWO) col[j] += (uint64_t)x2[j] * b2.x;
     }
     if constexpr (FEED) col[0] += (uint64_t)f.x + (lane0 ? 1u : 0u);  // R - m = sum (2^29 - 1 - m_i) 2^(29 i) + 1
+    // one row: the quotient digit of the current columns, then the columns of the next row (its digits nb1, nb2, nf)
+    auto row = [&](uint32_t nb1, uint32_t nb2, uint32_t nfd) -> uint32_t {
+        uint32_t lo[NLL];
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) lo[j] = (uint32_t)col[j] & RMASK;
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo[0]);
+        const uint32_t t = from_next<64>(lo[0]);
+        uint64_t sum[NLL];
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) {
+            sum[j] = (col[j] >> RB) + (uint64_t)x1[j] * nb1;
+            if constexpr (TWO) sum[j] += (uint64_t)x2[j] * nb2;
+            sum[j] += (uint64_t)(j + 1 < NLL ? lo[j + 1] : t);
+        }
+        if constexpr (FEED) sum[0] += (uint64_t)nfd;
+#pragma unroll
+        for (int j = 0; j < NLL; ++j) col[j] = (uint64_t)npp.v[j] * q + sum[j];
+        return q;
+    };
 #pragma unroll 1
     for (int g = 0; g < nrows; g += 4) {
         const uint4 n1 = ld4(dig1 + g + 4);                           // (the group beyond the last: zeros, see above)
@@ -156,23 +176,7 @@ PAI_DEV void pp_half(uint32_t (&r)[GC::NLL], const uint32_t (&x1)[GC::NLL], int 
         const uint32_t c1[5] = {b1.x, b1.y, b1.z, b1.w, n1.x}, c2[5] = {b2.x, b2.y, b2.z, b2.w, n2.x}, cf[5] = {f.x, f.y, f.z, f.w, nf.x};
         uint32_t q[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint32_t lo[NLL];
-#pragma unroll
-            for (int j = 0; j < NLL; ++j) lo[j] = (uint32_t)col[j] & RMASK;
-            q[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo[0]);
-            const uint32_t t = from_next<64>(lo[0]);
-            uint64_t sum[NLL];
-#pragma unroll
-            for (int j = 0; j < NLL; ++j) {
-                sum[j] = (col[j] >> RB) + (uint64_t)x1[j] * c1[u + 1];
-                if constexpr (TWO) sum[j] += (uint64_t)x2[j] * c2[u + 1];
-                sum[j] += (uint64_t)(j + 1 < NLL ? lo[j + 1] : t);
-            }
-            if constexpr (FEED) sum[0] += (uint64_t)cf[u + 1];
-#pragma unroll
-            for (int j = 0; j < NLL; ++j) col[j] = (uint64_t)npp.v[j] * q[u] + sum[j];
-        }
+        for (int u = 0; u < 4; ++u) q[u] = row(c1[u + 1], c2[u + 1], cf[u + 1]);
         if constexpr (EXPORT) *reinterpret_cast<uint4*>(lds + mq_off + g) = make_uint4(RMASK - q[0], RMASK - q[1], RMASK - q[2], RMASK - q[3]);
         b1 = n1; b2 = n2; f = nf;
     }

@@ -1043,8 +1043,7 @@ void build_pair_fb(pai_pubkey* pk, int wb, int J) {
 // Constants of the four-wave digit-pair pipeline (kernels_declat.hpp) for one modulus s: the minus-one context of s' = s k
 // (R = 2^(29 r) >= 2^8 s'), the base-s' digits of R^(i+2) mod s'^2 (an integer of in_bits bits into digit form) and
 // R^-1 R_sq^(j+2) mod (s^2 k2) (a + b s' into the Montgomery form of sq_m1, the minus-one context of s^2).
-// The chain's contexts: k of ONE limb (s' == -1 mod 2^29), the rows a multiple of the four the row loop takes at a time, one limb
-// per lane where s' fits 64 limbs, else two.
+// The chain's contexts: k of ONE limb (s' == -1 mod 2^29), one limb per lane where s' fits 60 limbs, else two.
 static const GeoOps* pp_chain_geo(int limbs) {
     static const GeoOps g1 = [] { GeoOps o{}; o.nll = 1; o.t = 64; o.u = 1; o.nl = 64; o.epb = 4; return o; }();
     static const GeoOps g2 = [] { GeoOps o{}; o.nll = 2; o.t = 64; o.u = 1; o.nl = 128; o.epb = 4; return o; }();
@@ -1057,13 +1056,13 @@ static bool build_pp_consts(const Limbs& smod, const ModSetup& sq_m1, const GeoO
     if (rows + 4 > PP_RMAX) return false;                 // (a digit row is read one group of four beyond its end)
     const int chain = rows <= 60 ? 1 : 2;                 // (rows < the limbs of the chain's geometry: the digit rows end in zeros)
     *chain_limbs_out = chain;
-    pp.init_m1(smod, pp_chain_geo(chain), 8, 4);
+    pp.init_m1(smod, pp_chain_geo(chain), 8, 4);           // rows a multiple of the four the row loop takes at a time (its tail costs more than the rows it saves)
     (void)ga;
     const int r = pp.m1_rows;
     const int nd = (in_bits + hbn::RB * r - 1) / (hbn::RB * r);
     const int rows_sq = sq_m1.m1_rows;
     const int nch = (2 * r + 2 + rows_sq - 1) / rows_sq;
-    if (r > PP_RMAX || nd > PP_MAXND || nch > PP_MAXCH || 2 * r + 2 > PP_YBUF) return false;
+    if (r + 4 > PP_RMAX || r >= 64 * chain || nd > PP_MAXND || nch > PP_MAXCH || 2 * r + 2 > PP_YBUF) return false;
     *nd_out = nd;
     *nch_out = nch;
     const Limbs& Mp = pp.M;
