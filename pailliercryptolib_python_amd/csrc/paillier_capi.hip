@@ -801,9 +801,15 @@ static size_t lat_rl_max(size_t ncu) {              // PAI_TUNE lat_rl: largest 
     long long v;
     return knob_tune("lat_rl", &v) ? (size_t)v : ncu;
 }
-static size_t lat_pp_max(size_t ncu) {              // PAI_TUNE lat_pp: most (ciphertext, prime) chains of the four-wave digit-pair decryption (0 disables)
-    long long v;                                    // two workgroups (70 KB of LDS each) share a CU up to 2 x CUs chains: 3.23 against 3.45 ms at
-    return knob_tune("lat_pp", &v) ? (size_t)v : 2 * ncu;       // 160 .. 256 ciphertexts (2.5 ms up to 128); beyond, the window kernel is ahead
+static size_t lat_pp_max(size_t ncu, int chain_limbs, int key_bits) {      // PAI_TUNE lat_pp: most (ciphertext, prime) chains of the four-wave
+    long long v;                                                            // digit-pair decryption (0 disables)
+    if (knob_tune("lat_pp", &v)) return (size_t)v;
+    // one limb per lane: 29 KB of LDS and < 100 registers per workgroup, five workgroups share a CU and further rounds follow —
+    // measured (profiles/r05/lat_pp_range.jsonl, k_dec_a alone, ms): 2048-bit keys 1.56 up to 128 ciphertexts, 1.92 / 2.2 / 2.6 / 3.25 /
+    // 3.85 at 256 / 384 / 512 / 640 / 768 against 3.8 (<= 512) and 4.6 of the window kernels, behind at 1 024 (4.9 / 4.6);
+    // 3072-bit 3.0 .. 11.9 up to 1 280 against 7.9 .. 15.8; two limbs per lane (4096-bit): 6.7 / 9.4 / 11.4 up to 384 against 12.4 .. 14.1
+    if (chain_limbs == 1) return (key_bits <= 2048 ? 6 : 10) * ncu;
+    return 3 * ncu;
 }
 static size_t lat_enc_tree_max(size_t ncu) {        // PAI_TUNE lat_enc_tree: largest batch of the wave-shared small-batch encryption (0 disables)
     long long v;
@@ -811,8 +817,8 @@ static size_t lat_enc_tree_max(size_t ncu) {        // PAI_TUNE lat_enc_tree: la
     return knob_tune("lat_enc_tree", &v) ? (size_t)v : (size_t)1 << 30;                         // measured ahead over the whole latency range (2048-bit keys: 0.29 vs 0.98 ms up to 256
 }                                                   // elements, 0.54 vs 1.01 at 1024, 1.63 vs 1.91 at 4096; profiles/r04/lat_enc_tree.jsonl)
 static size_t lat_mul_pp_max(size_t ncu) {          // PAI_TUNE lat_mul_pp: largest batch of the four-wave digit-pair ct * pt (0 disables)
-    long long v;
-    return knob_tune("lat_mul_pp", &v) ? (size_t)v : 2 * ncu;
+    long long v;                                    // 2048-bit keys, 53-bit exponents: 0.22 ms up to 256, 0.31 / 0.43 at 512 / 1 024 against 0.37 / 0.49
+    return knob_tune("lat_mul_pp", &v) ? (size_t)v : 4 * ncu;
 }
 static size_t lat_mul_rl_max(size_t ncu) {          // PAI_TUNE lat_mul_rl: largest batch of the wave-pair small-batch ct * pt (0 disables)
     long long v;
@@ -2924,7 +2930,7 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
                 B.u_is_L = 0;
                 g_last_times.clear();
                 // the smallest batches (a workgroup per (ciphertext, prime), at most two per CU): digit pairs on four waves
-                if (L.pp_ok && !dense && 2 * N <= lat_pp_max((size_t)dev.ncu)) {
+                if (L.pp_ok && 2 * N <= lat_pp_max((size_t)dev.ncu, L.pp_chain, pk->key_bits)) {
                     DecPPParams Q;
                     for (int w = 0; w < 2; ++w) {
                         Q.pp[w] = L.pp[w].d_ctx;

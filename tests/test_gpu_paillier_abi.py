@@ -733,7 +733,7 @@ def test_pubkey_trim_releases_the_tables_and_the_next_call_rebuilds_them(k2048):
     default window width); trim returns that memory, a second key's table fits next to the first, and the next encryption
     rebuilds the table and produces the same bits."""
     nk, key = k2048, k2048.key
-    N = 5000                                                      # beyond the latency path: the throughput kernel and its table
+    N = 16384                                                     # beyond the latency path (<= 11 776 at 2048-bit keys): the throughput kernel and its table
     m = plaintexts(key, N, 4242)
     r = orc.synth_r_limbs(4243, N, key.randbits)
     want = [orc.encrypt(key, x, rr) for x, rr in zip(m[:8], orc.limbs_to_ints(r[:8]))]

@@ -17,12 +17,12 @@ def tm(f, reps=5):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 g = torch.Generator(device=dev); g.manual_seed(1)
-for N in (1, 16, 64, 128):
+for N in ((1, 16, 64, 128) if len(sys.argv) < 3 else (16, 128, 256, 384, 512, 640, 768, 1024, 1280)):
     m = torch.randint(0, 2**31 - 1, (N, pub.n_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
     m[:, -1] &= 0x0FFFFFFF
     ct = pub.encrypt(m, pub.random_r(N, generator=g))
     row = {"bits": bits, "N": N}
-    for name, tune in (("pp", "lat_pp=100000"), ("rl", "lat_pp=0"), ("window", "lat_pp=0,lat_rl=0")):
+    for name, tune in (("pp", "lat_pp=100000"), ("rl", "lat_pp=0"), ("window", "lat_pp=0,lat_rl=0")) + ((("default", ""),) if len(sys.argv) > 2 else ()):
         os.environ["PAI_TUNE"] = tune
         ok = bool(torch.equal(priv.decrypt(ct), m))
         engine.profile_enable(True)
