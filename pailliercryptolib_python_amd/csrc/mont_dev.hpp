@@ -412,7 +412,10 @@ PAI_DEV void mont_mul_m1(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uin
     int since = 0;
     // (reading the digits of block k + 1 while block k multiplies — which pays in kernels_declat.hpp's split-window blocks —
     // measured NEGATIVE here: the two-block loop body loses the compiler's renaming of the window slide: k_dec_a_rl 3.37 ->
-    // 3.63 ms, ct x pt 0.372 -> 0.393 ms, profiles/r05/README.md)
+    // 3.63 ms, ct x pt 0.372 -> 0.393 ms, profiles/r05/README.md.  So did the ROW form that serves kernels_declat.hpp's chains —
+    // one 64-bit column per limb, one quotient digit per row: with three limbs per lane the block's single mask -> broadcast ->
+    // multiply chain per three rows is worth more than the row form's four instructions less: small-batch encrypt 0.160 -> 0.204 ms,
+    // k_dec_a_rl 3.34 -> 4.1 ms)
 #pragma unroll 1
     for (int blk = 0; blk < nblk; ++blk) {
         uint32_t bv[U];
