@@ -154,7 +154,7 @@ PAI_DEV void pp_half(uint32_t (&r)[GC::NLL], const uint32_t (&x1)[GC::NLL], int 
         uint32_t lo[NLL];
 #pragma unroll
         for (int j = 0; j < NLL; ++j) lo[j] = (uint32_t)col[j] & RMASK;
-        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo[0]);
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo[0]);      // (masking AFTER the broadcast, on the scalar side: 1.81 against 1.55 ms)
         const uint32_t t = from_next<64>(lo[0]);
         uint64_t sum[NLL];
 #pragma unroll
