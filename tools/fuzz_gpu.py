@@ -11,7 +11,13 @@ from tests.test_gpu_paillier_abi import NativeKey, bench_key, seeded_key
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(time.time()))
-keys = {b: NativeKey(bench_key() if b == 2048 else seeded_key(b)) for b in (1024, 2048, 3072, 4096)}
+KEY_BITS = (1024, 1536, 2048, 2560, 3072, 3328, 3584, 4096)      # 3328 / 3584: either side of the one- / two-limb chain layouts of the small-batch pipeline
+def key_for(b):
+    if b == 2048: return bench_key()
+    if b in (1024, 3072, 4096): return seeded_key(b)                  # the committed fixture primes
+    p, q = _native.keygen(b, True, seed=b)                             # the other sizes: the native generator, seeded
+    return orc.make_key(p, q, djn_x=(1 << 70) + 12345, bits=b)
+keys = {b: NativeKey(key_for(b)) for b in KEY_BITS}
 
 def pattern(M, n):
     out = []
@@ -29,7 +35,7 @@ def pattern(M, n):
 
 t0 = time.time(); rounds = 0; checks = 0
 while time.time() - t0 < budget:
-    bits = int(rng.choice([1024, 2048, 3072, 4096]))
+    bits = int(rng.choice(KEY_BITS))
     nk = keys[bits]; key = nk.key; M = key.nsq; lib = nk.lib
     N = int(rng.integers(1, 700))
     a, b = pattern(M, N), pattern(M, N)
