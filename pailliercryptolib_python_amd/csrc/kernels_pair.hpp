@@ -17,6 +17,7 @@ namespace pai {
 
 // waves per SIMD the pair kernels are compiled for, by group size (tools/variant_tu.sh for A/B timing)
 #define PAIR_WAVES_PER_SIMD(T) ((T) >= 8 ? 2 : 1)
+#define PAIR_CT_WAVES_PER_SIMD(G) (G::NLL <= 9 ? 2 : PAIR_WAVES_PER_SIMD(G::T))
 
 struct PairParams {
     const MontCtx* nctx;         // modulus n on the pair geometry (NL limbs, R = 2^(29 NL))
@@ -72,10 +73,12 @@ PAI_DEV void pair_load_modulus(typename G::NM& nm, const MontCtx* __restrict__ c
 // this lane's slices of a raw digit pair [2][NL] (16-byte vectors when the slice length allows, else 8-byte)
 template <class G>
 PAI_DEV void pair_load(uint32_t (&a)[G::NLL], uint32_t (&b)[G::NLL], const uint32_t* __restrict__ ent) {
-    static_assert(G::NLL % 2 == 0, "limb slices move as vectors");
     const uint32_t* pa = ent + G::NLL * G::gl();
     const uint32_t* pb = ent + G::NL + G::NLL * G::gl();
-    if constexpr (G::NLL % 4 == 0) {
+    if constexpr (G::NLL % 2 != 0) {                      // (odd slices: word by word)
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) { a[j] = pa[j]; b[j] = pb[j]; }
+    } else if constexpr (G::NLL % 4 == 0) {
         const uint4* a4 = reinterpret_cast<const uint4*>(pa);
         const uint4* b4 = reinterpret_cast<const uint4*>(pb);
 #pragma unroll
@@ -99,7 +102,10 @@ template <class G>
 PAI_DEV void pair_store(const uint32_t (&a)[G::NLL], const uint32_t (&b)[G::NLL], uint32_t* __restrict__ ent) {
     uint32_t* pa = ent + G::NLL * G::gl();
     uint32_t* pb = ent + G::NL + G::NLL * G::gl();
-    if constexpr (G::NLL % 4 == 0) {
+    if constexpr (G::NLL % 2 != 0) {
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) { pa[j] = a[j]; pb[j] = b[j]; }
+    } else if constexpr (G::NLL % 4 == 0) {
         uint4* a4 = reinterpret_cast<uint4*>(pa);
         uint4* b4 = reinterpret_cast<uint4*>(pb);
 #pragma unroll
@@ -121,7 +127,10 @@ PAI_DEV void pair_store(const uint32_t (&a)[G::NLL], const uint32_t (&b)[G::NLL]
 template <class G>
 PAI_DEV void digit_load(uint32_t (&a)[G::NLL], const uint32_t* __restrict__ dig) {
     const uint32_t* pa = dig + G::NLL * G::gl();
-    if constexpr (G::NLL % 4 == 0) {
+    if constexpr (G::NLL % 2 != 0) {
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) a[j] = pa[j];
+    } else if constexpr (G::NLL % 4 == 0) {
         const uint4* a4 = reinterpret_cast<const uint4*>(pa);
 #pragma unroll
         for (int c = 0; c < G::NLL / 4; ++c) { const uint4 va = a4[c]; a[4 * c] = va.x; a[4 * c + 1] = va.y; a[4 * c + 2] = va.z; a[4 * c + 3] = va.w; }
@@ -515,18 +524,35 @@ struct PairCtMulParams {
     const uint32_t* one_pair;    // pair(R mod n^2): the Montgomery digit form of 1
     uint32_t* table;             // [grid * EPB][2^wbits][2][NL]
     int nd, wbits, ct_words, e_words, ebits_max, e_bcast, out_words;
+    // a second modulus for the workgroups with blockIdx.y == 1 (decryption stage A of mid-size batches: s = p and s = q in one
+    // launch, the same ciphertexts, exponents s - 1); unused with gridDim.y == 1
+    const MontCtx* nctx1 = nullptr;
+    const uint32_t* nm11 = nullptr;
+    const uint32_t* kdig1 = nullptr;
+    const uint32_t* one_pair1 = nullptr;
+    uint32_t* table1 = nullptr;
+    const uint32_t* e1 = nullptr;
+    uint32_t* wv1 = nullptr;
+    int e_words1 = 0, ebits_max1 = 0;
 };
 
 template <class G>
-__global__ void __launch_bounds__(BLOCK_THREADS, PAIR_WAVES_PER_SIMD(G::T))
-k_pair_ctmul(PairCtMulParams P, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ e, uint32_t* __restrict__ wv_out, int n) {
+__global__ void __launch_bounds__(BLOCK_THREADS, PAIR_CT_WAVES_PER_SIMD(G))
+k_pair_ctmul(PairCtMulParams P, const uint32_t* __restrict__ ct, const uint32_t* __restrict__ e_, uint32_t* __restrict__ wv_out_, int n) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t* __restrict__ e = e_;
+    uint32_t* __restrict__ wv_out = wv_out_;
+    if (blockIdx.y == 1) {
+        P.nctx = P.nctx1; P.nm1 = P.nm11; P.kdig = P.kdig1; P.one_pair = P.one_pair1; P.table = P.table1;
+        P.e_words = P.e_words1; P.ebits_max = P.ebits_max1;
+        e = P.e1; wv_out = P.wv1;
+    }
     pair_setup<G>(lds, P.nm1);
     typename G::NM nm;
     pair_load_modulus<G>(nm, P.nctx, lds);
     const uint32_t n0inv = P.nctx->n0inv;
     constexpr int PAIR_OFF = 2 * G::LDS_WORDS + 2 * G::NL;          // second buffer pair (plain offsets: see k_pair_fixed_base)
-    constexpr int CH = (G::NLL % 4 == 0) ? 4 : 2, NCH = G::NLL / CH;
+    constexpr int CH = (G::NLL % 4 == 0) ? 4 : (G::NLL % 2 == 0 ? 2 : 1), NCH = G::NLL / CH;
     const int t = G::gl();
     const int W = P.wbits, NT = 1 << W;
     const int nwin = (P.ebits_max + W - 1) / W;

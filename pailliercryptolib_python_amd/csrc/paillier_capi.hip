@@ -567,6 +567,19 @@ struct pai_privkey {
     int nops[2] = {0, 0};
     int padic_nd = 0;
     DevBuf table, ubuf;
+    // Mid-size batches: stage A as the lane-group digit-pair exponentiation (k_pair_ctmul: modulus s, exponent s - 1, 4 lanes x 9
+    // limbs per chain, both primes in one launch), then w + v s on the s^2 geometry (k_pair_finish); built by the first such call
+    struct Mid {
+        bool tried = false, ok = false;
+        int nl = 0, nd = 0, out_words = 0;
+        ModSetup sp[2];                   // s on the pair geometry
+        ModSetup s2[2];                   // s^2 on its own lane-group geometry (k_pair_finish)
+        uint32_t* d_nm1[2] = {nullptr, nullptr};
+        uint32_t* d_kdig[2] = {nullptr, nullptr};
+        uint32_t* d_one[2] = {nullptr, nullptr};
+        uint32_t* d_sR[2] = {nullptr, nullptr};
+        DevBuf table[2], wv[2];
+    } mid;
     // Latency path (small batches): stage A and B on the wide-group geometries (an integer spread over 16 / 32 / 64
     // lanes), with their own Montgomery constants; built by the first small call (build_latency_consts).
     Limbs h_host[2], pinvq_host;
@@ -2784,6 +2797,16 @@ void pai_privkey_destroy(pai_privkey* sk) {
     }
     if (sk->d_pinvqR) (void)hipFree(sk->d_pinvqR);
     for (int w = 0; w < 2; ++w) {
+        sk->mid.sp[w].release();
+        sk->mid.s2[w].release();
+        if (sk->mid.d_nm1[w]) (void)hipFree(sk->mid.d_nm1[w]);
+        if (sk->mid.d_kdig[w]) (void)hipFree(sk->mid.d_kdig[w]);
+        if (sk->mid.d_one[w]) (void)hipFree(sk->mid.d_one[w]);
+        if (sk->mid.d_sR[w]) (void)hipFree(sk->mid.d_sR[w]);
+        sk->mid.table[w].release();
+        sk->mid.wv[w].release();
+    }
+    for (int w = 0; w < 2; ++w) {
         sk->lat.sq[w].release();
         sk->lat.pp[w].release();
         if (sk->lat.d_pp_kdig[w]) (void)hipFree(sk->lat.d_pp_kdig[w]);
@@ -2872,6 +2895,60 @@ static void build_latency_consts(pai_privkey* sk) {
     }
 }
 
+// Mid-size decryption (between the four-wave pipeline and the one-element-per-lane engine): constants of the lane-group digit
+// pairs with base s = p, q
+static bool ensure_mid(pai_privkey* sk) {
+    pai_privkey::Mid& M = sk->mid;
+    if (M.tried) return M.ok;
+    M.tried = true;
+    const Limbs prime[2] = {sk->p, sk->q};
+    const int nl = pair_nl_for_prime_bits(std::max(hbn::bitlen(sk->p), hbn::bitlen(sk->q)));
+    if (!nl || knob_disabled("pair")) return false;
+    M.nl = nl;
+    M.out_words = (hbn::RB * nl + 31) / 32;
+    M.nd = (32 * sk->pk->ct_words + hbn::RB * nl - 1) / (hbn::RB * nl);
+    for (int w = 0; w < 2; ++w) {
+        const Limbs& sp = prime[w];
+        const Limbs s2 = hbn::mul(sp, sp);
+        M.sp[w].init(sp, nl);
+        M.d_nm1[w] = upload_r29(hbn::sub(sp, Limbs{1u}), nl);
+        auto pair_of = [&](const Limbs& v, std::vector<uint32_t>& dst) {
+            Limbs rem;
+            Limbs quo = hbn::divq(v, sp, &rem);
+            auto ra = hbn::to_r29(rem, nl), rb = hbn::to_r29(quo, nl);
+            dst.insert(dst.end(), ra.begin(), ra.end());
+            dst.insert(dst.end(), rb.begin(), rb.end());
+        };
+        const Limbs Rm = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * nl), s2);
+        std::vector<uint32_t> kd, one;
+        Limbs K = hbn::mulmod(Rm, Rm, s2);
+        for (int i = 0; i < M.nd; ++i) {
+            pair_of(K, kd);
+            K = hbn::mulmod(K, Rm, s2);
+        }
+        pair_of(Rm, one);
+        M.d_kdig[w] = upload_vec(kd);
+        M.d_one[w] = upload_vec(one);
+        M.s2[w].init(s2);
+        M.d_sR[w] = upload_r29(hbn::mulmod(sp, M.s2[w].R, s2), M.s2[w].nl);          // s R mod s^2: v s as one Montgomery product (k_pair_finish)
+    }
+    M.ok = true;
+    return true;
+}
+// PAI_TUNE dec_mid_min / dec_mid_max: batch range of the lane-group digit-pair stage A (max 0 disables).  Measured at 2048-bit
+// keys (profiles/r05/dec_mid.jsonl): 7.3 ms up to 8 192 ciphertexts (one wave of 16 chains per SIMD), 12.0 / 12.3 ms at 12 288 /
+// 16 384 — against 9.4 / 12.1 ms of the window kernels at 3 072 / 4 096 and 14.8 ms of the one-element-per-lane engine from 6 144 on
+// (level at 2 048: 7.3 / 6.8, behind from ~20 000: 17.7 / 15.0 at 24 576)
+static size_t dec_mid_min(size_t ncu) {
+    long long v;
+    return knob_tune("dec_mid_min", &v) ? (size_t)v : 8 * ncu + 1;
+}
+static size_t dec_mid_max(size_t ncu, int prime_bits) {
+    long long v;
+    if (knob_tune("dec_mid_max", &v)) return (size_t)v;
+    return prime_bits > 900 && prime_bits <= 1024 ? 72 * ncu : 0;            // (the 36-limb geometry is sized for the primes of 2048-bit keys)
+}
+
 int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream) {
     return guarded([&] {
         require(sk && d_ct && d_m, "NULL argument");
@@ -2881,6 +2958,70 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         DeviceScope scope_(pk->device);
         DeviceInfo dev = scope_.info;
         hipStream_t s = (hipStream_t)stream;
+        if (N >= dec_mid_min((size_t)dev.ncu) && N <= dec_mid_max((size_t)dev.ncu, std::max(hbn::bitlen(sk->p), hbn::bitlen(sk->q))) && sk->u_words &&
+            ensure_mid(sk)) {
+            pai_privkey::Mid& M = sk->mid;
+            const GeoOps* ga = M.s2[0].geo;
+            const GeoOps* gb = sk->pr[0].geo;
+            const int wbits = var_window_bits(std::max(sk->ebits[0], sk->ebits[1]));
+            const int epb = pair_epb(M.nl);
+            const size_t tiles = (N + epb - 1) / epb;
+            const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)dev.ncu * 6));     // (x 2 primes)
+            for (int w = 0; w < 2; ++w) {
+                M.table[w].ensure(((size_t)pgrid * epb << wbits) * 2 * (size_t)M.nl * 4);
+                M.wv[w].ensure(N * 2 * (size_t)M.out_words * 4);
+            }
+            sk->ubuf.ensure(2 * N * (size_t)sk->u_words * 4);
+            sk->order.begin(s);
+            g_last_times.clear();
+            PairCtMulParams Q;
+            Q.nctx = M.sp[0].d_ctx; Q.nm1 = M.d_nm1[0]; Q.kdig = M.d_kdig[0]; Q.one_pair = M.d_one[0]; Q.table = M.table[0].as<uint32_t>();
+            Q.nctx1 = M.sp[1].d_ctx; Q.nm11 = M.d_nm1[1]; Q.kdig1 = M.d_kdig[1]; Q.one_pair1 = M.d_one[1]; Q.table1 = M.table[1].as<uint32_t>();
+            Q.nd = M.nd;
+            Q.wbits = wbits;
+            Q.ct_words = pk->ct_words;
+            Q.e_words = sk->ewords[0]; Q.ebits_max = sk->ebits[0];
+            Q.e_words1 = sk->ewords[1]; Q.ebits_max1 = sk->ebits[1];
+            Q.e1 = sk->d_expo[1];
+            Q.wv1 = M.wv[1].as<uint32_t>();
+            Q.e_bcast = 1;
+            Q.out_words = M.out_words;
+            {
+                ScopedKernelTimer t("k_dec_a", s);
+                if (!launch_pair_ctmul(M.nl, s, pgrid, Q, d_ct, sk->d_expo[0], M.wv[0].as<uint32_t>(), (int)N))
+                    throw PaiError(PAI_E_INTERNAL, "no digit-pair kernel for this prime size");
+                for (int w = 0; w < 2; ++w) {
+                    EncParams P{};
+                    P.nsq = M.s2[w].d_ctx;
+                    P.nR = M.d_sR[w];
+                    P.pt_words = pk->n_words;
+                    P.ct_words = sk->u_words;
+                    ga->pair_finish(s, grid_for(ga, N, dev.ncu), P, M.wv[w].as<uint32_t>(), M.out_words, nullptr,
+                                    sk->ubuf.as<uint32_t>() + (size_t)w * N * sk->u_words, (int)N, 0);
+                }
+                t.stop();
+            }
+            HIP_CHECK(hipGetLastError());
+            DecBParams B;
+            for (int w = 0; w < 2; ++w) {
+                B.pr[w] = sk->pr[w].d_ctx;
+                B.sinv2[w] = sk->d_sinv2[w];
+                B.nsinv2[w] = sk->d_nsinv2[w];
+                B.hR[w] = sk->d_hR[w];
+            }
+            B.pinvqR = sk->d_pinvqR;
+            B.u_words = sk->u_words;
+            B.pt_words = pk->n_words;
+            B.u_is_L = 0;
+            {
+                ScopedKernelTimer t("k_dec_b", s);
+                gb->dec_b(s, grid_for(gb, N, dev.ncu), B, sk->ubuf.as<uint32_t>(), d_m, (int)N);
+                t.stop();
+            }
+            HIP_CHECK(hipGetLastError());
+            sk->order.end(s);
+            return;
+        }
         if (N <= latency_max_elements(LAT_DEC, pk->key_bits)) {
             build_latency_consts(sk);
             if (sk->lat.usable) {

@@ -42,7 +42,7 @@ struct PairLaunch {
     }
     static void ctmul(hipStream_t s, int grid, const PairCtMulParams& P, const uint32_t* ct, const uint32_t* e, uint32_t* wv_out, int n) {
         (void)hipFuncSetAttribute((const void*)k_pair_ctmul<G>, hipFuncAttributeMaxDynamicSharedMemorySize, PairLds<G>::BYTES_CT);
-        hipLaunchKernelGGL(k_pair_ctmul<G>, dim3(grid), dim3(BLOCK_THREADS), PairLds<G>::BYTES_CT, s, P, ct, e, wv_out, n);
+        hipLaunchKernelGGL(k_pair_ctmul<G>, dim3(grid, P.nctx1 ? 2 : 1), dim3(BLOCK_THREADS), PairLds<G>::BYTES_CT, s, P, ct, e, wv_out, n);
     }
 };
 #ifndef PAIR_G112
@@ -58,6 +58,10 @@ using P112 = PairLaunch<G112>;
 using P144 = PairLaunch<G144>;
 // the table-conversion kernels run single Montgomery products (mont_mul: row blocks must divide its 24-row normalisation
 // interval); the table layout does not depend on the row-block size
+// 36 limbs on 4 lanes x 9: the PRIMES of keys up to 2048 bits — decryption stage A of mid-size batches (k_pair_ctmul with modulus
+// s, exponent s - 1: paillier_capi.hip, mid_decrypt)
+using G36 = Geo<9, 4, 3, false>;
+using P36 = PairLaunch<G36>;
 using P112C = PairLaunch<Geo<G112::NLL, G112::T, 4, false>>;
 using P144C = PairLaunch<Geo<G144::NLL, G144::T, 6, false>>;
 
@@ -67,7 +71,8 @@ int pair_nl_for_n_bits(int bits) {
     if (RB * 144 >= bits + 20) return 144;
     return 0;
 }
-int pair_epb(int nl) { return nl == 112 ? G112::EPB : (nl == 144 ? G144::EPB : 0); }
+int pair_nl_for_prime_bits(int bits) { return RB * 36 >= bits + 20 ? 36 : 0; }
+int pair_epb(int nl) { return nl == 112 ? G112::EPB : (nl == 144 ? G144::EPB : (nl == 36 ? G36::EPB : 0)); }
 bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
                           const uint32_t* one_pair, uint32_t* S, int nwin, int h, const FbBases& fb) {
     if (nl == 112) P112::chain(s, grid, nctx, nm1, bases, one_pair, S, nwin, h, fb);
@@ -109,6 +114,7 @@ bool launch_pair_ctmul(int nl, hipStream_t s, int grid, const PairCtMulParams& P
                        uint32_t* wv_out, int n) {
     if (nl == 112) P112::ctmul(s, grid, P, ct, e, wv_out, n);
     else if (nl == 144) P144::ctmul(s, grid, P, ct, e, wv_out, n);
+    else if (nl == 36) P36::ctmul(s, grid, P, ct, e, wv_out, n);
     else return false;
     return true;
 }

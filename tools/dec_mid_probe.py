@@ -1,0 +1,29 @@
+"""Dev probe: decryption of mid-size batches — stage A as the lane-group digit-pair exponentiation (k_pair_ctmul with modulus s,
+PAI_TUNE=dec_mid_min=0,dec_mid_max=huge) against the library's other paths (dec_mid_max=0).   python tools/dec_mid_probe.py [bits]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from bench import synthetic_key
+from pailliercryptolib_python_amd import engine
+dev = torch.device('cuda', 0)
+bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+key = synthetic_key(bits, 0x1234567)
+pub = engine.PublicKeyHandle(key.n, bits, key.hs, key.randbits, device=dev)
+priv = engine.PrivateKeyHandle(pub, key.p, key.q)
+def tm(f, reps=3):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+g = torch.Generator(device=dev); g.manual_seed(1)
+for N in (512, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536):
+    m = torch.randint(0, 2**31 - 1, (N, pub.n_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    m[:, -1] &= 0x0FFFFFFF
+    ct = pub.encrypt(m, pub.random_r(N, generator=g))
+    row = {"bits": bits, "N": N}
+    for name, tune in (("other", "dec_mid_max=0"), ("mid", "dec_mid_min=0,dec_mid_max=100000000")):
+        os.environ["PAI_TUNE"] = tune
+        ok = bool(torch.equal(priv.decrypt(ct), m))
+        row[name] = {"ok": ok, "ms": round(tm(lambda: priv.decrypt(ct)), 3)}
+    print(json.dumps(row), flush=True)
