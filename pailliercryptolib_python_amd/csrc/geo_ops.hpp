@@ -130,7 +130,7 @@ bool launch_encrypt_padic(int nl, hipStream_t s, int grid, const EncPadicParams&
 struct PairParams;
 struct PairCtMulParams;
 int pair_nl_for_n_bits(int bits);                 // 112 / 144 limbs, 0 = not served
-int pair_nl_for_prime_bits(int bits);             // 36 limbs (primes of keys up to 2048 bits), 0 = not served
+int pair_nl_for_prime_bits(int bits);             // 36 / 56 / 72 limbs (primes of keys up to 2048 / 3072 / 4096 bits), 0 = not served
 int pair_epb(int nl);                             // elements per workgroup
 bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
                           const uint32_t* one_pair, uint32_t* S, int nwin, int h, const FbBases& fb);

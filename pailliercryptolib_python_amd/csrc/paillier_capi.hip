@@ -2939,14 +2939,19 @@ static bool ensure_mid(pai_privkey* sk) {
 // keys (profiles/r05/dec_mid.jsonl): 7.3 ms up to 8 192 ciphertexts (one wave of 16 chains per SIMD), 12.0 / 12.3 ms at 12 288 /
 // 16 384 — against 9.4 / 12.1 ms of the window kernels at 3 072 / 4 096 and 14.8 ms of the one-element-per-lane engine from 6 144 on
 // (level at 2 048: 7.3 / 6.8, behind from ~20 000: 17.7 / 15.0 at 24 576)
-static size_t dec_mid_min(size_t ncu) {
+static size_t dec_mid_min(size_t ncu, int prime_bits) {
     long long v;
-    return knob_tune("dec_mid_min", &v) ? (size_t)v : 8 * ncu + 1;
+    if (knob_tune("dec_mid_min", &v)) return (size_t)v;
+    return prime_bits > 1900 ? 9 * ncu + 1 : 8 * ncu + 1;
 }
 static size_t dec_mid_max(size_t ncu, int prime_bits) {
     long long v;
     if (knob_tune("dec_mid_max", &v)) return (size_t)v;
-    return prime_bits > 900 && prime_bits <= 1024 ? 72 * ncu : 0;            // (the 36-limb geometry is sized for the primes of 2048-bit keys)
+    // (the geometries are sized for the primes of 2048 / 3072 / 4096-bit keys; measured there: 3072-bit 19.8 ms flat up to 8 192 against
+    // 38.2 at 4 096 and 55.9 beyond, 35 / 51 ms at 16 384 / 24 576; 4096-bit 40 ms up to 8 192 against 67 / 127, 80 / 120 at 16 384 / 24 576)
+    if (prime_bits > 900 && prime_bits <= 1024) return 72 * ncu;
+    if ((prime_bits > 1400 && prime_bits <= 1536) || (prime_bits > 1900 && prime_bits <= 2048)) return 96 * ncu;
+    return 0;
 }
 
 int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream) {
@@ -2958,8 +2963,8 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
         DeviceScope scope_(pk->device);
         DeviceInfo dev = scope_.info;
         hipStream_t s = (hipStream_t)stream;
-        if (N >= dec_mid_min((size_t)dev.ncu) && N <= dec_mid_max((size_t)dev.ncu, std::max(hbn::bitlen(sk->p), hbn::bitlen(sk->q))) && sk->u_words &&
-            ensure_mid(sk)) {
+        const int prime_bits = std::max(hbn::bitlen(sk->p), hbn::bitlen(sk->q));
+        if (N >= dec_mid_min((size_t)dev.ncu, prime_bits) && N <= dec_mid_max((size_t)dev.ncu, prime_bits) && sk->u_words && ensure_mid(sk)) {
             pai_privkey::Mid& M = sk->mid;
             const GeoOps* ga = M.s2[0].geo;
             const GeoOps* gb = sk->pr[0].geo;

@@ -62,6 +62,11 @@ using P144 = PairLaunch<G144>;
 // s, exponent s - 1: paillier_capi.hip, mid_decrypt)
 using G36 = Geo<9, 4, 3, false>;
 using P36 = PairLaunch<G36>;
+// ... 56 limbs on 4 x 14 and 72 limbs on 4 x 18: the primes of 3072- and 4096-bit keys
+using G56 = Geo<14, 4, 7, false>;
+using P56 = PairLaunch<G56>;
+using G72 = Geo<18, 4, 6, false>;
+using P72 = PairLaunch<G72>;
 using P112C = PairLaunch<Geo<G112::NLL, G112::T, 4, false>>;
 using P144C = PairLaunch<Geo<G144::NLL, G144::T, 6, false>>;
 
@@ -71,8 +76,8 @@ int pair_nl_for_n_bits(int bits) {
     if (RB * 144 >= bits + 20) return 144;
     return 0;
 }
-int pair_nl_for_prime_bits(int bits) { return RB * 36 >= bits + 20 ? 36 : 0; }
-int pair_epb(int nl) { return nl == 112 ? G112::EPB : (nl == 144 ? G144::EPB : (nl == 36 ? G36::EPB : 0)); }
+int pair_nl_for_prime_bits(int bits) { return RB * 36 >= bits + 20 ? 36 : (RB * 56 >= bits + 20 ? 56 : (RB * 72 >= bits + 20 ? 72 : 0)); }
+int pair_epb(int nl) { return nl == 112 ? G112::EPB : (nl == 144 ? G144::EPB : (nl == 36 || nl == 56 || nl == 72 ? G36::EPB : 0)); }
 bool launch_pair_fb_chain(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* bases,
                           const uint32_t* one_pair, uint32_t* S, int nwin, int h, const FbBases& fb) {
     if (nl == 112) P112::chain(s, grid, nctx, nm1, bases, one_pair, S, nwin, h, fb);
@@ -115,6 +120,8 @@ bool launch_pair_ctmul(int nl, hipStream_t s, int grid, const PairCtMulParams& P
     if (nl == 112) P112::ctmul(s, grid, P, ct, e, wv_out, n);
     else if (nl == 144) P144::ctmul(s, grid, P, ct, e, wv_out, n);
     else if (nl == 36) P36::ctmul(s, grid, P, ct, e, wv_out, n);
+    else if (nl == 56) P56::ctmul(s, grid, P, ct, e, wv_out, n);
+    else if (nl == 72) P72::ctmul(s, grid, P, ct, e, wv_out, n);
     else return false;
     return true;
 }

@@ -508,9 +508,9 @@ def test_decrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
             out = DevArray(shape=(N, nk.nw))
             _native.check(nk.lib.pai_decrypt(nk.sk, dct.ptr, N, out.ptr, None))
             assert limbs_to_ints(out.get()) == m, (bits, N, switch, rl, pp)
-        if bits <= 2048:
+        if True:
             # PAI_TUNE dec_mid_min / dec_mid_max: mid-size batches (2 049 ... 18 432 at 2048-bit keys) run stage A as the
-            # lane-group digit-pair exponentiation with modulus s (k_pair_ctmul, 4 lanes x 9 limbs, both primes in one launch)
+            # lane-group digit-pair exponentiation with modulus s (k_pair_ctmul, 4 lanes x 9 / 14 / 18 limbs, both primes in one launch)
             tune(monkeypatch, "dec_mid_min", 0)
             tune(monkeypatch, "dec_mid_max", 1 << 30)
             out = DevArray(shape=(N, nk.nw))

@@ -17,7 +17,7 @@ def tm(f, reps=3):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 g = torch.Generator(device=dev); g.manual_seed(1)
-for N in (512, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536):
+for N in ((512, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536) if bits <= 2048 else (1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768)):
     m = torch.randint(0, 2**31 - 1, (N, pub.n_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
     m[:, -1] &= 0x0FFFFFFF
     ct = pub.encrypt(m, pub.random_r(N, generator=g))
