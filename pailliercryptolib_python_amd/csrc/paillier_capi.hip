@@ -480,6 +480,14 @@ struct pai_pubkey {
     uint32_t* d_pair_one = nullptr;    // pair(R mod n^2)
     int pair_nd = 0;
     mutable DevBuf pair_ct_table;      // per-slot power tables of k_pair_ctmul
+    // mid-size ct * pt at keys the one-element-per-lane engine serves (<= 2048 bits): the same lane-group digit-pair exponentiation on
+    // 4 lanes x 18 limbs (16 ciphertexts per wavefront); constants built by the first such call
+    mutable bool midp_tried = false, midp_ok = false;
+    mutable ModSetup midp_n;
+    mutable uint32_t* d_midp_nm1 = nullptr;
+    mutable uint32_t* d_midp_kdig = nullptr;
+    mutable uint32_t* d_midp_one = nullptr;
+    mutable int midp_nl = 0, midp_nd = 0, midp_out_words = 0;
     int pair_windows = 0, pair_wbits = 0, pair_out_words = 0;
     mutable DevBuf pair_wv;            // plain digit pairs on their way to k_encrypt mode 5 / 6
     uint16_t* d_pow_ops = nullptr;     // sliding-window schedule of the exponent n (standard scheme)
@@ -1645,6 +1653,10 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     if (pk->d_pair_one) (void)hipFree(pk->d_pair_one);
     pk->pair_ct_table.release();
     pk->pair_wv.release();
+    pk->midp_n.release();
+    if (pk->d_midp_nm1) (void)hipFree(pk->d_midp_nm1);
+    if (pk->d_midp_kdig) (void)hipFree(pk->d_midp_kdig);
+    if (pk->d_midp_one) (void)hipFree(pk->d_midp_one);
     pk->ctmul_table.release();
     pk->pow2_expo.release();
     pk->mexp_table.release();
@@ -2089,6 +2101,95 @@ static void ctmul_padic_locked(const pai_pubkey* pk, hipStream_t s, const uint32
     pk->order.end(s);
 }
 
+// ct^e on lane-group digit pairs (k_pair_ctmul, then w + v n on the n^2 geometry: k_pair_finish); the caller holds pk->mu
+static void ctmul_pair_locked(const pai_pubkey* pk, hipStream_t s, int nl, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* kdig,
+                              const uint32_t* one, int nd, int out_words, const uint32_t* d_ct, const uint32_t* d_e, int e_words,
+                              int ebits_max, int e_bcast, size_t N, uint32_t* d_out) {
+    const GeoOps* g = pk->msq.geo;
+    const int grid = grid_for(g, N, pk->dev.ncu);
+    const int wbits = var_window_bits(ebits_max);
+    const int epb = pair_epb(nl);
+    const size_t tiles = (N + epb - 1) / epb;
+    const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu * (nl <= 72 ? 8 : 2)));
+    pk->pair_ct_table.ensure(((size_t)pgrid * epb << wbits) * 2 * (size_t)nl * 4);
+    pk->pair_wv.ensure(N * 2 * (size_t)out_words * 4);
+    PairCtMulParams Q;
+    Q.nctx = nctx;
+    Q.nm1 = nm1;
+    Q.kdig = kdig;
+    Q.one_pair = one;
+    Q.table = pk->pair_ct_table.as<uint32_t>();
+    Q.nd = nd;
+    Q.wbits = wbits;
+    Q.ct_words = pk->ct_words;
+    Q.e_words = e_words;
+    Q.ebits_max = ebits_max;
+    Q.e_bcast = e_bcast;
+    Q.out_words = out_words;
+    EncParams P;
+    P.nsq = pk->msq.d_ctx;
+    P.nR = pk->d_nR;
+    P.fb_table = nullptr;
+    P.fb_windows = 0;
+    P.fb_wbits = 0;
+    P.pt_words = pk->n_words;
+    P.ct_words = pk->ct_words;
+    P.r_words = pk->r_words;
+    OrderScope order_(pk->order, s);
+    ScopedKernelTimer t("k_ctmul", s);
+    if (!launch_pair_ctmul(nl, s, pgrid, Q, d_ct, d_e, pk->pair_wv.as<uint32_t>(), (int)N))
+        throw PaiError(PAI_E_INTERNAL, "no digit-pair ct * pt kernel for this limb count");
+    g->pair_finish(s, grid, P, pk->pair_wv.as<uint32_t>(), out_words, nullptr, d_out, (int)N, 0);
+    t.stop();
+    HIP_CHECK(hipGetLastError());
+}
+// constants of the same for n of a key the one-element-per-lane engine serves (mid-size batches); the caller holds pk->mu
+static bool ensure_midp(const pai_pubkey* pk) {
+    if (pk->midp_tried) return pk->midp_ok;
+    pk->midp_tried = true;
+    const int nbits = hbn::bitlen(pk->n);
+    const int nl = pair_nl_for_prime_bits(nbits);           // (the 4-lane geometries of the primes serve an n of the same size)
+    if (!nl || knob_disabled("pair") || !pk->d_nR) return false;
+    pk->midp_nl = nl;
+    pk->midp_n.init(pk->n, nl);
+    pk->d_midp_nm1 = upload_r29(hbn::sub(pk->n, Limbs{1u}), nl);
+    pk->midp_out_words = (hbn::RB * nl + 31) / 32;
+    pk->midp_nd = (32 * pk->ct_words + hbn::RB * nl - 1) / (hbn::RB * nl);
+    auto pair_of = [&](const Limbs& v, std::vector<uint32_t>& dst) {
+        Limbs rem;
+        Limbs quo = hbn::divq(v, pk->n, &rem);
+        auto ra = hbn::to_r29(rem, nl), rb = hbn::to_r29(quo, nl);
+        dst.insert(dst.end(), ra.begin(), ra.end());
+        dst.insert(dst.end(), rb.begin(), rb.end());
+    };
+    const Limbs Rm = hbn::mod(hbn::shl(Limbs{1u}, hbn::RB * nl), pk->nsq);
+    std::vector<uint32_t> kd, one;
+    Limbs K = hbn::mulmod(Rm, Rm, pk->nsq);
+    for (int i = 0; i < pk->midp_nd; ++i) {
+        pair_of(K, kd);
+        K = hbn::mulmod(K, Rm, pk->nsq);
+    }
+    pair_of(Rm, one);
+    pk->d_midp_kdig = upload_vec(kd);
+    pk->d_midp_one = upload_vec(one);
+    pk->midp_ok = true;
+    return true;
+}
+// PAI_TUNE ctmul_mid_min / ctmul_mid_max: batch range of it (max 0 disables).  Measured with 53-bit exponents
+// (profiles/r05/ctmul_mid.jsonl): 2048-bit keys 1.4 - 1.5 ms flat up to 16 384 ciphertexts (one wave of 16 per SIMD), 2.9 ms at 32 768,
+// against 2.2 / 4.1 ms of the small-batch kernels at 8 192 / 16 384 and 4.7 ms of the one-element-per-lane engine up to 65 536
+// (behind below ~5 000 and from ~55 000); 1024-bit keys 0.55 - 0.63 / 0.9 ms against 0.84 - 1.25 / 1.27
+static size_t ctmul_mid_min(size_t ncu) {
+    long long v;
+    return knob_tune("ctmul_mid_min", &v) ? (size_t)v : 20 * ncu;
+}
+static size_t ctmul_mid_max(size_t ncu, int n_bits) {
+    long long v;
+    if (knob_tune("ctmul_mid_max", &v)) return (size_t)v;
+    const bool fits = (n_bits > 900 && n_bits <= 1024) || (n_bits > 1400 && n_bits <= 1536) || (n_bits > 1900 && n_bits <= 2048);
+    return fits ? 192 * ncu : 0;
+}
+
 int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, int e_words, int ebits_max,
                int e_bcast, size_t N, uint32_t* d_out, void* stream) {
     return guarded([&] {
@@ -2098,6 +2199,14 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         DeviceScope scope_(pk->device);
         hipStream_t s = (hipStream_t)stream;
         g_last_times.clear();
+        if (!pk->pair_nl && ebits_max > 8 && N >= ctmul_mid_min((size_t)pk->dev.ncu) && N <= ctmul_mid_max((size_t)pk->dev.ncu, pk->key_bits)) {
+            std::lock_guard<std::mutex> lk(pk->mu);
+            if (ensure_midp(pk)) {
+                ctmul_pair_locked(pk, s, pk->midp_nl, pk->midp_n.d_ctx, pk->d_midp_nm1, pk->d_midp_kdig, pk->d_midp_one, pk->midp_nd,
+                                  pk->midp_out_words, d_ct, d_e, e_words, ebits_max, e_bcast, N, d_out);
+                return;
+            }
+        }
         if (N <= latency_max_elements(LAT_MUL, pk->key_bits) && ebits_max > 8) {
             // small batch: windowed exponentiation with n^2 spread over a whole wavefront per ciphertext
             std::lock_guard<std::mutex> lk(pk->mu);
@@ -2159,41 +2268,8 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
             // n of 2049 .. 4156 bits: squarings at 4 NL^2 and multiplications at 5 NL^2 limb products on lane-group digit
             // pairs (k_pair_ctmul) instead of 8 NL^2 per Montgomery product modulo n^2, then w + v n (k_pair_finish)
             std::lock_guard<std::mutex> lk(pk->mu);
-            const int wbits = var_window_bits(ebits_max);
-            const int epb = pair_epb(pk->pair_nl);
-            const size_t tiles = (N + epb - 1) / epb;
-            const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu * 2));
-            pk->pair_ct_table.ensure(((size_t)pgrid * epb << wbits) * 2 * (size_t)pk->pair_nl * 4);
-            pk->pair_wv.ensure(N * 2 * (size_t)pk->pair_out_words * 4);
-            PairCtMulParams Q;
-            Q.nctx = pk->npair.d_ctx;
-            Q.nm1 = pk->d_pair_nm1;
-            Q.kdig = pk->d_pair_kdig;
-            Q.one_pair = pk->d_pair_one;
-            Q.table = pk->pair_ct_table.as<uint32_t>();
-            Q.nd = pk->pair_nd;
-            Q.wbits = wbits;
-            Q.ct_words = pk->ct_words;
-            Q.e_words = e_words;
-            Q.ebits_max = ebits_max;
-            Q.e_bcast = e_bcast;
-            Q.out_words = pk->pair_out_words;
-            EncParams P;
-            P.nsq = pk->msq.d_ctx;
-            P.nR = pk->d_nR;
-            P.fb_table = nullptr;
-            P.fb_windows = 0;
-            P.fb_wbits = 0;
-            P.pt_words = pk->n_words;
-            P.ct_words = pk->ct_words;
-            P.r_words = pk->r_words;
-            OrderScope order_(pk->order, s);
-            ScopedKernelTimer t("k_ctmul", s);
-            if (!launch_pair_ctmul(pk->pair_nl, s, pgrid, Q, d_ct, d_e, pk->pair_wv.as<uint32_t>(), (int)N))
-                throw PaiError(PAI_E_INTERNAL, "no digit-pair ct * pt kernel for this limb count");
-            g->pair_finish(s, grid, P, pk->pair_wv.as<uint32_t>(), pk->pair_out_words, nullptr, d_out, (int)N, 0);
-            t.stop();
-            HIP_CHECK(hipGetLastError());
+            ctmul_pair_locked(pk, s, pk->pair_nl, pk->npair.d_ctx, pk->d_pair_nm1, pk->d_pair_kdig, pk->d_pair_one, pk->pair_nd,
+                              pk->pair_out_words, d_ct, d_e, e_words, ebits_max, e_bcast, N, d_out);
             return;
         }
         if (ebits_max > 8) {

@@ -546,6 +546,16 @@ def test_ct_mul_latency_and_throughput_paths_agree(bits, monkeypatch):
             out = DevArray(shape=(N, nk.cw))
             _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
             assert limbs_to_ints(out.get()) == want, (bits, N, ebits, switch, pp, rl)
+        if bits <= 2048:
+            # PAI_TUNE ctmul_mid_min / ctmul_mid_max: mid-size batches (5 120 ... 49 152) at keys the one-element-per-lane engine serves
+            # run the lane-group digit-pair exponentiation on 4 lanes per ciphertext (k_pair_ctmul with n on 36 / 72 limbs)
+            tune(monkeypatch, "ctmul_mid_min", 0)
+            tune(monkeypatch, "ctmul_mid_max", 1 << 30)
+            out = DevArray(shape=(N, nk.cw))
+            _native.check(nk.lib.pai_ct_mul(nk.pk, dc.ptr, de.ptr, ew, ebits, 0, N, out.ptr, None))
+            assert limbs_to_ints(out.get()) == want, (bits, N, ebits, "mid")
+            tune(monkeypatch, "ctmul_mid_min", None)
+            tune(monkeypatch, "ctmul_mid_max", None)
         # one broadcast exponent
         for pp in ("100000", "0"):
             tune(monkeypatch, "lat_mul_pp", pp)

@@ -1,0 +1,33 @@
+"""Dev probe: ct * pt (53-bit exponents) of mid-size batches at keys up to 2048 bits — the lane-group digit-pair exponentiation on
+4 lanes per ciphertext (PAI_TUNE=ctmul_mid_min=0,ctmul_mid_max=huge) against the library's other paths.   python tools/ctmul_mid_probe.py [bits]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from bench import synthetic_key
+from pailliercryptolib_python_amd import engine
+dev = torch.device('cuda', 0)
+bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+key = synthetic_key(bits, 0x1234567)
+pub = engine.PublicKeyHandle(key.n, bits, key.hs, key.randbits, device=dev)
+def tm(f, reps=3):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+g = torch.Generator(device=dev); g.manual_seed(1)
+for N in (1024, 2048, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 131072):
+    m = torch.randint(0, 2**31 - 1, (N, pub.n_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    m[:, -1] &= 0x0FFFFFFF
+    ct = pub.encrypt(m, pub.random_r(N, generator=g))
+    e = torch.randint(-2**31, 2**31 - 1, (N, 2), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    e[:, 1] &= (1 << 21) - 1
+    e[:, 1] |= 1 << 20
+    row = {"bits": bits, "N": N}
+    ref = None
+    for name, tune in (("other", "ctmul_mid_max=0"), ("mid", "ctmul_mid_min=0,ctmul_mid_max=100000000")):
+        os.environ["PAI_TUNE"] = tune
+        out = pub.ct_mul(ct, e, 53)
+        if ref is None: ref = out.clone()
+        row[name] = {"same": bool(torch.equal(out, ref)), "ms": round(tm(lambda: pub.ct_mul(ct, e, 53)), 3)}
+    print(json.dumps(row), flush=True)
