@@ -1748,6 +1748,21 @@ int pai_pubkey_table_info(const pai_pubkey* pk, size_t* table_bytes, int* window
     });
 }
 
+static bool ensure_midp(const pai_pubkey* pk);
+// PAI_TUNE enc_mid_min / enc_mid_max: batch range of the lane-group digit-pair DJN encryption at keys the one-element-per-lane engine
+// serves (max 0 disables).  Measured (profiles/r05/enc_mid.jsonl): 2048-bit keys 1.1 - 1.26 ms flat up to 16 384 elements, 2.3 ms at
+// 32 768, against 1.3 / 2.4 ms of the small-batch kernel at 4 096 / 8 192 and 3.34 ms of the one-element-per-lane engine up to 65 536
+// (level at ~3 500 and ~49 000); 1024-bit 0.27 - 0.31 / 0.40 ms against 0.26 - 0.50 / 0.50
+static size_t enc_mid_min(size_t ncu) {
+    long long v;
+    return knob_tune("enc_mid_min", &v) ? (size_t)v : 16 * ncu;
+}
+static size_t enc_mid_max(size_t ncu, int n_bits) {
+    long long v;
+    if (knob_tune("enc_mid_max", &v)) return (size_t)v;
+    const bool fits = (n_bits > 900 && n_bits <= 1024) || (n_bits > 1400 && n_bits <= 1536) || (n_bits > 1900 && n_bits <= 2048);
+    return fits ? 160 * ncu : 0;
+}
 static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint32_t* d_r, const uint32_t* d_ct_in,
                            uint32_t* d_ct_out, size_t N, void* stream, bool from_plain) {
     DeviceScope scope_(pk->device);
@@ -1758,6 +1773,39 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
     // every path below shares per-key device scratch (quotient-digit columns, window tables): one at a time per
     // handle, ordered across streams by pk->order
     std::lock_guard<std::mutex> lk(pk->mu);
+    if (d_r && pk->djn && pk->penc_nl && N >= enc_mid_min((size_t)pk->dev.ncu) && N <= enc_mid_max((size_t)pk->dev.ncu, pk->key_bits) &&
+        ensure_midp(pk) && pk->midp_nl == pk->penc_nl) {
+        // mid-size DJN batch at a key the one-element-per-lane engine serves: the same fixed-base table (raw [window][digit][2][NL]
+        // digit pairs, g-factored or not: the two engines share the layout and R = 2^(29 NL)) read by the lane-group digit-pair
+        // kernel with 4 lanes per element (16 elements per wavefront), then w + v n on the n^2 geometry (k_pair_finish)
+        build_fb_tables(pk);
+        if (pk->d_fb_dig) {
+            EncParams P = pk->enc_params();
+            PairParams Q;
+            Q.nctx = pk->midp_n.d_ctx;
+            Q.nm1 = pk->d_midp_nm1;
+            Q.fb_table = pk->d_fb_dig;
+            Q.fb_windows = pk->fbd_windows;
+            Q.fb_wbits = pk->fbd_wbits;
+            Q.pt_words = pk->n_words;
+            Q.r_words = pk->r_words;
+            Q.out_words = pk->midp_out_words;
+            Q.fb_gform = pk->fb_gform ? 1 : 0;
+            pk->pair_wv.ensure(N * 2 * (size_t)pk->midp_out_words * 4);
+            const int epb = pair_epb(pk->midp_nl);
+            const size_t tiles = (N + epb - 1) / epb;
+            const int pgrid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu * 8));
+            pk->order.begin(s);
+            ScopedKernelTimer t(from_plain ? "k_encrypt(djn)" : "k_encrypt(obfuscate)", s);
+            if (!launch_pair_fixed_base(pk->midp_nl, s, pgrid, Q, d_m, d_r, pk->pair_wv.as<uint32_t>(), (int)N, from_plain ? 1 : 0))
+                throw PaiError(PAI_E_INTERNAL, "no digit-pair kernel for this limb count");
+            g->pair_finish(s, grid, P, pk->pair_wv.as<uint32_t>(), pk->midp_out_words, d_ct_in, d_ct_out, (int)N, from_plain ? 0 : 1);
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            pk->order.end(s);
+            return;
+        }
+    }
     if (d_r && pk->djn && N <= latency_max_elements(LAT_ENC, pk->key_bits)) {
         // small DJN batch: n^2 spread over a wavefront per ciphertext, 10-bit fixed-base windows in that geometry
         if (!pk->lat_ready) {

@@ -96,6 +96,9 @@ bool launch_pair_fixed_base(int nl, hipStream_t s, int grid, const PairParams& P
                             uint32_t* wv_out, int n, int with_m) {
     if (nl == 112) P112::fixed_base(s, grid, P, m, r, wv_out, n, with_m);
     else if (nl == 144) P144::fixed_base(s, grid, P, m, r, wv_out, n, with_m);
+    else if (nl == 36) P36::fixed_base(s, grid, P, m, r, wv_out, n, with_m);         // (mid-size batches at keys up to 2048 bits: the
+    else if (nl == 56) P56::fixed_base(s, grid, P, m, r, wv_out, n, with_m);         //  one-element-per-lane engine's table has the
+    else if (nl == 72) P72::fixed_base(s, grid, P, m, r, wv_out, n, with_m);         //  same layout)
     else return false;
     return true;
 }

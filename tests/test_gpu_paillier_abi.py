@@ -592,6 +592,18 @@ def test_djn_encrypt_latency_and_throughput_paths_agree(bits, monkeypatch):
             assert limbs_to_ints(ct.get()) == want, (bits, N, switch, tree, m1)
             _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
             assert limbs_to_ints(ct.get()) == want2, (bits, N, switch, tree, m1)
+        if bits <= 2048:
+            # PAI_TUNE enc_mid_min / enc_mid_max: mid-size batches (4 096 ... 40 960) at keys the one-element-per-lane engine serves run
+            # the lane-group digit-pair kernel with 4 lanes per element on that engine's own fixed-base table (same layout, same R)
+            tune(monkeypatch, "enc_mid_min", 0)
+            tune(monkeypatch, "enc_mid_max", 1 << 30)
+            ct = DevArray(shape=(N, nk.cw))
+            _native.check(nk.lib.pai_encrypt(nk.pk, dm.ptr, dr.ptr, N, ct.ptr, None))
+            assert limbs_to_ints(ct.get()) == want, (bits, N, "mid")
+            _native.check(nk.lib.pai_obfuscate(nk.pk, ct.ptr, dr.ptr, N, None))
+            assert limbs_to_ints(ct.get()) == want2, (bits, N, "mid")
+            tune(monkeypatch, "enc_mid_min", None)
+            tune(monkeypatch, "enc_mid_max", None)
 
 
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])

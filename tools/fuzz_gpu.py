@@ -99,7 +99,8 @@ while time.time() - t0 < budget:
         os.environ["PAI_TUNE"] = (f"lat_pp={int(rng.choice([0, 100000]))},lat_rl={int(rng.choice([0, 100000]))},"   # every small-batch stage A
                                  f"lat_mul_pp={int(rng.choice([0, 100000]))},lat_mul_rl={int(rng.choice([0, 100000]))}"   # ... and ct * pt kernel
                                  + (",dec_mid_min=0,dec_mid_max=1000000" if rng.integers(0, 3) == 0 else "")   # lane-group digit-pair stage A
-                                 + (",ctmul_mid_min=0,ctmul_mid_max=1000000" if bits <= 2048 and rng.integers(0, 3) == 0 else ""))   # ... and ct * pt
+                                 + (",ctmul_mid_min=0,ctmul_mid_max=1000000" if bits <= 2048 and rng.integers(0, 3) == 0 else "")   # ... and ct * pt
+                                 + (",enc_mid_min=0,enc_mid_max=1000000" if bits <= 2048 and rng.integers(0, 3) == 0 else ""))   # ... and DJN encryption
         _native.check(lib.pai_encrypt(nk.pk, dmm.ptr, drr.ptr, n2, oe.ptr, None))
         assert limbs_to_ints(oe.get()) == want_enc, ("encrypt", bits, n2, sw)
         _native.check(lib.pai_decrypt(nk.sk, dct.ptr, n2, om.ptr, None))
