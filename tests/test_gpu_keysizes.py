@@ -14,10 +14,17 @@ pytestmark = pytest.mark.gpu
 
 
 def make(bits):
-    p = orc.seeded_prime(bits // 2, 7000 + bits)
-    q = orc.seeded_prime(bits // 2, 9000 + bits)
-    while q == p or (p * q).bit_length() != bits:
-        q = orc.seeded_prime(bits // 2, q % 100003)
+    if bits > 2560:
+        # (the oracle's CPython prime search takes seconds at these sizes: the native generator, seeded — its primes are checked
+        # by tests/test_keygen_cpu.py)
+        from pailliercryptolib_python_amd import _native
+
+        p, q = _native.keygen(bits, True, seed=7000 + bits)
+    else:
+        p = orc.seeded_prime(bits // 2, 7000 + bits)
+        q = orc.seeded_prime(bits // 2, 9000 + bits)
+        while q == p or (p * q).bit_length() != bits:
+            q = orc.seeded_prime(bits // 2, q % 100003)
     key = orc.make_key(p, q, djn_x=0xABCDEF1234567, bits=bits)
     pk = PaillierPublicKey(ipclPublicKey(key.n, bits, True, hs=key.hs, randbits=key.randbits))
     return key, pk, PaillierPrivateKey(pk, p, q)
