@@ -37,7 +37,7 @@ The JSON line also carries
   api_level    — host float64 array -> PaillierPublicKey.encrypt -> PaillierPrivateKey.decrypt_to_numpy -> host
                  float64 array (codec, CSPRNG-keyed randomness and PCIe included): SURVEY.md §8d(i).
   other_ops    — BASELINE configs[2]: ct+ct add, ct x pt mul (and ct^-1, sum) on the same resident batch, each
-                 checked against the oracle; small_batch — latency at the reference's own batch sizes 16 / 64.
+                 checked against the oracle; small_batch — latency at the reference's own batch sizes 16 / 64 and at a mid-size batch (8 192).
   reference_bench — the reference's own benchmark suite (bench/bench_ipcl_python.py:13-78: KeyGen, Encrypt, Decrypt,
                  Add_CTCT, Add_CTPT, Mul_CTPT at 16 / 64 with its inputs and key) through the PUBLIC API, microseconds per
                  call, with the same composition on the CPU port beside it and a bit-for-bit parity check of every
@@ -700,11 +700,13 @@ def main() -> None:
         del ct_b, ct2, e53
         # latency at the reference's own batch sizes (bench/bench_ipcl_python.py:24-25,34-35,45-46)
         small = {}
-        for nb in (16, 64):
+        for nb in (16, 64) + ((8192,) if B >= 8192 else ()):         # 8 192: a mid-size batch (lane-group digit pairs, 4 lanes per chain)
             ms_, rs_ = m[:nb].contiguous(), r[:nb].contiguous()
             cts_ = pub.encrypt(ms_, rs_)
+            if nb > 64 and not (torch.equal(cts_, ct[:nb]) and torch.equal(priv.decrypt(cts_), ms_)):
+                raise SystemExit("bench.py: the mid-size batch differs from the full batch's ciphertexts / plaintexts")
             # dense random 53-bit exponents: the SAME values the CPU leg of cpu_baseline.small_batch uses (default_rng(5))
-            e53_s = [int(v) | 1 << 52 for v in np.random.default_rng(5).integers(0, 1 << 52, 64)][:nb]
+            e53_s = [int(v) | 1 << 52 for v in np.random.default_rng(5).integers(0, 1 << 52, max(64, nb))][:nb]
             es_ = torch.from_numpy(np.array([[e & 0xFFFFFFFF, e >> 32] for e in e53_s], dtype=np.int64).astype(np.uint32)
                                    .view(np.int32)).to(device)
             small[str(nb)] = {
