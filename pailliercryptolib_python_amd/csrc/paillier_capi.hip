@@ -3066,16 +3066,18 @@ static bool ensure_mid(pai_privkey* sk) {
 static size_t dec_mid_min(size_t ncu, int prime_bits) {
     long long v;
     if (knob_tune("dec_mid_min", &v)) return (size_t)v;
-    return prime_bits > 1900 ? 9 * ncu + 1 : 8 * ncu + 1;
+    if ((prime_bits > 900 && prime_bits <= 1024) || (prime_bits > 1400 && prime_bits <= 1536)) return 8 * ncu + 1;      // measured cross-overs at the
+    if (prime_bits > 1900 && prime_bits <= 2048) return 9 * ncu + 1;                                                    // 2048 / 3072 / 4096-bit keys
+    return 12 * ncu + 1;                  // sizes in between (1536- / 2560- / 3584-bit keys measured: level near 3 000 / 3 600 / 2 700 ciphertexts)
 }
 static size_t dec_mid_max(size_t ncu, int prime_bits) {
     long long v;
     if (knob_tune("dec_mid_max", &v)) return (size_t)v;
-    // (the geometries are sized for the primes of 2048 / 3072 / 4096-bit keys; measured there: 3072-bit 19.8 ms flat up to 8 192 against
-    // 38.2 at 4 096 and 55.9 beyond, 35 / 51 ms at 16 384 / 24 576; 4096-bit 40 ms up to 8 192 against 67 / 127, 80 / 120 at 16 384 / 24 576)
-    if (prime_bits > 900 && prime_bits <= 1024) return 72 * ncu;
-    if ((prime_bits > 1400 && prime_bits <= 1536) || (prime_bits > 1900 && prime_bits <= 2048)) return 96 * ncu;
-    return 0;
+    // measured (profiles/r05/dec_mid.jsonl): 3072-bit keys 19.8 ms flat up to 8 192 against 38.2 at 4 096 and 55.9 beyond, 35 / 51 ms at
+    // 16 384 / 24 576; 4096-bit 40 ms up to 8 192 against 67 / 127, 80 / 120 at 16 384 / 24 576; keys in between on the next wider geometry:
+    // 1536-bit 5.6 ms against 11.4 at 8 192, 2560-bit 16.7 against 46.8, 3584-bit 35 against 112
+    if (prime_bits < 700 || prime_bits > 2048) return 0;
+    return prime_bits <= 1024 ? 72 * ncu : 96 * ncu;
 }
 
 int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream) {
