@@ -1760,8 +1760,8 @@ static size_t enc_mid_min(size_t ncu) {
 static size_t enc_mid_max(size_t ncu, int n_bits) {
     long long v;
     if (knob_tune("enc_mid_max", &v)) return (size_t)v;
-    const bool fits = (n_bits > 900 && n_bits <= 1024) || (n_bits > 1400 && n_bits <= 1536) || (n_bits > 1900 && n_bits <= 2048);
-    return fits ? 160 * ncu : 0;
+    // (the caller also needs the pair geometry's limb count to equal the digit engine's: 1024-class keys and 1537 .. 2048-bit keys)
+    return n_bits > 900 && n_bits <= 2048 ? 160 * ncu : 0;
 }
 static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint32_t* d_r, const uint32_t* d_ct_in,
                            uint32_t* d_ct_out, size_t N, void* stream, bool from_plain) {
@@ -2227,15 +2227,18 @@ static bool ensure_midp(const pai_pubkey* pk) {
 // (profiles/r05/ctmul_mid.jsonl): 2048-bit keys 1.4 - 1.5 ms flat up to 16 384 ciphertexts (one wave of 16 per SIMD), 2.9 ms at 32 768,
 // against 2.2 / 4.1 ms of the small-batch kernels at 8 192 / 16 384 and 4.7 ms of the one-element-per-lane engine up to 65 536
 // (behind below ~5 000 and from ~55 000); 1024-bit keys 0.55 - 0.63 / 0.9 ms against 0.84 - 1.25 / 1.27
-static size_t ctmul_mid_min(size_t ncu) {
+static bool mid_band(int n_bits) {                   // the key sizes the 4-lane geometries are cut for (measured); others take the next wider one
+    return (n_bits > 900 && n_bits <= 1024) || (n_bits > 1400 && n_bits <= 1536) || (n_bits > 1900 && n_bits <= 2048);
+}
+static size_t ctmul_mid_min(size_t ncu, int n_bits) {
     long long v;
-    return knob_tune("ctmul_mid_min", &v) ? (size_t)v : 20 * ncu;
+    if (knob_tune("ctmul_mid_min", &v)) return (size_t)v;
+    return (mid_band(n_bits) ? 20 : 28) * ncu;       // (1280- / 1792-bit keys: level near 7 000 / 5 500 ciphertexts)
 }
 static size_t ctmul_mid_max(size_t ncu, int n_bits) {
     long long v;
     if (knob_tune("ctmul_mid_max", &v)) return (size_t)v;
-    const bool fits = (n_bits > 900 && n_bits <= 1024) || (n_bits > 1400 && n_bits <= 1536) || (n_bits > 1900 && n_bits <= 2048);
-    return fits ? 192 * ncu : 0;
+    return n_bits > 900 && n_bits <= 2048 ? 192 * ncu : 0;
 }
 
 int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, int e_words, int ebits_max,
@@ -2247,7 +2250,8 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
         DeviceScope scope_(pk->device);
         hipStream_t s = (hipStream_t)stream;
         g_last_times.clear();
-        if (!pk->pair_nl && ebits_max > 8 && N >= ctmul_mid_min((size_t)pk->dev.ncu) && N <= ctmul_mid_max((size_t)pk->dev.ncu, pk->key_bits)) {
+        if (!pk->pair_nl && ebits_max > 8 && N >= ctmul_mid_min((size_t)pk->dev.ncu, pk->key_bits) &&
+            N <= ctmul_mid_max((size_t)pk->dev.ncu, pk->key_bits)) {
             std::lock_guard<std::mutex> lk(pk->mu);
             if (ensure_midp(pk)) {
                 ctmul_pair_locked(pk, s, pk->midp_nl, pk->midp_n.d_ctx, pk->d_midp_nm1, pk->d_midp_kdig, pk->d_midp_one, pk->midp_nd,

@@ -8,7 +8,14 @@ from bench import synthetic_key
 from pailliercryptolib_python_amd import engine
 dev = torch.device('cuda', 0)
 bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-key = synthetic_key(bits, 0x1234567)
+if bits in (1024, 2048, 3072, 4096):
+    key = synthetic_key(bits, 0x1234567)
+else:                                                    # other sizes: the native generator, seeded
+    from types import SimpleNamespace
+    from pailliercryptolib_python_amd import _native
+    p_, q_ = sorted(_native.keygen(bits, True, seed=bits))
+    n_ = p_ * q_
+    key = SimpleNamespace(bits=bits, p=p_, q=q_, n=n_, nsq=n_ * n_, hs=pow((-0x1234567 ** 2) % (n_ * n_), n_, n_ * n_), randbits=bits // 2)
 pub = engine.PublicKeyHandle(key.n, bits, key.hs, key.randbits, device=dev)
 def tm(f, reps=3):
     f(); torch.cuda.synchronize()
@@ -17,7 +24,7 @@ def tm(f, reps=3):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 g = torch.Generator(device=dev); g.manual_seed(1)
-for N in (1024, 2048, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 131072):
+for N in ((1024, 2048, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 131072) if bits in (1024, 2048) else (2048, 4096, 8192, 16384, 32768, 49152)):
     m = torch.randint(0, 2**31 - 1, (N, pub.n_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
     m[:, -1] &= 0x0FFFFFFF
     r = pub.random_r(N, generator=g)
