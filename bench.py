@@ -92,8 +92,8 @@ CONFIGS = {
 # PMC summaries by key size, newest first: (file, batch the profile was taken at)
 PMC_FILES = {2048: [("profiles/r05/pmc_bench_r05.json", 1 << 20), ("profiles/r04/pmc_bench_r04.json", 1 << 20), ("profiles/r03/pmc_bench_r03.json", 1 << 20),
                     ("profiles/r02/pmc_bench_r02.json", 1 << 20), ("profiles/r01/pmc_bench_r01d.json", 1 << 20)],
-             3072: [("profiles/r04/pmc_cfg4_r04.json", 1 << 20), ("profiles/r03/pmc_k3072_r03.json", 1 << 16)],
-             4096: [("profiles/r04/pmc_cfg5_r04.json", 1 << 18), ("profiles/r03/pmc_k4096_r03.json", 1 << 16)]}
+             3072: [("profiles/r05/pmc_cfg4_r05.json", 1 << 20), ("profiles/r04/pmc_cfg4_r04.json", 1 << 20), ("profiles/r03/pmc_k3072_r03.json", 1 << 16)],
+             4096: [("profiles/r05/pmc_cfg5_r05.json", 1 << 18), ("profiles/r04/pmc_cfg5_r04.json", 1 << 18), ("profiles/r03/pmc_k4096_r03.json", 1 << 16)]}
 
 
 def alg_bytes(bits: int):
@@ -168,6 +168,15 @@ def executed_macs_decrypt(p: int, q: int, w: int = 6) -> float:
         n_mul += (1 << (w - 1)) - 1 + 1             # table of odd powers + leaving Montgomery form
         total += n_sq * sq + n_mul * mul + nd * 4 * nl * nl
     return total
+
+
+def executed_macs_std_obfuscator(n: int, w: int = 6) -> float:
+    """29x29-bit MACs per element of the standard scheme's obfuscator r^n mod n^2 on base-n digit pairs (k_pow_padic,
+    csrc/kernels_padic_enc.hpp): the sliding-window schedule of n (windows of <= 6 bits), squarings at 4 NL^2, window and
+    table products (2^(w-1) odd powers) and the two entry products at 5 NL^2; plus the fused (1 + m n) r^n product."""
+    nl = padic_nl(n.bit_length())
+    nsq, nmul = _sliding_counts(n, w)
+    return nsq * 4.0 * nl * nl + (nmul + (1 << (w - 1)) + 2 + 1) * 5.0 * nl * nl
 
 
 def pmc_traffic(kernel_prefix: str, batch: int, key_bits: int = 2048):
@@ -749,6 +758,42 @@ def main() -> None:
                                 "what a handle builds when that many tables are resident or the cache budget is short "
                                 "(PAI_FB_SMALL_TABLE_MB, default 256); first_call_s includes the table build"}
 
+    # ---- the standard scheme (enable_DJN=False, ipcl_python.py:20-40; classes.cpp:24-27): ct = (1 + m n) r^n mod n^2 with a
+    # full-size r — r^n on base-n digit pairs (k_pow_padic) and one fused product; same batch, oracle bits on 64 samples
+    std_scheme = None
+    if extras and padic_nl(KEY_BITS):
+        pub_std = engine.PublicKeyHandle(key.n, KEY_BITS, None, 0, device=device)
+        gen_s = torch.Generator(device=device)
+        gen_s.manual_seed(977)
+        r_std = torch.randint(-(1 << 31), 1 << 31, (B, pub_std.r_words), dtype=torch.int64, device=device, generator=gen_s).to(torch.int32)
+        r_std[:, -1] &= (1 << ((key.n.bit_length() - 1) % 32)) - 1 if (key.n.bit_length() - 1) % 32 else 0    # r < 2^(bits-1) < n
+        ct_std = pub.empty_ct(B)
+        pub_std.encrypt(m, r_std, out=ct_std)                     # first call: schedule, scratch
+        torch.cuda.synchronize()
+        engine.profile_enable(True)
+        t1 = time.perf_counter()
+        pub_std.encrypt(m, r_std, out=ct_std)
+        torch.cuda.synchronize()
+        t_std = time.perf_counter() - t1
+        k_std = dict(engine.profile_last())
+        engine.profile_enable(False)
+        okey_std = orc.make_key(key.p, key.q, djn_x=None, bits=KEY_BITS)
+        chk_s = sorted({int(v) for v in np.linspace(0, B - 1, 64)})
+        want_s = [orc.encrypt(okey_std, mm, rr) for mm, rr in zip(engine.words_to_ints(res[chk_s]),
+                                                                  engine.words_to_ints(engine.to_host_words(r_std[chk_s])))]
+        if engine.words_to_ints(engine.to_host_words(ct_std[chk_s])) != want_s:
+            raise SystemExit("bench.py: standard-scheme ciphertext bits differ from the oracle")
+        if not torch.equal(priv.decrypt(ct_std), m):
+            raise SystemExit("bench.py: standard-scheme round trip failed")
+        macs_std = executed_macs_std_obfuscator(key.n)
+        std_scheme = {"encrypt_ops_per_s": B / t_std, "encrypt_ms": 1e3 * t_std, "batch": B, "key_bits": KEY_BITS, "kernel_ms": k_std,
+                      "executed_macs_per_element": macs_std, "executed_frac": macs_std * B / t_std / PEAK_MAC32_PER_S,
+                      "oracle_samples": len(chk_s), "round_trip_checked": True,
+                      "note": "enable_DJN=False: (1 + m n) r^n mod n^2, r of the key's size; r^n = sliding-window power on base-n "
+                              "digit pairs (squarings 4 NL^2, products 5 NL^2, NL = 72) + one fused product; bits against the "
+                              "oracle, decrypt(ct) == m on the whole batch"}
+        del pub_std, r_std, ct_std
+
     ref_bench = None
     if extras and KEY_BITS == 2048 and not args.no_reference_bench:
         ref_bench = reference_bench(key, okey, device)
@@ -865,6 +910,30 @@ def main() -> None:
             "fixed_base_table_points": table_points,
             "reference_bench": ref_bench,
             "parity_checked": True,
+        }
+        # ---- the LAST keys of the line (the driver keeps the tail of stdout): every configuration's number, compact ----
+        rl = line["roofline"]
+        line["roofline"]["note_traffic"] = (
+            None if not rl.get("traffic") else
+            f"traffic / algorithmic bytes = {rl['traffic'] / (BYTES_DEC * B):.0f}x (per-element window tables in HBM scratch) = "
+            f"{rl['traffic'] / max(kern.get('k_dec_a', 0.0) * 1e-3, 1e-9) / 1e9:.0f} GB/s of {HBM_PEAK_GBS:.0f}: not the limiter")
+        line["standard_scheme"] = std_scheme
+        if ref_bench:
+            line["reference_bench_summary_us"] = {
+                k_: [round(v_["gpu_api_us"], 1)] + [round(min(x_ for n_, x_ in v_.items() if n_.startswith("cpu_")), 1)
+                                                     for _ in (0,) if any(n_.startswith("cpu_") for n_ in v_)]
+                for k_, v_ in ref_bench.get("rows", {}).items()}           # [GPU public API, best CPU-port figure]
+        line["configs_summary"] = {
+            "fields": ["ops_per_s", "ms_per_step", "roofline_frac_executed", "k_encrypt_ms", "k_dec_a_ms", "cpu_ops_per_s"],
+            "headline": [round(value), round(1e3 * elapsed / args.steps, 2), rl["frac"] and round(rl["frac"], 4),
+                         kern.get("k_encrypt(djn)") and round(kern["k_encrypt(djn)"], 2), kern.get("k_dec_a") and round(kern["k_dec_a"], 2),
+                         cpu and round(cpu["value"])],
+            **({n_: [round(b_["value"]), round(b_["ms_per_step"], 2), b_["roofline"]["frac"] and round(b_["roofline"]["frac"], 4),
+                     b_["roofline"]["kernel_ms"].get("k_encrypt(djn)") and round(b_["roofline"]["kernel_ms"]["k_encrypt(djn)"], 2),
+                     b_["roofline"]["kernel_ms"].get("k_dec_a") and round(b_["roofline"]["kernel_ms"]["k_dec_a"], 2),
+                     b_["cpu_baseline"] and round(b_["cpu_baseline"]["value"])] for n_, b_ in (configs_block or {}).items()}),
+            "standard_scheme_2048": std_scheme and [round(std_scheme["encrypt_ops_per_s"]), round(std_scheme["encrypt_ms"], 1),
+                                                    round(std_scheme["executed_frac"], 4)],
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -287,6 +287,27 @@ ALIGN_SORT_MIN = 1 << 15
 # a lazily tagged sum (rows x R^k, bindings.ipclCipherText) is brought back to the wire form once |k| passes this bound
 DOM_MAX = 12
 
+# pai_ct_addn (csrc/paillier_capi.hip: pai_ct_addn; kernels_paillier.hpp: RPOW_SPAN): a tile's accumulator passes through domain
+# tags between c_lo and c_hi and is brought to dom_out by one product with R^(1 + dom_out - c) from a table of |m| <= 48.
+ADDN_RPOW_SPAN = 48
+ADDN_ACC_DOM_MAX = 16        # tags of the running accumulator between chunks of add_many (never leave that function)
+
+
+def _addn_tags_fit(tag0: int, tag: int, k: int, dom_out: int) -> bool:
+    c_lo = min(tag0, 1) + (k - 1) * min(tag - 1, 0)
+    c_hi = max(tag0, 1) + (k - 1) * max(tag - 1, 0)
+    return (abs(2 - tag) <= ADDN_RPOW_SPAN and abs(1 + dom_out - c_lo) <= ADDN_RPOW_SPAN
+            and abs(1 + dom_out - c_hi) <= ADDN_RPOW_SPAN)
+
+
+def _addn_dom_out(tag0: int, tag: int, k: int, last: bool) -> int:
+    """The tag a chunk of add_many leaves: the wire form at the end; in between the natural tag tag0 + (k - 1)(tag - 1) — no
+    fix-up product: sixteen fresh ciphertexts give -15 — as far as the NEXT chunk (this result + 15 operands at tag 0, or
+    retagged to 0) still fits the table."""
+    if last:
+        return 0
+    return max(-ADDN_ACC_DOM_MAX, min(ADDN_ACC_DOM_MAX, tag0 + (k - 1) * (tag - 1)))
+
 
 def _add_aligned(h: engine.PublicKeyHandle, ta: torch.Tensor, tb: torch.Tensor, delta: np.ndarray, dom: int = 0) -> torch.Tensor:
     """pai_ct_add_aligned on (ta, tb) with host-built exponent differences.  The kernel raises a whole wave tile (16 - 64
@@ -709,8 +730,20 @@ class PaillierEncryptedNumber:
             else:
                 tag0 = tags[0]
             last = pos >= k
-            # intermediate chunks keep their natural tag (no fix-up product); the final result is the wire form
-            dom_out = 0 if last else max(-DOM_MAX, min(DOM_MAX, tag0 + (len(ops) - 1) * (tag - 1)))
+            dom_out = _addn_dom_out(tag0, tag, len(ops), last)
+            if not _addn_tags_fit(tag0, tag, len(ops), dom_out):
+                # operands that each carry a long lazy chain (e.g. sixteen sums a + b + c + d at tag -3): the fix-up constant
+                # R^(1 + dom_out - c) would leave the key's table (pai_ct_addn: RPOW_SPAN) — bring operands 1.. to the wire
+                # form first (one product each), which always fits (tests/test_host_logic_cpu.py::test_addn_tag_plan)
+                # (operand 0 is the running sum or the first item; everything after it sits at `tag` by now)
+                if tag != 0:
+                    for i in range(1, len(ops)):
+                        ops[i] = h.ct_retag(ops[i], tag, 0)
+                if acc_t is None and rz[0] is not None and tag0 != 0:     # a raised first operand shares the others' tag
+                    ops[0] = h.ct_retag(ops[0], tag0, 0)
+                    tag0 = 0
+                tag = 0
+                dom_out = _addn_dom_out(tag0, tag, len(ops), last)
             acc_t = h.ct_addn(ops, rz, tag0, tag, dom_out)
             acc_tag = dom_out
         return first._wrap(acc_t, E.astype(np.int32), n, dom=acc_tag, others=items[1:])

@@ -795,6 +795,18 @@ def test_add_many_equals_the_chain_of_additions(fixed, monkeypatch):
     for e_ in encs[1:]:
         chain = chain + e_
     assert ct_ints(got) == ct_ints(chain) and got.exponent() == chain.exponent()
+    # every operand a long lazy chain (tag -3 each, 35 of them: three chunks): the fix-up exponent of the natural tags would
+    # leave the kernel's table of powers of R — add_many re-plans instead of raising
+    deep = [[int(v) for v in rng.integers(0, 9, N)] for _ in range(35)]
+    zero = pk.raw_encrypt([0] * N)
+    encs = [((pk.raw_encrypt(a) + zero) + zero) + zero for a in deep]
+    assert all(e_.ciphertext()._raw()[1] == -3 for e_ in encs)
+    got = PaillierEncryptedNumber.add_many(encs)
+    assert sk.decrypt(got) == [sum(col) for col in zip(*deep)]
+    chain = encs[0]
+    for e_ in encs[1:]:
+        chain = chain + e_
+    assert ct_ints(got) == ct_ints(chain) and got.exponent() == chain.exponent()
     # wide exponent spread: the chain itself (same bits by construction), still correct
     wide = [list(rng.uniform(-1000.0, 1000.0, N)) for _ in range(4)]
     encs = [pk.raw_encrypt(a) for a in wide]

@@ -1,0 +1,39 @@
+"""Host-side planning logic that needs no device."""
+import re
+from pathlib import Path
+
+from pailliercryptolib_python_amd import paillier
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_addn_tag_plan():
+    """PaillierEncryptedNumber.add_many's tag planning against pai_ct_addn's precondition (csrc/paillier_capi.hip:
+    |1 + dom_out - c| <= RPOW_SPAN over the tags c a tile passes through): for every legal combination of the running sum's tag,
+    the operands' common tag and the chunk length, either the natural plan fits or the re-plan with the operands retagged to the
+    wire form does — ADVICE r05: sixteen operands at tag -3 used to raise PAI_E_INVALID."""
+    src = (ROOT / "pailliercryptolib_python_amd" / "csrc" / "kernels_paillier.hpp").read_text()
+    span = int(re.search(r"constexpr int RPOW_SPAN = (\d+);", src).group(1))
+    assert span == paillier.ADDN_RPOW_SPAN
+    capi = "".join(p.read_text() for p in sorted((ROOT / "pailliercryptolib_python_amd" / "csrc").glob("*.hip")))
+    assert "std::min(tag0, 1) + (k - 1) * std::min(tag - 1, 0)" in capi and "std::max(tag0, 1) + (k - 1) * std::max(tag - 1, 0)" in capi
+    bad_natural = 0
+    for first_chunk in (True, False):
+        tag0_range = range(-paillier.DOM_MAX, paillier.DOM_MAX + 1) if first_chunk else \
+            range(-paillier.ADDN_ACC_DOM_MAX, paillier.ADDN_ACC_DOM_MAX + 1)
+        for tag0 in tag0_range:
+            for tag in range(-paillier.DOM_MAX, paillier.DOM_MAX + 1):
+                for k in range(2, 17):
+                    for last in (False, True):
+                        d = paillier._addn_dom_out(tag0, tag, k, last)
+                        assert d == 0 if last else abs(d) <= paillier.ADDN_ACC_DOM_MAX
+                        if paillier._addn_tags_fit(tag0, tag, k, d):
+                            continue
+                        bad_natural += 1
+                        d = paillier._addn_dom_out(tag0, 0, k, last)
+                        assert paillier._addn_tags_fit(tag0, 0, k, d), (tag0, tag, k, last)
+    assert bad_natural > 0
+    # the case of the finding: sixteen operands at tag -3
+    assert not paillier._addn_tags_fit(-3, -3, 16, 0)
+    # sixteen fresh ciphertexts keep their natural tag between chunks (no fix-up product)
+    assert paillier._addn_dom_out(0, 0, 16, False) == -15 and paillier._addn_tags_fit(0, 0, 16, -15)
