@@ -66,6 +66,17 @@ int pai_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes, voi
 int pai_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
 int pai_stream_sync(int device, void* stream);
 
+/* Small host operands of asynchronous calls without a copy on the stream (round 6).  The reference's pybind layer takes host
+ * vectors by value (bindings/ipcl_bindings_classes.cpp:318-325: the exponents of CipherText * PlainText, the shifts the
+ * Python layer computes for ipcl_python.py:570-741); at its own benchmark sizes (16 / 64 elements, bench/bench_ipcl_python.py:
+ * 22-78) an H2D copy per operand costs as much as the kernel.  pai_host_stage copies `parts` host arrays (together at most
+ * PAI_HOST_STAGE_MAX bytes, each part 16-byte aligned) into one slot of a pinned, device-mapped ring of the calling thread
+ * and returns, per part, a pointer a kernel may READ through directly.  Contract: the pointers may be passed as read-only
+ * device operands (exponents, shifts, codec inputs) of calls enqueued on `stream` BEFORE the calling thread's next
+ * pai_host_stage for that device; the library keeps the slot intact until those calls have executed. */
+#define PAI_HOST_STAGE_MAX 4096
+int pai_host_stage(int device, int parts, const void* const* h_src, const size_t* bytes, void* stream, void** d_ptrs);
+
 /* ---- container operations on device rows (no arithmetic) -----------------------------------------
  * ipclPlainText / ipclCipherText __getitem__ with a slice and rotate (bindings/ipcl_bindings_classes.cpp:224-262,328-366;
  * rotate is what the reference's reductions are built from, ipcl_python.py:810-827).  Rows of `row_words` words.

@@ -24,6 +24,11 @@ from typing import List, Optional, Sequence, Union
 import numpy as np
 import torch
 
+# Wire-form additions of at most this many elements return the wire form directly (one launch, pai_ct_add) instead of a lazily
+# tagged single product: such batches run on the latency geometry, where a tagged product costs two products anyway, and the
+# retag launch at the next boundary (export, decryption, ct * pt) is saved.  0 keeps every addition lazy.
+EAGER_ADD_MAX = 1024
+
 from . import _native, engine
 
 # ------------------------------------------------------------------------------------------------
@@ -238,6 +243,7 @@ class ipclPublicKey:
         if not devs:
             raise ValueError("set_devices: need at least one device")
         self._devices = devs
+        self.__dict__.pop("_home_handle", None)
 
     def handle_on(self, device: torch.device) -> engine.PublicKeyHandle:
         h = self._handles.get(device.index)
@@ -249,7 +255,11 @@ class ipclPublicKey:
     @property
     def handle(self) -> engine.PublicKeyHandle:
         """The handle on the home device."""
-        return self.handle_on(self._device_list()[0])
+        h = self.__dict__.get("_home_handle")
+        if h is None:
+            h = self.handle_on(self._device_list()[0])
+            self.__dict__["_home_handle"] = h
+        return h
 
     @property
     def device(self) -> torch.device:
@@ -393,6 +403,9 @@ class ipclPublicKey:
         """ct_i ^ e_i mod n^2 (classes.cpp:324-325) on the home device's limb matrices, sharded when large."""
         h = self.handle
         devs = self.fanout_devices(ct.shape[0])
+        if isinstance(e, np.ndarray):
+            # host exponents: small batches hand them to the kernel through a pinned slot (engine.small_operands), the others upload
+            e = engine.small_operands([e], h.device)[0] if devs is None else engine.to_device_words(e, h.device)
         if devs is None:
             return h.ct_mul(ct, e, ebits_max)
         ct_sh = engine.scatter_shards(ct, devs)
@@ -749,6 +762,9 @@ class ipclCipherText(_Container):
         if len(other) != len(self) and len(other) != 1:
             raise RuntimeError("Size mismatch")
         (ta, ka), (tb, kb) = self._raw(), other._raw()
+        if ka == 0 and kb == 0 and ta.shape[0] <= EAGER_ADD_MAX:
+            # small wire-form operands: the wire form at once (the latency geometry spends two products on a tagged result too)
+            return ipclCipherText(self._pk, h.ct_add(ta, tb), taint=merge_taint(self._taint, other._taint))
         return ipclCipherText(self._pk, h.ct_mont_mul(ta, tb), dom=ka + kb - 1,        # one product; the tag remembers the R^-1
                               taint=merge_taint(self._taint, other._taint))
 

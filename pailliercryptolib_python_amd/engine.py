@@ -10,6 +10,7 @@ streams and (in ``sharding.py``) ``torch.distributed``; all arithmetic is in ``l
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 import weakref
 from typing import Optional
@@ -82,12 +83,70 @@ def rows_rotate(t: torch.Tensor, shift: int) -> torch.Tensor:
     return out
 
 
-def _ptr(t: Optional[torch.Tensor]):
+def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device: torch.device):
+    if _raw_stream is not None and device.index is not None:
+        return C.c_void_p(_raw_stream(device.index))             # the current stream's handle without building a Stream object
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ---- small host operands (pai_host_stage): exponents, shifts and codec inputs of small batches are read by the kernel from a
+# pinned slot instead of crossing PCIe in a copy of their own (12 us per torch .to(device) at the reference's benchmark sizes)
+HOST_STAGE_MAX = 4096
+_TORCH_OF_NP = {np.dtype(np.int32): torch.int32, np.dtype(np.uint32): torch.int32, np.dtype(np.float64): torch.float64,
+                np.dtype(np.int64): torch.int64}
+
+
+class HostOperand:
+    """A staged host array standing where a read-only device tensor is expected by the engine's calls.  Valid for the NEXT
+    engine call on this thread only (the contract of pai_host_stage): stage, then consume."""
+    __slots__ = ("ptr", "shape", "dtype", "device")
+
+    def __init__(self, ptr: int, shape, dtype, device):
+        self.ptr, self.shape, self.dtype, self.device = ptr, tuple(shape), dtype, device
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    def dim(self) -> int:
+        return len(self.shape)
+
+    def is_contiguous(self) -> bool:
+        return True
+
+    def contiguous(self):
+        return self
+
+
+def host_stage_enabled() -> bool:
+    return os.environ.get("PAI_HOST_STAGE", "1") != "0"
+
+
+def stage_host(arrays, device: torch.device):
+    """The host arrays (numpy, C-contiguous; together <= HOST_STAGE_MAX bytes) as HostOperands in one pinned slot."""
+    k = len(arrays)
+    srcs = (C.c_void_p * k)(*[a.__array_interface__["data"][0] for a in arrays])
+    sizes = (C.c_size_t * k)(*[a.nbytes for a in arrays])
+    outs = (C.c_void_p * k)()
+    rc = _native.load().pai_host_stage(device.index, k, srcs, sizes, _stream(device), outs)
+    if rc:
+        _native.check(rc)
+    return [HostOperand(outs[i] or 0, a.shape, _TORCH_OF_NP[a.dtype], device) for i, a in enumerate(arrays)]
+
+
+def small_operands(arrays, device: torch.device):
+    """Device-readable forms of small host arrays for the next engine call: staged when they fit a slot, uploaded otherwise."""
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    if device.index is not None and host_stage_enabled() and \
+            sum((a.nbytes + 15) & ~15 for a in arrays) <= HOST_STAGE_MAX and all(a.dtype in _TORCH_OF_NP for a in arrays):
+        return stage_host(arrays, device)
+    return [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(device) for a in arrays]
 
 
 class PublicKeyHandle:
@@ -349,7 +408,7 @@ class PublicKeyHandle:
         if from_host:
             delta = np.ascontiguousarray(delta, dtype=np.int32).reshape(-1)
             max_delta = int(delta.max()) if delta.size else 0
-            delta = torch.from_numpy(delta).to(self.device)
+            delta = small_operands([delta], self.device)[0]
         if delta.dtype != torch.int32 or delta.dim() != 1 or not delta.is_contiguous():
             raise ValueError("delta: expected contiguous int32 [N] or [1]")
         bcast = 1 if (delta.shape[0] == 1 and ct.shape[0] != 1) else 0
@@ -411,11 +470,9 @@ class PublicKeyHandle:
         caller rejects those outside [1, n))."""
         if len(key) != 32 or len(nonce) != 12:
             raise ValueError("ChaCha20 needs a 32-byte key and a 12-byte nonce")
-        k = np.frombuffer(key, dtype="<u4").copy()
-        nn = np.frombuffer(nonce, dtype="<u4").copy()
         r = torch.empty((n, self.r_words), dtype=torch.int32, device=self.device)
-        _native.check(self.lib.pai_draw_r(self.h, k.ctypes.data_as(C.c_void_p), nn.ctypes.data_as(C.c_void_p),
-                                          int(counter0) & 0xFFFFFFFF, n, _ptr(r), _stream(self.device)))
+        # (bytes objects go through ctypes as read-only pointers: the library copies key and nonce before it returns)
+        _native.check(self.lib.pai_draw_r(self.h, bytes(key), bytes(nonce), int(counter0) & 0xFFFFFFFF, n, _ptr(r), _stream(self.device)))
         return r
 
     def random_r(self, n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:

@@ -125,6 +125,23 @@ def float64_mantissas(x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return mant, expo
 
 
+def float64_exponents(x: np.ndarray) -> np.ndarray:
+    """The exponents float64_mantissas / the device codec (csrc/kernels_codec.hpp: k_fp_encode_f64) assign to finite doubles."""
+    expo = (_MANT - np.frexp(x)[1]).astype(np.int32)
+    expo[np.abs(x) < 1e-200] = 0
+    return expo
+
+
+def float64_exponents_at(x: np.ndarray, target: np.ndarray, n_bits: int) -> np.ndarray:
+    """The exponents pai_fp_encode_at (kernels_codec.hpp: k_fp_encode_at) assigns: an element whose own exponent is below its
+    target moves to the target when it is zero or when its 53-bit mantissa shifted by the distance stays below 2^(bits(n) - 2)."""
+    e0 = float64_exponents(x).astype(np.int64)
+    t = np.broadcast_to(np.asarray(target, dtype=np.int64).reshape(-1), e0.shape)
+    dist = t - e0
+    move = (dist > 0) & ((np.abs(x) < 1e-200) | (_MANT + dist <= n_bits - 2))
+    return np.where(move, t, e0).astype(np.int32)
+
+
 def encode_float64_array(x: np.ndarray, n: int, n_words: int) -> Tuple[np.ndarray, np.ndarray]:
     """float64[N] -> (residues uint32[N][n_words], exponents int32[N]); requires n > 2^66."""
     x = np.ascontiguousarray(x, dtype=np.float64)

@@ -23,6 +23,7 @@ from typing import Callable, List, Optional, Tuple, Union
 import numpy as np
 import torch
 
+from . import bindings as _bindings
 from . import engine
 from . import fixedpoint as _fp
 from .bindings import (
@@ -161,13 +162,17 @@ class PaillierPublicKey:
             return PaillierEncryptedNumber(self, ipclCipherText(pub, ct), exponents=expos, length=len(values))
         if (is_f64 or is_i64) and tgt is not None:
             x = _fp.checked_float64(values) if is_f64 else np.ascontiguousarray(values, dtype=np.int64)
-            m, expo_d = h.fp_encode_at(torch.from_numpy(x).to(h.device), torch.from_numpy(tgt).to(h.device))
-            expos = expo_d.cpu().numpy()
+            xs, ts = engine.small_operands([x, tgt], h.device)
+            m, expo_d = h.fp_encode_at(xs, ts)
+            # small float batches: the exponents are a function of the inputs alone — computed here, no read-back (and no
+            # synchronisation) between the codec kernel and the encryption
+            expos = _fp.float64_exponents_at(x, tgt, self.n.bit_length()) if is_f64 and x.shape[0] <= HOST_EXPO_MAX \
+                else expo_d.cpu().numpy()
         elif is_f64:
             # float arrays: 8 B per element cross PCIe and the codec runs on the device (pai_fp_encode_f64)
             x = _fp.checked_float64(values)
-            m, expo_d = h.fp_encode_f64(torch.from_numpy(x).to(h.device))
-            expos = expo_d.cpu().numpy()
+            m, expo_d = h.fp_encode_f64(engine.small_operands([x], h.device)[0])
+            expos = _fp.float64_exponents(x) if x.shape[0] <= HOST_EXPO_MAX else expo_d.cpu().numpy()
         elif is_i64:
             # the integer dtypes the reference's codec accepts (fixedpoint.py:72): exponent 0, residue = x mod n
             m, expo_d = h.fp_encode_i64(torch.from_numpy(np.ascontiguousarray(values, dtype=np.int64)).to(h.device))
@@ -286,6 +291,7 @@ class PaillierPrivateKey:
 ALIGN_SORT_MIN = 1 << 15
 # a lazily tagged sum (rows x R^k, bindings.ipclCipherText) is brought back to the wire form once |k| passes this bound
 DOM_MAX = 12
+HOST_EXPO_MAX = 4096         # float batches up to this size take their exponents from the host codec rule (no device read-back)
 
 # pai_ct_addn (csrc/paillier_capi.hip: pai_ct_addn; kernels_paillier.hpp: RPOW_SPAN): a tile's accumulator passes through domain
 # tags between c_lo and c_hi and is brought to dom_out by one product with R^(1 + dom_out - c) from a table of |m| <= 48.
@@ -314,8 +320,15 @@ def _add_aligned(h: engine.PublicKeyHandle, ta: torch.Tensor, tb: torch.Tensor, 
     neighbouring elements) as often as its LARGEST |delta| asks; on random floats neighbours differ by 0 ... 6, so a tile
     pays for ~6 squarings where its mean element needs 1.3.  Large batches are therefore processed in the order of
     |delta| inside segments (device argsort + row gathers) and scattered back: the same residues in the same places."""
-    d_dev = torch.from_numpy(np.ascontiguousarray(delta, dtype=np.int32)).to(h.device)
     n = ta.shape[0]
+    delta = np.ascontiguousarray(delta, dtype=np.int32)
+    if 0 < n <= engine.HOST_STAGE_MAX // 4:
+        # small batches: the shifts are read by the kernel from a pinned slot (no copy on the stream); dom != 0 needs its entry
+        # constant BEFORE the shifts are staged (a staged operand belongs to the very next call)
+        if dom != 0:
+            h.dom_const(2 - dom)
+        return h.ct_add_aligned(ta, tb, engine.small_operands([delta], h.device)[0], dom=dom)
+    d_dev = torch.from_numpy(delta).to(h.device)
     try:
         sort_min = int(os.environ.get("PAI_ALIGN_SORT_MIN", ALIGN_SORT_MIN))
     except ValueError:
@@ -506,8 +519,7 @@ class PaillierEncryptedNumber:
         mags = [n - p if s else p for p, s in zip(pts, neg)]
         bits = max(1, max(v.bit_length() for v in mags))
         ew = (bits + 31) // 32
-        e = engine.to_device_words(engine.ints_to_words(mags, ew), h.device)
-        return self.public_key.pubkey.ct_mul_words(base, e, bits)
+        return self.public_key.pubkey.ct_mul_words(base, engine.ints_to_words(mags, ew), bits)
 
     def _pow_small(self, ct: torch.Tensor, mant: np.ndarray, flags: list) -> torch.Tensor:
         """The same for a batch of signed 64-bit multipliers (float mantissas): no per-element Python objects."""
@@ -529,7 +541,7 @@ class PaillierEncryptedNumber:
         e[:, 0] = (mag & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         e[:, 1] = (mag >> np.uint64(32)).astype(np.uint32)
         ew = (bits + 31) // 32
-        return self.public_key.pubkey.ct_mul_words(base, engine.to_device_words(np.ascontiguousarray(e[:, :ew]), h.device), bits)
+        return self.public_key.pubkey.ct_mul_words(base, np.ascontiguousarray(e[:, :ew]), bits)
 
     def __mul__(self, other):
         """ipcl_python.py:412-488."""
@@ -586,6 +598,11 @@ class PaillierEncryptedNumber:
             ye = np.broadcast_to(ye, xe.shape)
         delta = (xe - ye).astype(np.int32)
         if not delta.any():
+            if ka == 0 and kb == 0 and ta.shape[0] <= _bindings.EAGER_ADD_MAX:
+                # small batches run on the latency geometry, where the tagged product costs two products anyway (its result
+                # has to carry the throughput geometry's R): the wire form straight away — same kernel time, and no retag
+                # product (a second launch) when the result is exported, decrypted or multiplied
+                return self._wrap(h.ct_add(ta, tb), np.maximum(xe, ye).astype(np.int32), self.__length, dom=0, others=(other,))
             res, dom = h.ct_mont_mul(ta, tb), ka + kb - 1
             if abs(dom) > DOM_MAX:                       # long-lived accumulators: the tag (and the R^k constants it needs) stay bounded
                 res, dom = h.ct_retag(res, dom, 0), 0

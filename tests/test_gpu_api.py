@@ -20,6 +20,7 @@ from pailliercryptolib_python_amd import (
     hybridControl,
     hybridMode,
 )
+from pailliercryptolib_python_amd import bindings as bindings_mod
 from pailliercryptolib_python_amd.bindings import ipclPublicKey
 from tests._util import tune
 
@@ -539,11 +540,13 @@ def test_standard_scheme_key_declared_wider_than_its_modulus():
     assert [int(b) for b in back] == [0, 1, 2, 12345, n - 1]
 
 
-def test_lazy_domain_tags_never_change_the_bits(fixed):
-    """Sums are single Montgomery products whose stray R^-1 is remembered per container (bindings.ipclCipherText._raw);
+def test_lazy_domain_tags_never_change_the_bits(fixed, monkeypatch):
+    """(Small wire-form sums are exported at once since round 6 — bindings.EAGER_ADD_MAX; switched off here to reach the tags.)
+    Sums are single Montgomery products whose stray R^-1 is remembered per container (bindings.ipclCipherText._raw);
     every boundary (ciphertextBN, pickling, decryption, slices, further mixed-exponent additions, products, the
     binding-level CipherText + CipherText and rotate) shows the bits of the reference's composition."""
     pk, sk, okey = fixed
+    monkeypatch.setattr(bindings_mod, "EAGER_ADD_MAX", 0)
     rng = np.random.default_rng(17)
     N = 9
     vals = [np.round(rng.uniform(-100, 100, N), 3) for _ in range(4)]
@@ -644,13 +647,14 @@ def test_large_mixed_exponent_sums_are_sorted_by_shift_and_bit_identical(fixed, 
     assert np.allclose(sk.decrypt_to_numpy(a + b), x + y, rtol=0, atol=1e-6 * np.abs(x + y).max())
 
 
-def test_sums_of_sums_stay_lazy_and_tags_stay_bounded(fixed):
+def test_sums_of_sums_stay_lazy_and_tags_stay_bounded(fixed, monkeypatch):
     """(a+b)+(c+d) and x + acc keep their operands tagged (one product per addition: no operand is canonicalised just to
     read its shape), a long accumulator's tag is renormalised at paillier.DOM_MAX, the handle's R^k cache stays small
     and trim() drops it — bits always those of the reference's composition."""
     from pailliercryptolib_python_amd import paillier as P
 
     pk, sk, okey = fixed
+    monkeypatch.setattr(bindings_mod, "EAGER_ADD_MAX", 0)         # (small batches would export each sum at once)
     N = 7
     ints = [list(range(i, i + N)) for i in (1, 50, 700, 9000)]
     rs = [orc.synth_r_limbs(970 + i, N, okey.randbits) for i in range(4)]
@@ -760,6 +764,7 @@ def test_add_many_equals_the_chain_of_additions(fixed, monkeypatch):
     fallbacks (wide exponent spread, short arrays)."""
     pk, sk, okey = fixed
     monkeypatch.setattr(PaillierEncryptedNumber, "ADDN_MIN", 64)
+    monkeypatch.setattr(bindings_mod, "EAGER_ADD_MAX", 0)         # lazily tagged operands at this test's small size
     rng = np.random.default_rng(77)
     N = 200
 
@@ -813,3 +818,53 @@ def test_add_many_equals_the_chain_of_additions(fixed, monkeypatch):
     got = PaillierEncryptedNumber.add_many(encs)
     want_ct, want_e = oracle_chain(wide)
     assert ct_ints(got) == want_ct and got.exponent() == want_e
+
+
+def test_small_host_operands_are_staged_and_never_change_the_bits(fixed, monkeypatch):
+    """Round 6: shifts, exponents and codec inputs of small batches reach the kernels through a pinned ring (pai_host_stage)
+    instead of a copy on the stream, the exponents of float batches are computed on the host, and small wire-form additions
+    return the wire form at once.  (a) every operation gives the bits of the copy path (PAI_HOST_STAGE=0) and of the oracle;
+    (b) 300 back-to-back calls without a synchronisation in between — the 32-slot ring wraps nine times while earlier kernels
+    may still be queued — all decrypt correctly."""
+    import torch
+
+    pk, sk, okey = fixed
+    rng = np.random.default_rng(2024)
+    nb = 16
+    x = (np.arange(nb) + 11) * 5111.2834
+    y = (32768 - np.arange(nb)) * 1.3872
+    r = engine.ints_to_words([int(v) for v in rng.integers(1, 1 << 62, nb)], pk.pubkey.handle.r_words)
+
+    def run():
+        cx = pk.encrypt(x, r=r)
+        cy = pk.encrypt(y, r=r)
+        return {"enc": (ct_ints(cx), cx.exponent()),
+                "add": (ct_ints(cx + cy), (cx + cy).exponent()),
+                "add_same": (ct_ints(cx + cx), (cx + cx).exponent()),
+                "addpt": (ct_ints((cx * x) + y), ((cx * x) + y).exponent()),
+                "mul": (ct_ints(cx * y), (cx * y).exponent()),
+                "sub": (ct_ints(cx - cy), (cx - cy).exponent())}
+
+    staged = run()
+    monkeypatch.setenv("PAI_HOST_STAGE", "0")
+    copied = run()
+    monkeypatch.delenv("PAI_HOST_STAGE")
+    assert staged == copied
+    xc, xe = orc.api_encrypt(okey, list(x), engine.words_to_ints(r))
+    yc, ye = orc.api_encrypt(okey, list(y), engine.words_to_ints(r))
+    assert staged["enc"] == (xc, list(xe))
+    ac, ae = orc.api_add_ct(okey, xc, xe, yc, ye)
+    assert staged["add"] == (ac, list(ae))
+    mc, me = orc.api_mul_plain(okey, xc, xe, list(y))
+    assert staged["mul"] == (mc, list(me))
+    assert (cx_tag := (pk.encrypt(x) + pk.encrypt(x)).ciphertext()._raw()[1]) == 0, cx_tag       # wire form at once
+    # (b) a long unsynchronised run through the ring
+    cx = pk.encrypt(x)
+    outs, wants = [], []
+    for i in range(300):
+        yi = y + i
+        outs.append((cx + yi) if i % 3 == 0 else ((cx * yi) if i % 3 == 1 else (cx + pk.encrypt(yi))))
+        wants.append(x * yi if i % 3 == 1 else x + yi)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, wants):
+        assert np.allclose(sk.decrypt(o), w, rtol=1e-9, atol=1e-6)

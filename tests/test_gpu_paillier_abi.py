@@ -1050,3 +1050,37 @@ def test_many_keys_take_the_small_table_and_do_not_thrash(monkeypatch):
     r_int = orc.limbs_to_ints(r_l)
     for idx in (0, 1, 9, NK - 1):                                   # a big-table key and small-table keys against the oracle
         assert limbs_to_ints(first[idx][:4]) == [orc.encrypt(keys[idx], x, rr) for x, rr in zip(m[:4], r_int[:4])]
+
+
+def test_host_stage_operands_are_read_in_place(k2048):
+    """pai_host_stage (include/paillier_hip.h): exponents and shifts staged in the pinned ring are read by the kernels through
+    the returned pointers — same results as device-resident operands — over more stagings than the ring has slots, two parts
+    in one slot, and the size limit."""
+    key, N = k2048.key, 24
+    rng = np.random.default_rng(4242)
+    a = rand_below(rng, key.nsq, N)
+    b = rand_below(rng, key.nsq, N)
+    da, db = DevArray(ints_to_limbs(a, k2048.cw)), DevArray(ints_to_limbs(b, k2048.cw))
+    outs, wants = [], []
+    for it in range(40):                                     # 40 stagings: the 32-slot ring wraps, no synchronisation in between
+        es = [int(v) | 1 << 52 for v in rng.integers(0, 1 << 52, N)]
+        e_h = ints_to_limbs(es, 2)
+        delta = rng.integers(-3, 4, N).astype(np.int32)
+        srcs = (C.c_void_p * 2)(e_h.ctypes.data, delta.ctypes.data)
+        sizes = (C.c_size_t * 2)(e_h.nbytes, delta.nbytes)
+        ptrs = (C.c_void_p * 2)()
+        _native.check(k2048.lib.pai_host_stage(0, 2, srcs, sizes, None, ptrs))
+        assert ptrs[0] and ptrs[1] and ptrs[1] - ptrs[0] == (e_h.nbytes + 15) // 16 * 16
+        o1, o2 = DevArray(shape=(N, k2048.cw)), DevArray(shape=(N, k2048.cw))
+        _native.check(k2048.lib.pai_ct_mul(k2048.pk, da.ptr, C.c_void_p(ptrs[0]), 2, 53, 0, N, o1.ptr, None))
+        _native.check(k2048.lib.pai_ct_add_aligned(k2048.pk, da.ptr, db.ptr, 0, C.c_void_p(ptrs[1]), N, o2.ptr, None))
+        outs.append((o1, o2))
+        wants.append((pow_many(a, es, key.nsq),
+                      [pow(x, 1 << max(0, -int(d)), key.nsq) * pow(y, 1 << max(0, int(d)), key.nsq) % key.nsq for x, y, d in zip(a, b, delta)]))
+    for (o1, o2), (w1, w2) in zip(outs, wants):
+        assert limbs_to_ints(o1.get()) == w1 and limbs_to_ints(o2.get()) == w2
+    big = np.zeros(5000, dtype=np.uint8)
+    srcs = (C.c_void_p * 1)(big.ctypes.data)
+    sizes = (C.c_size_t * 1)(big.nbytes)
+    ptrs = (C.c_void_p * 1)()
+    assert k2048.lib.pai_host_stage(0, 1, srcs, sizes, None, ptrs) == -1

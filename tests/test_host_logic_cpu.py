@@ -37,3 +37,26 @@ def test_addn_tag_plan():
     assert not paillier._addn_tags_fit(-3, -3, 16, 0)
     # sixteen fresh ciphertexts keep their natural tag between chunks (no fix-up product)
     assert paillier._addn_dom_out(0, 0, 16, False) == -15 and paillier._addn_tags_fit(0, 0, 16, -15)
+
+
+def test_host_exponents_equal_the_codec():
+    """fixedpoint.float64_exponents / float64_exponents_at (what small float batches use instead of reading the device codec's
+    exponents back) against the host codec the goldens pin (encode_float64_array, align_encoded; reference fixedpoint.py:54-96)."""
+    import numpy as np
+
+    from pailliercryptolib_python_amd import fixedpoint as fp
+
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-1e6, 1e6, 300), rng.uniform(-1, 1, 100) * 10.0 ** rng.integers(-250, 250, 100),
+                        np.array([0.0, -0.0, 1e-200, 9.9e-201, -9.9e-201, 5e-324, 1.0, -1.0, 2.0 ** 52, 2.0 ** 53, 1.7e308])])
+    n = (1 << 2047) + 12345
+    max_int = n // 3 - 1
+    res, expo = fp.encode_float64_array(x, n, 64)
+    assert np.array_equal(fp.float64_exponents(x), expo)
+    for n_bits_n in (n, (1 << 255) + 7):
+        nw = (n_bits_n.bit_length() + 31) // 32
+        res, expo = fp.encode_float64_array(x, n_bits_n, nw)
+        for tgt in (np.array([int(expo.max())], dtype=np.int32), (expo + rng.integers(-3, 40, expo.shape[0])).astype(np.int32),
+                    np.array([2000], dtype=np.int32)):
+            _, want = fp.align_encoded(res, expo, tgt, n_bits_n, n_bits_n // 3 - 1)
+            assert np.array_equal(fp.float64_exponents_at(x, tgt, n_bits_n.bit_length()), want)

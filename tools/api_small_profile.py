@@ -32,8 +32,28 @@ def timeit(name, f, reps=400):
     for _ in range(reps):
         f(); torch.cuda.synchronize()
     print(f"{name:16s} {(time.perf_counter() - t0) / reps * 1e6:8.1f} us per call (synchronised)")
+def issue_rate(name, f, reps=400):
+    """unsynchronised: per-call cost when calls are issued back to back = max(host work per call, device work per call)"""
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"{name:16s} host issue {t_issue / reps * 1e6:8.1f} us per call, with the final drain {t_all / reps * 1e6:8.1f} us")
+def kernels(name, f):
+    from pailliercryptolib_python_amd import engine
+    engine.profile_enable(True)
+    f(); torch.cuda.synchronize()
+    print(f"{name:16s} kernels (last C call): {engine.profile_last()}")
+    engine.profile_enable(False)
 for name, f in rows.items():
     if want is None or name in want: timeit(name, f)
+for name, f in rows.items():
+    if want is None or name in want: issue_rate(name, f)
+for name, f in rows.items():
+    if want is None or name in want: kernels(name, f)
 for name, f in rows.items():
     if want is not None and name not in want: continue
     if want is None and name in ("add_ctct_lazy",): continue
