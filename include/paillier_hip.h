@@ -106,6 +106,12 @@ int pai_pubkey_info(const pai_pubkey* pk, int* key_bits, int* n_words, int* ct_w
  * eviction): device bytes, window width in bits, number of windows.  The first keys of a device get the big table (1/32 of
  * the device memory), later ones the small operating point (PAI_FB_BIG_KEYS / PAI_FB_SMALL_TABLE_MB). */
 int pai_pubkey_table_info(const pai_pubkey* pk, size_t* table_bytes, int* window_bits, int* windows);
+/* The batch sizes at which this key's calls change kernel family on its device (csrc/path_ranges.hpp: every range is a number
+ * of elements per compute unit times the device's CU count; PAI_LATENCY_MAX / PAI_LAT_ADD_MAX / PAI_TUNE overrides included):
+ * op 0 = pai_decrypt, 1 = pai_encrypt (DJN), 2 = pai_ct_mul, 3 = pai_ct_add*.  An edge E separates N = E from N = E + 1.
+ * Writes at most `cap` edges (ascending) and the full count.  For tests and probes that want to stand on both sides of a switch
+ * (tests/test_gpu_path_edges.py); no reference counterpart. */
+int pai_path_edges(const pai_pubkey* pk, int op, size_t* edges, int cap, int* count);
 
 /* ipclKeypair.generate_keypair(n_length, enable_DJN) — bindings/ipcl_bindings.cpp:12-15 -> ipcl::generateKeypair
  * (timed by the reference's BM_KeyGen, bench/bench_ipcl_python.py:13-19).  Host-only (no device work): two random primes

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "pai_host_modexp": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, voidp]),
     "pai_pubkey_info": (C.c_int, [voidp] + [C.POINTER(C.c_int)] * 7),
     "pai_pubkey_table_info": (C.c_int, [voidp, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pai_path_edges": (C.c_int, [voidp, C.c_int, C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]),
     "pai_privkey_create": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, C.POINTER(voidp)]),
     "pai_privkey_destroy": (None, [voidp]),
     "pai_raw_encrypt": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),

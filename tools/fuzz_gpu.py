@@ -1,6 +1,6 @@
 """Randomised differential run of the C ABI against CPython integers (dev tool; the committed tests are the fixed cases).
 Random batch sizes, operand patterns with long carry chains (all-ones runs, values next to 0 / M), every key size.
-    python tools/fuzz_gpu.py [seconds]"""
+    python tools/fuzz_gpu.py [seconds] [seed]        (tests/test_gpu_fuzz.py runs a bounded, seeded pass in the driver's suite)"""
 import ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -10,7 +10,8 @@ from tests._util import DevArray, host_ptr, ints_to_limbs, limbs_to_ints
 from tests.test_gpu_paillier_abi import NativeKey, bench_key, seeded_key
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(int(time.time()))
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = np.random.default_rng(SEED)
 KEY_BITS = (1024, 1536, 2048, 2560, 3072, 3328, 3584, 4096)      # 3328 / 3584: either side of the one- / two-limb chain layouts of the small-batch pipeline
 def key_for(b):
     if b == 2048: return bench_key()
@@ -165,4 +166,4 @@ while time.time() - t0 < budget:
             assert got2[i] == (pow(a[i], 1 << int(dl2[i]), M) if dl2[i] > 0 else a[i]), ("pow2_digit", bits, N, i)
         os.environ.pop("PAI_POW2_DIGIT_MIN", None)
     rounds += 1; checks += 13
-print(json.dumps({"rounds": rounds, "checks": checks, "seconds": round(time.time() - t0, 1), "failures": 0}))
+print(json.dumps({"rounds": rounds, "checks": checks, "seconds": round(time.time() - t0, 1), "failures": 0, "seed": SEED}))

@@ -1,11 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out/r06
-timeout 900 python -m pytest tests/test_gpu_api.py tests/test_gpu_transcripts.py -m gpu -q -x 2>&1 | tail -5
-timeout 300 python -m pytest tests/test_gpu_paillier_abi.py -m gpu -q -x -k "host_stage" 2>&1 | tail -3
-timeout 900 python bench.py --steps 2 --warmup 1 --no-configs --no-cpu-baseline > gpurun_out/r06/bench_b.json 2> gpurun_out/r06/bench_b.err; echo "bench rc=$?"
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r06/bench_b.json').read().strip().splitlines()[-1])
-print(json.dumps(d.get('reference_bench_summary_us')))
-print(json.dumps(d.get('small_batch')))
-PY
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > gpurun_out/r06/gputest_after_refactor.log; cat gpurun_out/r06/gputest_after_refactor.log
+timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/r06/bench_c.json 2> gpurun_out/r06/bench_c.err; echo "bench rc=$?"
+tail -c 1200 gpurun_out/r06/bench_c.json
