@@ -30,11 +30,13 @@ static void add_aligned_common(const pai_pubkey* pk, const uint32_t* d_a, const 
     // Montgomery domain itself, so the geometry's R does not show in the result
     const ModSetup* L = d_entry == nullptr ? lat_add_ctx(pk, N, false, 4) : nullptr;
     const GeoOps* g = L ? L->geo : pk->msq.geo;
+    // ... on the minus-one context of n^2 where the key has one (PAI_DISABLE=lat_add_m1: the conventional context)
+    const bool m1 = L != nullptr && pk->lat_m1_ok && g->t >= 16 && !knob_disabled("lat_add_m1");
     g_last_times.clear();
     ScopedKernelTimer t("k_add_aligned", (hipStream_t)stream);
-    g->add_aligned((hipStream_t)stream, L ? (int)((N + g->epb - 1) / g->epb) : grid_for(g, N, pk->dev.ncu), L ? L->d_ctx : pk->msq.d_ctx,
-                   d_a, d_b, b_bcast, d_delta, d_out, (int)N,
-                   pk->ct_words, d_entry);
+    g->add_aligned((hipStream_t)stream, L ? (int)((N + g->epb - 1) / g->epb) : grid_for(g, N, pk->dev.ncu),
+                   m1 ? pk->lat_msq_m1.d_ctx : (L ? L->d_ctx : pk->msq.d_ctx), d_a, d_b, b_bcast, d_delta, d_out, (int)N,
+                   pk->ct_words, d_entry, m1 ? pk->lat_msq.d_ctx : nullptr);
     t.stop();
     HIP_CHECK(hipGetLastError());
 }

@@ -273,12 +273,14 @@ static int ct_pow2_impl(const pai_pubkey* pk, uint32_t* d_ct, const int32_t* d_d
         ScopedKernelTimer t("k_pow2", (hipStream_t)stream);
         if (const ModSetup* L = lat_add_ctx(pk, N, false, 4)) {           // small batches: an integer per wavefront (as the aligned additions)
             const GeoOps* gl = L->geo;
-            gl->pow2((hipStream_t)stream, (int)((N + gl->epb - 1) / gl->epb), L->d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words);
+            const bool m1 = pk->lat_m1_ok && gl->t >= 16 && !knob_disabled("lat_add_m1");       // ... on the minus-one context of n^2
+            gl->pow2((hipStream_t)stream, (int)((N + gl->epb - 1) / gl->epb), m1 ? pk->lat_msq_m1.d_ctx : L->d_ctx, d_ct, d_delta, delta_bcast,
+                     (int)N, pk->ct_words, m1 ? pk->lat_msq.d_ctx : nullptr);
             t.stop();
             HIP_CHECK(hipGetLastError());
             return;
         }
-        g->pow2((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words);
+        g->pow2((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_ct, d_delta, delta_bcast, (int)N, pk->ct_words, nullptr);
         t.stop();
         HIP_CHECK(hipGetLastError());
     });

@@ -140,16 +140,32 @@ struct GeoInst {
         hipLaunchKernelGGL(k_sq_chain<G>, dim3(1), dim3(BLOCK_THREADS), G::LDS_BYTES, s, c, (const MontCtx*)nullptr, base, w32, out, h, nsnap);
     }
     static void pow2(hipStream_t s, int grid, const MontCtx* c, uint32_t* ct, const int32_t* delta, int delta_bcast,
-                     int n, int w32) {
+                     int n, int w32, const MontCtx* fin) {
         constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
+        if constexpr (G::T >= 16) {
+            if (fin != nullptr) {        // minus-one context (c) with the true modulus' context (fin): see add_aligned
+                using GA = Geo<G::NLL, G::T, G::U, false, true>;
+                set_lds((const void*)k_pow2<GA>, bytes);
+                hipLaunchKernelGGL(k_pow2<GA>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, ct, delta, delta_bcast, n, w32, fin);
+                return;
+            }
+        }
         set_lds((const void*)k_pow2<GM>, bytes);
-        hipLaunchKernelGGL(k_pow2<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, ct, delta, delta_bcast, n, w32);
+        hipLaunchKernelGGL(k_pow2<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, ct, delta, delta_bcast, n, w32, nullptr);
     }
     static void add_aligned(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, int b_bcast,
-                            const int32_t* delta, uint32_t* out, int n, int w32, const uint32_t* entry) {
+                            const int32_t* delta, uint32_t* out, int n, int w32, const uint32_t* entry, const MontCtx* fin) {
         constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;
+        if constexpr (G::T >= 16) {
+            if (fin != nullptr) {        // wide-group geometries with a minus-one context (c) and the true modulus' context (fin)
+                using GA = Geo<G::NLL, G::T, G::U, false, true>;
+                set_lds((const void*)k_add_aligned<GA>, bytes);
+                hipLaunchKernelGGL(k_add_aligned<GA>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, b_bcast, delta, out, n, w32, entry, fin);
+                return;
+            }
+        }
         set_lds((const void*)k_add_aligned<GM>, bytes);
-        hipLaunchKernelGGL(k_add_aligned<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, b_bcast, delta, out, n, w32, entry);
+        hipLaunchKernelGGL(k_add_aligned<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, b_bcast, delta, out, n, w32, entry, nullptr);
     }
     static void addn(hipStream_t s, int grid, const MontCtx* c, AddnArgs A, uint32_t* out, int n, int w32, const uint32_t* rpow) {
         constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the domain-entry constant

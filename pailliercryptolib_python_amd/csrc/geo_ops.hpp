@@ -34,12 +34,12 @@ struct GeoOps {
     void (*dec_a)(hipStream_t, int gridx, DecAParams, const uint32_t* ct, uint32_t* u_out, int n, uint32_t* table);
     void (*dec_b)(hipStream_t, int grid, DecBParams, const uint32_t* u_in, uint32_t* m_out, int n);
     void (*pow2)(hipStream_t, int grid, const MontCtx*, uint32_t* ct, const int32_t* delta, int delta_bcast, int n,
-                 int w32);
+                 int w32, const MontCtx* fin);
     // out_i = a_i * b_i with the lower-exponent side raised by ^(2^|delta_i|) first (delta = exponent(a) - exponent(b))
     // out[j] = base^(2^(h j)) mod M, j < nsnap, plain packed rows: one chain of squarings (fin: see modexp_var_win)
     void (*sq_chain)(hipStream_t, const MontCtx*, const MontCtx* fin, const uint32_t* base, int w32, uint32_t* out, int h, int nsnap);
     void (*add_aligned)(hipStream_t, int grid, const MontCtx*, const uint32_t* a, const uint32_t* b, int b_bcast,
-                        const int32_t* delta, uint32_t* out, int n, int w32, const uint32_t* entry);
+                        const int32_t* delta, uint32_t* out, int n, int w32, const uint32_t* entry, const MontCtx* fin);
     // n-ary sum (k_addn): out_i = prod_j op_j[i]^(2^raise_j[i]); rpow = the key's table of R^m, |m| <= RPOW_SPAN, NL limbs per row
     void (*addn)(hipStream_t, int grid, const MontCtx*, AddnArgs, uint32_t* out, int n, int w32, const uint32_t* rpow);
     // words of table scratch needed by modexp_fixed / dec_a for `blocks` resident workgroups

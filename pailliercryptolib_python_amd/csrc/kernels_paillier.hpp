@@ -821,7 +821,7 @@ k_dec_b(DecBParams P, const uint32_t* __restrict__ u_in /*[2][n][u_words]*/, uin
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_pow2(const MontCtx* __restrict__ ctx, uint32_t* ct, const int32_t* __restrict__ delta, int delta_bcast,
-       int n, int w32) {
+       int n, int w32, const MontCtx* __restrict__ fin) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using WT = WaveTile<G>;
     uint32_t* stage = lds + G::LDS_WORDS + G::NL;
@@ -830,7 +830,7 @@ k_pow2(const MontCtx* __restrict__ ctx, uint32_t* ct, const int32_t* __restrict_
     load_modulus<G>(nm, ctx, lds);
     for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) r2_lds[i] = ctx->r2[i];
     __syncthreads();
-    const uint32_t n0inv = ctx->n0inv;
+    const uint32_t n0inv = G::M1 ? ctx->rows / G::U : ctx->n0inv;      // minus-one contexts (small batches, as k_add_aligned): row blocks
     constexpr int WPB = BLOCK_THREADS / 64;
     const int wtiles = (n + WT::EPW - 1) / WT::EPW;
     clear_stage<G>(stage);
@@ -869,7 +869,8 @@ k_pow2(const MontCtx* __restrict__ ctx, uint32_t* ct, const int32_t* __restrict_
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) x[j] = keep ? z[j] : x[j];
         }
-        cond_sub<G::NLL, G::T>(x, nm);
+        if constexpr (G::M1) m1_reduce_to_true_modulus<G>(x, lds, fin);
+        else cond_sub<G::NLL, G::T>(x, nm);
         __builtin_amdgcn_s_setprio(2);
         pack_row<G>(x, stage);                                       // rows with delta <= 0 come back unchanged
         store_tile<G>(stage, ct + (size_t)row0 * w32, rows, w32);
@@ -922,14 +923,18 @@ k_sq_chain(const MontCtx* __restrict__ ctx, const MontCtx* __restrict__ fin, con
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_add_aligned(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, int b_bcast,
-              const int32_t* __restrict__ delta, uint32_t* out, int n, int w32, const uint32_t* __restrict__ entry) {
+              const int32_t* __restrict__ delta, uint32_t* out, int n, int w32, const uint32_t* __restrict__ entry,
+              const MontCtx* __restrict__ fin) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using WT = WaveTile<G>;
     uint32_t* stage = lds + G::LDS_WORDS + G::NL;
     uint32_t* r2_lds = stage + G::STAGE_WORDS;           // the domain-entry constant (R^2 mod M), one copy per workgroup
     typename G::NM nm;
     load_modulus<G>(nm, ctx, lds);
-    const uint32_t n0inv = ctx->n0inv;
+    // minus-one contexts (small batches on one integer per wavefront, round 6): ctx is the context of n^2 k, its scalar the number
+    // of row blocks, and `fin` the context of n^2 itself for the way out (m1_reduce_to_true_modulus) — a product without the
+    // dependent quotient digit per row: 51 -> 33 us for the reference's BM_Add_CTCT shifts (profiles/r06/lat_add_m1.jsonl)
+    const uint32_t n0inv = G::M1 ? ctx->rows / G::U : ctx->n0inv;
     constexpr int WPB = BLOCK_THREADS / 64;
     const int wtiles = (n + WT::EPW - 1) / WT::EPW;
     clear_stage<G>(stage);
@@ -981,12 +986,14 @@ k_add_aligned(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) lhs[j] = last ? o[j] : x[j];
             if (s >= 0) stage_b<G>(x, lds);              // the right operand of squarings and of the last product: x itself
-            mont_mul<G::NLL, G::U, G::T>(r, lhs, s < 0 ? r2_lds : o_lds, s < 0 ? 1 : G::EPB, nm, n0inv);
+            if constexpr (G::M1) mont_mul_m1<G::NLL, G::U, G::T>(r, lhs, s < 0 ? r2_lds : o_lds, s < 0 ? 1 : G::EPB, nm, (int)n0inv);
+            else mont_mul<G::NLL, G::U, G::T>(r, lhs, s < 0 ? r2_lds : o_lds, s < 0 ? 1 : G::EPB, nm, n0inv);
             const bool keep = s < 0 || last || s < cnt;
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) x[j] = keep ? r[j] : x[j];
         }
-        cond_sub<G::NLL, G::T>(x, nm);
+        if constexpr (G::M1) m1_reduce_to_true_modulus<G>(x, lds, fin);      // a residue modulo n^2 k -> the canonical one modulo n^2
+        else cond_sub<G::NLL, G::T>(x, nm);
         __builtin_amdgcn_s_setprio(2);
         pack_row<G>(x, stage);
         store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);

@@ -333,7 +333,7 @@ struct ScopedKernelTimer {
 // PAI_LATENCY_MAX, PAI_LAT_ADD_MAX, PAI_POW2_DIGIT_MIN).  Everything the tests and probes use to steer a call onto a
 // particular path lives in two lists, read at every use (tests change them between calls):
 //   PAI_DISABLE="padic,pair,..."   engines / forms to leave out: padic (digit-pair engines: lane-group and wide fallbacks
-//                                  serve), pair, pair_ctmul, wide, gform (plain fixed-base tables), fb_chain, lat_dense, lat_enc_m1
+//                                  serve), pair, pair_ctmul, wide, gform (plain fixed-base tables), fb_chain, lat_dense, lat_enc_m1, lat_add_m1
 //   PAI_TUNE="name=value,..."      fb_wbits, fb_digit_wbits, lat_fb_wbits, fb_gform_k, invert_chunk, mexp_wbits, mexp_lanes,
 //                                  mexp_by_rows, lat_rl, lat_mul_rl, lat_enc_tree (largest batch of that small-batch form, 0 = off)
 static const char* list_find(const char* list, const char* name) {       // -> the character behind `name` in the list, or NULL

@@ -22,13 +22,17 @@ for N in (16, 64, 256, 1024, 2048, 4096, 8192):
     delta = (torch.arange(N, device=dev) % 14).to(torch.int32)
     row = {"bits": bits, "N": N}
     ref = None
-    for lat in ("1000000", "0"):
-        os.environ["PAI_LAT_ADD_MAX"] = lat
+    for lat in ("1000000", "m1off", "0"):
+        os.environ["PAI_LAT_ADD_MAX"] = "1000000" if lat == "m1off" else lat
+        if lat == "m1off": os.environ["PAI_DISABLE"] = "lat_add_m1"          # the conventional context of n^2 (before round 6)
+        else: os.environ.pop("PAI_DISABLE", None)
         outs = (pub.ct_add(a, b), pub.ct_mont_mul(a, b), pub.ct_add_aligned(a, b, delta))
         if ref is None: ref = [o.clone() for o in outs]
         assert all(torch.equal(o, r) for o, r in zip(outs, ref)), (N, lat)
-        k = "lat" if lat != "0" else "thr"
+        k = {"1000000": "lat", "m1off": "lat_conv", "0": "thr"}[lat]
         row[f"add_{k}_ms"] = round(tm(lambda: pub.ct_add(a, b)), 4)
         row[f"mont_{k}_ms"] = round(tm(lambda: pub.ct_mont_mul(a, b)), 4)
         row[f"aligned13_{k}_ms"] = round(tm(lambda: pub.ct_add_aligned(a, b, delta)), 4)
+        d2 = (delta % 3).contiguous()
+        row[f"aligned2_{k}_ms"] = round(tm(lambda: pub.ct_add_aligned(a, b, d2)), 4)
     print(json.dumps(row), flush=True)

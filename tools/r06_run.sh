@@ -1,5 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out/r06
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > gpurun_out/r06/gputest_after_refactor.log; cat gpurun_out/r06/gputest_after_refactor.log
-timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/r06/bench_c.json 2> gpurun_out/r06/bench_c.err; echo "bench rc=$?"
-tail -c 1200 gpurun_out/r06/bench_c.json
+timeout 900 python -m pytest tests/test_gpu_paillier_abi.py tests/test_gpu_path_edges.py tests/test_gpu_keysizes.py tests/test_gpu_api.py -m gpu -q -x -k "pow2 or aligned or edges or sub or chains or staged" 2>&1 | tail -5
+timeout 200 python tools/fuzz_gpu.py 60 777 2>&1 | tail -2
