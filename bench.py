@@ -90,7 +90,7 @@ CONFIGS = {
     "cfg5": {"key_bits": 4096, "batch": 1 << 18, "baseline": "configs[4]: 4096-bit key, batch 2^18 encrypt with CRT decrypt"},
 }
 # PMC summaries by key size, newest first: (file, batch the profile was taken at)
-PMC_FILES = {2048: [("profiles/r05/pmc_bench_r05.json", 1 << 20), ("profiles/r04/pmc_bench_r04.json", 1 << 20), ("profiles/r03/pmc_bench_r03.json", 1 << 20),
+PMC_FILES = {2048: [("profiles/r06/pmc_bench_r06.json", 1 << 20), ("profiles/r05/pmc_bench_r05.json", 1 << 20), ("profiles/r04/pmc_bench_r04.json", 1 << 20), ("profiles/r03/pmc_bench_r03.json", 1 << 20),
                     ("profiles/r02/pmc_bench_r02.json", 1 << 20), ("profiles/r01/pmc_bench_r01d.json", 1 << 20)],
              3072: [("profiles/r05/pmc_cfg4_r05.json", 1 << 20), ("profiles/r04/pmc_cfg4_r04.json", 1 << 20), ("profiles/r03/pmc_k3072_r03.json", 1 << 16)],
              4096: [("profiles/r05/pmc_cfg5_r05.json", 1 << 18), ("profiles/r04/pmc_cfg5_r04.json", 1 << 18), ("profiles/r03/pmc_k4096_r03.json", 1 << 16)]}

@@ -10,6 +10,28 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
         if (N == 0) return;
         DeviceScope scope_(pk->device);
         g_last_times.clear();
+        if (pk->d_mu29 && N >= add_div_min((size_t)pk->dev.ncu)) {
+            // large wire-form batches at the key sizes whose n fills 71 limbs: base-n digits and Barrett division on the
+            // one-element-per-lane engine (kernels_ctadd_div.hpp), 10 units of 72^2 limb products instead of 16
+            hipStream_t s = (hipStream_t)stream;
+            std::lock_guard<std::mutex> lk(pk->mu);
+            const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
+            const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
+            pk->add_div_scratch.ensure(ctadd_div_scratch_bytes(pk->penc_nl, (size_t)grid));
+            CtAddDivParams Q;
+            Q.n29 = pk->d_n29;
+            Q.mu29 = pk->d_mu29;
+            Q.scratch = pk->add_div_scratch.as<uint4>();
+            Q.ct_words = pk->ct_words;
+            Q.b_bcast = b_bcast;
+            OrderScope order_(pk->order, s);
+            ScopedKernelTimer t("k_ctadd_div", s);
+            if (!launch_ctadd_div(pk->penc_nl, s, grid, Q, d_a, d_b, d_out, (int)N))
+                throw PaiError(PAI_E_INTERNAL, "no division kernel for this limb count");
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         const ModSetup* L = lat_add_ctx(pk, N, false, 2);
         const GeoOps* g = L ? L->geo : pk->msq.geo;
         ScopedKernelTimer t("k_modmul", (hipStream_t)stream);

@@ -148,6 +148,14 @@ static size_t pow2_digit_min_elements(size_t ncu) {
 // (profiles/r04/lat_add_probe.jsonl): wire-form a b 30 against 60 us up to 1 024 elements (39 / 65 at 2 048, level at 4 096), the
 // tagged single product 29 against 35 us up to 1 024 (level at 2 048), aligned additions with shifts up to 13: 0.18 against 0.44 ms
 // up to 1 024, 0.31 / 0.45 at 4 096 — hence the callers' scale factors 2 (wire form) / 1 (tagged) / 4 (aligned, pow2) / 2 (raw encrypt)
+// PAI_TUNE add_div_min: wire-form ct + ct batches of at least this many elements take the division kernel on the one-element-per-lane
+// engine (0 < v; PAI_DISABLE=add_div switches it off).  One workgroup per CU, one element per lane: 256 elements per CU fill a round
+static size_t add_div_min(size_t ncu) {
+    if (knob_disabled("add_div")) return (size_t)-1;
+    long long v;
+    if (knob_tune("add_div_min", &v)) return (size_t)v;
+    return 192 * ncu;
+}
 static size_t lat_add_max(size_t ncu) {
     if (const char* env = std::getenv("PAI_LAT_ADD_MAX")) return (size_t)std::strtoull(env, nullptr, 10);
     return 4 * ncu;
@@ -172,7 +180,7 @@ static std::vector<size_t> path_edges(int op, int key_bits, size_t ncu) {
              latency_max_elements(LAT_MUL, key_bits, ncu)};
         break;
     case 3:
-        e = {lat_add_max(ncu), 2 * lat_add_max(ncu), 4 * lat_add_max(ncu), pow2_digit_min_elements(ncu) - 1};
+        e = {lat_add_max(ncu), 2 * lat_add_max(ncu), 4 * lat_add_max(ncu), pow2_digit_min_elements(ncu) - 1, add_div_min(ncu) - 1};
         break;
     default:
         break;

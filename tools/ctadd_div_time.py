@@ -1,0 +1,35 @@
+"""Dev probe: wire-form ct + ct of 2^20 resident ciphertexts at a 2048-bit key: the division kernel on the one-element-per-lane engine
+(kernels_ctadd_div.hpp) against the two Montgomery products on lane groups, and the lazy single product beside them.
+python tools/ctadd_div_time.py [log2 batch = 20]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from bench import synthetic_key
+from pailliercryptolib_python_amd import engine
+dev = torch.device('cuda', 0)
+key = synthetic_key(2048, 0x1234567)
+pub = engine.PublicKeyHandle(key.n, 2048, key.hs, key.randbits, device=dev)
+B = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
+g = torch.Generator(device=dev); g.manual_seed(1)
+a = torch.randint(-(2**31), 2**31, (B, pub.ct_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+b = torch.randint(-(2**31), 2**31, (B, pub.ct_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+a[:, -1] &= 0x00FFFFFF; b[:, -1] &= 0x00FFFFFF
+out = pub.empty_ct(B); ref = pub.empty_ct(B)
+def tm(f, reps=5):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+row = {"batch": B}
+row["div_ms"] = round(tm(lambda: pub.ct_add(a, b, out=out)), 3)
+engine.profile_enable(True); pub.ct_add(a, b, out=out); row["div_kernel"] = engine.profile_last(); engine.profile_enable(False)
+os.environ["PAI_DISABLE"] = "add_div"
+row["montgomery_x2_ms"] = round(tm(lambda: pub.ct_add(a, b, out=ref)), 3)
+row["lazy_single_product_ms"] = round(tm(lambda: pub.ct_mont_mul(a, b, out=ref)), 3)
+pub.ct_add(a, b, out=ref)
+os.environ.pop("PAI_DISABLE")
+row["same_bits"] = bool(torch.equal(out, ref))
+row["div_M_per_s"] = round(B / row["div_ms"] / 1e3, 1)
+row["montgomery_M_per_s"] = round(B / row["montgomery_x2_ms"] / 1e3, 1)
+print(json.dumps(row))
