@@ -23,7 +23,6 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
             Q.mu29 = pk->d_mu29;
             Q.scratch = pk->add_div_scratch.as<uint4>();
             Q.ct_words = pk->ct_words;
-            Q.b_bcast = b_bcast;
             OrderScope order_(pk->order, s);
             ScopedKernelTimer t("k_ctadd_div", s);
             if (!launch_ctadd_div(pk->penc_nl, s, grid, Q, d_a, d_b, d_out, (int)N))

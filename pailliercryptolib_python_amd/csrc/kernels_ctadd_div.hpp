@@ -10,7 +10,8 @@
 //     q1 = limbs K-1 .. 2K of x  (NL limbs) ;  q3 = floor(q1 mu / B^NL),  mu = floor(B^(2K) / n)  (NL limbs) — the HIGH half of one product
 //     r  = (x mod B^NL) - (q3 n mod B^NL)  — the LOW half of one product, half its limb products — ;  r -= n at most three times (the high half
 //          is cut two limbs below its first column, which can cost one more unit of q3), q3 follows
-// On the one-element-per-lane engine a half product costs half: 10 units wire -> wire (4 divisions of 1.5, products 1 + 2 + 1) against 16
+// On the one-element-per-lane engine a half product costs about half (0.63 / 0.58 at chunk granularity): 8.8 units wire -> wire (4 divisions of
+// 1.21, products 1 + 2 + 1) against 16 — measured 3.2 ms per 2^20 against 3.5-3.7 (67 % multiplies, one wave per SIMD)
 // — and on lane groups it would not (the lanes that own the unused columns idle), which is why this lives here.  Serves the key sizes
 // whose n fills 71 limbs (2031 .. 2059 bits: the 2048-bit keys), large batches; every other case keeps the Montgomery kernels.
 // Buffers per lane: two NL-limb digit buffers in LDS (A, B: the operand of the running product and the addend / remainder), six in a
@@ -24,7 +25,7 @@ struct CtAddDivParams {
     const uint32_t* n29;         // n, NL limbs radix 29
     const uint32_t* mu29;        // floor(B^(2 (NL-1)) / n), NL limbs
     uint4* scratch;              // [6][NC][nslots]
-    int ct_words, b_bcast;
+    int ct_words;
 };
 
 enum DvHalf { DV_FULL = 0, DV_LOW = 1, DV_HIGH = 2 };
@@ -131,9 +132,6 @@ struct DvOps {
     }
     static PAI_DEV auto uniform(const uint32_t* __restrict__ k) {
         return [=](int blk, uint32_t (&xv)[U]) { E::digits_uniform(k, blk, xv); };
-    }
-    static PAI_DEV auto lds_digits(const uint4* X) {
-        return [=](int blk, uint32_t (&xv)[U]) { E::digits(X, blk, xv); };
     }
     static PAI_DEV void to_buf(MBuf G, const uint32_t (&r)[NL]) {
 #pragma unroll
@@ -284,7 +282,7 @@ k_ctadd_div(CtAddDivParams P, const uint32_t* __restrict__ a, const uint32_t* __
         uint32_t r[NL], q[NL], none[NL];
         uint32_t corr;
         // ---- (b1, b0) = divmod(b, n): b0 -> G2, b1 -> G3 -------------------------------------------------------
-        load_dividend(b + (size_t)(P.b_bcast ? 0 : es) * P.ct_words);
+        load_dividend(b + (size_t)es * P.ct_words);
         D::divmod(r, &corr, A, B, nm, mu);
         D::to_buf(G(2), r);
         D::quotient(q, A, corr);
