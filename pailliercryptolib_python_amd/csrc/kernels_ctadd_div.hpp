@@ -93,8 +93,9 @@ PAI_DEV void dv_product(uint32_t (&hi)[E::NC * 4], const uint32_t (&W)[E::NC * 4
         }
         sink(blk, low);
         E::slide(acc);
-        // two products per column and row (TWO) fill the 64-bit columns twice as fast
-        if (blk != E::NB - 1 && ((blk + 1) * U) % (TWO ? E::P2 : E::P1) == 0) E::normalize(acc);
+        // a column takes U products of < 2^58 per block (2 U with TWO): 36 of them (three blocks; two with TWO) stay below 2^63.2 on top of a
+        // normalised column — one carry sweep of the window per product instead of the engine's conservative cadence
+        if (blk != E::NB - 1 && (blk + 1) % (TWO ? 2 : 3) == 0) E::normalize(acc);
     }
     if constexpr (HALF != DV_LOW) E::finish(acc, hi);
 }
@@ -167,6 +168,12 @@ struct DvOps {
         return ge ? 1u : 0u;
     }
 
+    static PAI_DEV bool ge_mod(const uint32_t (&x)[NL], const uint32_t* __restrict__ nm) {       // x >= n
+        int32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) borrow = ((int32_t)x[j] - (int32_t)nm[j] + borrow) >> RB;
+        return borrow == 0;
+    }
     // Barrett division of the 2 NL-limb dividend whose limbs K-1 .. 2K sit in A and whose low NL limbs sit in B (K = NL - 1).
     // Returns the remainder in r (registers) and leaves q3 (the quotient BEFORE its correction) in A; *corr = 0, 1 or 2 is to be added to it.
     static PAI_DEV void divmod(uint32_t (&r)[NL], uint32_t* corr, uint4* A, uint4* B, const uint32_t* __restrict__ nm,
@@ -198,9 +205,13 @@ struct DvOps {
         dv_product<E, DV_LOW, false, false>(none, none, A, uniform(nm), A, uniform(nm), sub_into_b);
         wave_lds_fence();
         lds_to_regs(r, B);
-        uint32_t c = cond_sub_cnt(r, nm);             // q - 3 <= q3 <= q (HAC 14.42 with the truncated high product)
-        c += cond_sub_cnt(r, nm);
-        c += cond_sub_cnt(r, nm);
+        // q - 3 <= q3 <= q (HAC 14.42 with the truncated high product): up to three subtractions of n — the second and the third only when
+        // some lane of the wave still needs one (a 72-limb compare instead of a compare-subtract-select; both are rare)
+        uint32_t c = cond_sub_cnt(r, nm);
+        if (__any(ge_mod(r, nm))) {
+            c += cond_sub_cnt(r, nm);
+            if (__any(ge_mod(r, nm))) c += cond_sub_cnt(r, nm);
+        }
         *corr = c;
     }
     // q (registers) <- the quotient: q3 from A plus its correction
