@@ -535,13 +535,11 @@ class PaillierEncryptedNumber:
                 base[idx] = h.ct_invert(ct[idx].contiguous(), flag=flags[-1])
         else:
             base = ct
-        mag = np.abs(mant).astype(np.uint64)
+        mag = np.abs(mant)                               # |mantissa| < 2^53: the int64 bit pattern IS the little-endian word pair
         bits = max(1, int(mag.max()).bit_length())
-        e = np.empty((mant.shape[0], 2), dtype=np.uint32)
-        e[:, 0] = (mag & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        e[:, 1] = (mag >> np.uint64(32)).astype(np.uint32)
+        e = mag.view(np.uint32).reshape(-1, 2)
         ew = (bits + 31) // 32
-        return self.public_key.pubkey.ct_mul_words(base, np.ascontiguousarray(e[:, :ew]), bits)
+        return self.public_key.pubkey.ct_mul_words(base, e if ew == 2 else np.ascontiguousarray(e[:, :ew]), bits)
 
     def __mul__(self, other):
         """ipcl_python.py:412-488."""
