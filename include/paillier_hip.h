@@ -137,6 +137,12 @@ void pai_privkey_destroy(pai_privkey* sk);
 /* ipclPublicKey.encrypt(pt, make_secure=false) — classes.cpp:53-60; L3 raw_encrypt, ipcl_python.py:103-106.
  * d_ct[i] = (1 + d_m[i] * n) mod n^2.   d_m: [N][n_words], each < n.   d_ct: [N][ct_words]. */
 int pai_raw_encrypt(const pai_pubkey* pk, const uint32_t* d_m, size_t N, uint32_t* d_ct, void* stream);
+/* PaillierEncryptedNumber + plaintext — ipcl_python.py:495-504 raw-encrypts the plaintext (classes.cpp:53-60 with make_secure=false)
+ * and :365-381 / classes.cpp:318-321 multiply the two ciphertexts; in ONE pass here:
+ * d_out[i] = d_ct[i] * (1 + d_m[i] * n) mod n^2, wire form in and out (round 6: the reference's BM_Add_CTPT is two launches and an
+ * intermediate array otherwise).  d_m: [N][n_words] residues < n (already encoded AT the ciphertext's exponents: pai_fp_encode_at).
+ * d_out may alias d_ct.  Small batches run on the latency geometry (three sequential products), others on lane groups. */
+int pai_ct_add_plain(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_m, size_t N, uint32_t* d_out, void* stream);
 
 /* ipclPublicKey.encrypt(pt, make_secure=true) — classes.cpp:53-60 with the randomness made explicit.
  * DJN keys:      d_r: [N][r_words], r_i < 2^randbits;   ct_i = (1 + m_i n) * hs^{r_i} mod n^2.

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "pai_privkey_create": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, C.POINTER(voidp)]),
     "pai_privkey_destroy": (None, [voidp]),
     "pai_raw_encrypt": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
+    "pai_ct_add_plain": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp, voidp]),
     "pai_encrypt": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp, voidp]),
     "pai_obfuscate": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp]),
     "pai_decrypt": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),

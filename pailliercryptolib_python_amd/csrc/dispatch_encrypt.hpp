@@ -261,3 +261,39 @@ int pai_obfuscate(const pai_pubkey* pk, uint32_t* d_ct, const uint32_t* d_r, siz
         encrypt_common(pk, nullptr, d_r, d_ct, d_ct, N, stream, false);
     });
 }
+
+// ct + plaintext in one pass: k_encrypt mode 3 with the ciphertext in the obfuscator's place ((1 + m n) * ct)
+int pai_ct_add_plain(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_m, size_t N, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && d_ct && d_m && d_out, "NULL argument");
+        if (N == 0) return;
+        DeviceScope scope_(pk->device);
+        hipStream_t s = (hipStream_t)stream;
+        g_last_times.clear();
+        std::lock_guard<std::mutex> lk(pk->mu);
+        ScopedKernelTimer t("k_encrypt(add_plain)", s);
+        if (N <= 2 * lat_add_max((size_t)pk->dev.ncu) && ensure_lat_ctx(pk)) {
+            const GeoOps* gl = pk->lat_msq.geo;
+            // ... on the minus-one context of n^2 where the key has one (as the small aligned additions; PAI_DISABLE=lat_add_m1)
+            const bool m1 = pk->lat_m1_ok && gl->t >= 16 && gl->t <= 64 && !knob_disabled("lat_add_m1");
+            if (m1 && !pk->d_lat_nR_m1) pk->d_lat_nR_m1 = upload_r29(hbn::mulmod(pk->n, pk->lat_msq_m1.R, pk->lat_msq_m1.M), pk->lat_msq_m1.nl);
+            if (!m1 && !pk->d_lat_nR) pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
+            EncParams PL;
+            PL.nsq = m1 ? pk->lat_msq_m1.d_ctx : pk->lat_msq.d_ctx;
+            PL.nR = m1 ? pk->d_lat_nR_m1 : pk->d_lat_nR;
+            PL.fin = m1 ? pk->lat_msq.d_ctx : nullptr;
+            PL.fb_table = nullptr;
+            PL.fb_windows = 0;
+            PL.fb_wbits = 0;
+            PL.pt_words = pk->n_words;
+            PL.ct_words = pk->ct_words;
+            PL.r_words = pk->r_words;
+            gl->encrypt(s, (int)((N + gl->epb - 1) / gl->epb), PL, d_m, d_ct, nullptr, d_out, (int)N, 3);
+        } else {
+            const GeoOps* g = pk->msq.geo;
+            g->encrypt(s, grid_for(g, N, pk->dev.ncu), pk->enc_params(), d_m, d_ct, nullptr, d_out, (int)N, 3);
+        }
+        t.stop();
+        HIP_CHECK(hipGetLastError());
+    });
+}

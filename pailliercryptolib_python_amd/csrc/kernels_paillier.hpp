@@ -70,7 +70,9 @@ k_encrypt(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restric
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     typename G::NM nm;
     load_modulus<G>(nm, P.nsq, lds);
-    const uint32_t n0inv = P.nsq->n0inv;
+    // (minus-one contexts, mode 3 on the wide-group geometries — pai_ct_add_plain: P.nsq is the context of n^2 k, P.nR = n R' in it, its
+    // scalar the number of row blocks, P.fin the context of n^2 itself for the way out)
+    const uint32_t n0inv = G::M1 ? P.nsq->rows / G::U : P.nsq->n0inv;
     const int t = G::gl();
     const int tiles = (n + G::EPB - 1) / G::EPB;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -124,7 +126,8 @@ k_encrypt(EncParams P, const uint32_t* __restrict__ m, const uint32_t* __restric
             load_const_slice<G>(r2, P.nsq->r2);
             mm_times<G>(c0, r2, lds, nm, n0inv);
         }
-        cond_sub<G::NLL, G::T>(c0, nm);
+        if constexpr (G::M1) m1_reduce_to_true_modulus<G>(c0, lds, P.fin);
+        else cond_sub<G::NLL, G::T>(c0, nm);
         if (live) store_elem<G>(c0, ct_out + (size_t)ei * P.ct_words, P.ct_words, lds);
     }
 }

@@ -200,6 +200,16 @@ class PublicKeyHandle:
         _native.check(self.lib.pai_raw_encrypt(self.h, _ptr(m), m.shape[0], _ptr(out), _stream(self.device)))
         return out
 
+    def ct_add_plain(self, ct: torch.Tensor, m: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ct_i * (1 + m_i n) mod n^2 in one pass (pai_ct_add_plain): ciphertext + raw-encrypted plaintext, wire form."""
+        self._chk(ct, self.ct_words, "ct")
+        self._chk(m, self.n_words, "m")
+        if m.shape[0] != ct.shape[0]:
+            raise RuntimeError("Size mismatch")
+        out = self.empty_ct(ct.shape[0]) if out is None else out
+        _native.check(self.lib.pai_ct_add_plain(self.h, _ptr(ct), _ptr(m), ct.shape[0], _ptr(out), _stream(self.device)))
+        return out
+
     def encrypt(self, m: torch.Tensor, r: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(m, self.n_words, "m")
         self._chk(r, self.r_words, "r")

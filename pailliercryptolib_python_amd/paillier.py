@@ -100,6 +100,27 @@ class PaillierPublicKey:
     def raw_encrypt(self, plaintext: Union[np.ndarray, list, int, float]) -> "PaillierEncryptedNumber":
         return self.encrypt(plaintext, apply_obfuscator=False)
 
+    def _encode_plain_addend(self, values, target: np.ndarray):
+        """(device residues [N, n_words], exponents int32[N]) of a float batch or an integer ndarray encoded AT the target
+        exponents (pai_fp_encode_at: the plaintext side of ct + plaintext, see encrypt's _align_to), or None when the batch
+        takes encrypt's general path (other element types, tiny moduli, device lists).  Raises what encrypt raises for NaN / inf."""
+        pub = self.pubkey
+        is_f64 = _fp.is_float_batch(values) and self.n.bit_length() > 66
+        is_i64 = (isinstance(values, np.ndarray) and values.dtype in (np.int16, np.int32, np.int64) and values.ndim == 1
+                  and values.shape[0] > 0 and self.n.bit_length() > 66)
+        if not (is_f64 or is_i64) or pub.fanout_devices(len(values)) is not None:
+            return None
+        tgt = np.ascontiguousarray(np.asarray(target, dtype=np.int32).reshape(-1))
+        if tgt.shape[0] not in (1, len(values)):
+            return None
+        h = pub.handle
+        x = _fp.checked_float64(values) if is_f64 else np.ascontiguousarray(values, dtype=np.int64)
+        # (the host rule first: nothing then stands between the codec launch and the caller's next launch)
+        expos = _fp.float64_exponents_at(x, tgt, self.n.bit_length()) if is_f64 and x.shape[0] <= HOST_EXPO_MAX else None
+        xs, ts = engine.small_operands([x, tgt], h.device)
+        m, expo_d = h.fp_encode_at(xs, ts)
+        return m, (expos if expos is not None else expo_d.cpu().numpy())
+
     def encrypt(self, values: Union[np.ndarray, list, int, float], apply_obfuscator: bool = True, *,
                 r: Optional[Union[torch.Tensor, np.ndarray]] = None, _align_to=None) -> "PaillierEncryptedNumber":
         """ipcl_python.py:108-147.  Scalars, lists and 1-D arrays of ints/floats; anything else is a
@@ -573,7 +594,20 @@ class PaillierEncryptedNumber:
             if self.__length != len(other):
                 raise ValueError("PaillierEncryptedNumber.__raw_add: array(list) size mismatch with PaillierEncryptedNumber")
             # the plaintext side is aligned in the plaintext domain (PaillierPublicKey.encrypt: _align_to)
-            other = self.public_key.encrypt(other, apply_obfuscator=False, _align_to=self._expo)
+            if 0 < self.__length <= _bindings.EAGER_ADD_MAX and self.__ipclCipherText._raw()[1] == 0:
+                # small batches: encode at the ciphertext's exponents and, when that aligned every element (the rule — an element
+                # that could not be shifted that far is the exception), ct * (1 + m n) in ONE pass (pai_ct_add_plain) instead
+                # of a raw encryption, an intermediate array and an addition
+                enc = self.public_key._encode_plain_addend(other, self._expo)
+                if enc is not None:
+                    m_dev, ye = enc
+                    if np.array_equal(ye, self._expo):
+                        res = self._h().ct_add_plain(self.__ipclCipherText._raw()[0], m_dev)
+                        return self._wrap(res, self._expo, self.__length, dom=0)
+                    other = PaillierEncryptedNumber(self.public_key, ipclCipherText(self.public_key.pubkey, self._h().raw_encrypt(m_dev)),
+                                                    exponents=ye, length=self.__length)
+            if not isinstance(other, PaillierEncryptedNumber):
+                other = self.public_key.encrypt(other, apply_obfuscator=False, _align_to=self._expo)
         elif np.isscalar(other) and isinstance(other, (int, float, np.integer, np.floating)):
             other = self.public_key.encrypt(other, apply_obfuscator=False,
                                             _align_to=[int(self._expo.min())] if self.__length else None)

@@ -1125,3 +1125,24 @@ def test_ct_add_by_division_matches_the_product_of_residues(k2048, monkeypatch):
     assert np.array_equal(got, ref)
     idx = [0, 1, 255, 256, N // 2, N - 1]
     assert limbs_to_ints(got[idx]) == [x * y % M for x, y in zip(limbs_to_ints(a[idx]), limbs_to_ints(b[idx]))]
+
+
+@pytest.mark.parametrize("lat_add", ["0", "4096"])
+def test_ct_add_plain_is_the_product_with_the_raw_encryption(k2048, lat_add, monkeypatch):
+    """pai_ct_add_plain (include/paillier_hip.h): ct * (1 + m n) mod n^2 in one pass — ipcl_python.py:495-504 followed by the
+    ciphertext product of classes.cpp:318-321 — on the latency geometry and on lane groups, edge residues, in place."""
+    monkeypatch.setenv("PAI_LAT_ADD_MAX", lat_add)
+    key = k2048.key
+    rng = np.random.default_rng(515)
+    for N in (1, 16, 300):
+        ct = rand_below(rng, key.nsq, N)
+        m = rand_below(rng, key.n, N)
+        m[0] = 0
+        if N > 2:
+            m[1], m[2], ct[2] = key.n - 1, 1, key.nsq - 1
+        dct, dm, out = DevArray(ints_to_limbs(ct, k2048.cw)), DevArray(ints_to_limbs(m, k2048.nw)), DevArray(shape=(N, k2048.cw))
+        _native.check(k2048.lib.pai_ct_add_plain(k2048.pk, dct.ptr, dm.ptr, N, out.ptr, None))
+        want = [c * (1 + x * key.n) % key.nsq for c, x in zip(ct, m)]
+        assert limbs_to_ints(out.get()) == want, (lat_add, N)
+        _native.check(k2048.lib.pai_ct_add_plain(k2048.pk, dct.ptr, dm.ptr, N, dct.ptr, None))
+        assert limbs_to_ints(dct.get()) == want, (lat_add, N, "in place")
