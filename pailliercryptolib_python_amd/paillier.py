@@ -193,7 +193,11 @@ class PaillierPublicKey:
             # float arrays: 8 B per element cross PCIe and the codec runs on the device (pai_fp_encode_f64)
             x = _fp.checked_float64(values)
             m, expo_d = h.fp_encode_f64(engine.small_operands([x], h.device)[0])
-            expos = _fp.float64_exponents(x) if x.shape[0] <= HOST_EXPO_MAX else expo_d.cpu().numpy()
+            if x.shape[0] <= HOST_EXPO_MAX:
+                # small batches: every launch first — the exponents (a host rule, no read-back) are computed while the device works
+                ct = pub.encrypt_words(m, apply_obfuscator, r)
+                return PaillierEncryptedNumber(self, ipclCipherText(self.pubkey, ct), exponents=_fp.float64_exponents(x), length=len(values))
+            expos = expo_d.cpu().numpy()
         elif is_i64:
             # the integer dtypes the reference's codec accepts (fixedpoint.py:72): exponent 0, residue = x mod n
             m, expo_d = h.fp_encode_i64(torch.from_numpy(np.ascontiguousarray(values, dtype=np.int64)).to(h.device))
