@@ -10,7 +10,7 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
         if (N == 0) return;
         DeviceScope scope_(pk->device);
         g_last_times.clear();
-        if (pk->d_mu29 && !b_bcast && N >= add_div_min((size_t)pk->dev.ncu)) {          // (a broadcast addend keeps the lane-group kernel: its one row is staged once per tile there)
+        if (pk->d_mu29 && !b_bcast && add_div_pays(N, (size_t)pk->dev.ncu)) {          // (a broadcast addend keeps the lane-group kernel: its one row is staged once per tile there)
             // large wire-form batches at the key sizes whose n fills 71 limbs: base-n digits and Barrett division on the
             // one-element-per-lane engine (kernels_ctadd_div.hpp), 10 units of 72^2 limb products instead of 16
             hipStream_t s = (hipStream_t)stream;

@@ -1111,8 +1111,7 @@ def test_ct_add_by_division_matches_the_product_of_residues(k2048, monkeypatch):
         _native.check(k2048.lib.pai_ct_add(k2048.pk, da.ptr, db.ptr, 0, N, da.ptr, None))         # in place
         assert limbs_to_ints(da.get()) == [x * y % M for x, y in zip(a, b)], N
     # the two kernels on one large batch
-    tune(monkeypatch, "add_div_min", None)
-    N = 70000
+    N = 70000                                                 # (1.07 rounds of 65 536: the default rule would leave it on lane groups)
     a = rng.integers(0, 1 << 32, (N, k2048.cw), dtype=np.uint64).astype(np.uint32)
     b = rng.integers(0, 1 << 32, (N, k2048.cw), dtype=np.uint64).astype(np.uint32)
     a[:, -1] &= 0x00FFFFFF

@@ -9,7 +9,7 @@ from pailliercryptolib_python_amd import engine
 dev = torch.device('cuda', 0)
 key = synthetic_key(2048, 0x1234567)
 pub = engine.PublicKeyHandle(key.n, 2048, key.hs, key.randbits, device=dev)
-B = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
+B = (int(sys.argv[1][2:]) if len(sys.argv) > 1 and sys.argv[1].startswith('n=') else 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20))
 g = torch.Generator(device=dev); g.manual_seed(1)
 a = torch.randint(-(2**31), 2**31, (B, pub.ct_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
 b = torch.randint(-(2**31), 2**31, (B, pub.ct_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
@@ -22,8 +22,11 @@ def tm(f, reps=5):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 row = {"batch": B}
+os.environ["PAI_TUNE"] = "add_div_min=1"
 row["div_ms"] = round(tm(lambda: pub.ct_add(a, b, out=out)), 3)
 engine.profile_enable(True); pub.ct_add(a, b, out=out); row["div_kernel"] = engine.profile_last(); engine.profile_enable(False)
+os.environ.pop("PAI_TUNE")
+row["default_ms"] = round(tm(lambda: pub.ct_add(a, b, out=out)), 3)
 os.environ["PAI_DISABLE"] = "add_div"
 row["montgomery_x2_ms"] = round(tm(lambda: pub.ct_add(a, b, out=ref)), 3)
 row["lazy_single_product_ms"] = round(tm(lambda: pub.ct_mont_mul(a, b, out=ref)), 3)
