@@ -33,10 +33,12 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
         }
         const ModSetup* L = lat_add_ctx(pk, N, false, 2);
         const GeoOps* g = L ? L->geo : pk->msq.geo;
+        // small batches without a broadcast addend: the two products on the minus-one context of n^2 (PAI_DISABLE=lat_add_m1)
+        const bool m1 = L != nullptr && !b_bcast && pk->lat_m1_ok && g->t >= 16 && !knob_disabled("lat_add_m1");
         ScopedKernelTimer t("k_modmul", (hipStream_t)stream);
-        g->modmul((hipStream_t)stream, L ? (int)((N + g->epb - 1) / g->epb) : grid_for(g, N, pk->dev.ncu), L ? L->d_ctx : pk->msq.d_ctx,
-                  d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
-                  MODMUL_FULL);
+        g->modmul((hipStream_t)stream, L ? (int)((N + g->epb - 1) / g->epb) : grid_for(g, N, pk->dev.ncu),
+                  m1 ? pk->lat_msq_m1.d_ctx : (L ? L->d_ctx : pk->msq.d_ctx), d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
+                  MODMUL_FULL, m1 ? pk->lat_msq.d_ctx : nullptr);
         t.stop();
         HIP_CHECK(hipGetLastError());
     });
@@ -86,7 +88,7 @@ int pai_ct_mont_mul(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d
             const GeoOps* gl = L->geo;
             ScopedKernelTimer t("k_modmul", (hipStream_t)stream);
             gl->modmul((hipStream_t)stream, (int)((N + gl->epb - 1) / gl->epb), L->d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
-                       MODMUL_FULL);
+                       MODMUL_FULL, nullptr);
             t.stop();
             HIP_CHECK(hipGetLastError());
             return;
@@ -94,7 +96,7 @@ int pai_ct_mont_mul(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d
         const GeoOps* g = pk->msq.geo;
         ScopedKernelTimer t("k_modmul", (hipStream_t)stream);
         g->modmul((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->msq.d_ctx, d_a, d_b, d_out, (int)N, pk->ct_words, b_bcast,
-                  MODMUL_MONT);
+                  MODMUL_MONT, nullptr);
         t.stop();
         HIP_CHECK(hipGetLastError());
     });

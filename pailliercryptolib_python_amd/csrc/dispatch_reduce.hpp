@@ -6,7 +6,7 @@
 static void tree_mul(const pai_pubkey* pk, hipStream_t s, const uint32_t* a, const uint32_t* b, int b_bcast, uint32_t* out, size_t n) {
     if (n == 0) return;
     const GeoOps* g = pk->msq.geo;
-    g->modmul(s, grid_for(g, n, pk->dev.ncu), pk->msq.d_ctx, a, b, out, (int)n, pk->ct_words, b_bcast, MODMUL_MONT);
+    g->modmul(s, grid_for(g, n, pk->dev.ncu), pk->msq.d_ctx, a, b, out, (int)n, pk->ct_words, b_bcast, MODMUL_MONT, nullptr);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -28,11 +28,19 @@ struct GeoInst {
     // (measured and dropped, profiles/r04/ctadd_ab_*.jsonl: the same products on per-wave LDS regions with 18 limbs x 8 lanes at
     // three or four waves per SIMD: 2.14-2.35 ms per 2^20 against 1.98 ms here)
     static void modmul(hipStream_t s, int grid, const MontCtx* c, const uint32_t* a, const uint32_t* b, uint32_t* out,
-                       int n, int w32, int b_bcast, int mode) {
+                       int n, int w32, int b_bcast, int mode, const MontCtx* fin) {
         constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the R^2 copy
+        if constexpr (G::T >= 16) {
+            if (fin != nullptr) {        // minus-one context (c) with the true modulus' context (fin): see add_aligned
+                using GA = Geo<G::NLL, G::T, G::U, false, true>;
+                set_lds((const void*)k_modmul<GA>, bytes);
+                hipLaunchKernelGGL(k_modmul<GA>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode, fin);
+                return;
+            }
+        }
         set_lds((const void*)k_modmul<GM>, bytes);
         report_occupancy("k_modmul", (const void*)k_modmul<GM>, bytes);
-        hipLaunchKernelGGL(k_modmul<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode);
+        hipLaunchKernelGGL(k_modmul<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32, b_bcast, mode, nullptr);
     }
     static void modexp_fixed(hipStream_t s, int grid, const MontCtx* c, const uint32_t* base, int base_w32,
                              const uint32_t* expo, int ewords, int ebits, uint32_t* out, int out_w32, int n,

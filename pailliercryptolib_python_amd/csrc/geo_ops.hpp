@@ -16,7 +16,7 @@ struct GeoOps {
     int lds_bytes_b;      // stage-B decrypt kernel (two operand buffers)
     // mode: MODMUL_FULL (a*b mod M) or MODMUL_MONT (a*b*R^-1 mod M), kernels_modexp.hpp
     void (*modmul)(hipStream_t, int grid, const MontCtx*, const uint32_t* a, const uint32_t* b, uint32_t* out,
-                   int n, int w32, int b_bcast, int mode);
+                   int n, int w32, int b_bcast, int mode, const MontCtx* fin);
     void (*modexp_fixed)(hipStream_t, int grid, const MontCtx*, const uint32_t* base, int base_w32,
                          const uint32_t* expo, int ewords, int ebits, uint32_t* out, int out_w32, int n,
                          uint32_t* table, int keep_mont);

@@ -21,7 +21,7 @@ namespace pai {
 template <class G>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
-         int n, int w32, int b_bcast, int mode) {
+         int n, int w32, int b_bcast, int mode, const MontCtx* __restrict__ fin) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using WT = WaveTile<G>;
     uint32_t* stage = lds + G::LDS_WORDS + G::NL;        // behind the operand buffer and the modulus copy
@@ -30,7 +30,9 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
     load_modulus<G>(nm, ctx, lds);
     for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) r2_lds[i] = ctx->r2[i];
     __syncthreads();
-    const uint32_t n0inv = ctx->n0inv;
+    // minus-one contexts (G::M1: small wire-form batches on one integer per wavefront, MODMUL_FULL without broadcast only — as
+    // k_add_aligned): ctx is the context of M k, its scalar the number of row blocks, fin the context of M itself for the way out
+    const uint32_t n0inv = G::M1 ? ctx->rows / G::U : ctx->n0inv;
     constexpr int WPB = BLOCK_THREADS / 64;
     const int wtiles = (n + WT::EPW - 1) / WT::EPW;
     clear_stage<G>(stage);
@@ -44,7 +46,8 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
         unpack_row<G>(bb, stage);
         if (mode == MODMUL_FULL) {                       // b*R (lazy, < 2M): a broadcast addend then costs ONE product per element
             uint32_t t[G::NLL];
-            mont_mul<G::NLL, G::U, G::T>(t, bb, r2_lds, 1, nm, n0inv);
+            if constexpr (G::M1) mont_mul_m1<G::NLL, G::U, G::T>(t, bb, r2_lds, 1, nm, (int)n0inv);
+            else mont_mul<G::NLL, G::U, G::T>(t, bb, r2_lds, 1, nm, n0inv);
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) bb[j] = t[j];
         }
@@ -80,11 +83,13 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
         for (int pass = 0; pass < npass; ++pass) {
             uint32_t r[G::NLL];
             // pass 0: a*b*R^-1 (a*b when the staged operand is b*R); pass 1: * R^2 * R^-1
-            mont_mul<G::NLL, G::U, G::T>(r, x, pass == 0 ? b_lds : r2_lds, pass == 0 ? G::EPB : 1, nm, n0inv);
+            if constexpr (G::M1) mont_mul_m1<G::NLL, G::U, G::T>(r, x, pass == 0 ? b_lds : r2_lds, pass == 0 ? G::EPB : 1, nm, (int)n0inv);
+            else mont_mul<G::NLL, G::U, G::T>(r, x, pass == 0 ? b_lds : r2_lds, pass == 0 ? G::EPB : 1, nm, n0inv);
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
         }
-        cond_sub<G::NLL, G::T>(x, nm);
+        if constexpr (G::M1) m1_reduce_to_true_modulus<G>(x, lds, fin);
+        else cond_sub<G::NLL, G::T>(x, nm);
         __builtin_amdgcn_s_setprio(2);
         pack_row<G>(x, stage);
         store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);

@@ -830,7 +830,7 @@ int pai_modmul(pai_modulus* m, const uint32_t* d_a, const uint32_t* d_b, int b_b
         if (N == 0) return;
         DeviceScope scope_(m->device);
         const GeoOps* g = m->ms.geo;
-        g->modmul((hipStream_t)stream, grid_for(g, N, m->dev.ncu), m->ms.d_ctx, d_a, d_b, d_out, (int)N, m->ms.w32, b_bcast, MODMUL_FULL);
+        g->modmul((hipStream_t)stream, grid_for(g, N, m->dev.ncu), m->ms.d_ctx, d_a, d_b, d_out, (int)N, m->ms.w32, b_bcast, MODMUL_FULL, nullptr);
         HIP_CHECK(hipGetLastError());
     });
 }

@@ -20,7 +20,7 @@ def test_differential_fuzz_bounded(seed):
     env = dict(os.environ)
     for k in ("PAI_LATENCY_MAX", "PAI_TUNE", "PAI_DISABLE", "PAI_LAT_ADD_MAX", "PAI_POW2_DIGIT_MIN"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_gpu.py"), "25", str(seed)], capture_output=True, text=True,
+    res = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_gpu.py"), "15", str(seed)], capture_output=True, text=True,
                          cwd=str(ROOT), env=env, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
