@@ -132,11 +132,15 @@ static void encrypt_common(const pai_pubkey* pk, const uint32_t* d_m, const uint
     if (d_r == nullptr && from_plain && N <= 2 * lat_add_max((size_t)pk->dev.ncu) && ensure_lat_ctx(pk)) {
         // small raw encryptions (the plaintext side of ct + pt): 1 + m n as ONE product with n^2 spread over a wavefront
         // (k_encrypt mode 0 on the latency geometry): 25 against 60 us of kernel time
-        if (!pk->d_lat_nR) pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
         const GeoOps* gl = pk->lat_msq.geo;
+        // ... on the minus-one context of n^2 where the key has one (PAI_DISABLE=lat_add_m1: the conventional context)
+        const bool m1 = pk->lat_m1_ok && gl->t >= 16 && gl->t <= 64 && !knob_disabled("lat_add_m1");
+        if (m1 && !pk->d_lat_nR_m1) pk->d_lat_nR_m1 = upload_r29(hbn::mulmod(pk->n, pk->lat_msq_m1.R, pk->lat_msq_m1.M), pk->lat_msq_m1.nl);
+        if (!m1 && !pk->d_lat_nR) pk->d_lat_nR = upload_r29(hbn::mulmod(pk->n, pk->lat_msq.R, pk->nsq), pk->lat_msq.nl);
         EncParams PL;
-        PL.nsq = pk->lat_msq.d_ctx;
-        PL.nR = pk->d_lat_nR;
+        PL.nsq = m1 ? pk->lat_msq_m1.d_ctx : pk->lat_msq.d_ctx;
+        PL.nR = m1 ? pk->d_lat_nR_m1 : pk->d_lat_nR;
+        PL.fin = m1 ? pk->lat_msq.d_ctx : nullptr;
         PL.fb_table = nullptr;
         PL.fb_windows = 0;
         PL.fb_wbits = 0;

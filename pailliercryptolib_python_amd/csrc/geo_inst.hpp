@@ -65,7 +65,7 @@ struct GeoInst {
                 hipLaunchKernelGGL(k_fb_to_m1<GM1>, dim3(grid), dim3(BLOCK_THREADS), GM1::LDS_BYTES, s, P.nsq, m, ct_out, n, r);
                 return;
             }
-            if (mode == 3 && P.fin != nullptr) {     // ct + plaintext of small batches (pai_ct_add_plain) on a minus-one context
+            if ((mode == 3 || mode == 0) && P.fin != nullptr) {     // ct + plaintext / raw encryption of small batches on a minus-one context
                 set_lds((const void*)k_encrypt<GM1>, GM1::LDS_BYTES);
                 hipLaunchKernelGGL(k_encrypt<GM1>, dim3(grid), dim3(BLOCK_THREADS), GM1::LDS_BYTES, s, P, m, r, ct_in, ct_out, n, mode);
                 return;
