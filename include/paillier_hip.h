@@ -76,6 +76,12 @@ int pai_stream_sync(int device, void* stream);
  * pai_host_stage for that device; the library keeps the slot intact until those calls have executed. */
 #define PAI_HOST_STAGE_MAX 4096
 int pai_host_stage(int device, int parts, const void* const* h_src, const size_t* bytes, void* stream, void** d_ptrs);
+/* pai_ct_add_aligned / pai_ct_mul (below) with their small operand — the shifts, the exponents — still on the HOST (at most
+ * PAI_HOST_STAGE_MAX bytes): staged as by pai_host_stage and read by the kernel in place, in one call. */
+int pai_ct_add_aligned_host(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* h_delta,
+                            size_t N, uint32_t* d_out, void* stream);
+int pai_ct_mul_host(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* h_e, int e_words, int ebits_max, int e_bcast, size_t N,
+                    uint32_t* d_out, void* stream);
 
 /* ---- container operations on device rows (no arithmetic) -----------------------------------------
  * ipclPlainText / ipclCipherText __getitem__ with a slice and rotate (bindings/ipcl_bindings_classes.cpp:224-262,328-366;

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "pai_buf_rotate": (C.c_int, [C.c_int, voidp, C.c_int, C.c_size_t, C.c_longlong, voidp, voidp]),
     "pai_stream_sync": (C.c_int, [C.c_int, voidp]),
     "pai_host_stage": (C.c_int, [C.c_int, C.c_int, C.POINTER(voidp), C.POINTER(C.c_size_t), voidp, C.POINTER(voidp)]),
+    "pai_ct_add_aligned_host": (C.c_int, [voidp, voidp, voidp, C.c_int, voidp, C.c_size_t, voidp, voidp]),
+    "pai_ct_mul_host": (C.c_int, [voidp, voidp, voidp, C.c_int, C.c_int, C.c_int, C.c_size_t, voidp, voidp]),
     "pai_pubkey_create": (C.c_int, [voidp, C.c_int, C.c_int, voidp, C.c_int, C.c_int, C.c_int, C.POINTER(voidp)]),
     "pai_pubkey_destroy": (None, [voidp]),
     "pai_keygen": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint64), voidp, voidp]),

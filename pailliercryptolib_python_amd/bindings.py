@@ -403,10 +403,9 @@ class ipclPublicKey:
         """ct_i ^ e_i mod n^2 (classes.cpp:324-325) on the home device's limb matrices, sharded when large."""
         h = self.handle
         devs = self.fanout_devices(ct.shape[0])
-        if isinstance(e, np.ndarray):
-            # host exponents: small batches hand them to the kernel through a pinned slot (engine.small_operands), the others upload
-            e = engine.small_operands([e], h.device)[0] if devs is None else engine.to_device_words(e, h.device)
-        if devs is None:
+        if isinstance(e, np.ndarray) and devs is not None:
+            e = engine.to_device_words(e, h.device)
+        if devs is None:          # (host exponents of a small batch reach the kernel through a pinned slot: engine.ct_mul)
             return h.ct_mul(ct, e, ebits_max)
         ct_sh = engine.scatter_shards(ct, devs)
         bcast = e.shape[0] == 1 and ct.shape[0] != 1

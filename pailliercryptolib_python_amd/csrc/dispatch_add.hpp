@@ -69,6 +69,20 @@ int pai_ct_add_aligned(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t
     return guarded([&] { add_aligned_common(pk, d_a, d_b, b_bcast, d_delta, N, d_out, nullptr, stream); });
 }
 
+// pai_ct_add_aligned with the shifts still on the host (<= PAI_HOST_STAGE_MAX bytes): staged and read by the kernel in place — one call
+// where pai_host_stage + pai_ct_add_aligned are two (the reference's BM_Add_CTCT: ~4 us of its 57)
+int pai_ct_add_aligned_host(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* h_delta,
+                            size_t N, uint32_t* d_out, void* stream) {
+    return guarded([&] {
+        require(pk && h_delta, "NULL argument");
+        const void* src[1] = {h_delta};
+        const size_t len[1] = {N * sizeof(int32_t)};
+        void* dp[1] = {nullptr};
+        host_stage_parts(pk->device, 1, src, len, stream, dp);
+        add_aligned_common(pk, d_a, d_b, b_bcast, static_cast<const int32_t*>(dp[0]), N, d_out, nullptr, stream);
+    });
+}
+
 int pai_ct_add_aligned_dom(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, const int32_t* d_delta,
                            size_t N, uint32_t* d_out, const uint32_t* d_entry, void* stream) {
     return guarded([&] {

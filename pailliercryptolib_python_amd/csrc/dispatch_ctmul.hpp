@@ -208,6 +208,22 @@ int pai_ct_mul(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* d_e, 
     });
 }
 
+// pai_ct_mul with the exponents still on the host (<= PAI_HOST_STAGE_MAX bytes): staged and read by the kernel in place
+int pai_ct_mul_host(const pai_pubkey* pk, const uint32_t* d_ct, const uint32_t* h_e, int e_words, int ebits_max, int e_bcast, size_t N,
+                    uint32_t* d_out, void* stream) {
+    const void* dp0 = nullptr;
+    const int rc = guarded([&] {
+        require(pk && h_e && e_words > 0, "NULL argument");
+        const void* src[1] = {h_e};
+        const size_t len[1] = {(e_bcast ? 1 : N) * (size_t)e_words * 4};
+        void* dp[1] = {nullptr};
+        host_stage_parts(pk->device, 1, src, len, stream, dp);
+        dp0 = dp[0];
+    });
+    if (rc != PAI_OK) return rc;
+    return pai_ct_mul(pk, d_ct, static_cast<const uint32_t*>(dp0), e_words, ebits_max, e_bcast, N, d_out, stream);
+}
+
 static int* status_word(const pai_pubkey* pk, hipStream_t s) {      // under pk->mu
     if (!pk->status.p) {
         pk->status.ensure(4);

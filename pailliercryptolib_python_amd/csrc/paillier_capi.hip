@@ -760,42 +760,49 @@ thread_local HostStageRings tl_stage;
 }  // namespace
 extern "C" {
 
+}  // extern "C"
+namespace {
+// the body of pai_host_stage; also behind the calls that take a host operand themselves (pai_ct_add_aligned_host, pai_ct_mul_host)
+void host_stage_parts(int device, int parts, const void* const* h_src, const size_t* bytes, void* stream, void** d_ptrs) {
+    require(parts >= 1 && parts <= 8 && h_src && bytes && d_ptrs, "bad arguments");
+    size_t total = 0;
+    for (int i = 0; i < parts; ++i) { require(h_src[i] != nullptr || bytes[i] == 0, "NULL part"); total += (bytes[i] + 15) & ~(size_t)15; }
+    require(total <= PAI_HOST_STAGE_MAX, "pai_host_stage: more than PAI_HOST_STAGE_MAX bytes");
+    DeviceScope scope_(device);
+    if ((int)tl_stage.per_device.size() <= device) tl_stage.per_device.resize((size_t)device + 1);
+    if (!tl_stage.per_device[device]) tl_stage.per_device[device].reset(new HostStageRing());
+    HostStageRing& R = *tl_stage.per_device[device];
+    if (!R.base) HIP_CHECK(hipHostMalloc((void**)&R.base, (size_t)HostStageRing::SLOTS * PAI_HOST_STAGE_MAX, hipHostMallocPortable | hipHostMallocMapped));
+    // the readers of the previous slot have been enqueued by now (the contract): mark the point behind them
+    if (R.pending >= 0) {
+        const int k = R.pending;
+        if (!R.ev[k]) HIP_CHECK(hipEventCreateWithFlags(&R.ev[k], hipEventDisableTiming));
+        if (hipEventRecord(R.ev[k], R.pending_stream) == hipSuccess) {
+            R.recorded[k] = true;
+        } else {                                         // e.g. the stream no longer exists: everything enqueued has to finish
+            (void)hipGetLastError();
+            HIP_CHECK(hipDeviceSynchronize());
+            R.recorded[k] = false;
+        }
+        R.pending = -1;
+    }
+    const int k = R.next;
+    R.next = (R.next + 1) % HostStageRing::SLOTS;
+    if (R.recorded[k]) HIP_CHECK(hipEventSynchronize(R.ev[k]));      // 31 stagings ago: normally long done
+    char* p = R.base + (size_t)k * PAI_HOST_STAGE_MAX;
+    for (int i = 0; i < parts; ++i) {
+        if (bytes[i]) std::memcpy(p, h_src[i], bytes[i]);
+        d_ptrs[i] = p;
+        p += (bytes[i] + 15) & ~(size_t)15;
+    }
+    R.pending = k;
+    R.pending_stream = (hipStream_t)stream;
+}
+}  // namespace
+extern "C" {
+
 int pai_host_stage(int device, int parts, const void* const* h_src, const size_t* bytes, void* stream, void** d_ptrs) {
-    return guarded([&] {
-        require(parts >= 1 && parts <= 8 && h_src && bytes && d_ptrs, "bad arguments");
-        size_t total = 0;
-        for (int i = 0; i < parts; ++i) { require(h_src[i] != nullptr || bytes[i] == 0, "NULL part"); total += (bytes[i] + 15) & ~(size_t)15; }
-        require(total <= PAI_HOST_STAGE_MAX, "pai_host_stage: more than PAI_HOST_STAGE_MAX bytes");
-        DeviceScope scope_(device);
-        if ((int)tl_stage.per_device.size() <= device) tl_stage.per_device.resize((size_t)device + 1);
-        if (!tl_stage.per_device[device]) tl_stage.per_device[device].reset(new HostStageRing());
-        HostStageRing& R = *tl_stage.per_device[device];
-        if (!R.base) HIP_CHECK(hipHostMalloc((void**)&R.base, (size_t)HostStageRing::SLOTS * PAI_HOST_STAGE_MAX, hipHostMallocPortable | hipHostMallocMapped));
-        // the readers of the previous slot have been enqueued by now (the contract): mark the point behind them
-        if (R.pending >= 0) {
-            const int k = R.pending;
-            if (!R.ev[k]) HIP_CHECK(hipEventCreateWithFlags(&R.ev[k], hipEventDisableTiming));
-            if (hipEventRecord(R.ev[k], R.pending_stream) == hipSuccess) {
-                R.recorded[k] = true;
-            } else {                                         // e.g. the stream no longer exists: everything enqueued has to finish
-                (void)hipGetLastError();
-                HIP_CHECK(hipDeviceSynchronize());
-                R.recorded[k] = false;
-            }
-            R.pending = -1;
-        }
-        const int k = R.next;
-        R.next = (R.next + 1) % HostStageRing::SLOTS;
-        if (R.recorded[k]) HIP_CHECK(hipEventSynchronize(R.ev[k]));      // 31 stagings ago: normally long done
-        char* p = R.base + (size_t)k * PAI_HOST_STAGE_MAX;
-        for (int i = 0; i < parts; ++i) {
-            if (bytes[i]) std::memcpy(p, h_src[i], bytes[i]);
-            d_ptrs[i] = p;
-            p += (bytes[i] + 15) & ~(size_t)15;
-        }
-        R.pending = k;
-        R.pending_stream = (hipStream_t)stream;
-    });
+    return guarded([&] { host_stage_parts(device, parts, h_src, bytes, stream, d_ptrs); });
 }
 
 // ---- generic modulus ------------------------------------------------------------------------------

@@ -325,6 +325,20 @@ class PublicKeyHandle:
         bcast = 1 if (b.shape[0] == 1 and a.shape[0] != 1) else 0
         if not bcast and a.shape[0] != b.shape[0]:
             raise RuntimeError("Size mismatch")
+        if isinstance(delta, np.ndarray):
+            # host shifts: one call stages them and launches (pai_ct_add_aligned_host) when they fit a slot and the operands are
+            # in the wire form; otherwise staged / uploaded here
+            delta = np.ascontiguousarray(delta, dtype=np.int32)
+            if delta.ndim != 1 or delta.shape[0] != a.shape[0]:
+                raise ValueError("delta: expected int32 [N]")
+            if dom == 0 and 0 < delta.nbytes <= HOST_STAGE_MAX and host_stage_enabled():
+                out = self.empty_ct(a.shape[0]) if out is None else out
+                _native.check(self.lib.pai_ct_add_aligned_host(self.h, _ptr(a), _ptr(b), bcast, delta.__array_interface__["data"][0],
+                                                               a.shape[0], _ptr(out), _stream(self.device)))
+                return out
+            if dom != 0:
+                self.dom_const(2 - dom)                 # (before the shifts are staged: a staged operand belongs to the very next call)
+            delta = small_operands([delta], self.device)[0]
         if delta.dtype != torch.int32 or delta.dim() != 1 or delta.shape[0] != a.shape[0] or not delta.is_contiguous():
             raise ValueError("delta: expected contiguous int32 [N]")
         out = self.empty_ct(a.shape[0]) if out is None else out
@@ -338,6 +352,19 @@ class PublicKeyHandle:
 
     def ct_mul(self, ct: torch.Tensor, e: torch.Tensor, ebits_max: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(ct, self.ct_words, "ct")
+        if isinstance(e, np.ndarray):                   # host exponents: staged and launched in one call when they fit a slot
+            e = np.ascontiguousarray(e)
+            if e.ndim != 2 or e.dtype not in (np.uint32, np.int32):
+                raise ValueError("e: expected uint32 [N or 1, e_words]")
+            if 0 < e.nbytes <= HOST_STAGE_MAX and host_stage_enabled():
+                bcast = 1 if (e.shape[0] == 1 and ct.shape[0] != 1) else 0
+                if not bcast and e.shape[0] != ct.shape[0]:
+                    raise RuntimeError("Size mismatch")
+                out = self.empty_ct(ct.shape[0]) if out is None else out
+                _native.check(self.lib.pai_ct_mul_host(self.h, _ptr(ct), e.__array_interface__["data"][0], e.shape[1], int(ebits_max), bcast,
+                                                       ct.shape[0], _ptr(out), _stream(self.device)))
+                return out
+            e = to_device_words(e, self.device)
         if e.dtype != torch.int32 or e.dim() != 2 or not e.is_contiguous():
             raise ValueError("e: expected contiguous int32 [N or 1, e_words]")
         bcast = 1 if (e.shape[0] == 1 and ct.shape[0] != 1) else 0

@@ -350,9 +350,7 @@ def _add_aligned(h: engine.PublicKeyHandle, ta: torch.Tensor, tb: torch.Tensor, 
     if 0 < n <= engine.HOST_STAGE_MAX // 4:
         # small batches: the shifts are read by the kernel from a pinned slot (no copy on the stream); dom != 0 needs its entry
         # constant BEFORE the shifts are staged (a staged operand belongs to the very next call)
-        if dom != 0:
-            h.dom_const(2 - dom)
-        return h.ct_add_aligned(ta, tb, engine.small_operands([delta], h.device)[0], dom=dom)
+        return h.ct_add_aligned(ta, tb, delta, dom=dom)
     d_dev = torch.from_numpy(delta).to(h.device)
     try:
         sort_min = int(os.environ.get("PAI_ALIGN_SORT_MIN", ALIGN_SORT_MIN))

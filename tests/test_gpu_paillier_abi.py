@@ -1079,6 +1079,18 @@ def test_host_stage_operands_are_read_in_place(k2048):
                       [pow(x, 1 << max(0, -int(d)), key.nsq) * pow(y, 1 << max(0, int(d)), key.nsq) % key.nsq for x, y, d in zip(a, b, delta)]))
     for (o1, o2), (w1, w2) in zip(outs, wants):
         assert limbs_to_ints(o1.get()) == w1 and limbs_to_ints(o2.get()) == w2
+    # the calls that take the host operand themselves (stage + launch in one): pai_ct_mul_host, pai_ct_add_aligned_host
+    es = [int(v) | 1 << 52 for v in rng.integers(0, 1 << 52, N)]
+    e_h = ints_to_limbs(es, 2)
+    delta = rng.integers(-3, 4, N).astype(np.int32)
+    o1, o2 = DevArray(shape=(N, k2048.cw)), DevArray(shape=(N, k2048.cw))
+    _native.check(k2048.lib.pai_ct_mul_host(k2048.pk, da.ptr, e_h.ctypes.data, 2, 53, 0, N, o1.ptr, None))
+    _native.check(k2048.lib.pai_ct_add_aligned_host(k2048.pk, da.ptr, db.ptr, 0, delta.ctypes.data, N, o2.ptr, None))
+    assert limbs_to_ints(o1.get()) == pow_many(a, es, key.nsq)
+    assert limbs_to_ints(o2.get()) == [pow(x, 1 << max(0, -int(d)), key.nsq) * pow(y, 1 << max(0, int(d)), key.nsq) % key.nsq
+                                       for x, y, d in zip(a, b, delta)]
+    big_e = np.zeros((3000, 2), dtype=np.uint32)
+    assert k2048.lib.pai_ct_mul_host(k2048.pk, da.ptr, big_e.ctypes.data, 2, 53, 0, 3000, o1.ptr, None) == -1      # more than a slot
     big = np.zeros(5000, dtype=np.uint8)
     srcs = (C.c_void_p * 1)(big.ctypes.data)
     sizes = (C.c_size_t * 1)(big.nbytes)
