@@ -10,6 +10,18 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
         if (N == 0) return;
         DeviceScope scope_(pk->device);
         g_last_times.clear();
+        const ModSetup* L = lat_add_ctx(pk, N, false, 2);
+        // beyond the small-batch range, two wire-form operands: ONE most-significant-limb-first product (mont_msb.hpp) where the key
+        // has the context (PAI_DISABLE=add_msb: the routes below)
+        const bool msb = L == nullptr && pk->d_msb != nullptr && !b_bcast && !add_div_forced() && !knob_disabled("add_msb");
+        if (msb) {
+            const GeoOps* g = pk->msq.geo;
+            ScopedKernelTimer t("k_modmul_msb", (hipStream_t)stream);
+            g->modmul_msb((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->d_msb, d_a, d_b, d_out, (int)N, pk->ct_words);
+            t.stop();
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         if (pk->d_mu29 && !b_bcast && add_div_pays(N, (size_t)pk->dev.ncu)) {          // (a broadcast addend keeps the lane-group kernel: its one row is staged once per tile there)
             // large wire-form batches at the key sizes whose n fills 71 limbs: base-n digits and Barrett division on the
             // one-element-per-lane engine (kernels_ctadd_div.hpp), 10 units of 72^2 limb products instead of 16
@@ -31,7 +43,6 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
             HIP_CHECK(hipGetLastError());
             return;
         }
-        const ModSetup* L = lat_add_ctx(pk, N, false, 2);
         const GeoOps* g = L ? L->geo : pk->msq.geo;
         // small batches without a broadcast addend: the two products on the minus-one context of n^2 (PAI_DISABLE=lat_add_m1)
         const bool m1 = L != nullptr && !b_bcast && pk->lat_m1_ok && g->t >= 16 && !knob_disabled("lat_add_m1");

@@ -197,11 +197,20 @@ struct GeoInst {
         set_lds((const void*)k_mexp<GX>, GX::LDS_BYTES);
         hipLaunchKernelGGL(k_mexp<GX>, dim3(grid), dim3(BLOCK_THREADS), GX::LDS_BYTES, s, c, P, table, e, sign, out, nlanes);
     }
+    static void modmul_msb(hipStream_t s, int grid, const MsbCtx* c, const uint32_t* a, const uint32_t* b, uint32_t* out, int n, int w32) {
+        if constexpr (G::T <= 8) {
+            constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the copy of W
+            set_lds((const void*)k_modmul_msb<GM>, bytes);
+            report_occupancy("k_modmul_msb", (const void*)k_modmul_msb<GM>, bytes);
+            hipLaunchKernelGGL(k_modmul_msb<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32);
+        }
+    }
     static size_t table_words(size_t blocks) { return (size_t)(1u << MODEXP_WINDOW) * G::NL * blocks * G::EPB; }
 
     static const GeoOps* ops() {
         static const GeoOps o = {G::NLL, G::T, G::U, G::NL, G::EPB, G::LDS_BYTES, 2 * G::LDS_WORDS * 4,
-                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &sq_chain, &add_aligned, &addn, &table_words, &pair_finish, &mexp_table, &mexp};
+                                 &modmul, &modexp_fixed, &modexp_var, &modexp_var_win, &encrypt, &fb_expand, &dec_a, &dec_b, &pow2, &sq_chain, &add_aligned, &addn, &table_words, &pair_finish, &mexp_table, &mexp,
+                                 G::T <= 8 ? &modmul_msb : nullptr};
         return &o;
     }
 };

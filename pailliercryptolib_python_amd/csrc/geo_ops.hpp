@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "kernels_paillier.hpp"
+#include "mont_msb.hpp"
 
 namespace pai {
 
@@ -52,6 +53,8 @@ struct GeoOps {
                        int nentries, int nsigns, int wbits);
     void (*mexp)(hipStream_t, int grid, const MontCtx*, MexpParams, const uint32_t* table, const uint32_t* e, const uint8_t* sign,
                  uint32_t* out, int nlanes);
+    // out = a * b mod M on wire-form rows by one most-significant-limb-first product (k_modmul_msb; NULL on the latency geometries)
+    void (*modmul_msb)(hipStream_t, int grid, const MsbCtx*, const uint32_t* a, const uint32_t* b, uint32_t* out, int n, int w32);
 };
 
 const GeoOps* geo_ops_36x1();

@@ -5,6 +5,7 @@
 // All operands are packed little-endian u32 words, row-major [N][W32]; results are canonical residues.
 #pragma once
 #include "kernels_common.hpp"
+#include "mont_msb.hpp"
 
 namespace pai {
 
@@ -91,6 +92,93 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
         if constexpr (G::M1) m1_reduce_to_true_modulus<G>(x, lds, fin);
         else cond_sub<G::NLL, G::T>(x, nm);
         __builtin_amdgcn_s_setprio(2);
+        pack_row<G>(x, stage);
+        store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// out_i = a_i * b_i mod M on canonical packed rows by ONE most-significant-limb-first product (mont_msb.hpp) — k_modmul's
+// MODMUL_FULL without a broadcast operand at half the limb products.  Same tile loop, same LDS plan; the modulus copy
+// behind the operand buffer holds Mt = M B^off for the two conditional subtractions, and the result's B^off leaves
+// through the operand buffer (limb j + off read back as limb j).  Operands may be any word pattern of the row.
+template <class G>
+__global__ void __launch_bounds__(BLOCK_THREADS, 2)
+k_modmul_msb(const MsbCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, int n, int w32) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using WT = WaveTile<G>;
+    uint32_t* mt_lds = lds + G::LDS_WORDS;
+    uint32_t* stage = lds + G::LDS_WORDS + G::NL;
+    uint32_t* w_lds = stage + G::STAGE_WORDS;            // W = B^NL - Mt, one copy per workgroup
+    const int t = G::gl();
+    // W's slice: registers where the accumulator window leaves room, else re-read from LDS during the q W step (the window, a's
+    // slice and W's are 156 of the 256 registers at 36 limbs per lane: with W in registers the compiler spills loop invariants)
+    constexpr bool W_LDS = G::NLL % 4 == 0 && G::NLL >= 32;
+    typename std::conditional<W_LDS, NmLds<G::NLL>, NmRegs<G::NLL>>::type wm;
+    if constexpr (W_LDS) wm.p = w_lds + G::NLL * t;
+    else {
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) wm.v[j] = ctx->w[G::NLL * t + j];
+    }
+    for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) { mt_lds[i] = ctx->mt[i]; w_lds[i] = ctx->w[i]; }
+    __syncthreads();
+    NmLds<G::NLL> mt;
+    mt.p = mt_lds + G::NLL * t;
+    const uint32_t tb = ctx->tb;
+    const int off = (int)ctx->off;
+    MsbK k;
+    k.mu = ctx->mu;
+    k.sh1 = tb - 3u;
+    k.sh2 = 32u - tb;
+    k.sh3 = (uint32_t)RB - tb;
+    k.m2 = ctx->m2;
+    k.eight = ctx->eight;
+    k.one = ctx->one;
+    k.topmask = t == G::T - 1 ? 0xFFFFFFFFu : 0u;
+    constexpr int WPB = BLOCK_THREADS / 64;
+    const int wtiles = (n + WT::EPW - 1) / WT::EPW;
+    clear_stage<G>(stage);
+    const uint32_t* b_lds = lds + G::elem();
+    const int per_wave = (wtiles + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
+    const int wt_begin = ((int)blockIdx.x * WPB + WT::wave()) * per_wave;
+    const int wt_end = min(wtiles, wt_begin + per_wave);
+    for (int wt = wt_begin; wt < wt_end; ++wt) {
+        const int row0 = wt * WT::EPW;
+        const int rows = min(WT::EPW, n - row0);
+        uint32_t x[G::NLL];
+        __builtin_amdgcn_s_setprio(2);
+        load_tile<G>(stage, b + (size_t)row0 * w32, rows, w32);
+        unpack_row<G>(x, stage);
+        // b B^off as the multiplier: limb j is staged as limb j + off (what would land beyond the geometry is zero: b fits the
+        // row's words), the lowest `off` limbs read zero
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) {
+            const int idx = G::NLL * t + j + off;
+            if (idx < G::NL) lds[idx * G::EPB + G::elem()] = x[j];
+        }
+        if (t == 0)
+            for (int i = 0; i < off; ++i) lds[i * G::EPB + G::elem()] = 0u;
+        wave_lds_fence();
+        load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
+        unpack_row<G>(x, stage);
+        __builtin_amdgcn_s_setprio(0);
+        {
+            uint32_t r[G::NLL];
+            msb_mul<G::NLL, G::U, G::T>(r, x, b_lds, G::EPB, wm, k);
+#pragma unroll
+            for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
+        }
+        cond_sub<G::NLL, G::T>(x, mt);
+        __builtin_amdgcn_s_setprio(2);
+        stage_b<G>(x, lds);                                  // / B^off: the low `off` limbs are zero
+#pragma unroll
+        for (int j = 0; j < G::NLL; ++j) {
+            const int idx = G::NLL * t + j + off;
+            const uint32_t v = lds[(idx < G::NL ? idx : G::NL - 1) * G::EPB + G::elem()];
+            x[j] = idx < G::NL ? v : 0u;
+        }
         pack_row<G>(x, stage);
         store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
     }

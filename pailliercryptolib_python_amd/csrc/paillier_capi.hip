@@ -296,6 +296,43 @@ struct ModSetup {
     }
 };
 
+// Constants of the most-significant-limb-first product (mont_msb.hpp) for modulus M on geometry g and rows of w32 words, or
+// nullptr where its conditions do not hold: a lane-group geometry with the estimate's four cells in one lane, M's top limb at
+// least one limb below the geometry's (off >= 1: the products a b_i then stay below 4 Mt for ANY word pattern of the row), 3 .. 26
+// bits of M in its top limb, rows no wider than the limbs the multiplier is read from.
+static MsbCtx* build_msb_ctx(const Limbs& M, const GeoOps* g, int w32) {
+    if (!g || !g->modmul_msb || g->t > 8 || g->nll < 4) return nullptr;
+    const int NL = g->nl, bits = hbn::bitlen(M);
+    const int mtop = (bits - 1) / hbn::RB, off = NL - 1 - mtop;
+    if (off < 1) return nullptr;
+    const int tb = bits - hbn::RB * mtop;
+    if (tb < 3 || tb > 26) return nullptr;
+    if (32 * w32 > hbn::RB * (mtop + 1) || 32 * w32 > bits + 2) return nullptr;
+    const Limbs one{1u};
+    const Limbs Mt = hbn::shl(M, hbn::RB * off);
+    const int P = hbn::bitlen(Mt);
+    const Limbs W = hbn::sub(hbn::shl(one, hbn::RB * NL), Mt);
+    const Limbs mu = hbn::divq(hbn::shl(one, P + 31), Mt, nullptr);
+    require(hbn::bitlen(mu) <= 32 && P == hbn::RB * (NL - 1) + tb, "msb context: construction failed");
+    MsbCtx h;
+    std::memset(&h, 0, sizeof(h));
+    const auto w = hbn::to_r29(W, NL), mt = hbn::to_r29(Mt, NL);
+    std::memcpy(h.w, w.data(), (size_t)NL * 4);
+    std::memcpy(h.mt, mt.data(), (size_t)NL * 4);
+    h.w[NL - 1] += 0xE0000000u;                       // + 2^32 - 2^29: with the - q 2^32 in the kernel this is the - q B^NL
+    h.mu = mu.empty() ? 0u : mu[0];
+    h.tb = (uint32_t)tb;
+    h.off = (uint32_t)off;
+    h.nl = (uint32_t)NL;
+    h.m2 = 1u << (32 - tb);
+    h.eight = 8u;
+    h.one = 1u;
+    MsbCtx* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, sizeof(MsbCtx)));
+    HIP_CHECK(hipMemcpy(d, &h, sizeof(MsbCtx), hipMemcpyHostToDevice));
+    return d;
+}
+
 // Optional per-kernel timing with HIP events on the caller's stream (pai_profile_enable): used by
 // bench.py to report the dominant kernel's duration next to the rocprofv3 numbers.
 bool g_profile = false;
@@ -434,6 +471,7 @@ struct pai_pubkey {
     Limbs n, nsq, hs;
     ModSetup msq;                 // n^2
     uint32_t* d_nR = nullptr;     // n * R mod n^2 (radix 29)
+    MsbCtx* d_msb = nullptr;      // wire-form ct + ct by one most-significant-limb-first product (mont_msb.hpp), where the key allows it
     uint32_t* d_fb = nullptr;     // fixed-base table [J][256][NL]
     uint32_t* d_nexp = nullptr;   // n as packed words (exponent of the standard obfuscator)
     int fb_windows = 0, fb_wbits = 8;
@@ -954,6 +992,7 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
         pk->msq.init(pk->nsq);
         const int nl = pk->msq.nl;
         pk->d_nR = upload_r29(hbn::mulmod(pk->n, pk->msq.R, pk->nsq), nl);
+        if (!knob_disabled("add_msb")) pk->d_msb = build_msb_ctx(pk->nsq, pk->msq.geo, pk->ct_words);
         pk->d_nexp = upload_words(pk->n, pk->n_words);
         pk->d_nsq_words = upload_words(pk->nsq, pk->ct_words);
         {   // per-level constants of the single-product trees (see pai_pubkey::d_tree_c)
@@ -1066,6 +1105,7 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     (void)hipSetDevice(pk->device);
     pk->msq.release();
     if (pk->d_nR) (void)hipFree(pk->d_nR);
+    if (pk->d_msb) (void)hipFree(pk->d_msb);
     if (pk->d_fb) (void)hipFree(pk->d_fb);
     if (pk->d_nexp) (void)hipFree(pk->d_nexp);
     pk->nmod.release();

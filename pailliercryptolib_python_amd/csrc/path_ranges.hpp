@@ -162,6 +162,12 @@ static bool add_div_pays(size_t N, size_t ncu) {
     const size_t round = 256 * ncu, rounds = (N + round - 1) / round;
     return rounds * 84 * round <= N * 100;
 }
+// PAI_TUNE add_div_min present: tests and probes ask for the division kernel by name (it then also wins over the
+// most-significant-limb-first product, which serves these batches otherwise: dispatch_add.hpp)
+static bool add_div_forced() {
+    long long v;
+    return !knob_disabled("add_div") && knob_tune("add_div_min", &v);
+}
 // the first three switch points of that rule (for pai_path_edges)
 static void add_div_edges(size_t ncu, std::vector<size_t>& e) {
     if (knob_disabled("add_div")) return;

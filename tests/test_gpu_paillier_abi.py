@@ -1138,6 +1138,69 @@ def test_ct_add_by_division_matches_the_product_of_residues(k2048, monkeypatch):
     assert limbs_to_ints(got[idx]) == [x * y % M for x, y in zip(limbs_to_ints(a[idx]), limbs_to_ints(b[idx]))]
 
 
+def _last_kernels(lib):
+    names, i = [], 0
+    name, ms = C.create_string_buffer(64), C.c_float(0)
+    while lib.pai_profile_last(i, name, 64, C.byref(ms)) == 0:
+        names.append(name.value.decode())
+        i += 1
+    return names
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
+def test_ct_add_by_one_msb_first_product(bits, monkeypatch):
+    """pai_ct_add of wire-form batches beyond the small-batch range: ONE most-significant-limb-first product on lane groups
+    (csrc/mont_msb.hpp, k_modmul_msb) instead of two Montgomery products — every element against CPython at the four key sizes'
+    geometries (36 x 2, 36 x 4, 28 x 8, 36 x 8): residues that make the quotient digits, the top cells and the final subtraction
+    extreme, operands that are NOT reduced (any word pattern of the row), ragged tiles, in place, and the same bits from the
+    Montgomery route on a large batch.  classes.cpp:318-321."""
+    K = NativeKey(seeded_key(bits))
+    key, M, W = K.key, K.key.nsq, K.cw
+    n = key.n
+    full = (1 << (32 * W)) - 1
+    rng = np.random.default_rng(bits + 1)
+    special = [0, 1, 2, n - 1, n, n + 1, M - 1, M - 2, M - n, (n - 1) * n, M // 2, (1 << (M.bit_length() - 1)) - 1, 1 << (M.bit_length() - 1),
+               full, full - 1, full >> 1, M, M + 1, 2 * M - 1 if 2 * M - 1 <= full else full, (1 << 29) - 1, (1 << (29 * 5)) - 1]
+    monkeypatch.setenv("PAI_LAT_ADD_MAX", "0")              # the throughput route at every batch size
+    _native.check(K.lib.pai_profile_enable(1))
+    try:
+        for N in (1, 33, 257, 700):
+            a = (special + rand_below(rng, M, N))[:N] if N > 30 else rand_below(rng, M, N)
+            b = (list(reversed(special)) + rand_below(rng, M, N))[:N] if N > 30 else rand_below(rng, M, N)
+            if N == 700:
+                a[40:61] = special                          # every special value against a rotation of the list
+                b[40:61] = special[7:] + special[:7]
+                a[100:110] = [int.from_bytes(rng.bytes(4 * W), "little") for _ in range(10)]      # unreduced words
+                b[105:115] = [int.from_bytes(rng.bytes(4 * W), "little") for _ in range(10)]
+            da, db = DevArray(ints_to_limbs(a, W)), DevArray(ints_to_limbs(b, W))
+            out = DevArray(shape=(N, W))
+            _native.check(K.lib.pai_ct_add(K.pk, da.ptr, db.ptr, 0, N, out.ptr, None))
+            assert _last_kernels(K.lib) == ["k_modmul_msb"]
+            assert limbs_to_ints(out.get()) == [x * y % M for x, y in zip(a, b)], N
+            _native.check(K.lib.pai_ct_add(K.pk, da.ptr, db.ptr, 0, N, da.ptr, None))         # in place
+            assert limbs_to_ints(da.get()) == [x * y % M for x, y in zip(a, b)], N
+    finally:
+        _native.check(K.lib.pai_profile_enable(0))
+    N = 20011
+    a = rng.integers(0, 1 << 32, (N, W), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 1 << 32, (N, W), dtype=np.uint64).astype(np.uint32)
+    a[::3, -1] &= 0x00FFFFFF                                 # two thirds unreduced
+    da, db, o1, o2 = DevArray(a), DevArray(b), DevArray(shape=(N, W)), DevArray(shape=(N, W))
+    _native.check(K.lib.pai_ct_add(K.pk, da.ptr, db.ptr, 0, N, o1.ptr, None))
+    knob_disable(monkeypatch, "add_msb")
+    knob_disable(monkeypatch, "add_div")
+    _native.check(K.lib.pai_ct_add(K.pk, da.ptr, db.ptr, 0, N, o2.ptr, None))
+    got, ref = o1.get(), o2.get()
+    idx = [0, 1, 2, 255, 256, N // 2, N - 2, N - 1]
+    assert limbs_to_ints(got[idx]) == [x * y % M for x, y in zip(limbs_to_ints(a[idx]), limbs_to_ints(b[idx]))]
+    # (the Montgomery route is defined for reduced operands and agrees on every row that has them)
+    red = np.arange(N) % 3 == 0
+    ared = np.array([v < M for v in limbs_to_ints(a[red][:, :])])
+    bred = np.array([v < M for v in limbs_to_ints(b[red][:, :])])
+    rows = np.flatnonzero(red)[ared & bred]
+    assert rows.size and np.array_equal(got[rows], ref[rows])
+
+
 @pytest.mark.parametrize("lat_add", ["0", "4096"])
 def test_ct_add_plain_is_the_product_with_the_raw_encryption(k2048, lat_add, monkeypatch):
     """pai_ct_add_plain (include/paillier_hip.h): ct * (1 + m n) mod n^2 in one pass — ipcl_python.py:495-504 followed by the
