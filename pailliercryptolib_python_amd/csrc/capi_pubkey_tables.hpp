@@ -247,7 +247,9 @@ static bool ensure_lat_ctx(const pai_pubkey* pk) {
 // constant R_lat^2 / R = 2^(29 (2 nl_lat - nl)) in place of R_lat^2.
 // Measured at 2048-bit keys (profiles/r04/lat_add_probe.jsonl): wire-form a b 30 against 60 us up to 1024 elements (39 / 65 at
 // 2048, level at 4096), the tagged single product 29 against 35 us up to 1024 (level at 2048), aligned additions with shifts
-// up to 13: 0.18 against 0.44 ms up to 1024, 0.31 / 0.45 at 4096 — hence the scale factors 2 / 1 / 4 on PAI_LAT_ADD_MAX.
+// up to 13: 0.18 against 0.44 ms up to 1024, 0.31 / 0.45 at 4096 — hence the scale factors 1 / 4 on PAI_LAT_ADD_MAX; the wire form's
+// factor is per key size since round 6 (path_ranges.hpp: lat_add_wire_scale, measured with the minus-one contexts on this side and
+// the most-significant-limb-first product on the other).
 static const ModSetup* lat_add_ctx(const pai_pubkey* pk, size_t N, bool tagged, int scale = 1) {
     if (N > (size_t)scale * lat_add_max((size_t)pk->dev.ncu)) return nullptr;
     std::lock_guard<std::mutex> lk(pk->mu);

@@ -10,7 +10,7 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
         if (N == 0) return;
         DeviceScope scope_(pk->device);
         g_last_times.clear();
-        const ModSetup* L = lat_add_ctx(pk, N, false, 2);
+        const ModSetup* L = lat_add_ctx(pk, N, false, lat_add_wire_scale(pk->key_bits));
         // beyond the small-batch range, two wire-form operands: ONE most-significant-limb-first product (mont_msb.hpp) where the key
         // has the context (PAI_DISABLE=add_msb: the routes below)
         const bool msb = L == nullptr && pk->d_msb != nullptr && !b_bcast && !add_div_forced() && !knob_disabled("add_msb");

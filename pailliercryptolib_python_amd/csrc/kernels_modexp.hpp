@@ -103,7 +103,7 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
 // MODMUL_FULL without a broadcast operand at half the limb products.  Same tile loop, same LDS plan; the modulus copy
 // behind the operand buffer holds Mt = M B^off for the two conditional subtractions, and the result's B^off leaves
 // through the operand buffer (limb j + off read back as limb j).  Operands may be any word pattern of the row.
-template <class G>
+template <class G, int UM = G::U>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_modmul_msb(const MsbCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, int n, int w32) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -166,7 +166,7 @@ k_modmul_msb(const MsbCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* 
         __builtin_amdgcn_s_setprio(0);
         {
             uint32_t r[G::NLL];
-            msb_mul<G::NLL, G::U, G::T>(r, x, b_lds, G::EPB, wm, k);
+            msb_mul<G::NLL, UM, G::T>(r, x, b_lds, G::EPB, wm, k);
 #pragma unroll
             for (int j = 0; j < G::NLL; ++j) x[j] = r[j];
         }

@@ -76,7 +76,7 @@ struct RowsMsb {
     static constexpr int NW = NLL + U;
     static constexpr int NL = NLL * T;
     static constexpr int NORM_BLOCKS = MSB_NORM_ROWS / U;
-    static_assert(NLL >= 4 && NL % U == 0 && T <= 8, "geometry");
+    static_assert(NLL >= 4 && NL % U == 0 && T <= 8 && NORM_BLOCKS >= 1, "geometry");
 
     // U rows (multiplier limbs bv[0] = the highest).  Row u works at cell offset U - 1 - u: aligned column c of lane t is cell
     // c - t NLL + U - 1 - u.

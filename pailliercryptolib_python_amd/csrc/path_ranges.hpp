@@ -17,8 +17,9 @@
 //             digit engine's own table (enc_mid: 16 .. 160 ncu) | one element per lane
 //   ct x pt   four-wave digit pairs (lat_mul_pp: <= 4 ncu) | wave pairs (lat_mul_rl: <= 2 ncu) | window kernel (<= 20 ncu) |
 //             lane-group digit pairs (ctmul_mid: 20 .. 192 ncu) | one element per lane
-//   ct + ct   one integer per wavefront (<= 4 ncu; aligned additions and pow2 <= 16 ncu, raw encryption <= 8 ncu) | wave tiles |
-//             wire form at 2048-bit keys: the division kernel where its rounds of 256 ncu elements are full enough (add_div_pays)
+//   ct + ct   one integer per wavefront (tagged <= 4 ncu; wire form <= 8 .. 24 ncu by key size: lat_add_wire_scale; aligned additions and
+//             pow2 <= 16 ncu, raw encryption <= 8 ncu) | wave tiles: wire form by ONE most-significant-limb-first product (mont_msb.hpp) where
+//             the key has the context, else two Montgomery products (the division kernel of 2048-bit keys: PAI_TUNE add_div_min only)
 #pragma once
 
 enum LatOp { LAT_DEC, LAT_ENC, LAT_MUL };
@@ -182,6 +183,13 @@ static size_t lat_add_max(size_t ncu) {
     if (const char* env = std::getenv("PAI_LAT_ADD_MAX")) return (size_t)std::strtoull(env, nullptr, 10);
     return 4 * ncu;
 }
+// wire-form ct + ct stays on one integer per wavefront up to this multiple of lat_add_max: measured against the
+// most-significant-limb-first product on lane groups (profiles/r06/ctadd_msb_sweep.jsonl, 256 CUs, us per call, latency / lane groups):
+// 1024-bit keys 29.3 / 35.5 at 6 144 (36.1 / 35.7 at 7 168); 2048 bits 48.9 / 52.2 at 5 120 (55.7 / 52.1 at 6 144); 3072 bits
+// 51.2 / 51.4 at 2 048 (73.6 / 50.6 at 3 072); 4096 bits 88.1 / 90.0 at 4 096 (118 / 96 at 5 120)
+static int lat_add_wire_scale(int key_bits) {
+    return key_bits <= 1024 ? 6 : key_bits <= 2048 ? 5 : key_bits <= 3072 ? 2 : key_bits <= 4096 ? 4 : 2;
+}
 
 // ---- the switch points of one key, for tests and probes (pai_path_edges) --------------------------------------------------------
 // every batch size E at which the path of `op` (0 decrypt, 1 DJN encrypt, 2 ct x pt, 3 ct + ct) may change between N = E and
@@ -202,7 +210,8 @@ static std::vector<size_t> path_edges(int op, int key_bits, size_t ncu) {
              latency_max_elements(LAT_MUL, key_bits, ncu)};
         break;
     case 3:
-        e = {lat_add_max(ncu), 2 * lat_add_max(ncu), 4 * lat_add_max(ncu), pow2_digit_min_elements(ncu) - 1};
+        e = {lat_add_max(ncu), 2 * lat_add_max(ncu), 4 * lat_add_max(ncu), (size_t)lat_add_wire_scale(key_bits) * lat_add_max(ncu),
+             pow2_digit_min_elements(ncu) - 1};
         add_div_edges(ncu, e);
         break;
     default:

@@ -83,6 +83,31 @@ def timing(bits, B):
 if __name__ == "__main__":
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(7)
+    if len(sys.argv) > 2 and sys.argv[2] == "quick":            # the 2048-bit timing alone (profiles)
+        print(json.dumps(timing(2048, 1 << lg)), flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "sweep":            # small batches: the latency route against the throughput route
+        for bits in (2048, 1024, 3072, 4096):
+            key = synthetic_key(bits, 0x1234567)
+            pub = engine.PublicKeyHandle(key.n, bits, key.hs, key.randbits, device=dev)
+            for N in (2048, 3072, 4096, 5120, 6144, 7168, 8192, 10240, 12288, 16384):
+                g = torch.Generator(device=dev); g.manual_seed(1)
+                a = torch.randint(-(2**31), 2**31, (N, pub.ct_words), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+                a[:, -1] &= 0x00FFFFFF
+                b = a.flip(0).contiguous()
+                out = pub.empty_ct(N)
+                row = {"key_bits": bits, "batch": N}
+                for name, env in (("default", None), ("throughput", "0"), ("latency", "1000000")):
+                    if env is None: os.environ.pop("PAI_LAT_ADD_MAX", None)
+                    else: os.environ["PAI_LAT_ADD_MAX"] = env
+                    pub.ct_add(a, b, out=out); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(50): pub.ct_add(a, b, out=out)
+                    torch.cuda.synchronize()
+                    row[name + "_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+                os.environ.pop("PAI_LAT_ADD_MAX", None)
+                print(json.dumps(row), flush=True)
+        sys.exit(0)
     for bits in (2048, 1024, 3072, 4096):
         print(json.dumps(check(bits, 4099, rng)), flush=True)
     for bits, B in ((2048, 1 << lg), (1024, 1 << lg), (3072, 1 << (lg - 1)), (4096, 1 << (lg - 2)), (2048, 70000), (2048, 5000)):
