@@ -691,16 +691,12 @@ def main() -> None:
         engine.profile_enable(True)
         pub.ct_add(ct, ct_b, out=ct2)
         k_add_all = dict(engine.profile_last())
-        k_add_name = next((k for k in ("k_modmul_msb", "k_ctadd_div", "k_modmul") if k in k_add_all), None)
+        k_add_name = next((k for k in ("k_modmul_msb", "k_modmul") if k in k_add_all), None)
         k_add = k_add_all.get(k_add_name)
         engine.profile_enable(False)
-        # wire-form additions of large batches at 2048-bit keys: base-n digits + Barrett division on the one-element-per-lane engine
-        # (csrc/kernels_ctadd_div.hpp): 4 divisions of (0.63 + 0.58) and products 1 + 2 + 1 in units of 72^2 limb products
-        # (the default since the most-significant-limb-first product: ONE pass of 2 NL^2 limb products + 2 per row for the quotient
-        # digit, csrc/mont_msb.hpp; the division kernel and the two Montgomery products remain behind PAI_TUNE / PAI_DISABLE)
-        add_by_division = k_add_name == "k_ctadd_div"
-        macs_add_wire = ((4 * (68 + 63) / 108.0 + 4) * 72 * 72 if add_by_division
-                         else (2 * NLSQ * NLSQ + 2 * NLSQ) if k_add_name == "k_modmul_msb" else 2 * 2 * NLSQ * NLSQ)
+        # wire-form additions of large batches: ONE most-significant-limb-first pass of 2 NL^2 limb products + 2 per row for the
+        # quotient digit (csrc/mont_msb.hpp) where the key has the context, else two Montgomery products
+        macs_add_wire = (2 * NLSQ * NLSQ + 2 * NLSQ) if k_add_name == "k_modmul_msb" else 2 * 2 * NLSQ * NLSQ
         other = {
             "ct_add_ops_per_s": B / t_add, "ct_add_bcast_ops_per_s": B / t_add_b, "ct_mul_53bit_ops_per_s": B / t_mul,
             "ct_add_in_chain_ops_per_s": B / t_add_1, "ct_retag_ops_per_s": B / t_retag,

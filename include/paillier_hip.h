@@ -163,7 +163,9 @@ int pai_obfuscate(const pai_pubkey* pk, uint32_t* d_ct, const uint32_t* d_r, siz
 int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, void* stream);
 
 /* ipclCipherText.__add__(ct, ct) — classes.cpp:318-321: d_out[i] = d_a[i] * d_b[i] mod n^2.
- * b_bcast != 0: d_b holds one ciphertext used for every i (size-1 broadcast).  d_out may alias d_a. */
+ * b_bcast != 0: d_b holds one ciphertext used for every i (size-1 broadcast).  d_out may alias d_a.
+ * (Batches beyond the small-batch range: one most-significant-limb-first product per element, csrc/mont_msb.hpp — the canonical
+ * residue for ANY word pattern of the rows, reduced or not.) */
 int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N,
                uint32_t* d_out, void* stream);
 
@@ -208,7 +210,7 @@ int pai_ct_addn(const pai_pubkey* pk, const uint32_t* const* h_ops, const int32_
 /* Lazy Montgomery domain for chains of additions (extension).  A ciphertext buffer may hold x R^k mod n^2
  * instead of x (R = 2^bits of pai_pubkey_mont_bits; the caller tracks the integer k per buffer — k = 0 is the wire form).
  * pai_ct_mont_mul: d_out[i] = d_a[i] * d_b[i] * R^-1 mod n^2 (canonical residue), ONE Montgomery product per element where
- * pai_ct_add needs two: operands with tags ka, kb give ciphertext-addition with tag ka + kb - 1.  Multiplying by the
+ * pai_ct_add needs two (or the 1.4 x dearer most-significant-limb-first product): operands with tags ka, kb give ciphertext-addition with tag ka + kb - 1.  Multiplying by the
  * broadcast constant R^(1 + k' - k) mod n^2 (b_bcast != 0) moves a buffer from tag k to tag k', e.g. back to the wire
  * form before decryption, export or pickling — the bits at every boundary are those of CipherText::operator+
  * (classes.cpp:318-321).  d_out may alias d_a. */

@@ -37,7 +37,6 @@ SOURCES = [
     "padic_dec_kernels.hip",
     "padic_enc_kernels.hip",
     "padic_enc36_kernels.hip",
-    "padic_add_kernels.hip",
     "pair_kernels.hip",
     "paillier_capi.hip",
 ]

@@ -12,33 +12,13 @@ int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, i
         g_last_times.clear();
         const ModSetup* L = lat_add_ctx(pk, N, false, lat_add_wire_scale(pk->key_bits));
         // beyond the small-batch range, two wire-form operands: ONE most-significant-limb-first product (mont_msb.hpp) where the key
-        // has the context (PAI_DISABLE=add_msb: the routes below)
-        const bool msb = L == nullptr && pk->d_msb != nullptr && !b_bcast && !add_div_forced() && !knob_disabled("add_msb");
+        // has the context (PAI_DISABLE=add_msb: the two Montgomery products below).  (The division kernel of round 6 — base-n digits and
+        // Barrett division on the one-element-per-lane engine, 3.1 ms per 2^20 at 2048 bits against 2.8 here — is in the history: DESIGN.md section 8.)
+        const bool msb = L == nullptr && pk->d_msb != nullptr && !b_bcast && !knob_disabled("add_msb");
         if (msb) {
             const GeoOps* g = pk->msq.geo;
             ScopedKernelTimer t("k_modmul_msb", (hipStream_t)stream);
             g->modmul_msb((hipStream_t)stream, grid_for(g, N, pk->dev.ncu), pk->d_msb, d_a, d_b, d_out, (int)N, pk->ct_words);
-            t.stop();
-            HIP_CHECK(hipGetLastError());
-            return;
-        }
-        if (pk->d_mu29 && !b_bcast && add_div_pays(N, (size_t)pk->dev.ncu)) {          // (a broadcast addend keeps the lane-group kernel: its one row is staged once per tile there)
-            // large wire-form batches at the key sizes whose n fills 71 limbs: base-n digits and Barrett division on the
-            // one-element-per-lane engine (kernels_ctadd_div.hpp), 10 units of 72^2 limb products instead of 16
-            hipStream_t s = (hipStream_t)stream;
-            std::lock_guard<std::mutex> lk(pk->mu);
-            const size_t tiles = (N + BLOCK_THREADS - 1) / BLOCK_THREADS;
-            const int grid = (int)std::max<size_t>(1, std::min<size_t>(tiles, (size_t)pk->dev.ncu));
-            pk->add_div_scratch.ensure(ctadd_div_scratch_bytes(pk->penc_nl, (size_t)grid));
-            CtAddDivParams Q;
-            Q.n29 = pk->d_n29;
-            Q.mu29 = pk->d_mu29;
-            Q.scratch = pk->add_div_scratch.as<uint4>();
-            Q.ct_words = pk->ct_words;
-            OrderScope order_(pk->order, s);
-            ScopedKernelTimer t("k_ctadd_div", s);
-            if (!launch_ctadd_div(pk->penc_nl, s, grid, Q, d_a, d_b, d_out, (int)N))
-                throw PaiError(PAI_E_INTERNAL, "no division kernel for this limb count");
             t.stop();
             HIP_CHECK(hipGetLastError());
             return;

@@ -111,9 +111,6 @@ bool launch_fb_table_padic(int nl, hipStream_t s, const MontCtx* nctx, const uin
                            const uint32_t* one_dig, uint32_t* table, int J, int wb, const FbBases& fb);
 bool launch_fb_expand_padic(int nl, hipStream_t s, int grid, const MontCtx* nctx, const uint32_t* nm1, const uint32_t* S,
                             uint32_t* T, int J, int h, uint32_t* mscratch);
-struct CtAddDivParams;
-size_t ctadd_div_scratch_bytes(int nl, size_t blocks);
-bool launch_ctadd_div(int nl, hipStream_t s, int grid, const CtAddDivParams& P, const uint32_t* a, const uint32_t* b, uint32_t* out, int n);
 struct PowPadicParams;
 bool launch_pow_padic(int nl, hipStream_t s, int grid, const PowPadicParams& P, const uint32_t* base, uint32_t* out, int n);
 struct CtMulPadicParams;

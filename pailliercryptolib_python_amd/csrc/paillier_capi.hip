@@ -21,7 +21,6 @@
 #include "kernels_pair.hpp"
 #include "kernels_codec.hpp"
 #include "kernels_declat.hpp"
-#include "kernels_ctadd_div.hpp"
 
 using namespace pai;
 using hbn::Limbs;
@@ -482,10 +481,6 @@ struct pai_pubkey {
     ModSetup nmod;
     uint32_t* d_nm1 = nullptr;
     uint32_t* d_nsq29 = nullptr;
-    // ct + ct by true division (kernels_ctadd_div.hpp): n and floor(B^(2 (NL-1)) / n) as NL limbs, set when n fills NL - 1 limbs
-    uint32_t* d_n29 = nullptr;
-    uint32_t* d_mu29 = nullptr;
-    mutable DevBuf add_div_scratch;
     uint32_t* d_fb_dig = nullptr;
     uint32_t* d_mscratch = nullptr;
     uint32_t* d_one_dig = nullptr;     // digit pair of R mod n^2 (the element 1 in Montgomery digit form)
@@ -1024,10 +1019,6 @@ int pai_pubkey_create(const uint32_t* h_n, int n_words, int key_bits, const uint
             const Limbs one{1u};
             pk->d_nm1 = upload_r29(hbn::sub(pk->n, one), pnl);
             pk->d_nsq29 = upload_r29(pk->nsq, 2 * pnl);
-            if (pnl == 72 && pk->ct_words == 128 && hbn::bitlen(pk->n) > hbn::RB * (pnl - 2)) {          // B^(K-1) <= n < B^K with K = pnl - 1: Barrett on pnl limbs
-                pk->d_n29 = upload_r29(pk->n, pnl);
-                pk->d_mu29 = upload_r29(hbn::divq(hbn::shl(Limbs{1u}, hbn::RB * 2 * (pnl - 1)), pk->n), pnl);
-            }
             const Limbs Rm = hbn::mod(hbn::shl(one, hbn::RB * pnl), pk->nsq);
             pk->d_one_dig = upload_vec(pubkey_digits_of(pk.get(), Rm));
             HIP_CHECK(hipMalloc((void**)&pk->d_mscratch, 2 * (size_t)pk->dev.ncu * BLOCK_THREADS * (size_t)pnl * 4));
@@ -1111,9 +1102,6 @@ void pai_pubkey_destroy(pai_pubkey* pk) {
     pk->nmod.release();
     if (pk->d_nm1) (void)hipFree(pk->d_nm1);
     if (pk->d_nsq29) (void)hipFree(pk->d_nsq29);
-    if (pk->d_n29) (void)hipFree(pk->d_n29);
-    if (pk->d_mu29) (void)hipFree(pk->d_mu29);
-    pk->add_div_scratch.release();
     if (pk->d_fb_dig) (void)hipFree(pk->d_fb_dig);
     if (pk->d_mscratch) (void)hipFree(pk->d_mscratch);
     if (pk->d_one_dig) (void)hipFree(pk->d_one_dig);

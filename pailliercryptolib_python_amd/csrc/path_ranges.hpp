@@ -19,7 +19,7 @@
 //             lane-group digit pairs (ctmul_mid: 20 .. 192 ncu) | one element per lane
 //   ct + ct   one integer per wavefront (tagged <= 4 ncu; wire form <= 8 .. 24 ncu by key size: lat_add_wire_scale; aligned additions and
 //             pow2 <= 16 ncu, raw encryption <= 8 ncu) | wave tiles: wire form by ONE most-significant-limb-first product (mont_msb.hpp) where
-//             the key has the context, else two Montgomery products (the division kernel of 2048-bit keys: PAI_TUNE add_div_min only)
+//             the key has the context (PAI_DISABLE=add_msb: off), else two Montgomery products
 #pragma once
 
 enum LatOp { LAT_DEC, LAT_ENC, LAT_MUL };
@@ -150,35 +150,6 @@ static size_t pow2_digit_min_elements(size_t ncu) {
 // (profiles/r04/lat_add_probe.jsonl): wire-form a b 30 against 60 us up to 1 024 elements (39 / 65 at 2 048, level at 4 096), the
 // tagged single product 29 against 35 us up to 1 024 (level at 2 048), aligned additions with shifts up to 13: 0.18 against 0.44 ms
 // up to 1 024, 0.31 / 0.45 at 4 096 — hence the callers' scale factors 2 (wire form) / 1 (tagged) / 4 (aligned, pow2) / 2 (raw encrypt)
-// Wire-form ct + ct on the division kernel of the one-element-per-lane engine (kernels_ctadd_div.hpp; PAI_DISABLE=add_div switches it off).
-// The kernel runs in ROUNDS of 256 elements per CU (one workgroup per CU, one element per lane); a round costs about 0.84 of what the two
-// Montgomery products on lane groups take for as many elements (measured per call at 256 CUs, profiles/r06/ctadd_div_rule.txt: 50 000
-// elements 0.217 against 0.238 ms, 70 000 0.403 against 0.344, 110 000 0.423 against 0.461, 300 000 1.04 against 1.10, 2^20 3.03 against
-// 3.49) — so it pays when the last round is full enough: ceil(x) * 0.84 <= x, x = N / (256 ncu): 0.84 .. 1 rounds, 1.68 .. 2, 2.52 .. 3, ...,
-// and always from 5.04 rounds on.  PAI_TUNE add_div_min=v (tests, probes): every batch of >= v.
-static bool add_div_pays(size_t N, size_t ncu) {
-    if (knob_disabled("add_div")) return false;
-    long long v;
-    if (knob_tune("add_div_min", &v)) return N >= (size_t)v;
-    const size_t round = 256 * ncu, rounds = (N + round - 1) / round;
-    return rounds * 84 * round <= N * 100;
-}
-// PAI_TUNE add_div_min present: tests and probes ask for the division kernel by name (it then also wins over the
-// most-significant-limb-first product, which serves these batches otherwise: dispatch_add.hpp)
-static bool add_div_forced() {
-    long long v;
-    return !knob_disabled("add_div") && knob_tune("add_div_min", &v);
-}
-// the first three switch points of that rule (for pai_path_edges)
-static void add_div_edges(size_t ncu, std::vector<size_t>& e) {
-    if (knob_disabled("add_div")) return;
-    long long v;
-    if (knob_tune("add_div_min", &v)) { if (v > 0) e.push_back((size_t)v - 1); return; }
-    const size_t round = 256 * ncu;
-    e.push_back((84 * round + 99) / 100 - 1);            // below it: lane groups; from it: one round of the division kernel
-    e.push_back(round);                                  // a second round that is nearly empty: lane groups again
-    e.push_back((2 * 84 * round + 99) / 100 - 1);        // ... until it is 0.68 full
-}
 static size_t lat_add_max(size_t ncu) {
     if (const char* env = std::getenv("PAI_LAT_ADD_MAX")) return (size_t)std::strtoull(env, nullptr, 10);
     return 4 * ncu;
@@ -212,7 +183,6 @@ static std::vector<size_t> path_edges(int op, int key_bits, size_t ncu) {
     case 3:
         e = {lat_add_max(ncu), 2 * lat_add_max(ncu), 4 * lat_add_max(ncu), (size_t)lat_add_wire_scale(key_bits) * lat_add_max(ncu),
              pow2_digit_min_elements(ncu) - 1};
-        add_div_edges(ncu, e);
         break;
     default:
         break;

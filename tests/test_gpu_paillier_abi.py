@@ -1098,46 +1098,6 @@ def test_host_stage_operands_are_read_in_place(k2048):
     assert k2048.lib.pai_host_stage(0, 1, srcs, sizes, None, ptrs) == -1
 
 
-def test_ct_add_by_division_matches_the_product_of_residues(k2048, monkeypatch):
-    """pai_ct_add of large wire-form batches at 2048-bit keys: base-n digits and Barrett division on the one-element-per-lane
-    engine (csrc/kernels_ctadd_div.hpp) instead of two Montgomery products — every element against CPython, operands that make
-    digits, quotient corrections and carries extreme, broadcast, in place, ragged tiles, and the switch itself."""
-    key = k2048.key
-    n, M = key.n, key.nsq
-    rng = np.random.default_rng(606)
-    special = [0, 1, 2, n - 1, n, n + 1, 2 * n, M - 1, M - 2, M - n, M - n - 1, M - n + 1, (n - 1) * n, (n - 1) * n + n - 1,
-               (1 << 4095) % M, ((1 << 2048) - 1) % M, (n >> 1) * n + (n >> 1), n * n // 2, 3 * n - 1, (1 << 2030), (1 << 2059) % M]
-    tune(monkeypatch, "add_div_min", 1)
-    for N in (1, 255, 257, 700):
-        a = (special + rand_below(rng, M, N))[:N] if N > 30 else rand_below(rng, M, N)
-        b = (list(reversed(special)) + rand_below(rng, M, N))[:N] if N > 30 else rand_below(rng, M, N)
-        if N == 700:
-            a[40:61] = special                              # every special value against every other one nearby
-            b[40:61] = special[7:] + special[:7]
-        da, db = DevArray(ints_to_limbs(a, k2048.cw)), DevArray(ints_to_limbs(b, k2048.cw))
-        out = DevArray(shape=(N, k2048.cw))
-        _native.check(k2048.lib.pai_ct_add(k2048.pk, da.ptr, db.ptr, 0, N, out.ptr, None))
-        assert limbs_to_ints(out.get()) == [x * y % M for x, y in zip(a, b)], N
-        _native.check(k2048.lib.pai_ct_add(k2048.pk, da.ptr, db.ptr, 1, N, out.ptr, None))        # broadcast b[0]
-        assert limbs_to_ints(out.get()) == [x * b[0] % M for x in a], N
-        _native.check(k2048.lib.pai_ct_add(k2048.pk, da.ptr, db.ptr, 0, N, da.ptr, None))         # in place
-        assert limbs_to_ints(da.get()) == [x * y % M for x, y in zip(a, b)], N
-    # the two kernels on one large batch
-    N = 70000                                                 # (1.07 rounds of 65 536: the default rule would leave it on lane groups)
-    a = rng.integers(0, 1 << 32, (N, k2048.cw), dtype=np.uint64).astype(np.uint32)
-    b = rng.integers(0, 1 << 32, (N, k2048.cw), dtype=np.uint64).astype(np.uint32)
-    a[:, -1] &= 0x00FFFFFF
-    b[:, -1] &= 0x00FFFFFF                                   # < n^2 (a 4095-bit modulus: the top byte clear is enough)
-    da, db, o1, o2 = DevArray(a), DevArray(b), DevArray(shape=(N, k2048.cw)), DevArray(shape=(N, k2048.cw))
-    _native.check(k2048.lib.pai_ct_add(k2048.pk, da.ptr, db.ptr, 0, N, o1.ptr, None))
-    knob_disable(monkeypatch, "add_div")
-    _native.check(k2048.lib.pai_ct_add(k2048.pk, da.ptr, db.ptr, 0, N, o2.ptr, None))
-    got, ref = o1.get(), o2.get()
-    assert np.array_equal(got, ref)
-    idx = [0, 1, 255, 256, N // 2, N - 1]
-    assert limbs_to_ints(got[idx]) == [x * y % M for x, y in zip(limbs_to_ints(a[idx]), limbs_to_ints(b[idx]))]
-
-
 def _last_kernels(lib):
     names, i = [], 0
     name, ms = C.create_string_buffer(64), C.c_float(0)
@@ -1188,7 +1148,6 @@ def test_ct_add_by_one_msb_first_product(bits, monkeypatch):
     da, db, o1, o2 = DevArray(a), DevArray(b), DevArray(shape=(N, W)), DevArray(shape=(N, W))
     _native.check(K.lib.pai_ct_add(K.pk, da.ptr, db.ptr, 0, N, o1.ptr, None))
     knob_disable(monkeypatch, "add_msb")
-    knob_disable(monkeypatch, "add_div")
     _native.check(K.lib.pai_ct_add(K.pk, da.ptr, db.ptr, 0, N, o2.ptr, None))
     got, ref = o1.get(), o2.get()
     idx = [0, 1, 2, 255, 256, N // 2, N - 2, N - 1]

@@ -1,6 +1,6 @@
 """Dev probe: wire-form ct + ct by ONE most-significant-limb-first product (csrc/mont_msb.hpp, k_modmul_msb) — every element against
-CPython at four key sizes (reduced, extreme and unreduced operands), then the timing beside the division kernel, the two Montgomery
-products and the lazy single product.   python tools/ctadd_msb_check.py [log2 batch = 20]"""
+CPython at four key sizes (reduced, extreme and unreduced operands), then the timing beside the two Montgomery products and the lazy single
+product; `sweep`: small batches on the latency route against the throughput route.   python tools/ctadd_msb_check.py [log2 batch = 20]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -64,12 +64,7 @@ def timing(bits, B):
     row = {"key_bits": bits, "batch": B}
     row["msb_ms"] = round(tm(lambda: pub.ct_add(a, b, out=out)), 3)
     engine.profile_enable(True); pub.ct_add(a, b, out=out); row["msb_kernel"] = engine.profile_last(); engine.profile_enable(False)
-    if bits == 2048:
-        os.environ["PAI_TUNE"] = "add_div_min=1"
-        row["div_ms"] = round(tm(lambda: pub.ct_add(a, b, out=ref)), 3)
-        os.environ.pop("PAI_TUNE")
-        row["div_same_bits"] = bool(torch.equal(out, ref))
-    os.environ["PAI_DISABLE"] = "add_div,add_msb"
+    os.environ["PAI_DISABLE"] = "add_msb"
     row["montgomery_x2_ms"] = round(tm(lambda: pub.ct_add(a, b, out=ref)), 3)
     row["lazy_single_product_ms"] = round(tm(lambda: pub.ct_mont_mul(a, b, out=ref)), 3)
     pub.ct_add(a, b, out=ref)

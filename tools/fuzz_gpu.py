@@ -43,9 +43,9 @@ while time.time() - t0 < budget:
     da, db = DevArray(ints_to_limbs(a, nk.cw)), DevArray(ints_to_limbs(b, nk.cw))
     out = DevArray(shape=(N, nk.cw))
     bc = int(rng.integers(0, 2))
-    if rng.integers(0, 2): os.environ["PAI_TUNE"] = "add_div_min=1"      # 2048-bit keys: the division kernel (kernels_ctadd_div.hpp) at any batch size
+    if rng.integers(0, 2): os.environ["PAI_DISABLE"] = "add_msb"         # two Montgomery products instead of the most-significant-limb-first one
     _native.check(lib.pai_ct_add(nk.pk, da.ptr, db.ptr, bc, N, out.ptr, None))
-    os.environ.pop("PAI_TUNE", None)
+    os.environ.pop("PAI_DISABLE", None)
     assert limbs_to_ints(out.get()) == [x * (b[0] if bc else y) % M for x, y in zip(a, b)], ("ct_add", bits, N, bc)
     # lazy Montgomery domain: the single product, and the aligned addition on a random common tag
     rb = C.c_int(0)
