@@ -29,6 +29,15 @@ import torch
 # retag launch at the next boundary (export, decryption, ct * pt) is saved.  0 keeps every addition lazy.
 EAGER_ADD_MAX = 1024
 
+
+def eager_ctct_max(key_bits: int) -> int:
+    """Largest ct + ct batch of two wire-form operands that is summed into the wire form at once: the range the library keeps on one
+    integer per wavefront (csrc/path_ranges.hpp: lat_add_wire_scale x 4 elements per compute unit; measured on 256 CUs,
+    profiles/r06/ctadd_msb_sweep.jsonl) — 2048-bit keys: 25 us at 2 048 and 49 us at 5 120 elements, where a lazily tagged product on
+    wave tiles costs ~37 us and its retag as much again."""
+    scale = 6 if key_bits <= 1024 else 5 if key_bits <= 2048 else 2 if key_bits <= 3072 else 4 if key_bits <= 4096 else 2
+    return scale * EAGER_ADD_MAX
+
 from . import _native, engine
 
 # ------------------------------------------------------------------------------------------------
@@ -761,7 +770,7 @@ class ipclCipherText(_Container):
         if len(other) != len(self) and len(other) != 1:
             raise RuntimeError("Size mismatch")
         (ta, ka), (tb, kb) = self._raw(), other._raw()
-        if ka == 0 and kb == 0 and ta.shape[0] <= EAGER_ADD_MAX:
+        if ka == 0 and kb == 0 and ta.shape[0] <= eager_ctct_max(self._pk._bits):
             # small wire-form operands: the wire form at once (the latency geometry spends two products on a tagged result too)
             return ipclCipherText(self._pk, h.ct_add(ta, tb), taint=merge_taint(self._taint, other._taint))
         return ipclCipherText(self._pk, h.ct_mont_mul(ta, tb), dom=ka + kb - 1,        # one product; the tag remembers the R^-1

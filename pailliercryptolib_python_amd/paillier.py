@@ -632,7 +632,7 @@ class PaillierEncryptedNumber:
             ye = np.broadcast_to(ye, xe.shape)
         delta = (xe - ye).astype(np.int32)
         if not delta.any():
-            if ka == 0 and kb == 0 and ta.shape[0] <= _bindings.EAGER_ADD_MAX:
+            if ka == 0 and kb == 0 and ta.shape[0] <= _bindings.eager_ctct_max(self.public_key.pubkey._bits):
                 # small batches run on the latency geometry, where the tagged product costs two products anyway (its result
                 # has to carry the throughput geometry's R): the wire form straight away — same kernel time, and no retag
                 # product (a second launch) when the result is exported, decrypted or multiplied

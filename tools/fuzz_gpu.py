@@ -44,8 +44,10 @@ while time.time() - t0 < budget:
     out = DevArray(shape=(N, nk.cw))
     bc = int(rng.integers(0, 2))
     if rng.integers(0, 2): os.environ["PAI_DISABLE"] = "add_msb"         # two Montgomery products instead of the most-significant-limb-first one
+    if rng.integers(0, 2): os.environ["PAI_LAT_ADD_MAX"] = "0"           # lane groups (wave tiles) at any batch size
     _native.check(lib.pai_ct_add(nk.pk, da.ptr, db.ptr, bc, N, out.ptr, None))
     os.environ.pop("PAI_DISABLE", None)
+    os.environ.pop("PAI_LAT_ADD_MAX", None)
     assert limbs_to_ints(out.get()) == [x * (b[0] if bc else y) % M for x, y in zip(a, b)], ("ct_add", bits, N, bc)
     # lazy Montgomery domain: the single product, and the aligned addition on a random common tag
     rb = C.c_int(0)
