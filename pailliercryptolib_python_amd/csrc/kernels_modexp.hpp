@@ -134,8 +134,6 @@ k_modmul_msb(const MsbCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* 
     k.sh3 = (uint32_t)RB - tb;
     k.m2 = ctx->m2;
     k.eight = ctx->eight;
-    k.one = ctx->one;
-    k.topmask = t == G::T - 1 ? 0xFFFFFFFFu : 0u;
     constexpr int WPB = BLOCK_THREADS / 64;
     const int wtiles = (n + WT::EPW - 1) / WT::EPW;
     clear_stage<G>(stage);

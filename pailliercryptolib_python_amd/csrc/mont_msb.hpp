@@ -9,11 +9,11 @@
 // the bottom:  q^ = floor(V mu / 2^63),  V = the accumulator's highest ~62 bits,  mu = floor(2^(P+31) / Mt).
 //   * Mt = M B^off puts the modulus' top limb at limb NL - 1 for every key size (compile-time cell positions); the
 //     multiplier enters as b B^off (rows below `off` read zero) and the result leaves as r B^off — a limb shift on the way out.
-//   * the reduction ADDS q^ W, W = B^NL - Mt, so every cell stays an unsigned lazy 64-bit column; the - q^ B^NL that
-//     completes - q^ Mt is one 32-bit subtraction from the high word of the group's last lane's top own cell (its limb of
-//     W carries + 2^32 - 2^29).  That cell and the one above it are kept modulo 2^64 only: with tb = the bits of Mt in
-//     limb NL - 1 (3 <= tb <= 26, MsbCtx::tb) every column from aligned NL + 1 up weighs a multiple of 2^(P+32), the
-//     accumulator is < 2 Mt < 2^(P+1) after every row, so those columns are never read and simply fall off the window.
+//   * the reduction ADDS q^ W, W = B^NL - Mt, so every cell stays an unsigned lazy 64-bit column — and the q^ B^NL this leaves
+//     on top of acc - q^ Mt needs NO correction: it sits at aligned column NL, the next row moves it to NL + 1, and with tb =
+//     the bits of Mt in limb NL - 1 (3 <= tb <= 26, MsbCtx::tb) every column from NL + 1 up weighs a multiple of 2^(P+32) while
+//     the accumulator proper is < 2 Mt < 2^(P+1): the digit estimate (computed modulo 2^64 from cells whose weights it knows)
+//     never sees it, the slide drops it, and the final carry sweep masks it off the top limb.
 //   * q^ is never above the true digit (all roundings go down; a window that reads negative because the lazy columns below
 //     it still hold the carries gives 0) and at most 1 below it: by induction 0 <= acc < 2 Mt (then acc B + a b_i <
 //     (2 B + 4) Mt for any a of the row's word size, off >= 1; V < 2^62 (1 + 2^-28), and the roundings — mu's, < V / 2^63, the
@@ -29,19 +29,19 @@ namespace pai {
 constexpr int MSB_NORM_ROWS = 20;           // rows between carry normalisations: the largest multiple of U below (3 x 2^58 per row and column)
 
 struct MsbCtx {
-    uint32_t w[NLMAX];        // B^NL - Mt, limb NL - 1 with + 2^32 - 2^29 (see above)
+    uint32_t w[NLMAX];        // B^NL - Mt
     uint32_t mt[NLMAX];       // Mt = M B^off
     uint32_t mu;              // floor(2^(P + 31) / Mt), P = bit length of Mt
     uint32_t tb;              // P - 29 (NL - 1)
     uint32_t off;             // limbs M was shifted up by (>= 1)
     uint32_t nl;
-    uint32_t m2, eight, one;  // 2^(32 - tb), 8, 1: multipliers of v_mad_u64_u32 the compiler must not see as literals (MsbK)
+    uint32_t m2, eight;       // 2^(32 - tb), 8: multipliers of v_mad_u64_u32 the compiler must not see as literals (MsbK)
 };
 
 // uniform constants of the digit estimate (eight / m2 are run-time values on purpose: as literals the compiler turns the
 // multiply-adds that carry a free 64-bit addition into shift / mask / add sequences three times as long)
 struct MsbK {
-    uint32_t mu, sh1 /* tb - 3 */, sh2 /* 32 - tb */, sh3 /* 29 - tb */, m2 /* 2^(32 - tb) */, eight, one, topmask /* ~0 in the group's last lane */;
+    uint32_t mu, sh1 /* tb - 3 */, sh2 /* 32 - tb */, sh3 /* 29 - tb */, m2 /* 2^(32 - tb) */, eight;
 };
 
 // value held by the LAST lane of the caller's group
@@ -89,9 +89,6 @@ struct RowsMsb {
             for (int j = NLL - 1; j >= 0; --j) acc[j + o] += (uint64_t)a[j] * bv[u];
             const uint32_t q = bcast_last<T>(msb_digit(acc[o + NLL], acc[o + NLL - 1], acc[o + NLL - 2], acc[o + NLL - 3], k));
             wm.template mac<NLL>(acc, o, q);
-            // - q B^NL: off the high word of the top own cell of the group's last lane
-            const uint32_t hi = (uint32_t)(acc[o + NLL - 1] >> 32) - (q & k.topmask);
-            acc[o + NLL - 1] = ((uint64_t)hi << 32) | (uint32_t)acc[o + NLL - 1];
         }
     }
     // carry-save normalisation of the WHOLE window, the top cell included: its carry (returned) belongs to the next lane's cell U.
@@ -105,25 +102,19 @@ struct RowsMsb {
         return top >> RB;
     }
     // the U cells above the lane's own range (and the normalisation's carry, if any) go to the next lane; the window moves up by U
-    // acc += the 64-bit value (hi : lo) without building a register pair: v_mad_u64_u32 adds a zero-extended word for free
-    PAI_DEV static void add64(uint64_t& acc, uint32_t lo, uint32_t hi, const MsbK& k) {
-        const uint64_t t = (uint64_t)lo * k.one + acc;
-        acc = ((uint64_t)((uint32_t)(t >> 32) + hi) << 32) | (uint32_t)t;
+    // acc += nf01 * (hi : lo) (nf01 = 0 in the group's first lane, which has no previous lane, else 1) without building a register
+    // pair: v_mad_u64_u32 adds a zero-extended word times nf01 for free, the high word takes one masked addition
+    PAI_DEV static void add64(uint64_t& acc, uint32_t lo, uint32_t hi, uint32_t nf01) {
+        const uint64_t t = (uint64_t)lo * nf01 + acc;
+        acc = ((uint64_t)((uint32_t)(t >> 32) + (hi & (0u - nf01))) << 32) | (uint32_t)t;
     }
     template <bool CARRY>
-    PAI_DEV static void handover_slide(uint64_t (&acc)[NW], uint64_t carry, uint32_t nfmask, const MsbK& k) {
+    PAI_DEV static void handover_slide(uint64_t (&acc)[NW], uint64_t carry, uint32_t nf01) {
         if constexpr (T > 1) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {                        // (nfmask: the group's first lane has no previous lane)
-                const uint32_t lo = from_prev_raw<T>((uint32_t)acc[NLL + u]) & nfmask;
-                const uint32_t hi = from_prev_raw<T>((uint32_t)(acc[NLL + u] >> 32)) & nfmask;
-                add64(acc[u], lo, hi, k);
-            }
-            if constexpr (CARRY) {
-                const uint32_t lo = from_prev_raw<T>((uint32_t)carry) & nfmask;
-                const uint32_t hi = from_prev_raw<T>((uint32_t)(carry >> 32)) & nfmask;
-                add64(acc[U], lo, hi, k);
-            }
+            for (int u = 0; u < U; ++u)
+                add64(acc[u], from_prev_raw<T>((uint32_t)acc[NLL + u]), from_prev_raw<T>((uint32_t)(acc[NLL + u] >> 32)), nf01);
+            if constexpr (CARRY) add64(acc[U], from_prev_raw<T>((uint32_t)carry), from_prev_raw<T>((uint32_t)(carry >> 32)), nf01);
         }
 #pragma unroll
         for (int j = NLL - 1; j >= 0; --j) acc[j + U] = acc[j];
@@ -141,7 +132,7 @@ PAI_DEV void msb_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32_
 #pragma unroll
     for (int j = 0; j < RW::NW; ++j) acc[j] = 0;
     constexpr int NB = RW::NL / U;
-    const uint32_t nfmask = group_lane<T>() != 0 ? 0xFFFFFFFFu : 0u;
+    const uint32_t nf01 = group_lane<T>() != 0 ? 1u : 0u;
     int since = 0;
 #pragma unroll 1
     for (int blk = 0; blk < NB; ++blk) {
@@ -160,9 +151,9 @@ PAI_DEV void msb_mul(uint32_t (&r)[NLL], const uint32_t (&a)[NLL], const uint32_
         if (++since == RW::NORM_BLOCKS && blk != NB - 1) {
             since = 0;
             const uint64_t carry = RW::normalize(acc);
-            RW::template handover_slide<true>(acc, carry, nfmask, k);
+            RW::template handover_slide<true>(acc, carry, nf01);
         } else {
-            RW::template handover_slide<false>(acc, 0, nfmask, k);
+            RW::template handover_slide<false>(acc, 0, nf01);
         }
     }
     // the last block slid too: the own cells are [U, NLL + U)

@@ -318,14 +318,12 @@ static MsbCtx* build_msb_ctx(const Limbs& M, const GeoOps* g, int w32) {
     const auto w = hbn::to_r29(W, NL), mt = hbn::to_r29(Mt, NL);
     std::memcpy(h.w, w.data(), (size_t)NL * 4);
     std::memcpy(h.mt, mt.data(), (size_t)NL * 4);
-    h.w[NL - 1] += 0xE0000000u;                       // + 2^32 - 2^29: with the - q 2^32 in the kernel this is the - q B^NL
     h.mu = mu.empty() ? 0u : mu[0];
     h.tb = (uint32_t)tb;
     h.off = (uint32_t)off;
     h.nl = (uint32_t)NL;
     h.m2 = 1u << (32 - tb);
     h.eight = 8u;
-    h.one = 1u;
     MsbCtx* d = nullptr;
     HIP_CHECK(hipMalloc((void**)&d, sizeof(MsbCtx)));
     HIP_CHECK(hipMemcpy(d, &h, sizeof(MsbCtx), hipMemcpyHostToDevice));

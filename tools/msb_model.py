@@ -1,7 +1,7 @@
 """Cell-exact model of the MSB-first interleaved product on the lane-group engine (csrc/mont_msb.hpp).
 
-Every lane's window cell is a 64-bit register with wrap-around; beside it the model keeps the unbounded value of every cell that
-must NOT wrap (all but the top lane's two highest aligned columns) and asserts the budget.  Run: python tools/msb_model.py [rounds]
+Every lane's window cell is a 64-bit register with wrap-around; beside it the model keeps the unbounded value of every cell and
+asserts that none of a lane's own cells ever wraps, that every quotient digit is the true one or one below, and the product.  Run: python tools/msb_model.py [rounds]
 """
 import random
 import sys
@@ -25,8 +25,6 @@ class Params:
         self.ok = 3 <= self.tb <= 26 and self.off >= 1
         W = B ** NL - self.Mt
         self.w = [(W >> (RB * i)) & MASK for i in range(NL)]
-        self.w[NL - 1] += (1 << 32) - (1 << RB)
-        assert self.w[NL - 1] < (1 << 32)
         self.mu = (1 << (self.P + 31)) // self.Mt
         assert self.mu < (1 << 32)
         self.norm_blocks = (20 // U)
@@ -81,14 +79,14 @@ def msb_mul(p, a, b, stats=None):
                     pr = p.w[t * NLL + j] * q
                     acc[t][j + o] = (acc[t][j + o] + pr) & M64
                     big[t][j + o] += pr
-            top[o + NLL - 1] = (top[o + NLL - 1] - (q << 32)) & M64
             A_true -= q * p.Mt
             assert 0 <= A_true < 2 * p.Mt
         last = blk == NB - 1
-        # budget: every cell that must not wrap (top lane: cells at aligned columns >= NL - 1 may)
+        # budget: no cell wraps, but the last lane's cells above its own range (aligned columns >= NL: what every reduction's q W leaves
+        # there is a multiple of B^NL, read through its low bits only and dropped by the slide)
         for t in range(T):
             for j in range(NW):
-                if t == T - 1 and j >= NLL - 1:
+                if t == T - 1 and j >= NLL:
                     continue
                 assert big[t][j] <= M64, ("cell overflow", blk, t, j)
         # every norm_blocks blocks: carry-save normalisation of the whole window BEFORE the hand-over, the top cell included
@@ -128,7 +126,7 @@ def msb_mul(p, a, b, stats=None):
             v = acc[t][j + U] + c
             r |= (v & MASK) << (RB * (t * NLL + j))
             c = v >> RB
-    assert r == A_true, "finish mismatch"
+    assert r == A_true, "finish mismatch"          # (the q B^NL every reduction leaves above the window never reaches the limbs)
     if r >= p.Mt:
         r -= p.Mt
     assert r < p.Mt
