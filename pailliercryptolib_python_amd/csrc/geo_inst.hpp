@@ -200,7 +200,7 @@ struct GeoInst {
     static void modmul_msb(hipStream_t s, int grid, const MsbCtx* c, const uint32_t* a, const uint32_t* b, uint32_t* out, int n, int w32) {
         if constexpr (G::T <= 8) {
             // (rows per block: the geometry's own — 9 / 12 / 18 on 36 x 4 spill inside the row loop, /tmp probe of round 6)
-            constexpr int bytes = GM::LDS_BYTES + GM::STAGE_BYTES + GM::NL * 4;     // + the copy of W
+            constexpr int bytes = MsbLds<GM>::WORDS * 4;
             set_lds((const void*)k_modmul_msb<GM>, bytes);
             report_occupancy("k_modmul_msb", (const void*)k_modmul_msb<GM>, bytes);
             hipLaunchKernelGGL(k_modmul_msb<GM>, dim3(grid), dim3(BLOCK_THREADS), bytes, s, c, a, b, out, n, w32);

@@ -103,14 +103,21 @@ k_modmul(const MontCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, 
 // MODMUL_FULL without a broadcast operand at half the limb products.  Same tile loop, same LDS plan; the modulus copy
 // behind the operand buffer holds Mt = M B^off for the two conditional subtractions, and the result's B^off leaves
 // through the operand buffer (limb j + off read back as limb j).  Operands may be any word pattern of the row.
+template <class G>
+struct MsbLds {                                          // LDS plan of k_modmul_msb, in words
+    static constexpr int OP = (G::NL + MSB_OFF_MAX) * G::EPB;      // operand buffer [limb][element] + MSB_OFF_MAX limbs of zeros behind it
+    static constexpr int MT = OP, STAGE = MT + G::NL, W = STAGE + G::STAGE_WORDS, WORDS = W + G::NL;
+};
+
 template <class G, int UM = G::U>
 __global__ void __launch_bounds__(BLOCK_THREADS, 2)
 k_modmul_msb(const MsbCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, int n, int w32) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using WT = WaveTile<G>;
-    uint32_t* mt_lds = lds + G::LDS_WORDS;
-    uint32_t* stage = lds + G::LDS_WORDS + G::NL;
-    uint32_t* w_lds = stage + G::STAGE_WORDS;            // W = B^NL - Mt, one copy per workgroup
+    using L = MsbLds<G>;
+    uint32_t* mt_lds = lds + L::MT;                      // Mt = M B^off, for the conditional subtraction
+    uint32_t* stage = lds + L::STAGE;
+    uint32_t* w_lds = lds + L::W;                        // W = B^NL - Mt, one copy per workgroup
     const int t = G::gl();
     // W's slice: registers where the accumulator window leaves room, else re-read from LDS during the q W step (the window, a's
     // slice and W's are 156 of the 256 registers at 36 limbs per lane: with W in registers the compiler spills loop invariants)
@@ -122,11 +129,16 @@ k_modmul_msb(const MsbCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* 
         for (int j = 0; j < G::NLL; ++j) wm.v[j] = ctx->w[G::NLL * t + j];
     }
     for (int i = threadIdx.x; i < G::NL; i += BLOCK_THREADS) { mt_lds[i] = ctx->mt[i]; w_lds[i] = ctx->w[i]; }
+    for (int i = threadIdx.x; i < L::OP; i += BLOCK_THREADS) lds[i] = 0u;
     __syncthreads();
     NmLds<G::NLL> mt;
     mt.p = mt_lds + G::NLL * t;
     const uint32_t tb = ctx->tb;
-    const int off = (int)ctx->off;
+    // The multiplier enters as b B^off and the result leaves as r B^off: limb j is staged as limb j + off and read back from
+    // there — ONE base address and compile-time offsets, no bounds to test: what lands in the MSB_OFF_MAX limbs behind the
+    // buffer is zero (b fits the row's words), and the lowest `off` limbs stay zero from tile to tile (the buffer was cleared; a
+    // tile leaves r B^off, a multiple of B^off, behind).
+    uint32_t* opsh = lds + (G::NLL * t + (int)ctx->off) * G::EPB + G::elem();
     MsbK k;
     k.mu = ctx->mu;
     k.sh1 = tb - 3u;
@@ -148,16 +160,9 @@ k_modmul_msb(const MsbCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* 
         __builtin_amdgcn_s_setprio(2);
         load_tile<G>(stage, b + (size_t)row0 * w32, rows, w32);
         unpack_row<G>(x, stage);
-        // b B^off as the multiplier: limb j is staged as limb j + off (what would land beyond the geometry is zero: b fits the
-        // row's words), the lowest `off` limbs read zero
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < G::NLL; ++j) {
-            const int idx = G::NLL * t + j + off;
-            if (idx < G::NL) lds[idx * G::EPB + G::elem()] = x[j];
-        }
-        if (t == 0)
-            for (int i = 0; i < off; ++i) lds[i * G::EPB + G::elem()] = 0u;
+        for (int j = 0; j < G::NLL; ++j) opsh[j * G::EPB] = x[j];
         wave_lds_fence();
         load_tile<G>(stage, a + (size_t)row0 * w32, rows, w32);
         unpack_row<G>(x, stage);
@@ -170,13 +175,9 @@ k_modmul_msb(const MsbCtx* __restrict__ ctx, const uint32_t* a, const uint32_t* 
         }
         cond_sub<G::NLL, G::T>(x, mt);
         __builtin_amdgcn_s_setprio(2);
-        stage_b<G>(x, lds);                                  // / B^off: the low `off` limbs are zero
+        stage_b<G>(x, lds);                                  // / B^off
 #pragma unroll
-        for (int j = 0; j < G::NLL; ++j) {
-            const int idx = G::NLL * t + j + off;
-            const uint32_t v = lds[(idx < G::NL ? idx : G::NL - 1) * G::EPB + G::elem()];
-            x[j] = idx < G::NL ? v : 0u;
-        }
+        for (int j = 0; j < G::NLL; ++j) x[j] = opsh[j * G::EPB];
         pack_row<G>(x, stage);
         store_tile<G>(stage, out + (size_t)row0 * w32, rows, w32);
     }

@@ -26,6 +26,7 @@
 
 namespace pai {
 
+constexpr int MSB_OFF_MAX = 16;             // limbs the modulus may be shifted up by (zero limbs behind k_modmul_msb's operand buffer)
 constexpr int MSB_NORM_ROWS = 20;           // rows between carry normalisations: the largest multiple of U below (3 x 2^58 per row and column)
 
 struct MsbCtx {

@@ -303,7 +303,7 @@ static MsbCtx* build_msb_ctx(const Limbs& M, const GeoOps* g, int w32) {
     if (!g || !g->modmul_msb || g->t > 8 || g->nll < 4) return nullptr;
     const int NL = g->nl, bits = hbn::bitlen(M);
     const int mtop = (bits - 1) / hbn::RB, off = NL - 1 - mtop;
-    if (off < 1) return nullptr;
+    if (off < 1 || off > MSB_OFF_MAX) return nullptr;
     const int tb = bits - hbn::RB * mtop;
     if (tb < 3 || tb > 26) return nullptr;
     if (32 * w32 > hbn::RB * (mtop + 1) || 32 * w32 > bits + 2) return nullptr;
