@@ -60,3 +60,28 @@ def test_host_exponents_equal_the_codec():
                     np.array([2000], dtype=np.int32)):
             _, want = fp.align_encoded(res, expo, tgt, n_bits_n, n_bits_n // 3 - 1)
             assert np.array_equal(fp.float64_exponents_at(x, tgt, n_bits_n.bit_length()), want)
+
+
+def test_msb_first_product_model_bounds():
+    """The cell-exact model of the most-significant-limb-first product (csrc/mont_msb.hpp, tools/msb_model.py): on the four key
+    sizes' geometries — random, all-ones-limb and unreduced operands, random and extreme moduli — no lane's own 64-bit cell wraps,
+    every quotient digit is the true one or one below, the accumulator stays below 2 Mt, and the product is a b mod M.  (The kernel
+    itself is held to CPython on the GPU: tests/test_gpu_paillier_abi.py::test_ct_add_by_one_msb_first_product.)"""
+    import importlib.util
+    import random
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("msb_model", Path(__file__).resolve().parent.parent / "tools" / "msb_model.py")
+    mm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mm)
+    rng = random.Random(5)
+    for key, (NLL, T, U) in mm.GEOS.items():
+        for M in (mm.rand_modulus(2 * key, rng), (1 << (2 * key)) - 1 - 2 * rng.getrandbits(40), (1 << (2 * key - 1)) + 1 + 2 * rng.getrandbits(40)):
+            p = mm.Params(M, NLL, T, U)
+            assert p.ok
+            full = (1 << (2 * key)) - 1
+            ones = (1 << (M.bit_length() - 1)) - 1
+            stats = {}
+            for a, b in ((M - 1, M - 1), (1, 1), (0, 5), (full, full), (ones, ones), (rng.randrange(M), rng.randrange(M)), (full, rng.getrandbits(2 * key))):
+                assert mm.msb_mul(p, a, b, stats) == a * b % M
+            assert set(stats) <= {0, 1, "qmax"}
