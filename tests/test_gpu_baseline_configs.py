@@ -82,7 +82,12 @@ def test_config2_2048bit_batch_1M_add_and_mul():
     ca = pub.raw_encrypt(engine.to_device_words(ra, pub.device))
     cb = pub.raw_encrypt(engine.to_device_words(rb, pub.device))
     # ct + ct: D(E(a) E(b)) = a + b mod n  (same exponent classes only: compare residues, no alignment here)
-    s = priv.decrypt(pub.ct_add(ca, cb))
+    cs = pub.ct_add(ca, cb)                                # wire form in and out: one most-significant-limb-first product per element
+    s = priv.decrypt(cs)
+    # ... and the same bits, whole batch, from the lazy route (one Montgomery product, then the retag product at the boundary)
+    lazy = pub.ct_mont_mul(ca, cb)
+    assert torch.equal(cs, pub.ct_retag(lazy, -1, 0, out=lazy))
+    del lazy, cs
     # ct * k: D(E(a)^k) = k a mod n with 53-bit multipliers
     k = rng.integers(1, 1 << 53, size=N, dtype=np.uint64)
     kw = np.stack([(k & 0xFFFFFFFF).astype(np.uint32), (k >> np.uint64(32)).astype(np.uint32)], axis=1)
