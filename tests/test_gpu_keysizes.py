@@ -151,3 +151,29 @@ def test_lane_group_digit_pair_ct_times_pt(bits, monkeypatch):
         _native.check(nk.lib.pai_ct_mul(nk.pk, d2.ptr, de.ptr, 2, 53, 0, N, d2.ptr, None))                # in place
         assert limbs_to_ints(d2.get()) == pow_many(c, e, M), (bits, disable, "in place")
         del nk
+
+
+@pytest.mark.parametrize("bits", [384, 800, 1280, 1536, 2560, 3584])
+def test_wire_form_sum_on_lane_groups_at_odd_key_sizes(bits, monkeypatch):
+    """pai_ct_add beyond the small-batch range at key sizes whose n^2 sits anywhere in its geometry: the most-significant-limb-first
+    product (csrc/mont_msb.hpp) where the key has the context — 384 bits: one lane per integer; 800 bits: n^2 shifted up by the
+    largest offset served (16 limbs) — and the two Montgomery products where it has not; reduced operands, every element against
+    CPython, and the two routes against each other."""
+    from pailliercryptolib_python_amd import engine
+    from tests._util import disable as knob_disable
+
+    key, pk, _ = make(bits)
+    h = pk.pubkey.handle
+    M = key.n * key.n
+    rng = np.random.default_rng(bits + 5)
+    N = 257
+    W = h.ct_words
+    a = [M - 1, 1, 0, M - 2] + [int.from_bytes(rng.bytes(4 * W), "little") % M for _ in range(N - 4)]
+    b = [M - 1, M - 1, 7, 2] + [int.from_bytes(rng.bytes(4 * W), "little") % M for _ in range(N - 4)]
+    ta = engine.to_device_words(engine.ints_to_words(a, W), h.device)
+    tb = engine.to_device_words(engine.ints_to_words(b, W), h.device)
+    monkeypatch.setenv("PAI_LAT_ADD_MAX", "0")
+    got = engine.words_to_ints(engine.to_host_words(h.ct_add(ta, tb)))
+    assert got == [x * y % M for x, y in zip(a, b)]
+    knob_disable(monkeypatch, "add_msb")
+    assert engine.words_to_ints(engine.to_host_words(h.ct_add(ta, tb))) == got
