@@ -695,18 +695,22 @@ PAI_DEV void cond_sub(uint32_t (&x)[NLL], const NM& nm) {
         }
         borrow = (sum < xs) ? -1 : 0;
     } else if constexpr (T > 1) {
-        // ripple the borrow through the group, lane by lane (T <= 8, once per operation)
-        for (int step = 1; step < T; ++step) {
-            int32_t bin = (int32_t)from_prev<T>((uint32_t)borrow);   // 0 or 0xffffffff(-1)
-            int32_t b2 = (group_lane<T>() == step) ? bin : 0;
-            int32_t bo = b2;
+        // Every lane hands its borrow to the next one AT ONCE and the receivers re-propagate in one pass.  A received borrow
+        // changes a lane's own borrow-out only if all its limbs are zero (then the NEW borrow goes round again: practically never),
+        // so the loop runs one pass where the lane-by-lane ripple of rounds 1-5 ran T - 1 (31 on the 32-lane latency geometries).
+        int32_t pend = borrow;                               // the borrow this lane has not handed on yet (0 / -1)
+        while (true) {
+            const int32_t bin = (int32_t)from_prev<T>((uint32_t)pend);      // the group's first lane receives 0
+            if (!__any(bin != 0)) break;
+            int32_t bo = bin;
 #pragma unroll
             for (int j = 0; j < NLL; ++j) {
                 int32_t t = (int32_t)d[j] + bo;
                 d[j] = (uint32_t)t & RMASK;
                 bo = t >> RB;
             }
-            if (group_lane<T>() == step) borrow = borrow + bo;   // combined borrow-out is 0 or -1
+            pend = borrow == 0 ? bo : 0;                     // a lane that had borrowed out already hands nothing new
+            borrow |= bo;
         }
         // the decision is the borrow out of the group's last lane
         int32_t last = (int32_t)__shfl((int)borrow, (int)(((threadIdx.x & 63) & ~(T - 1)) + T - 1), 64);

@@ -1132,6 +1132,10 @@ def test_ct_add_by_one_msb_first_product(bits, monkeypatch):
                 b[40:61] = special[7:] + special[:7]
                 a[100:110] = [int.from_bytes(rng.bytes(4 * W), "little") for _ in range(10)]      # unreduced words
                 b[105:115] = [int.from_bytes(rng.bytes(4 * W), "little") for _ in range(10)]
+                # the sum M - 1: before the final subtraction every lane above the first holds exactly the modulus' limbs, so the
+                # borrow of the first lane runs through all of them (cond_sub's second and later rounds)
+                a[120:124] = [M - 1, 1, n - 1, M - 1]
+                b[120:124] = [1, M - 1, n + 1, M - 1]          # (n - 1)(n + 1) = M - 1;  (M - 1)^2 = 1
             da, db = DevArray(ints_to_limbs(a, W)), DevArray(ints_to_limbs(b, W))
             out = DevArray(shape=(N, W))
             _native.check(K.lib.pai_ct_add(K.pk, da.ptr, db.ptr, 0, N, out.ptr, None))
