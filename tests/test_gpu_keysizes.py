@@ -177,3 +177,6 @@ def test_wire_form_sum_on_lane_groups_at_odd_key_sizes(bits, monkeypatch):
     assert got == [x * y % M for x, y in zip(a, b)]
     knob_disable(monkeypatch, "add_msb")
     assert engine.words_to_ints(engine.to_host_words(h.ct_add(ta, tb))) == got
+    # ... and on one integer per wavefront (16 / 32 / 64 lanes per integer: the borrow of (1, M - 1) -> M - 1 runs through every lane)
+    monkeypatch.delenv("PAI_LAT_ADD_MAX")
+    assert engine.words_to_ints(engine.to_host_words(h.ct_add(ta, tb))) == got
