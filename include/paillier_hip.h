@@ -164,8 +164,9 @@ int pai_decrypt(pai_privkey* sk, const uint32_t* d_ct, size_t N, uint32_t* d_m, 
 
 /* ipclCipherText.__add__(ct, ct) — classes.cpp:318-321: d_out[i] = d_a[i] * d_b[i] mod n^2.
  * b_bcast != 0: d_b holds one ciphertext used for every i (size-1 broadcast).  d_out may alias d_a.
- * (Batches beyond the small-batch range: one most-significant-limb-first product per element, csrc/mont_msb.hpp — the canonical
- * residue for ANY word pattern of the rows, reduced or not.) */
+ * Operands are residues modulo n^2 (as everywhere in this ABI); the result is the canonical residue.  (Batches beyond the
+ * small-batch range run one most-significant-limb-first product per element, csrc/mont_msb.hpp, which would also accept rows that
+ * are not reduced; the small-batch route does not promise that.) */
 int pai_ct_add(const pai_pubkey* pk, const uint32_t* d_a, const uint32_t* d_b, int b_bcast, size_t N,
                uint32_t* d_out, void* stream);
 
