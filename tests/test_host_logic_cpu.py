@@ -85,3 +85,16 @@ def test_msb_first_product_model_bounds():
             for a, b in ((M - 1, M - 1), (1, 1), (0, 5), (full, full), (ones, ones), (rng.randrange(M), rng.randrange(M)), (full, rng.getrandbits(2 * key))):
                 assert mm.msb_mul(p, a, b, stats) == a * b % M
             assert set(stats) <= {0, 1, "qmax"}
+    # the corners of the context's conditions (csrc/paillier_capi.hip: build_msb_ctx): 3 and 26 bits of the modulus in its top limb,
+    # shifted up by 1 and by 16 limbs, smallest and largest modulus of the bit length
+    for NLL, T, U in ((36, 4, 6), (28, 8, 4)):
+        NL = NLL * T
+        for off in (1, 16):
+            for tb in (3, 26):
+                bits = 29 * (NL - 1 - off) + tb
+                for M in ((1 << bits) - 1 - 2 * rng.getrandbits(30), (1 << (bits - 1)) + 1 + 2 * rng.getrandbits(30)):
+                    p = mm.Params(M, NLL, T, U)
+                    assert p.ok and (p.tb, p.off) == (tb, off)
+                    full = (1 << bits) - 1
+                    for a, b in ((M - 1, M - 1), (full, full), (rng.randrange(M), rng.randrange(M))):
+                        assert mm.msb_mul(p, a, b) == a * b % M
